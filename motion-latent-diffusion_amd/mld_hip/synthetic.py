@@ -1,0 +1,173 @@
+"""Deterministic synthetic weights / inputs for the MLD sampling hot path.
+
+No checkpoint, CLIP weights or HumanML3D statistics are reachable offline, so every
+test and benchmark in this repo runs on *synthetic* tensors produced here.  The
+generator is pure numpy (PCG64 streams keyed by tensor name) so the very same bytes
+are produced in the build container and on the GPU box.
+
+Key names and shapes follow the reference checkpoint contract:
+  denoiser  -> mld/models/architectures/mld_denoiser.py:40-133  (126 tensors, 8 349 184 params)
+  vae       -> mld/models/architectures/mld_vae.py:35-112       (297 tensors, 18 032 135 params)
+Lightning checkpoints prefix them with ``denoiser.`` / ``vae.`` (mld/models/modeltype/base.py:96-127).
+
+Init statistics mimic the reference's (xavier-uniform matrices inside the skip
+transformers, cross_attention.py:36-39; U(-1/sqrt(fan_in), +) elsewhere; U[0,1)
+learned PEs, position_encoding.py:150-151) except that LayerNorm affine
+parameters and attention biases are perturbed away from (1, 0) so a kernel that
+drops a bias or a gamma cannot pass parity by accident.
+"""
+from __future__ import annotations
+
+import zlib
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+NFEATS = 263          # configs/base.yaml DATASET.HUMANML3D (HumanML3D feature width)
+NJOINTS = 22
+TEXT_DIM = 768        # configs/modules/denoiser.yaml:4
+MAX_PE = 500          # position_encoding.py:140
+
+
+@dataclass
+class ModelDims:
+    """Shape hyper-parameters of config_mld_humanml3d.yaml (model.* block)."""
+    latent_dim: int = 256
+    latent_size: int = 1
+    ff_size: int = 1024
+    num_layers: int = 9
+    num_heads: int = 4
+    nfeats: int = NFEATS
+    text_dim: int = TEXT_DIM
+
+    @property
+    def num_block(self) -> int:
+        return (self.num_layers - 1) // 2
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+
+
+def _uniform(seed, name, shape, bound):
+    return _rng(seed, name).uniform(-bound, bound, size=shape).astype(np.float32)
+
+
+def _xavier(seed, name, shape):
+    fan_out, fan_in = shape
+    return _uniform(seed, name, shape, float(np.sqrt(6.0 / (fan_in + fan_out))))
+
+
+def _linear(sd, seed, prefix, n_out, n_in, xavier=False):
+    w = f"{prefix}.weight"
+    sd[w] = _xavier(seed, w, (n_out, n_in)) if xavier else _uniform(seed, w, (n_out, n_in), 1.0 / np.sqrt(n_in))
+    sd[f"{prefix}.bias"] = _uniform(seed, f"{prefix}.bias", (n_out,), 1.0 / np.sqrt(n_in))
+
+
+def _norm(sd, seed, prefix, d):
+    sd[f"{prefix}.weight"] = (1.0 + _uniform(seed, f"{prefix}.weight", (d,), 0.1)).astype(np.float32)
+    sd[f"{prefix}.bias"] = _uniform(seed, f"{prefix}.bias", (d,), 0.05)
+
+
+def _mha(sd, seed, prefix, d):
+    sd[f"{prefix}.in_proj_weight"] = _xavier(seed, f"{prefix}.in_proj_weight", (3 * d, d))
+    sd[f"{prefix}.in_proj_bias"] = _uniform(seed, f"{prefix}.in_proj_bias", (3 * d,), 0.02)
+    sd[f"{prefix}.out_proj.weight"] = _xavier(seed, f"{prefix}.out_proj.weight", (d, d))
+    sd[f"{prefix}.out_proj.bias"] = _uniform(seed, f"{prefix}.out_proj.bias", (d,), 0.02)
+
+
+def block_names(num_block: int) -> List[str]:
+    """Layer prefixes of a Skip transformer in execution order (cross_attention.py:41-60)."""
+    return ([f"input_blocks.{i}" for i in range(num_block)] + ["middle_block"] +
+            [f"output_blocks.{i}" for i in range(num_block)])
+
+
+def _skip_transformer(sd, seed, prefix, dims: ModelDims, decoder: bool):
+    d, ff = dims.latent_dim, dims.ff_size
+    for blk in block_names(dims.num_block):
+        p = f"{prefix}.{blk}"
+        _mha(sd, seed, f"{p}.self_attn", d)
+        if decoder:
+            _mha(sd, seed, f"{p}.multihead_attn", d)
+        _linear(sd, seed, f"{p}.linear1", ff, d, xavier=True)
+        _linear(sd, seed, f"{p}.linear2", d, ff, xavier=True)
+        for n in (("norm1", "norm2", "norm3") if decoder else ("norm1", "norm2")):
+            _norm(sd, seed, f"{p}.{n}", d)
+    for i in range(dims.num_block):
+        _linear(sd, seed, f"{prefix}.linear_blocks.{i}", d, 2 * d, xavier=True)
+    _norm(sd, seed, f"{prefix}.norm", d)
+
+
+def make_denoiser_state_dict(seed: int = 0, dims: ModelDims = ModelDims()) -> Dict[str, np.ndarray]:
+    """Synthetic ``MldDenoiser`` weights (text condition, trans_enc + skip, learned PE)."""
+    sd: Dict[str, np.ndarray] = {}
+    d = dims.latent_dim
+    _linear(sd, seed, "time_embedding.linear_1", d, dims.text_dim)
+    _linear(sd, seed, "time_embedding.linear_2", d, d)
+    _linear(sd, seed, "emb_proj.1", d, dims.text_dim)
+    sd["query_pos.pe"] = _rng(seed, "query_pos.pe").uniform(0, 1, (MAX_PE, 1, d)).astype(np.float32)
+    sd["mem_pos.pe"] = _rng(seed, "mem_pos.pe").uniform(0, 1, (MAX_PE, 1, d)).astype(np.float32)
+    _skip_transformer(sd, seed, "encoder", dims, decoder=False)
+    return sd
+
+
+def make_vae_state_dict(seed: int = 1, dims: ModelDims = ModelDims()) -> Dict[str, np.ndarray]:
+    """Synthetic ``MldVae`` weights (arch encoder_decoder, PE_TYPE mld, MLP_DIST false)."""
+    sd: Dict[str, np.ndarray] = {}
+    d = dims.latent_dim
+    sd["global_motion_token"] = _rng(seed, "global_motion_token").standard_normal(
+        (2 * dims.latent_size, d)).astype(np.float32)
+    sd["query_pos_encoder.pe"] = _rng(seed, "query_pos_encoder.pe").uniform(0, 1, (MAX_PE, 1, d)).astype(np.float32)
+    sd["query_pos_decoder.pe"] = _rng(seed, "query_pos_decoder.pe").uniform(0, 1, (MAX_PE, 1, d)).astype(np.float32)
+    _skip_transformer(sd, seed, "encoder", dims, decoder=False)
+    _skip_transformer(sd, seed, "decoder", dims, decoder=True)
+    _linear(sd, seed, "skel_embedding", d, dims.nfeats)
+    _linear(sd, seed, "final_layer", dims.nfeats, d)
+    return sd
+
+
+def make_mean_std(nfeats: int = NFEATS) -> Tuple[np.ndarray, np.ndarray]:
+    """Physically scaled stand-ins for HumanML3D ``Mean.npy`` / ``Std.npy`` (get_data.py:38-40).
+
+    Made-up magnitudes: small std on the root
+    yaw / XZ velocity channels so the integrated trajectory stays physical; with
+    mean=0, std=1 the joint metric is chaotic and the 1e-3 tolerance meaningless.
+    """
+    mean = np.zeros(nfeats, np.float32)
+    std = np.full(nfeats, 0.3, np.float32)
+    std[0] = 0.05
+    std[1:3] = 0.03
+    std[3] = 0.1
+    mean[3] = 0.9
+    return mean, std
+
+
+@dataclass
+class SyntheticBatch:
+    text_emb: np.ndarray        # [2B, 1, 768]; rows 0..B-1 = the shared "" (unconditional) embedding
+    init_latents: np.ndarray    # [B, 1, 256]
+    lengths: List[int] = field(default_factory=list)
+
+
+def make_batch(batch: int, lengths=None, seed: int = 1234, max_len: int = 196,
+               dims: ModelDims = ModelDims()) -> SyntheticBatch:
+    """HumanML3D-shaped sampler inputs: CLIP-like embeddings, N(0,1) start noise.
+
+    ``lengths='ragged'`` draws multiples of 4 in [40, max_len]; ``None`` = all ``max_len``.
+    Real CLIP ViT-L/14 text features have norm ~ 10-20 over 768 dims, i.e. O(0.5)
+    per element; we draw N(0, 0.5^2).
+    """
+    g = _rng(seed, f"batch{batch}")
+    uncond = (0.5 * g.standard_normal((1, 1, dims.text_dim))).astype(np.float32)
+    cond = (0.5 * g.standard_normal((batch, 1, dims.text_dim))).astype(np.float32)
+    text = np.concatenate([np.repeat(uncond, batch, 0), cond], 0)
+    lat = g.standard_normal((batch, dims.latent_size, dims.latent_dim)).astype(np.float32)
+    if lengths is None:
+        lens = [max_len] * batch
+    elif isinstance(lengths, str) and lengths == "ragged":
+        lens = [int(x) for x in 4 * g.integers(10, max_len // 4 + 1, size=batch)]
+    else:
+        lens = [int(x) for x in lengths]
+        assert len(lens) == batch
+    return SyntheticBatch(text, lat, lens)

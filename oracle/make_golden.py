@@ -1,0 +1,139 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (build container only).
+
+Run:  python oracle/make_golden.py            (needs /root/reference; CPU; ~1 min)
+
+The reference is Python and cannot travel to the GPU box, so its outputs on the seeded
+synthetic weights/inputs of ``mld_hip.synthetic`` are frozen here as small fixtures.
+What comes from where:
+
+  MldDenoiser / MldVae / recover_from_ric   imported from /root/reference (the real code)
+  DDIM scheduler                            oracle.mld_oracle.DDIMSchedule (diffusers is not
+                                            installed -> restated, PARITY UNPINNED)
+  orchestration (CFG batching, loop)        the 20 lines below, following mld.py:216-265,290-360
+
+Each fixture also records the oracle-vs-reference max-abs difference measured at
+generation time (``oracle_diff_*``), so the pinning evidence is in the file itself.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle._paths  # noqa: E402,F401
+from mld_hip import synthetic as syn  # noqa: E402
+from oracle import mld_oracle as O  # noqa: E402
+
+REF = os.environ.get("MLD_REFERENCE", "/root/reference")
+OUT = os.path.join(oracle._paths.REPO, "tests", "golden")
+
+
+def build_reference():
+    sys.path.insert(0, REF)
+    from mld.models.architectures.mld_denoiser import MldDenoiser
+    from mld.models.architectures.mld_vae import MldVae
+    from mld.data.humanml.scripts.motion_process import recover_from_ric
+
+    class Abl:  # TRAIN.ABLATION of config_mld_humanml3d.yaml:33-36 (+ base.yaml defaults)
+        SKIP_CONNECT = True
+        VAE_TYPE = "mld"
+        PE_TYPE = "mld"
+        DIFF_PE_TYPE = "mld"
+        MLP_DIST = False
+
+    den = MldDenoiser(ablation=Abl, nfeats=263, condition="text", latent_dim=[1, 256], ff_size=1024,
+                      num_layers=9, num_heads=4, dropout=0.1, normalize_before=False, activation="gelu",
+                      flip_sin_to_cos=True, position_embedding="learned", arch="trans_enc", freq_shift=0,
+                      guidance_scale=7.5, guidance_uncondp=0.1, text_encoded_dim=768).eval()
+    vae = MldVae(ablation=Abl, nfeats=263, latent_dim=[1, 256], ff_size=1024, num_layers=9, num_heads=4,
+                 dropout=0.1, arch="encoder_decoder", normalize_before=False, activation="gelu",
+                 position_embedding="learned").eval()
+    sdd, sdv = syn.make_denoiser_state_dict(), syn.make_vae_state_dict()
+    den.load_state_dict({k: torch.from_numpy(v) for k, v in sdd.items()}, strict=True)
+    vae.load_state_dict({k: torch.from_numpy(v) for k, v in sdv.items()}, strict=True)
+    return den, vae, recover_from_ric, sdd, sdv
+
+
+@torch.no_grad()
+def reference_sample(den, vae, recover_from_ric, text_emb, init_latents, lengths, mean, std,
+                     guidance=7.5, steps=50):
+    """mld.py:290-360 + 237-240 + 264 with the reference modules and the restated DDIM."""
+    sch = O.DDIMSchedule()
+    lat = torch.from_numpy(init_latents) * sch.init_noise_sigma
+    enc = torch.from_numpy(text_emb)
+    for t in sch.set_timesteps(steps):
+        x = torch.cat([lat] * 2)
+        eps = den(sample=x, timestep=torch.tensor(int(t)), encoder_hidden_states=enc, lengths=list(lengths) * 2)[0]
+        u, c = eps.chunk(2)
+        eps = u + guidance * (c - u)
+        sa, sb, pa, pb = (float(v) for v in sch.coeffs(t))
+        x0 = (lat - sb * eps) / sa
+        lat = pa * x0 + pb * eps
+    z = lat.permute(1, 0, 2)
+    feats = vae.decode(z, list(lengths))
+    joints = recover_from_ric(feats * torch.from_numpy(std) + torch.from_numpy(mean), 22)
+    return lat.numpy(), feats.numpy(), joints.numpy()
+
+
+def main():
+    torch.manual_seed(0)
+    os.makedirs(OUT, exist_ok=True)
+    den, vae, recover_from_ric, sdd, sdv = build_reference()
+    ops = O.NumpyOps(np.float32)
+    bd, bv = O.to_backend(ops, sdd), O.to_backend(ops, sdv)
+    mean, std = syn.make_mean_std()
+
+    # ---- 1. single denoiser calls (first and last DDIM timesteps), B=3 CFG batch
+    b3 = syn.make_batch(3, [50, 100, 100])                       # demo/example.txt lengths
+    x = np.concatenate([b3.init_latents] * 2)
+    den_out = {}
+    for t in (981, 1):
+        with torch.no_grad():
+            ref = den(sample=torch.from_numpy(x), timestep=torch.tensor(t),
+                      encoder_hidden_states=torch.from_numpy(b3.text_emb), lengths=b3.lengths * 2)[0].numpy()
+        mine = O.denoiser_forward(ops, bd, x, t, b3.text_emb)
+        den_out[f"out_t{t}"] = ref
+        den_out[f"oracle_diff_t{t}"] = np.abs(ref - mine).max()
+    np.savez_compressed(os.path.join(OUT, "denoiser_b3.npz"), sample=x, text_emb=b3.text_emb, **den_out)
+
+    # ---- 2. VAE decode + joints, ragged B=3
+    z = syn._rng(7, "golden_z").standard_normal((3, 1, 256)).astype(np.float32)
+    with torch.no_grad():
+        feats = vae.decode(torch.from_numpy(z).permute(1, 0, 2), b3.lengths).numpy()
+        joints = recover_from_ric(torch.from_numpy(feats) * torch.from_numpy(std) + torch.from_numpy(mean), 22).numpy()
+    fm = O.vae_decode(ops, bv, z, b3.lengths)
+    jm = O.feats2joints(ops, feats, mean, std)
+    np.savez_compressed(os.path.join(OUT, "vae_decode_b3.npz"), z=z, lengths=np.array(b3.lengths), feats=feats,
+                        joints=joints, oracle_diff_feats=np.abs(feats - fm).max(),
+                        oracle_diff_joints=np.abs(joints - jm).max())
+
+    # ---- 3. full pipeline, config 1 shape (B=3, lengths 50/100/100)
+    lat, feats, joints = reference_sample(den, vae, recover_from_ric, b3.text_emb, b3.init_latents, b3.lengths, mean, std)
+    jo, fo, lo = O.sample(ops, bd, bv, b3.text_emb, b3.init_latents, b3.lengths, mean, std, return_intermediates=True)
+    np.savez_compressed(os.path.join(OUT, "pipeline_b3.npz"), text_emb=b3.text_emb, init_latents=b3.init_latents,
+                        lengths=np.array(b3.lengths), latents=lat, feats=feats, joints=joints,
+                        oracle_diff_latents=np.abs(lat - lo).max(), oracle_diff_feats=np.abs(feats - fo).max(),
+                        oracle_diff_joints=np.abs(joints - jo).max())
+    print("pipeline_b3 oracle-vs-reference:", np.abs(lat - lo).max(), np.abs(feats - fo).max(), np.abs(joints - jo).max())
+
+    # ---- 4. full pipeline, config 2 shape (B=64, T=196): latents + every 4th frame of joints
+    b64 = syn.make_batch(64)
+    lat, feats, joints = reference_sample(den, vae, recover_from_ric, b64.text_emb, b64.init_latents, b64.lengths, mean, std)
+    jo, fo, lo = O.sample(ops, bd, bv, b64.text_emb, b64.init_latents, b64.lengths, mean, std, return_intermediates=True)
+    np.savez_compressed(os.path.join(OUT, "pipeline_b64.npz"), latents=lat, joints_every4=joints[:, ::4],
+                        feats_frame_last=feats[:, -1], oracle_diff_latents=np.abs(lat - lo).max(),
+                        oracle_diff_feats=np.abs(feats - fo).max(), oracle_diff_joints=np.abs(joints - jo).max())
+    print("pipeline_b64 oracle-vs-reference:", np.abs(lat - lo).max(), np.abs(feats - fo).max(), np.abs(joints - jo).max())
+
+    # ---- 5. scheduler table (self-consistency only: diffusers absent => unpinned)
+    sch = O.DDIMSchedule()
+    ts = sch.set_timesteps(50)
+    np.savez_compressed(os.path.join(OUT, "ddim_table.npz"), timesteps=ts, alphas_cumprod=sch.alphas_cumprod,
+                        coeffs=np.array([sch.coeffs(t) for t in ts], np.float32))
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
