@@ -1,0 +1,147 @@
+/* mldhip.h -- C ABI of libmldhip.so, the MI355X (gfx950) engine for the Motion-Latent-Diffusion
+ * sampling hot path:  text embedding -> 50-step DDIM latent sampling with classifier-free
+ * guidance -> motion-VAE decode -> (nframe, 22, 3) joints.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * ChenFengYe/motion-latent-diffusion tree).  The reference has no FFI of its own (it is pure
+ * Python/PyTorch), so "what its FFI for this path would bind" is its plugin surface:
+ * instantiate_from_config targets (mld/config.py:16-31) for denoiser / motion_vae / scheduler
+ * and the MLD.forward / _diffusion_reverse orchestration (mld/models/modeltype/mld.py:216-360).
+ * INTEGRATION.md shows the ctypes binding and the YAML `target:` swap.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; `*_dev` pointers are device (HBM) addresses, `*_host` host.
+ *   - all tensors are contiguous row-major float32 unless stated; int32 for lengths.
+ *   - every call returns 0 on success or a negative MLDHIP_E* code; nothing throws across the ABI;
+ *     mldhip_last_error() gives the message of the last failure on that handle (or globally for
+ *     a failed create).
+ *   - work is enqueued on the caller's `stream` (a hipStream_t passed as void*, NULL = the null
+ *     stream) and is stream-ordered: no implicit device synchronisation.
+ *   - the caller owns every I/O buffer; the engine owns weights, workspace and the hipGraph.
+ *   - one handle per device; a handle is not thread-safe.
+ */
+#ifndef MLDHIP_H_
+#define MLDHIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLDHIP_ABI_VERSION 1
+
+enum {
+  MLDHIP_OK = 0,
+  MLDHIP_EINVAL = -1,      /* bad argument / shape / unsupported configuration */
+  MLDHIP_ENOKEY = -2,      /* finalize: a required tensor was never loaded */
+  MLDHIP_ESTATE = -3,      /* call order violated (e.g. sample before finalize) */
+  MLDHIP_EHIP = -4,        /* a HIP runtime call failed (message has the hipError string) */
+  MLDHIP_ENODEV = -5       /* no gfx950 device visible */
+};
+
+enum { MLDHIP_F32 = 0 };   /* dtype codes for mldhip_load_tensor */
+
+enum {                     /* arithmetic mode of the matrix kernels */
+  MLDHIP_PREC_F32 = 0      /* exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): the parity mode */
+};
+
+/* Mirrors the keys of configs/config_mld_humanml3d.yaml + configs/modules/{denoiser,motion_vae,
+ * scheduler}.yaml that the hot path consumes. */
+typedef struct mldhip_config {
+  int32_t struct_size;          /* sizeof(mldhip_config), for ABI evolution */
+  int32_t latent_dim;           /* model.latent_dim[1]  = 256 */
+  int32_t latent_size;          /* model.latent_dim[0]  = 1   */
+  int32_t ff_size;              /* 1024 */
+  int32_t num_layers;           /* 9 (odd: SkipTransformer, cross_attention.py:26) */
+  int32_t num_heads;            /* 4 */
+  int32_t nfeats;               /* DATASET.NFEATS = 263 */
+  int32_t njoints;              /* 22 */
+  int32_t text_dim;             /* denoiser.params.text_encoded_dim = 768 */
+  int32_t max_batch;            /* capacity: motions per sample() call */
+  int32_t max_frames;           /* capacity: frames per motion (<= 288 in this release) */
+  int32_t num_train_timesteps;  /* scheduler.params.num_train_timesteps = 1000 */
+  int32_t num_inference_steps;  /* scheduler.num_inference_timesteps = 50 */
+  int32_t steps_offset;         /* 1 */
+  int32_t set_alpha_to_one;     /* 0 */
+  float beta_start;             /* 0.00085 (scaled_linear) */
+  float beta_end;               /* 0.012 */
+  float guidance_scale;         /* model.guidance_scale = 7.5 */
+  int32_t precision;            /* MLDHIP_PREC_* */
+  int32_t use_graph;            /* 1: capture sample() into a hipGraph and replay it */
+} mldhip_config;
+
+typedef struct mldhip_engine mldhip_handle;
+
+/* Fill *cfg with the config_mld_humanml3d.yaml defaults (max_batch 64, max_frames 196). */
+void mldhip_default_config(mldhip_config* cfg);
+
+/* Replaces: get_model(cfg, datamodule) -> MLD.__init__ instantiating denoiser / vae / scheduler
+ * (mld/models/get_model.py:4-17, mld/models/modeltype/mld.py:56-83). */
+int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out);
+void mldhip_destroy(mldhip_handle* h);
+
+/* Replaces: model.load_state_dict(ckpt["state_dict"], strict=True) (demo.py:129-150) plus the
+ * datamodule's Mean.npy/Std.npy (mld/data/get_data.py:38-40).  `key` is the checkpoint key
+ * ("denoiser.encoder.input_blocks.0.self_attn.in_proj_weight", "vae.final_layer.bias", ...) or
+ * "mean" / "std".  Keys the sampling path never reads (vae.encoder.*, vae.skel_embedding.*,
+ * vae.global_motion_token, vae.query_pos_encoder.pe, denoiser.mem_pos.pe, text_encoder.*, t2m_*)
+ * are accepted and ignored (returns 1).  `src_is_device` != 0 when `data` is a device pointer. */
+int mldhip_load_tensor(mldhip_handle* h, const char* key, const void* data, const int64_t* shape,
+                       int32_t ndim, int32_t dtype, int32_t src_is_device);
+
+/* Checks every required key arrived, derives step-invariant tables (DDIM coefficients,
+ * time-MLP outputs for the scheduler's timesteps, PE-folded biases).  Runs on `stream`. */
+int mldhip_finalize_weights(mldhip_handle* h, void* stream);
+
+/* Number of tensors the engine requires / names of those still missing (NUL-separated list
+ * written to buf, returns the count missing). */
+int mldhip_missing_keys(mldhip_handle* h, char* buf, int64_t buflen);
+
+/* Replaces: MLD.forward after the text encoder = _diffusion_reverse + vae.decode + feats2joints
+ * (mld/models/modeltype/mld.py:232-240,264; 290-360).
+ *   text_emb_dev      [2B, 1, text_dim]  unconditional half first (mld.py:224-231)
+ *   init_latents_dev  [B, latent_size, latent_dim]  the torch.randn of mld.py:303 (injected)
+ *   lengths_host      [B] int32
+ *   latents_out_dev   [B, latent_size, latent_dim]  final latents (may be NULL)
+ *   feats_out_dev     [B, Tmax, nfeats]   Tmax = max(lengths); zeros at padded frames (may be NULL)
+ *   joints_out_dev    [B, Tmax, njoints, 3]  (may be NULL) */
+int mldhip_sample(mldhip_handle* h, const float* text_emb_dev, const float* init_latents_dev,
+                  const int32_t* lengths_host, int32_t B, float* latents_out_dev, float* feats_out_dev,
+                  float* joints_out_dev, void* stream);
+
+/* Replaces: MldDenoiser.forward(sample, timestep, encoder_hidden_states)[0]
+ * (mld/models/architectures/mld_denoiser.py:135-228).  sample [R,1,D], text [R,1,text_dim],
+ * out [R,1,D]; any integer timestep in [0, num_train_timesteps). */
+int mldhip_denoiser_forward(mldhip_handle* h, const float* sample_dev, int32_t timestep,
+                            const float* text_emb_dev, int32_t R, float* out_dev, void* stream);
+
+/* Replaces: MldVae.decode(z, lengths) (mld/models/architectures/mld_vae.py:186-248).
+ * z [latent_size, B, D] (== [B, D] for latent_size 1) -> feats [B, Tmax, nfeats]. */
+int mldhip_vae_decode(mldhip_handle* h, const float* z_dev, const int32_t* lengths_host, int32_t B,
+                      float* feats_out_dev, void* stream);
+
+/* Replaces: DDIMScheduler.step(model_output, t, sample, eta=0).prev_sample (call site
+ * mld.py:345-346).  n elements, in/out may alias. */
+int mldhip_ddim_step(mldhip_handle* h, const float* eps_dev, int32_t timestep, const float* sample_dev,
+                     float* prev_sample_dev, int64_t n, void* stream);
+
+/* Replaces: HumanML3DDataModule.feats2joints (mld/data/HumanML3D.py:41-45 -> recover_from_ric,
+ * mld/data/humanml/scripts/motion_process.py:415-432).  feats [B,T,nfeats] -> joints [B,T,njoints,3]. */
+int mldhip_feats2joints(mldhip_handle* h, const float* feats_dev, int32_t B, int32_t T,
+                        float* joints_out_dev, void* stream);
+
+/* Scheduler introspection (DDIMScheduler.timesteps / alphas_cumprod): copies min(n, available). */
+int mldhip_get_timesteps(mldhip_handle* h, int32_t* out_host, int32_t n);
+int mldhip_get_alphas_cumprod(mldhip_handle* h, float* out_host, int32_t n);
+
+/* Per-phase kernel launch counts of the last sample() (denoise loop, decode, joints). */
+int mldhip_get_launch_counts(mldhip_handle* h, int32_t* out_host /*[3]*/);
+
+const char* mldhip_last_error(mldhip_handle* h /* may be NULL */);
+int mldhip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLDHIP_H_ */

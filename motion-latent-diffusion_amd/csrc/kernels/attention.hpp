@@ -1,0 +1,205 @@
+// Self-attention kernels of the MLD engine (exact-fp32 MFMA path).
+//
+// Both replace nn.MultiheadAttention's slow path as invoked by the reference
+// (cross_attention.py:265-266 encoder layers, :332-333 decoder self-attention): q pre-scaled by
+// 1/sqrt(head_dim), scores, float -inf key-padding mask, softmax, P·V.  The [B·H, L, S] score
+// tensor and the discarded head-averaged weights of the reference are never materialised.
+//
+// Input is the packed in-projection output qkv[row][3*D] (q | k | v, heads = contiguous 64-col
+// slices); output o[row][D] feeds the out-proj GEMM.
+#pragma once
+#include "rt.hpp"
+
+namespace mld {
+
+// ----------------------------------------------------------------------------------------------
+// Denoiser: sequences of S=3 tokens (latent, time, text) per sample (mld_denoiser.py:187).
+// Rows are token-major: row = s*R + r.  One thread per (sample r, head h, query i, 16-wide d chunk);
+// the 4 d-chunks of a query are adjacent lanes and combine with two xor-shuffles.  ~0.6 MFLOP per
+// call: latency-only kernel, no LDS, no MFMA.
+template <int S, int HD>
+__global__ __launch_bounds__(256) void attn_tiny_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                        int R, int H) {
+  static_assert(HD == 64, "head_dim 64");
+  const int D = H * HD;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = R * H * S * 4;
+  const bool live = gid < total;
+  int idx = live ? gid : total - 1;
+  const int dc = idx & 3; idx >>= 2;
+  const int i = idx % S; idx /= S;
+  const int h = idx % H;
+  const int r = idx / H;
+  const float scale = 0.125f;  // 1/sqrt(64)
+  const float* qp = qkv + (long long)(i * R + r) * 3 * D + h * HD + dc * 16;
+  float q[16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    F4 t = ld4(qp + c * 4);
+    q[c * 4] = t.x * scale; q[c * 4 + 1] = t.y * scale; q[c * 4 + 2] = t.z * scale; q[c * 4 + 3] = t.w * scale;
+  }
+  float sc[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    const float* kp = qkv + (long long)(j * R + r) * 3 * D + D + h * HD + dc * 16;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      F4 t = ld4(kp + c * 4);
+      s = fmaf(q[c * 4], t.x, s); s = fmaf(q[c * 4 + 1], t.y, s);
+      s = fmaf(q[c * 4 + 2], t.z, s); s = fmaf(q[c * 4 + 3], t.w, s);
+    }
+    s += wave_xor(s, 1);
+    s += wave_xor(s, 2);
+    sc[j] = s;
+  }
+  float m = sc[0];
+#pragma unroll
+  for (int j = 1; j < S; ++j) m = fmaxf(m, sc[j]);
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < S; ++j) { sc[j] = expf(sc[j] - m); den += sc[j]; }
+  const float inv = 1.0f / den;
+  float out[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) out[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    const float* vp = qkv + (long long)(j * R + r) * 3 * D + 2 * D + h * HD + dc * 16;
+    const float pj = sc[j] * inv;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      F4 t = ld4(vp + c * 4);
+      out[c * 4] = fmaf(pj, t.x, out[c * 4]); out[c * 4 + 1] = fmaf(pj, t.y, out[c * 4 + 1]);
+      out[c * 4 + 2] = fmaf(pj, t.z, out[c * 4 + 2]); out[c * 4 + 3] = fmaf(pj, t.w, out[c * 4 + 3]);
+    }
+  }
+  if (live) {
+    float* op = o + (long long)(i * R + r) * D + h * HD + dc * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) st4(op + c * 4, F4{out[c * 4], out[c * 4 + 1], out[c * 4 + 2], out[c * 4 + 3]});
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// VAE decoder self-attention over T frames with the key-padding mask of mld_vae.py:229
+// (key t' of sample b masked iff t' >= len_b).  Rows are sample-major: row = b*T + t.
+//
+// One workgroup (4 waves) per (sample, head).  K and V of that (sample, head) -- T x 64 fp32 each,
+// <= 2 x 56 KB -- are staged once in LDS (row stride 68 floats: conflict-free ds_read_b32 for V,
+// <=2-way ds_read_b128 for K) and every wave walks 16-query tiles:
+//   Sᵀ = K · Qᵀ (swapped operands): C tile col = query, row = key, so a lane owns ONE query column
+//        and the softmax reductions are in-register + two xor-shuffles over the 4 row groups;
+//   the P registers are then directly the A operand of P·V (k-slot g <-> key kt*16+4g+i) -- no
+//   transpose, no LDS round trip for P (cdna_hip_programming.md T12 idea, fp32 form).
+// Single pass (all scores of a 16-query tile live in registers: NKT tiles x 4 VGPRs), no online
+// rescale needed at T <= 16*NKT.
+template <int NKT>   // max key tiles (NKT*16 >= T)
+__global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                          const int* __restrict__ lens, int T, int H) {
+  constexpr int HD = 64, LDS_STRIDE = 68;
+#if defined(MLDHIP_SIM)
+  float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
+#else
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+#endif
+  const int D = H * HD;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int len = lens[b] < T ? lens[b] : T;
+  const int nkt = (len + 15) >> 4;          // key tiles that contain at least one valid key
+  const int nqt = (T + 15) >> 4;            // query tiles (padded queries are computed, as the reference does)
+  float* Ks = smem;
+  float* Vs = smem + (size_t)NKT * 16 * LDS_STRIDE;
+
+  // ---- stage K and V (rows >= len are zero: P is 0 there and 0*garbage must not be NaN)
+  for (int idx = tid; idx < nkt * 16 * 16; idx += 256) {
+    const int key = idx >> 4, c4 = idx & 15;
+    F4 kv = F4{0.f, 0.f, 0.f, 0.f}, vv = kv;
+    if (key < len) {
+      const float* base = qkv + (long long)(b * T + key) * 3 * D + h * HD + c4 * 4;
+      kv = ld4(base + D);
+      vv = ld4(base + 2 * D);
+    }
+    st4(Ks + key * LDS_STRIDE + c4 * 4, kv);
+    st4(Vs + key * LDS_STRIDE + c4 * 4, vv);
+  }
+  __syncthreads();
+
+  for (int qt = wave; qt < nqt; qt += 4) {
+    // Q fragment: query q0+r, head dims g*16 .. g*16+15, pre-scaled by 1/sqrt(64)
+    int qrow = qt * 16 + r;
+    qrow = qrow < T ? qrow : T - 1;
+    const float* qp = qkv + (long long)(b * T + qrow) * 3 * D + h * HD + g * 16;
+    float qf[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      F4 t = ld4(qp + c * 4);
+      qf[c * 4] = t.x * 0.125f; qf[c * 4 + 1] = t.y * 0.125f; qf[c * 4 + 2] = t.z * 0.125f; qf[c * 4 + 3] = t.w * 0.125f;
+    }
+    f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt < nkt) {
+        const float* kp = Ks + (kt * 16 + r) * LDS_STRIDE + g * 16;
+        float kf[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          F4 t = ld4(kp + c * 4);
+          kf[c * 4] = t.x; kf[c * 4 + 1] = t.y; kf[c * 4 + 2] = t.z; kf[c * 4 + 3] = t.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[kt] = mfma_f32_16x16x4(kf[i], qf[i], s[kt]);
+      }
+    }
+    // masked softmax down each query column: this lane holds keys kt*16 + g*4 + i
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool valid = (kt < nkt) && (kt * 16 + g * 4 + i < len);
+        s[kt][i] = valid ? s[kt][i] : -INFINITY;
+        m = fmaxf(m, s[kt][i]);
+      }
+    m = max_groups(m);
+    float den = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float e = expf(s[kt][i] - m);   // exp(-inf) = 0 for masked keys
+        s[kt][i] = e;
+        den += e;
+      }
+    den = sum_groups(den);
+    const float inv = 1.0f / den;
+    // O = P · V
+    f32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < nkt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float pv = s[kt][i] * inv;
+          const float* vp = Vs + (kt * 16 + g * 4 + i) * LDS_STRIDE + r;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) oacc[dt] = mfma_f32_16x16x4(pv, vp[dt * 16], oacc[dt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = qt * 16 + g * 4 + i;
+        if (q < T) o[(long long)(b * T + q) * D + h * HD + dt * 16 + r] = oacc[dt][i];
+      }
+  }
+}
+
+}  // namespace mld

@@ -1,0 +1,224 @@
+// Small fused row kernels of the MLD engine: token assembly, final-norm + CFG + DDIM update,
+// LayerNorm rows, decoder query init, feats -> joints.  All are latency/HBM-trivial (KBs per call);
+// they exist to keep the 50-step loop free of host work so it can live in one hipGraph.
+#pragma once
+#include "rt.hpp"
+
+namespace mld {
+
+// block-wide sum for a 256-thread workgroup (4 waves); every thread gets the result.
+__device__ __forceinline__ float block_sum_256(float v, float* sh /*[4]*/, int tid) {
+  v = sum64(v);
+  __syncthreads();                 // protect sh from the previous use
+  if ((tid & 63) == 0) sh[tid >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ----------------------------------------------------------------------------------------------
+// X0 assembly at the start of the reverse process (mld_denoiser.py:143-196, tokens [lat, time, text],
+// token-major rows s*R + r, R = 2B with the unconditional half first, mld.py:224-231,325):
+//   X0[r]     = latents[r mod B] * init_sigma + pe[0]
+//   X0[R + r] = T1[step 0]            (time-MLP output + pe[1], precomputed per scheduler step)
+// (text rows X0[2R + r] are written by the text-projection GEMM whose bias already holds pe[2]).
+// Also copies init noise into the engine's latent state.  grid = B, block = D (256).
+__global__ __launch_bounds__(256) void init_x0_kernel(const float* __restrict__ init_lat, float* __restrict__ lat,
+                                                      float* __restrict__ X0, const float* __restrict__ pe0,
+                                                      const float* __restrict__ t1_row, int B, int D, float init_sigma) {
+  const int b = blockIdx.x, d = threadIdx.x;
+  const int R = 2 * B;
+  const float x = init_lat[(long long)b * D + d] * init_sigma;
+  lat[(long long)b * D + d] = x;
+  const float tok = x + pe0[d];
+  X0[(long long)b * D + d] = tok;
+  X0[(long long)(B + b) * D + d] = tok;
+  const float tt = t1_row[d];
+  X0[(long long)(R + b) * D + d] = tt;
+  X0[(long long)(R + B + b) * D + d] = tt;
+}
+
+// ----------------------------------------------------------------------------------------------
+// End of one reverse step, fused: final encoder LayerNorm on token 0 only (cross_attention.py:62-63,
+// mld_denoiser.py:206), classifier-free guidance (mld.py:339-342), DDIM update (diffusers
+// DDIMScheduler.step, eta = 0, epsilon prediction) and assembly of the next
+// step's token-0 / time rows.  grid = B, block = D (256).
+struct DdimCoef { float sqrt_at, sqrt_1mat, sqrt_ap, sqrt_1map; };
+
+__global__ __launch_bounds__(256) void final_ln_cfg_ddim_kernel(
+    const float* __restrict__ Hfin, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ lat, float* __restrict__ X0, const float* __restrict__ pe0,
+    const float* __restrict__ t1_next /* null on the last step */, float* __restrict__ eps_out /* optional [2B, D] */,
+    int B, int D, float guidance, DdimCoef c) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x, d = threadIdx.x;
+  const int R = 2 * B;
+  const float inv_d = 1.0f / float(D);
+  float e[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const float x = Hfin[(long long)(half * B + b) * D + d];
+    const float mean = block_sum_256(x, sh, d) * inv_d;
+    const float xc = x - mean;
+    const float var = block_sum_256(xc * xc, sh, d) * inv_d;
+    e[half] = xc * rsqrtf(var + kLnEps) * gamma[d] + beta[d];
+    if (eps_out) eps_out[(long long)(half * B + b) * D + d] = e[half];
+  }
+  const float eps = e[0] + guidance * (e[1] - e[0]);
+  const float x = lat[(long long)b * D + d];
+  const float x0 = (x - c.sqrt_1mat * eps) / c.sqrt_at;
+  const float xn = c.sqrt_ap * x0 + c.sqrt_1map * eps;
+  lat[(long long)b * D + d] = xn;
+  const float tok = xn + pe0[d];
+  X0[(long long)b * D + d] = tok;
+  X0[(long long)(B + b) * D + d] = tok;
+  if (t1_next) {
+    const float tt = t1_next[d];
+    X0[(long long)(R + b) * D + d] = tt;
+    X0[(long long)(R + B + b) * D + d] = tt;
+  }
+}
+
+// LayerNorm over rows of width 256: one wave per row, 4 rows per workgroup.
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ X, float* __restrict__ Y,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int M) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int row = blockIdx.x * 4 + wave;
+  const bool live = row < M;
+  row = live ? row : M - 1;
+  const F4 x = ld4(X + (long long)row * 256 + lane * 4);
+  const float mean = sum64(x.x + x.y + x.z + x.w) * (1.0f / 256.0f);
+  const float a = x.x - mean, b = x.y - mean, c = x.z - mean, d = x.w - mean;
+  const float var = sum64(a * a + b * b + c * c + d * d) * (1.0f / 256.0f);
+  const float rs = rsqrtf(var + kLnEps);
+  const F4 gm = ld4(gamma + lane * 4), bt = ld4(beta + lane * 4);
+  if (live) st4(Y + (long long)row * 256 + lane * 4, F4{a * rs * gm.x + bt.x, b * rs * gm.y + bt.y, c * rs * gm.z + bt.z, d * rs * gm.w + bt.w});
+}
+
+// Decoder queries: zeros + learned PE (mld_vae.py:190,224): Hq[b*T + t] = pe[t].  grid = B*T/… rows.
+__global__ __launch_bounds__(256) void init_queries_kernel(float* __restrict__ Hq, const float* __restrict__ pe,
+                                                           int B, int T, int D) {
+  const long long n4 = (long long)B * T * D / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4;
+    const int d = int(e % D);
+    const int t = int((e / D) % T);
+    st4(Hq + e, ld4(pe + (long long)t * D + d));
+  }
+}
+
+__global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ dst, const float* __restrict__ a,
+                                                       const float* __restrict__ vec, int rows, int D) {
+  // dst[r][d] = a[r][d] + vec[d]
+  const long long n = (long long)rows * D;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = a[i] + vec[i % D];
+}
+
+__global__ __launch_bounds__(256) void bcast_rows_kernel(float* __restrict__ dst, const float* __restrict__ vec, int rows, int D) {
+  const long long n = (long long)rows * D;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = vec[i % D];
+}
+
+// ----------------------------------------------------------------------------------------------
+// feats -> joints: HumanML3DDataModule.feats2joints + recover_from_ric
+// (HumanML3D.py:41-45, motion_process.py:362-381,415-432, quaternion.py:16-20,54-73).
+// One workgroup per sample.  Wave 0 integrates the root: yaw_t = sum_{s<t} f[s,0] and
+// root_xz(t) = sum_{s<=t} R_y(yaw_s)^-1 [f[s-1,1], 0, f[s-1,2]] as two wave-level inclusive scans
+// (each lane owns a run of consecutive frames), then all 256 threads rotate the 21 root-relative
+// joints of every frame.  Only feature columns 0..66 are read.
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float u = wave_bcast(v, lane >= off ? lane - off : lane);
+    if (lane >= off) v += u;
+  }
+  return v;
+}
+
+template <int MAXT>
+__global__ __launch_bounds__(256) void feats2joints_kernel(const float* __restrict__ feats, float* __restrict__ joints,
+                                                           const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                           int T, int nfeats, int njoints) {
+  __shared__ float s_cos[MAXT], s_sin[MAXT], s_rx[MAXT], s_rz[MAXT];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const float* F = feats + (long long)b * T * nfeats;
+  constexpr int PER = (MAXT + 63) / 64;
+  if (tid < 64) {
+    const float m0 = mean[0], s0 = stdv[0], m1 = mean[1], s1 = stdv[1], m2 = mean[2], s2 = stdv[2];
+    // ---- yaw: exclusive prefix sum of the de-normalised rotation velocity
+    float loc[PER];
+    float run = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int t = lane * PER + j;            // frame t receives rot_vel of frame t-1
+      const float v = (t >= 1 && t < T) ? (F[(long long)(t - 1) * nfeats] * s0 + m0) : 0.f;
+      run += v;
+      loc[j] = run;
+    }
+    float incl = wave_incl_scan(run, lane);
+    float base = incl - run;
+    float cs[PER], sn[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int t = lane * PER + j;
+      const float ang = base + loc[j];
+      cs[j] = cosf(ang);
+      sn[j] = sinf(ang);
+      if (t < T) { s_cos[t] = cs[j]; s_sin[t] = sn[j]; }
+    }
+    // ---- root xz: inclusive prefix sum of the rotated previous-frame velocity
+    float lx[PER], lz[PER];
+    float runx = 0.f, runz = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int t = lane * PER + j;
+      float vx = 0.f, vz = 0.f;
+      if (t >= 1 && t < T) {
+        vx = F[(long long)(t - 1) * nfeats + 1] * s1 + m1;
+        vz = F[(long long)(t - 1) * nfeats + 2] * s2 + m2;
+      }
+      // qrot(qinv((c,0,s,0)), (vx,0,vz)) with u = (0,-s,0), w = c
+      const float c = cs[j], s = sn[j];
+      const float uvx = -s * vz, uvz = s * vx;
+      const float uuvx = -s * uvz, uuvz = s * uvx;
+      runx += vx + 2.f * (c * uvx + uuvx);
+      runz += vz + 2.f * (c * uvz + uuvz);
+      lx[j] = runx;
+      lz[j] = runz;
+    }
+    const float ix = wave_incl_scan(runx, lane), iz = wave_incl_scan(runz, lane);
+    const float bx = ix - runx, bz = iz - runz;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int t = lane * PER + j;
+      if (t < T) { s_rx[t] = bx + lx[j]; s_rz[t] = bz + lz[j]; }
+    }
+  }
+  __syncthreads();
+  const int total = T * njoints;
+  for (int idx = tid; idx < total; idx += 256) {
+    const int t = idx / njoints, j = idx - t * njoints;
+    float* out = joints + ((long long)(b * T + t) * njoints + j) * 3;
+    const float rx = s_rx[t], rz = s_rz[t];
+    if (j == 0) {
+      out[0] = rx;
+      out[1] = F[(long long)t * nfeats + 3] * stdv[3] + mean[3];
+      out[2] = rz;
+    } else {
+      const int c0 = 4 + (j - 1) * 3;
+      const float px = F[(long long)t * nfeats + c0] * stdv[c0] + mean[c0];
+      const float py = F[(long long)t * nfeats + c0 + 1] * stdv[c0 + 1] + mean[c0 + 1];
+      const float pz = F[(long long)t * nfeats + c0 + 2] * stdv[c0 + 2] + mean[c0 + 2];
+      const float c = s_cos[t], s = s_sin[t];
+      const float uvx = -s * pz, uvz = s * px;
+      const float uuvx = -s * uvz, uuvz = s * uvx;
+      out[0] = px + 2.f * (c * uvx + uuvx) + rx;
+      out[1] = py;
+      out[2] = pz + 2.f * (c * uvz + uuvz) + rz;
+    }
+  }
+}
+
+}  // namespace mld

@@ -1,0 +1,246 @@
+// Y = epilogue(X · Wᵀ + b): the one GEMM family of the MLD engine (exact-fp32 MFMA path).
+//
+// Replaces every nn.Linear / packed in-proj / out-proj of the reference's hot path
+// (cross_attention.py:56-58,113-115,259-272,323-345; mld_denoiser.py:65-68; embeddings.py:298-305;
+//  mld_vae.py:243) and fuses what follows it there: bias, erf-GELU / SiLU, residual add,
+// post-norm LayerNorm, the 1-key cross-attention shortcut (+cvec, second LayerNorm), the
+// `output[~mask.T] = 0` of mld_vae.py:245 and the `cat([x, skip])` of the skip connection
+// (as a second K segment, no concat buffer).
+//
+// Data layout: activations [rows, K] row-major fp32; weights exactly as nn.Linear stores them,
+// [N, K] row-major -- both operands are K-contiguous, so an MFMA fragment is two 16-byte loads.
+//
+// MFMA mapping (v_mfma_f32_16x16x4_f32): within a 32-wide K chunk lane l=(g=l>>4, r=l&15) holds the
+// 8 consecutive K values k0+8g..k0+8g+7 of row r for A and of weight row r for B; MFMA number i of
+// the chunk consumes element i of both fragments.  Any pairing of k-slots is legal as long as A and B
+// agree, and this one turns the fragment fetch into contiguous 32-byte reads.
+//
+// Roofline: MFMA-bound (fp32 matrix rate 157 TF); operands are L2/MALL resident (weights 74 MB).
+#pragma once
+#include "rt.hpp"
+
+namespace mld {
+
+enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
+
+struct GemmArgs {
+  const float* A = nullptr;  int lda = 0;  int K1 = 0;   // first K segment  [M, K1]
+  const float* A2 = nullptr; int lda2 = 0; int K2 = 0;   // optional second K segment (skip concat)
+  const float* W = nullptr;  int ldw = 0;                // [N, K1+K2]
+  const float* bias = nullptr;                           // [N]
+  float* Y = nullptr; int ldy = 0;
+  int M = 0, N = 0;
+  int relu_in = 0;                                       // ReLU on A while loading (mld_denoiser.py:65-68)
+  int act = ACT_NONE;
+  const int* lens = nullptr; int rows_per_group = 1;     // zero rows with (row % rpg) >= lens[row / rpg]
+  long long sA = 0, sW = 0, sBias = 0, sY = 0;           // blockIdx.z strides (elements)
+  // LayerNorm epilogue (N must equal the block's BN)
+  const float* res = nullptr; int ldres = 0;
+  const float* g1 = nullptr; const float* b1 = nullptr;
+  const float* cvec = nullptr; int ldcvec = 0;           // + cvec[row / rows_per_group] then LN(g2,b2)
+  const float* g2 = nullptr; const float* b2 = nullptr;
+};
+
+struct Frag { float v[8]; };
+
+template <int REP>
+__device__ __forceinline__ void load_frags(Frag (&f)[REP], const float* base, int ld, int row0, int nrows,
+                                           int k, int r, int g, bool relu) {
+#pragma unroll
+  for (int t = 0; t < REP; ++t) {
+    int row = row0 + t * 16 + r;
+    row = row < nrows ? row : nrows - 1;
+    const float* p = base + (long long)row * ld + k + g * 8;
+    F4 a = ld4(p), b = ld4(p + 4);
+    if (relu) {
+      a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+      b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f);
+    }
+    f[t].v[0] = a.x; f[t].v[1] = a.y; f[t].v[2] = a.z; f[t].v[3] = a.w;
+    f[t].v[4] = b.x; f[t].v[5] = b.y; f[t].v[6] = b.z; f[t].v[7] = b.w;
+  }
+}
+
+// WM x WN waves per workgroup, each wave owns MREP x NREP tiles of 16x16.
+template <int WM, int WN, int MREP, int NREP, bool LN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
+  constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
+  constexpr bool SPLIT = (MREP * NREP == 1);   // one tile per wave: split the k-chain over 2 accumulators
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM + wm * MREP * 16;
+  const int n0 = blockIdx.y * BN + wn * NREP * 16;
+  const long long z = blockIdx.z;
+  const float* A = p.A + z * p.sA;
+  const float* W = p.W + z * p.sW;
+  const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
+  float* Y = p.Y + z * p.sY;
+  const int K = p.K1 + p.K2;
+  const int KC = K / 32;
+  const bool relu = p.relu_in != 0;
+
+  f32x4 acc[MREP][NREP];
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < MREP; ++a)
+#pragma unroll
+    for (int b = 0; b < NREP; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Frag fa0[MREP], fb0[NREP], fa1[MREP], fb1[NREP];
+
+  auto load = [&](Frag(&fa)[MREP], Frag(&fb)[NREP], int kc) {
+    int k = kc * 32;
+    if (k < p.K1) load_frags<MREP>(fa, A, p.lda, m0, p.M, k, r, g, relu);
+    else load_frags<MREP>(fa, p.A2, p.lda2, m0, p.M, k - p.K1, r, g, relu);
+    load_frags<NREP>(fb, W, p.ldw, n0, p.N, k, r, g, false);
+  };
+  auto compute = [&](Frag(&fa)[MREP], Frag(&fb)[NREP]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int a = 0; a < MREP; ++a)
+#pragma unroll
+        for (int b = 0; b < NREP; ++b) {
+          if (SPLIT && (i & 1)) acc2 = mfma_f32_16x16x4(fa[a].v[i], fb[b].v[i], acc2);
+          else acc[a][b] = mfma_f32_16x16x4(fa[a].v[i], fb[b].v[i], acc[a][b]);
+        }
+  };
+
+  load(fa0, fb0, 0);
+  for (int kc = 0; kc < KC; kc += 2) {
+    if (kc + 1 < KC) load(fa1, fb1, kc + 1);
+    compute(fa0, fb0);
+    if (kc + 1 < KC) {
+      if (kc + 2 < KC) load(fa0, fb0, kc + 2);
+      compute(fa1, fb1);
+    }
+  }
+  if (SPLIT) acc[0][0] += acc2;
+
+  if constexpr (!LN) {
+#pragma unroll
+    for (int a = 0; a < MREP; ++a)
+#pragma unroll
+      for (int b = 0; b < NREP; ++b) {
+        const int col = n0 + b * 16 + r;
+        const float bv = (bias && col < p.N) ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = m0 + a * 16 + g * 4 + i;
+          if (row < p.M && col < p.N) {
+            float v = acc[a][b][i] + bv;
+            if (p.act == ACT_GELU) v = gelu_erf(v);
+            else if (p.act == ACT_SILU) v = silu(v);
+            if (p.lens) {
+              int grp = row / p.rows_per_group, t = row - grp * p.rows_per_group;
+              if (t >= p.lens[grp]) v = 0.f;
+            }
+            Y[(long long)row * p.ldy + col] = v;
+          }
+        }
+      }
+    return;
+  } else {
+  // ---------------- residual + LayerNorm epilogue (full rows live in this workgroup) -------------
+  __shared__ float red[4][BM][WN];
+  const int nstage = p.cvec ? 2 : 1;
+  float vals[MREP][NREP][4];
+#pragma unroll
+  for (int a = 0; a < MREP; ++a)
+#pragma unroll
+    for (int b = 0; b < NREP; ++b) {
+      const int col = n0 + b * 16 + r;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int row = m0 + a * 16 + g * 4 + i;
+        row = row < p.M ? row : p.M - 1;
+        float v = acc[a][b][i] + bv;
+        if (p.res) v += p.res[(long long)row * p.ldres + col];
+        vals[a][b][i] = v;
+      }
+    }
+  const float inv_n = 1.0f / float(BN);
+  for (int st = 0; st < nstage; ++st) {
+    const float* gam = st == 0 ? p.g1 : p.g2;
+    const float* bet = st == 0 ? p.b1 : p.b2;
+    float mean[MREP][4], rstd[MREP][4];
+    // pass 1: mean
+#pragma unroll
+    for (int a = 0; a < MREP; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int b = 0; b < NREP; ++b) s += vals[a][b][i];
+        s = sum16(s);
+        if (r == 0) red[st * 2][wm * MREP * 16 + a * 16 + g * 4 + i][wn] = s;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < MREP; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) s += red[st * 2][wm * MREP * 16 + a * 16 + g * 4 + i][w];
+        mean[a][i] = s * inv_n;
+      }
+    // pass 2: variance about the mean (two-pass, like ATen's LayerNorm)
+#pragma unroll
+    for (int a = 0; a < MREP; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int b = 0; b < NREP; ++b) {
+          float d = vals[a][b][i] - mean[a][i];
+          s += d * d;
+        }
+        s = sum16(s);
+        if (r == 0) red[st * 2 + 1][wm * MREP * 16 + a * 16 + g * 4 + i][wn] = s;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < MREP; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) s += red[st * 2 + 1][wm * MREP * 16 + a * 16 + g * 4 + i][w];
+        rstd[a][i] = rsqrtf(s * inv_n + kLnEps);
+      }
+#pragma unroll
+    for (int a = 0; a < MREP; ++a)
+#pragma unroll
+      for (int b = 0; b < NREP; ++b) {
+        const int col = n0 + b * 16 + r;
+        const float gm = gam[col], bt = bet[col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = (vals[a][b][i] - mean[a][i]) * rstd[a][i] * gm + bt;
+          if (st == 0 && nstage == 2) {
+            int row = m0 + a * 16 + g * 4 + i;
+            row = row < p.M ? row : p.M - 1;
+            v += p.cvec[(long long)(row / p.rows_per_group) * p.ldcvec + col];
+          }
+          vals[a][b][i] = v;
+        }
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < MREP; ++a)
+#pragma unroll
+    for (int b = 0; b < NREP; ++b) {
+      const int col = n0 + b * 16 + r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + a * 16 + g * 4 + i;
+        if (row < p.M) Y[(long long)row * p.ldy + col] = vals[a][b][i];
+      }
+    }
+  }
+}
+
+}  // namespace mld

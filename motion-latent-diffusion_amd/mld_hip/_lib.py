@@ -1,0 +1,192 @@
+"""ctypes binding of include/mldhip.h -- the only door between Python and the HIP engine.
+
+There is no CPU implementation behind this module: if ``libmldhip.so`` is missing, was not built
+for gfx950, or no MI355X is visible, loading / ``Engine()`` raises.  (The test-suite's functional
+simulator is injected explicitly by tests via ``load_library(path)``; nothing here looks for it.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libmldhip.so")
+ABI_VERSION = 1
+
+
+class MldHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"mldhip error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    """Mirror of ``mldhip_config`` (include/mldhip.h)."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("latent_dim", C.c_int32), ("latent_size", C.c_int32), ("ff_size", C.c_int32),
+        ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("nfeats", C.c_int32), ("njoints", C.c_int32),
+        ("text_dim", C.c_int32), ("max_batch", C.c_int32), ("max_frames", C.c_int32),
+        ("num_train_timesteps", C.c_int32), ("num_inference_steps", C.c_int32), ("steps_offset", C.c_int32),
+        ("set_alpha_to_one", C.c_int32), ("beta_start", C.c_float), ("beta_end", C.c_float),
+        ("guidance_scale", C.c_float), ("precision", C.c_int32), ("use_graph", C.c_int32),
+    ]
+
+
+_SYMBOLS = {
+    # name: (restype, argtypes)
+    "mldhip_abi_version": (C.c_int, []),
+    "mldhip_default_config": (None, [C.POINTER(Config)]),
+    "mldhip_create": (C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(C.c_void_p)]),
+    "mldhip_destroy": (None, [C.c_void_p]),
+    "mldhip_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32]),
+    "mldhip_finalize_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mldhip_missing_keys": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "mldhip_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mldhip_denoiser_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mldhip_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p]),
+    "mldhip_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mldhip_feats2joints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mldhip_get_timesteps": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]),
+    "mldhip_get_alphas_cumprod": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
+    "mldhip_get_launch_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "mldhip_last_error": (C.c_char_p, [C.c_void_p]),
+}
+
+
+def exported_symbols() -> List[str]:
+    return sorted(_SYMBOLS)
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+            "mld_hip has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export the ABI
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mldhip_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"ABI version mismatch: library {lib.mldhip_abi_version()}, binding {ABI_VERSION}")
+    return lib
+
+
+def _ptr(x) -> int:
+    """Device/host address of a torch tensor, numpy array, or raw int."""
+    if x is None:
+        return 0
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return x.data_ptr()          # torch.Tensor
+
+
+class Engine:
+    """Thin RAII wrapper over an ``mldhip_handle``."""
+
+    def __init__(self, lib: Optional[C.CDLL] = None, device: int = 0, **overrides):
+        self.lib = lib or load_library()
+        self.cfg = Config()
+        self.lib.mldhip_default_config(C.byref(self.cfg))
+        for k, v in overrides.items():
+            if not hasattr(self.cfg, k):
+                raise TypeError(f"unknown mldhip_config field {k!r}")
+            setattr(self.cfg, k, v)
+        self._h = C.c_void_p()
+        rc = self.lib.mldhip_create(C.byref(self.cfg), device, C.byref(self._h))
+        if rc != 0:
+            raise MldHipError(rc, (self.lib.mldhip_last_error(None) or b"").decode())
+        self.device = device
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc: int) -> int:
+        if rc < 0:
+            raise MldHipError(rc, (self.lib.mldhip_last_error(self._h) or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.mldhip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_tensor(self, key: str, array, on_device: bool = False) -> bool:
+        """Returns False when the engine ignores the key (not on the sampling path)."""
+        if isinstance(array, np.ndarray):
+            array = np.ascontiguousarray(array, dtype=np.float32)
+            shape = array.shape
+        else:
+            array = array.detach().contiguous().float()
+            shape = tuple(array.shape)
+            on_device = array.is_cuda
+        shp = (C.c_int64 * len(shape))(*shape)
+        rc = self._check(self.lib.mldhip_load_tensor(self._h, key.encode(), _ptr(array), shp, len(shape), 0,
+                                                     1 if on_device else 0))
+        return rc == 0
+
+    def load_state_dict(self, tensors: Dict[str, object], prefix: str = "") -> List[str]:
+        ignored = []
+        for k, v in tensors.items():
+            if not self.load_tensor(prefix + k, v):
+                ignored.append(prefix + k)
+        return ignored
+
+    def missing_keys(self) -> List[str]:
+        buf = C.create_string_buffer(1 << 16)
+        n = self.lib.mldhip_missing_keys(self._h, buf, len(buf))
+        if n <= 0:
+            return []
+        return [s.decode() for s in buf.raw.split(b"\0") if s][:n]
+
+    def finalize(self, stream: int = 0):
+        self._check(self.lib.mldhip_finalize_weights(self._h, stream))
+
+    # ------------------------------------------------------------------ ops (raw pointers in, nothing allocated here)
+    def sample(self, text_emb, init_latents, lengths: Sequence[int], latents_out=None, feats_out=None, joints_out=None,
+               stream: int = 0):
+        lens = (C.c_int32 * len(lengths))(*[int(x) for x in lengths])
+        self._check(self.lib.mldhip_sample(self._h, _ptr(text_emb), _ptr(init_latents), lens, len(lengths),
+                                           _ptr(latents_out), _ptr(feats_out), _ptr(joints_out), stream))
+
+    def denoiser_forward(self, sample, timestep: int, text_emb, R: int, out, stream: int = 0):
+        self._check(self.lib.mldhip_denoiser_forward(self._h, _ptr(sample), int(timestep), _ptr(text_emb), R, _ptr(out), stream))
+
+    def vae_decode(self, z, lengths: Sequence[int], feats_out, stream: int = 0):
+        lens = (C.c_int32 * len(lengths))(*[int(x) for x in lengths])
+        self._check(self.lib.mldhip_vae_decode(self._h, _ptr(z), lens, len(lengths), _ptr(feats_out), stream))
+
+    def ddim_step(self, eps, timestep: int, sample, prev_sample, n: int, stream: int = 0):
+        self._check(self.lib.mldhip_ddim_step(self._h, _ptr(eps), int(timestep), _ptr(sample), _ptr(prev_sample), n, stream))
+
+    def feats2joints(self, feats, B: int, T: int, joints_out, stream: int = 0):
+        self._check(self.lib.mldhip_feats2joints(self._h, _ptr(feats), B, T, _ptr(joints_out), stream))
+
+    def timesteps(self) -> np.ndarray:
+        n = self.cfg.num_inference_steps
+        buf = (C.c_int32 * n)()
+        self._check(self.lib.mldhip_get_timesteps(self._h, buf, n))
+        return np.array(buf[:], dtype=np.int64)
+
+    def alphas_cumprod(self) -> np.ndarray:
+        n = self.cfg.num_train_timesteps
+        buf = (C.c_float * n)()
+        self._check(self.lib.mldhip_get_alphas_cumprod(self._h, buf, n))
+        return np.array(buf[:], dtype=np.float32)
+
+    def launch_counts(self) -> List[int]:
+        buf = (C.c_int32 * 3)()
+        self._check(self.lib.mldhip_get_launch_counts(self._h, buf))
+        return list(buf[:])
