@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""motions/sec of the MLD sampling hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch: 50-step DDIM latent sampling with
+classifier-free guidance -> motion-VAE decode -> (T,22,3) joints for B=64 synthetic HumanML3D-shaped
+prompts (config_mld_humanml3d.yaml, T=196), inputs resident in HBM, text embeddings precomputed
+(the frozen CLIP encoder is outside this path).  Ranks are pure data parallel: weights are broadcast
+once from rank 0 (one RCCL broadcast of the packed blob), every rank samples its own 64 prompts, no
+data-path collective.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "motion-latent-diffusion_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+from mld_hip import _lib  # noqa: E402
+from mld_hip import synthetic as syn  # noqa: E402
+
+FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+BATCH, FRAMES, STEPS_DDIM = 64, 196, 50
+
+
+def algorithmic_gflop(B, T, D=256, F=1024, L=9, NF=263, steps=STEPS_DDIM):
+    """SURVEY.md App. C / BASELINE.md §5 (2*MAC GEMMs + 4*S*d attention; 1-key cross-attn shortcut)."""
+    lin = lambda m, k, n: 2.0 * m * k * n
+    m = 3 * 2 * B
+    den = L * (lin(m, D, 3 * D) + lin(m, D, D) + 4.0 * m * 3 * D + lin(m, D, F) + lin(m, F, D)) + (L - 1) / 2 * lin(m, 2 * D, D)
+    md = B * T
+    dec = L * (lin(md, D, 3 * D) + lin(md, D, D) + 4.0 * md * T * D + lin(md, D, F) + lin(md, F, D) + 2 * lin(B, D, D)) \
+        + (L - 1) / 2 * lin(md, 2 * D, D) + lin(md, D, NF)
+    return (den * steps + dec) / 1e9, den / 1e9, dec / 1e9
+
+
+def pack_and_broadcast_weights(rank, world, dev):
+    """Rank 0 builds the synthetic checkpoint; ONE broadcast ships it (RCCL over xGMI when world > 1)."""
+    sd_d, sd_v = syn.make_denoiser_state_dict(), syn.make_vae_state_dict()      # cheap: gives keys/shapes everywhere
+    mean, std = syn.make_mean_std()
+    items = [("denoiser." + k, v) for k, v in sd_d.items()] + [("vae." + k, v) for k, v in sd_v.items()] + \
+            [("mean", mean), ("std", std)]
+    total = sum(v.size for _, v in items)
+    if rank == 0:
+        blob = torch.from_numpy(np.concatenate([v.ravel() for _, v in items])).to(dev)
+    else:
+        blob = torch.empty(total, dtype=torch.float32, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast(blob, src=0)
+    out, off = {}, 0
+    for k, v in items:
+        out[k] = blob[off:off + v.size].view(*v.shape)
+        off += v.size
+    return out, total * 4
+
+
+def time_kernel(eng, name, B, T, iters, stream):
+    """Average duration (ms) of one named kernel, HIP events on the stream it is launched on."""
+    eng.profile_kernel(name, B, T, 3, stream.cuda_stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    flops = eng.profile_kernel(name, B, T, iters, stream.cuda_stream)
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters, flops
+
+
+def cpu_baseline(batch, mean, std):
+    """The oracle ("port" of the reference path, torch-CPU backend) on the host cores, one full batch."""
+    from oracle import mld_oracle as O
+    ops = O.TorchOps()
+    bd = O.to_backend(ops, syn.make_denoiser_state_dict())
+    bv = O.to_backend(ops, syn.make_vae_state_dict())
+    args = (ops.asarray(batch.text_emb), ops.asarray(batch.init_latents), batch.lengths, ops.asarray(mean), ops.asarray(std))
+    with torch.no_grad():
+        t0 = time.time()
+        joints = O.sample(ops, bd, bv, *args)
+        dt = time.time() - t0
+    return dt, ops.to_numpy(joints)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="disable hipGraph replay (debug)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    eng = _lib.Engine(device=local, max_batch=BATCH, max_frames=FRAMES, use_graph=0 if a.eager else 1)
+    weights, weight_bytes = pack_and_broadcast_weights(rank, world, dev)
+    eng.load_state_dict(weights)
+    eng.finalize()
+
+    batch = syn.make_batch(BATCH, None, seed=1234 + rank, max_len=FRAMES)      # per-rank shard of the prompts
+    mean, std = syn.make_mean_std()
+    text = torch.from_numpy(batch.text_emb).to(dev)
+    lat0 = torch.from_numpy(batch.init_latents).to(dev)
+    lat = torch.empty(BATCH, 1, 256, device=dev)
+    feats = torch.empty(BATCH, FRAMES, 263, device=dev)
+    joints = torch.empty(BATCH, FRAMES, 22, 3, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        eng.sample(text, lat0, batch.lengths, lat, feats, joints, stream.cuda_stream)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    value = world * BATCH * a.steps / dt
+
+    out = {
+        "metric": "motions/sec (50-step DDIM + VAE decode), HumanML3D bs64", "value": round(value, 2),
+        "unit": "motions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "config_mld_humanml3d.yaml, bs=64 per GPU, T=196, 50-step DDIM, CFG 7.5, VAE decode + feats2joints",
+                   "global_batch": BATCH * world, "parallelism": f"dp{world}", "graph": not a.eager,
+                   "weights": "synthetic (seeded numpy), one broadcast of %.1f MB" % (weight_bytes / 1e6),
+                   "launches_per_step": eng.launch_counts()},
+    }
+    if rank == 0:
+        # ---- roofline: per-kernel durations with HIP events on the launch stream, weighted by launch counts
+        gf_total, gf_den, gf_dec = algorithmic_gflop(BATCH, FRAMES)
+        nb = 4
+        per_sample = {"den_qkv": 9 * STEPS_DDIM, "den_attn": 9 * STEPS_DDIM, "den_outproj_ln": 9 * STEPS_DDIM,
+                      "den_ffn1": 9 * STEPS_DDIM, "den_ffn2_ln": 9 * STEPS_DDIM,
+                      "dec_qkv": 9, "dec_attn": 9, "dec_outproj_ln": 9, "dec_ffn1": 9, "dec_ffn2_ln": 9}
+        kern = {}
+        for name, cnt in per_sample.items():
+            ms, fl = time_kernel(eng, name, BATCH, FRAMES, 200 if name.startswith("den") else 30, stream)
+            kern[name] = {"avg_us": round(ms * 1e3, 2), "gflop": round(fl / 1e9, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                          "launches_per_sample": cnt, "share_ms": round(ms * cnt, 3)}
+        dom = max(kern, key=lambda k: kern[k]["share_ms"])
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": FP32_MFMA_PEAK_TF,
+                           "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                           "avg_us": kern[dom]["avg_us"], "gflop_per_launch": kern[dom]["gflop"]}
+        out["kernels"] = kern
+        out["whole_job"] = {"algorithmic_gflop_per_batch": round(gf_total, 1), "denoise_gflop_per_step": round(gf_den, 3),
+                            "decode_gflop": round(gf_dec, 1),
+                            "achieved_tflops": round(gf_total / 1e3 / (ms_per_step * 1e-3), 2),
+                            "frac_of_fp32_mfma_peak": round(gf_total / 1e3 / (ms_per_step * 1e-3) / FP32_MFMA_PEAK_TF, 4)}
+        if world == 1 and not a.no_cpu_baseline:
+            torch.set_num_threads(os.cpu_count() or 1)
+            cdt, cj = cpu_baseline(batch, mean, std)
+            err = float(np.abs(joints.cpu().numpy() - cj).max())
+            out["cpu_baseline"] = {"value": round(BATCH / cdt, 2), "unit": "motions/s", "cores": torch.get_num_threads(),
+                                   "kind": "port", "sample": "1 batch of 64 motions (T=196, 50 steps) through oracle.mld_oracle "
+                                   "(torch-CPU backend), %.1f s" % cdt}
+            out["parity"] = {"max_abs_joints_vs_oracle": err, "tolerance": 1e-3}
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

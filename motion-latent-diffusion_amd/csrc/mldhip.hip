@@ -40,6 +40,7 @@ struct Param {
   size_t offset = 0;   // floats into the arena
   size_t numel = 0;
   bool loaded = false;
+  int group = 0;       // 0 denoiser, 1 vae decoder, 2 dataset statistics
 };
 
 struct EncLayerP {   // TransformerEncoderLayer (cross_attention.py:236-272)
@@ -67,6 +68,7 @@ struct mldhip_engine {
   int device = 0;
   std::string err;
   bool finalized = false;
+  bool group_ready[3] = {false, false, false};
 
   // ---- parameters
   std::vector<Param> params;
@@ -138,6 +140,7 @@ size_t add_param(E* e, const std::string& key, std::vector<int64_t> shape) {
   p.numel = 1;
   for (auto s : shape) p.numel *= size_t(s);
   p.offset = e->arena_floats;
+  p.group = key.rfind("denoiser.", 0) == 0 ? 0 : key.rfind("vae.", 0) == 0 ? 1 : 2;
   e->arena_floats += align_up(p.numel);
   e->index[key] = int(e->params.size());
   e->params.push_back(p);
@@ -686,23 +689,31 @@ int mldhip_missing_keys(mldhip_handle* e, char* buf, int64_t buflen) {
 
 int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  // A group (denoiser / vae decoder / mean+std) must be loaded completely or not at all; ops of an
+  // absent group fail with MLDHIP_ESTATE, sample() needs all three.
+  int have[3] = {0, 0, 0}, total[3] = {0, 0, 0};
+  for (auto& p : e->params) { total[p.group]++; have[p.group] += p.loaded; }
   for (auto& p : e->params)
-    if (!p.loaded) return e->fail(MLDHIP_ENOKEY, "missing tensor %s (strict load)", p.key.c_str());
+    if (!p.loaded && have[p.group] != 0) return e->fail(MLDHIP_ENOKEY, "missing tensor %s (strict load)", p.key.c_str());
+  if (have[0] + have[1] + have[2] == 0) return e->fail(MLDHIP_ENOKEY, "no tensors loaded");
+  for (int g = 0; g < 3; ++g) e->group_ready[g] = have[g] == total[g];
   hipStream_t stream = (hipStream_t)stream_;
   bind_layers(e);
   Ctx c{e, stream};
   const int D = e->cfg.latent_dim, TD = e->cfg.text_dim, n = e->cfg.num_inference_steps;
-  // PE-folded biases: token 1 (time) gets pe[1], token 2 (text) gets pe[2] (mld_denoiser.py:187,196)
-  const float* pe = P(e, "denoiser.query_pos.pe");
-  MLD_LAUNCH(add_rows_kernel, dim3(1), dim3(256), 0, stream, e->time_b2pe, P(e, "denoiser.time_embedding.linear_2.bias"), pe + D, 1, D);
-  MLD_LAUNCH(add_rows_kernel, dim3(1), dim3(256), 0, stream, e->text_bias, P(e, "denoiser.emb_proj.1.bias"), pe + 2 * D, 1, D);
-  if (check_launch(c, "add_rows")) return c.rc;
-  // time-MLP output for every scheduler timestep (sample independent; embeddings.py:245-305)
-  std::vector<float> host((size_t)n * TD);
-  for (int s = 0; s < n; ++s) timestep_sincos(float(e->timesteps[s]), TD, host.data() + (size_t)s * TD);
-  HIP_TRY(e, hipMemcpy(e->temb0, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
-  time_mlp(c, e->temb0, e->tmid, e->T1, n);
-  if (c.rc) return c.rc;
+  if (e->group_ready[0]) {
+    // PE-folded biases: token 1 (time) gets pe[1], token 2 (text) gets pe[2] (mld_denoiser.py:187,196)
+    const float* pe = P(e, "denoiser.query_pos.pe");
+    MLD_LAUNCH(add_rows_kernel, dim3(1), dim3(256), 0, stream, e->time_b2pe, P(e, "denoiser.time_embedding.linear_2.bias"), pe + D, 1, D);
+    MLD_LAUNCH(add_rows_kernel, dim3(1), dim3(256), 0, stream, e->text_bias, P(e, "denoiser.emb_proj.1.bias"), pe + 2 * D, 1, D);
+    if (check_launch(c, "add_rows")) return c.rc;
+    // time-MLP output for every scheduler timestep (sample independent; embeddings.py:245-305)
+    std::vector<float> host((size_t)n * TD);
+    for (int s = 0; s < n; ++s) timestep_sincos(float(e->timesteps[s]), TD, host.data() + (size_t)s * TD);
+    HIP_TRY(e, hipMemcpy(e->temb0, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    time_mlp(c, e->temb0, e->tmid, e->T1, n);
+    if (c.rc) return c.rc;
+  }
   HIP_TRY(e, hipStreamSynchronize(stream));
 #if !defined(MLDHIP_SIM)
   for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
@@ -716,6 +727,8 @@ int mldhip_sample(mldhip_handle* e, const float* text_emb_dev, const float* init
                   int32_t B, float* latents_out_dev, float* feats_out_dev, float* joints_out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
   if (!e->finalized) return e->fail(MLDHIP_ESTATE, "mldhip_sample before mldhip_finalize_weights");
+  if (!e->group_ready[0] || !e->group_ready[1] || (joints_out_dev && !e->group_ready[2]))
+    return e->fail(MLDHIP_ESTATE, "mldhip_sample needs denoiser.*, vae.decoder.* (and mean/std for joints) loaded");
   if (!text_emb_dev || !init_latents_dev) return e->fail(MLDHIP_EINVAL, "null input pointer");
   int T = 0;
   if (int rc = validate_lengths(e, lengths_host, B, &T)) return rc;
@@ -752,7 +765,7 @@ int mldhip_sample(mldhip_handle* e, const float* text_emb_dev, const float* init
 int mldhip_denoiser_forward(mldhip_handle* e, const float* sample_dev, int32_t timestep, const float* text_emb_dev,
                             int32_t R, float* out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
-  if (!e->finalized) return e->fail(MLDHIP_ESTATE, "denoiser_forward before finalize");
+  if (!e->finalized || !e->group_ready[0]) return e->fail(MLDHIP_ESTATE, "denoiser_forward before finalize / denoiser.* not loaded");
   if (!sample_dev || !text_emb_dev || !out_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
   if (R < 1 || R > 2 * e->cfg.max_batch) return e->fail(MLDHIP_EINVAL, "R=%d outside [1, 2*max_batch]", R);
   if (timestep < 0 || timestep >= e->cfg.num_train_timesteps) return e->fail(MLDHIP_EINVAL, "timestep %d out of range", timestep);
@@ -780,7 +793,7 @@ int mldhip_denoiser_forward(mldhip_handle* e, const float* sample_dev, int32_t t
 int mldhip_vae_decode(mldhip_handle* e, const float* z_dev, const int32_t* lengths_host, int32_t B, float* feats_out_dev,
                       void* stream_) {
   if (!e) return MLDHIP_EINVAL;
-  if (!e->finalized) return e->fail(MLDHIP_ESTATE, "vae_decode before finalize");
+  if (!e->finalized || !e->group_ready[1]) return e->fail(MLDHIP_ESTATE, "vae_decode before finalize / vae.* not loaded");
   if (!z_dev || !feats_out_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
   int T = 0;
   if (int rc = validate_lengths(e, lengths_host, B, &T)) return rc;
@@ -813,12 +826,74 @@ int mldhip_ddim_step(mldhip_handle* e, const float* eps_dev, int32_t timestep, c
 
 int mldhip_feats2joints(mldhip_handle* e, const float* feats_dev, int32_t B, int32_t T, float* joints_out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
-  if (!e->finalized) return e->fail(MLDHIP_ESTATE, "feats2joints before finalize (mean/std not loaded)");
+  if (!e->finalized || !e->group_ready[2]) return e->fail(MLDHIP_ESTATE, "feats2joints before finalize / mean,std not loaded");
   if (!feats_dev || !joints_out_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
   if (B < 1 || T < 1 || T > 512) return e->fail(MLDHIP_EINVAL, "B >= 1 and 1 <= T <= 512 required");
   Ctx c{e, (hipStream_t)stream_};
   e->phase = 2;
   joints_body(c, feats_dev, B, T, joints_out_dev);
+  return c.rc;
+}
+
+
+int mldhip_profile_kernel(mldhip_handle* e, const char* name, int32_t B, int32_t T, int32_t iters, double* flops_per_launch,
+                          void* stream_) {
+  // Launches ONE kernel of the sampling path `iters` times back-to-back on `stream` at its production
+  // shape, on the engine's own buffers (call after a sample() so they hold real activations).  The
+  // caller brackets the call with events on the same stream (bench.py does) -- no timing happens here.
+  if (!e || !name || !flops_per_launch) return MLDHIP_EINVAL;
+  if (!e->finalized || !e->group_ready[0] || !e->group_ready[1]) return e->fail(MLDHIP_ESTATE, "profile before finalize");
+  if (B < 1 || B > e->cfg.max_batch || T < 1 || T > e->cfg.max_frames || iters < 1) return e->fail(MLDHIP_EINVAL, "bad B/T/iters");
+  Ctx c{e, (hipStream_t)stream_};
+  const int D = e->cfg.latent_dim, F = e->cfg.ff_size, H = e->cfg.num_heads;
+  const std::string n = name;
+  const bool dec = n.rfind("dec_", 0) == 0;
+  const int R = 2 * B;
+  const long long M = dec ? (long long)B * T : 3LL * R;
+  const int mid = (e->cfg.num_layers - 1) / 2;
+  int saved_phase = e->phase;
+  e->phase = dec ? 1 : 0;
+  for (int it = 0; it < iters && !c.rc; ++it) {
+    if (n == "dec_qkv" || n == "den_qkv") {
+      const float* w = dec ? e->dec[mid].in_w : e->den[mid].in_w;
+      const float* b = dec ? e->dec[mid].in_b : e->den[mid].in_b;
+      gemm(c, lin_args(e->S[0], D, D, w, b, e->QKV, 3 * D, (int)M, 3 * D));
+      *flops_per_launch = 2.0 * M * D * 3 * D;
+    } else if (n == "dec_ffn1" || n == "den_ffn1") {
+      GemmArgs f1 = lin_args(e->H1, D, D, dec ? e->dec[mid].l1_w : e->den[mid].l1_w, dec ? e->dec[mid].l1_b : e->den[mid].l1_b,
+                             e->FF, F, (int)M, F);
+      f1.act = ACT_GELU;
+      gemm(c, f1);
+      *flops_per_launch = 2.0 * M * D * F;
+    } else if (n == "dec_ffn2_ln" || n == "den_ffn2_ln") {
+      GemmArgs f2 = lin_args(e->FF, F, F, dec ? e->dec[mid].l2_w : e->den[mid].l2_w, dec ? e->dec[mid].l2_b : e->den[mid].l2_b,
+                             e->Hb, D, (int)M, D);
+      f2.res = e->H1; f2.ldres = D;
+      f2.g1 = dec ? e->dec[mid].n3_w : e->den[mid].n2_w; f2.b1 = dec ? e->dec[mid].n3_b : e->den[mid].n2_b;
+      gemm_ln(c, f2);
+      *flops_per_launch = 2.0 * M * D * F;
+    } else if (n == "dec_outproj_ln" || n == "den_outproj_ln") {
+      GemmArgs o = lin_args(e->AO, D, D, dec ? e->dec[mid].out_w : e->den[mid].out_w, dec ? e->dec[mid].out_b : e->den[mid].out_b,
+                            e->Hb, D, (int)M, D);
+      o.res = e->S[0]; o.ldres = D;
+      o.g1 = dec ? e->dec[mid].n1_w : e->den[mid].n1_w; o.b1 = dec ? e->dec[mid].n1_b : e->den[mid].n1_b;
+      if (dec) { o.cvec = e->cvec; o.ldcvec = D; o.rows_per_group = T; o.g2 = e->dec[mid].n2_w; o.b2 = e->dec[mid].n2_b; }
+      gemm_ln(c, o);
+      *flops_per_launch = 2.0 * M * D * D;
+    } else if (n == "dec_attn") {
+      dec_attention(c, B, T);
+      *flops_per_launch = 4.0 * B * H * (double)T * T * 64;
+    } else if (n == "den_attn") {
+      const int total = R * H * 3 * 4;
+      MLD_LAUNCH((attn_tiny_kernel<3, 64>), dim3((total + 255) / 256), dim3(256), 0, c.stream, (const float*)e->QKV, e->AO, R, H);
+      check_launch(c, "attn_tiny");
+      *flops_per_launch = 4.0 * R * H * 3 * 3 * 64;
+    } else {
+      e->phase = saved_phase;
+      return e->fail(MLDHIP_EINVAL, "unknown kernel name %s", name);
+    }
+  }
+  e->phase = saved_phase;
   return c.rc;
 }
 

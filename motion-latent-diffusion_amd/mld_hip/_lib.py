@@ -50,6 +50,7 @@ _SYMBOLS = {
     "mldhip_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p]),
     "mldhip_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mldhip_feats2joints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mldhip_profile_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
     "mldhip_get_timesteps": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]),
     "mldhip_get_alphas_cumprod": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
     "mldhip_get_launch_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
@@ -173,6 +174,12 @@ class Engine:
 
     def feats2joints(self, feats, B: int, T: int, joints_out, stream: int = 0):
         self._check(self.lib.mldhip_feats2joints(self._h, _ptr(feats), B, T, _ptr(joints_out), stream))
+
+    def profile_kernel(self, name: str, B: int, T: int, iters: int, stream: int = 0) -> float:
+        """Enqueue one kernel `iters` times; returns its algorithmic FLOPs per launch."""
+        fl = C.c_double(0.0)
+        self._check(self.lib.mldhip_profile_kernel(self._h, name.encode(), B, T, iters, C.byref(fl), stream))
+        return fl.value
 
     def timesteps(self) -> np.ndarray:
         n = self.cfg.num_inference_steps
