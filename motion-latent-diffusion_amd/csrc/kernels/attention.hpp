@@ -1,7 +1,8 @@
-// Self-attention kernels of the MLD engine (exact-fp32 MFMA path).
+// Decoder self-attention kernel of the MLD engine (exact-fp32 MFMA path).  (The denoiser's 3-token
+// attention lives in the A-prologue of tile32.hpp.)
 //
-// Both replace nn.MultiheadAttention's slow path as invoked by the reference
-// (cross_attention.py:265-266 encoder layers, :332-333 decoder self-attention): q pre-scaled by
+// Replaces nn.MultiheadAttention's slow path as invoked by the reference
+// (cross_attention.py:332-333 decoder self-attention): q pre-scaled by
 // 1/sqrt(head_dim), scores, float -inf key-padding mask, softmax, P·V.  The [B·H, L, S] score
 // tensor and the discarded head-averaged weights of the reference are never materialised.
 //
@@ -11,75 +12,6 @@
 #include "rt.hpp"
 
 namespace mld {
-
-// ----------------------------------------------------------------------------------------------
-// Denoiser: sequences of S=3 tokens (latent, time, text) per sample (mld_denoiser.py:187).
-// Rows are token-major: row = s*R + r.  One thread per (sample r, head h, query i, 16-wide d chunk);
-// the 4 d-chunks of a query are adjacent lanes and combine with two xor-shuffles.  ~0.6 MFLOP per
-// call: latency-only kernel, no LDS, no MFMA.
-template <int S, int HD>
-__global__ __launch_bounds__(256) void attn_tiny_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                        int R, int H) {
-  static_assert(HD == 64, "head_dim 64");
-  const int D = H * HD;
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int total = R * H * S * 4;
-  const bool live = gid < total;
-  int idx = live ? gid : total - 1;
-  const int dc = idx & 3; idx >>= 2;
-  const int i = idx % S; idx /= S;
-  const int h = idx % H;
-  const int r = idx / H;
-  const float scale = 0.125f;  // 1/sqrt(64)
-  const float* qp = qkv + (long long)(i * R + r) * 3 * D + h * HD + dc * 16;
-  float q[16];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    F4 t = ld4(qp + c * 4);
-    q[c * 4] = t.x * scale; q[c * 4 + 1] = t.y * scale; q[c * 4 + 2] = t.z * scale; q[c * 4 + 3] = t.w * scale;
-  }
-  float sc[S];
-#pragma unroll
-  for (int j = 0; j < S; ++j) {
-    const float* kp = qkv + (long long)(j * R + r) * 3 * D + D + h * HD + dc * 16;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      F4 t = ld4(kp + c * 4);
-      s = fmaf(q[c * 4], t.x, s); s = fmaf(q[c * 4 + 1], t.y, s);
-      s = fmaf(q[c * 4 + 2], t.z, s); s = fmaf(q[c * 4 + 3], t.w, s);
-    }
-    s += wave_xor(s, 1);
-    s += wave_xor(s, 2);
-    sc[j] = s;
-  }
-  float m = sc[0];
-#pragma unroll
-  for (int j = 1; j < S; ++j) m = fmaxf(m, sc[j]);
-  float den = 0.f;
-#pragma unroll
-  for (int j = 0; j < S; ++j) { sc[j] = expf(sc[j] - m); den += sc[j]; }
-  const float inv = 1.0f / den;
-  float out[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) out[c] = 0.f;
-#pragma unroll
-  for (int j = 0; j < S; ++j) {
-    const float* vp = qkv + (long long)(j * R + r) * 3 * D + 2 * D + h * HD + dc * 16;
-    const float pj = sc[j] * inv;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      F4 t = ld4(vp + c * 4);
-      out[c * 4] = fmaf(pj, t.x, out[c * 4]); out[c * 4 + 1] = fmaf(pj, t.y, out[c * 4 + 1]);
-      out[c * 4 + 2] = fmaf(pj, t.z, out[c * 4 + 2]); out[c * 4 + 3] = fmaf(pj, t.w, out[c * 4 + 3]);
-    }
-  }
-  if (live) {
-    float* op = o + (long long)(i * R + r) * D + h * HD + dc * 16;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) st4(op + c * 4, F4{out[c * 4], out[c * 4 + 1], out[c * 4 + 2], out[c * 4 + 3]});
-  }
-}
 
 // ----------------------------------------------------------------------------------------------
 // VAE decoder self-attention over T frames with the key-padding mask of mld_vae.py:229

@@ -37,46 +37,7 @@ __global__ __launch_bounds__(256) void init_x0_kernel(const float* __restrict__ 
   X0[(long long)(R + B + b) * D + d] = tt;
 }
 
-// ----------------------------------------------------------------------------------------------
-// End of one reverse step, fused: final encoder LayerNorm on token 0 only (cross_attention.py:62-63,
-// mld_denoiser.py:206), classifier-free guidance (mld.py:339-342), DDIM update (diffusers
-// DDIMScheduler.step, eta = 0, epsilon prediction) and assembly of the next
-// step's token-0 / time rows.  grid = B, block = D (256).
-struct DdimCoef { float sqrt_at, sqrt_1mat, sqrt_ap, sqrt_1map; };
-
-__global__ __launch_bounds__(256) void final_ln_cfg_ddim_kernel(
-    const float* __restrict__ Hfin, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ lat, float* __restrict__ X0, const float* __restrict__ pe0,
-    const float* __restrict__ t1_next /* null on the last step */, float* __restrict__ eps_out /* optional [2B, D] */,
-    int B, int D, float guidance, DdimCoef c) {
-  __shared__ float sh[4];
-  const int b = blockIdx.x, d = threadIdx.x;
-  const int R = 2 * B;
-  const float inv_d = 1.0f / float(D);
-  float e[2];
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const float x = Hfin[(long long)(half * B + b) * D + d];
-    const float mean = block_sum_256(x, sh, d) * inv_d;
-    const float xc = x - mean;
-    const float var = block_sum_256(xc * xc, sh, d) * inv_d;
-    e[half] = xc * rsqrtf(var + kLnEps) * gamma[d] + beta[d];
-    if (eps_out) eps_out[(long long)(half * B + b) * D + d] = e[half];
-  }
-  const float eps = e[0] + guidance * (e[1] - e[0]);
-  const float x = lat[(long long)b * D + d];
-  const float x0 = (x - c.sqrt_1mat * eps) / c.sqrt_at;
-  const float xn = c.sqrt_ap * x0 + c.sqrt_1map * eps;
-  lat[(long long)b * D + d] = xn;
-  const float tok = xn + pe0[d];
-  X0[(long long)b * D + d] = tok;
-  X0[(long long)(B + b) * D + d] = tok;
-  if (t1_next) {
-    const float tt = t1_next[d];
-    X0[(long long)(R + b) * D + d] = tt;
-    X0[(long long)(R + B + b) * D + d] = tt;
-  }
-}
+struct DdimCoef { float sqrt_at, sqrt_1mat, sqrt_ap, sqrt_1map; };   // DDIM eta=0 coefficients of one step
 
 // LayerNorm over rows of width 256: one wave per row, 4 rows per workgroup.
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ X, float* __restrict__ Y,

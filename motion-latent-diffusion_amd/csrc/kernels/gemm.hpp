@@ -61,8 +61,19 @@ __device__ __forceinline__ void load_frags(Frag (&f)[REP], const float* base, in
   }
 }
 
+constexpr int kGemmLdsStride = 36;   // floats per staged row: one 32-wide K chunk + 4 pad (bank spread)
+template <int WM, int WN, int MREP, int NREP>
+constexpr int gemm_lds_bytes() { return 2 * (WM * MREP * 16 + WN * NREP * 16) * kGemmLdsStride * 4; }
+
 // WM x WN waves per workgroup, each wave owns MREP x NREP tiles of 16x16.
-template <int WM, int WN, int MREP, int NREP, bool LN>
+// STAGED = false: fragments are fetched straight from global memory (first version; kept for the tiny
+//                 one-off GEMMs: time MLP, text projection, per-sample cross-attention vectors).
+// STAGED = true : the workgroup streams 32-wide K chunks of its A and W panels through LDS in full
+//                 128-byte lines (coalesced 16 B/lane), double buffered: chunk k+1's global loads are in
+//                 flight while chunk k's MFMAs run; one barrier per chunk.  (The register-direct form
+//                 reached only ~50 of 157 TF on the decoder: fragment-shaped loads saturate the TA path,
+//                 cdna_hip_programming.md "x through LDS in full lines".)
+template <int WM, int WN, int MREP, int NREP, bool LN, bool STAGED = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
   constexpr bool SPLIT = (MREP * NREP == 1);   // one tile per wave: split the k-chain over 2 accumulators
@@ -107,13 +118,81 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         }
   };
 
-  load(fa0, fb0, 0);
-  for (int kc = 0; kc < KC; kc += 2) {
-    if (kc + 1 < KC) load(fa1, fb1, kc + 1);
-    compute(fa0, fb0);
-    if (kc + 1 < KC) {
-      if (kc + 2 < KC) load(fa0, fb0, kc + 2);
-      compute(fa1, fb1);
+  if constexpr (!STAGED) {
+    load(fa0, fb0, 0);
+    for (int kc = 0; kc < KC; kc += 2) {
+      if (kc + 1 < KC) load(fa1, fb1, kc + 1);
+      compute(fa0, fb0);
+      if (kc + 1 < KC) {
+        if (kc + 2 < KC) load(fa0, fb0, kc + 2);
+        compute(fa1, fb1);
+      }
+    }
+  } else {
+#if defined(MLDHIP_SIM)
+    float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
+#else
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+#endif
+    constexpr int NT = WM * WN * 64, ROWS = BM + BN, NLD = ROWS * 8 / NT;
+    static_assert(ROWS * 8 % NT == 0, "panel rows must tile the workgroup");
+    const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+    F4 stage[NLD];
+    auto gload = [&](int kc) {
+      const int k = kc * 32;
+      const bool first = k < p.K1;
+      const float* abase = first ? A : p.A2;
+      const int ald = first ? p.lda : p.lda2;
+      const int ak = first ? k : k - p.K1;
+#pragma unroll
+      for (int j = 0; j < NLD; ++j) {
+        const int idx = tid + j * NT, row = idx >> 3, c4 = idx & 7;
+        if (row < BM) {
+          int m = bm0 + row;
+          m = m < p.M ? m : p.M - 1;
+          F4 v = ld4(abase + (long long)m * ald + ak + c4 * 4);
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          stage[j] = v;
+        } else {
+          int n = bn0 + row - BM;
+          n = n < p.N ? n : p.N - 1;
+          stage[j] = ld4(W + (long long)n * p.ldw + k + c4 * 4);
+        }
+      }
+    };
+    auto lstore = [&](int buf) {
+      float* dst = smem + buf * ROWS * kGemmLdsStride;
+#pragma unroll
+      for (int j = 0; j < NLD; ++j) {
+        const int idx = tid + j * NT, row = idx >> 3, c4 = idx & 7;
+        st4(dst + row * kGemmLdsStride + c4 * 4, stage[j]);
+      }
+    };
+    auto lfrags = [&](int buf) {
+      const float* as = smem + buf * ROWS * kGemmLdsStride + (wm * MREP * 16 + r) * kGemmLdsStride + g * 8;
+      const float* ws = smem + buf * ROWS * kGemmLdsStride + (BM + wn * NREP * 16 + r) * kGemmLdsStride + g * 8;
+#pragma unroll
+      for (int t = 0; t < MREP; ++t) {
+        const F4 a = ld4(as + t * 16 * kGemmLdsStride), b = ld4(as + t * 16 * kGemmLdsStride + 4);
+        fa0[t].v[0] = a.x; fa0[t].v[1] = a.y; fa0[t].v[2] = a.z; fa0[t].v[3] = a.w;
+        fa0[t].v[4] = b.x; fa0[t].v[5] = b.y; fa0[t].v[6] = b.z; fa0[t].v[7] = b.w;
+      }
+#pragma unroll
+      for (int t = 0; t < NREP; ++t) {
+        const F4 a = ld4(ws + t * 16 * kGemmLdsStride), b = ld4(ws + t * 16 * kGemmLdsStride + 4);
+        fb0[t].v[0] = a.x; fb0[t].v[1] = a.y; fb0[t].v[2] = a.z; fb0[t].v[3] = a.w;
+        fb0[t].v[4] = b.x; fb0[t].v[5] = b.y; fb0[t].v[6] = b.z; fb0[t].v[7] = b.w;
+      }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kc = 0; kc < KC; ++kc) {
+      if (kc + 1 < KC) gload(kc + 1);          // in flight while this chunk's MFMAs run
+      lfrags(kc & 1);
+      compute(fa0, fb0);
+      if (kc + 1 < KC) lstore((kc + 1) & 1);   // that buffer was last read in iteration kc-1 (barrier passed)
+      __syncthreads();
     }
   }
   if (SPLIT) acc[0][0] += acc2;

@@ -68,6 +68,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         raise FileNotFoundError(
             f"{path} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
             "mld_hip has no CPU fallback.")
+    # torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7) and finds it by file name; if the
+    # system copy were loaded first the process would end up with two HIP runtimes.  Import torch first
+    # so libmldhip binds to the one runtime torch uses (device memory and streams are shared with it).
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in _SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export the ABI

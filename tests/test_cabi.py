@@ -34,7 +34,7 @@ def test_library_contains_gfx950_code_object():
         pytest.skip("libmldhip.so not built yet")
     blob = open(_lib.DEFAULT_LIB, "rb").read()
     assert b"gfx950" in blob
-    for kernel in (b"gemm_kernel", b"attn_decode_kernel", b"attn_tiny_kernel", b"final_ln_cfg_ddim_kernel", b"feats2joints_kernel"):
+    for kernel in (b"gemm_kernel", b"gemm_tile32_kernel", b"attn_decode_kernel", b"den_final_step_kernel", b"feats2joints_kernel"):
         assert kernel in blob
 
 

@@ -58,7 +58,7 @@ def _cuda(x, dev):
     return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 
 
-def test_native_library_is_loaded():
+def test_native_library_is_loaded(eng):
     """The parity below must come from libmldhip.so, not from anything else."""
     maps = open("/proc/self/maps").read()
     assert "libmldhip.so" in maps

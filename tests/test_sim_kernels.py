@@ -111,7 +111,7 @@ def test_full_sample_sim(eng, ow):
     assert np.abs(feats - fr).max() < 1e-4
     assert np.abs(joints - jr).max() < 1e-4
     den, dec, jn = eng.launch_counts()
-    assert den == 2 + 2 * (9 * 5 + 4 + 1) and dec == 2 + 1 + 9 * 5 + 4 + 2 and jn == 1
+    assert den == 2 + 2 * (9 * 4 + 4 + 1) and dec == 2 + 1 + 9 * 5 + 4 + 2 and jn == 1
 
 
 def test_abi_errors_sim(eng):
