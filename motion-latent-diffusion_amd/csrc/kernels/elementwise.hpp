@@ -16,25 +16,28 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh /*[4]*/, int t
 }
 
 // ----------------------------------------------------------------------------------------------
-// X0 assembly at the start of the reverse process (mld_denoiser.py:143-196, tokens [lat, time, text],
-// token-major rows s*R + r, R = 2B with the unconditional half first, mld.py:224-231,325):
-//   X0[r]     = latents[r mod B] * init_sigma + pe[0]
-//   X0[R + r] = T1[step 0]            (time-MLP output + pe[1], precomputed per scheduler step)
-// (text rows X0[2R + r] are written by the text-projection GEMM whose bias already holds pe[2]).
-// Also copies init noise into the engine's latent state.  grid = B, block = D (256).
-__global__ __launch_bounds__(256) void init_x0_kernel(const float* __restrict__ init_lat, float* __restrict__ lat,
-                                                      float* __restrict__ X0, const float* __restrict__ pe0,
-                                                      const float* __restrict__ t1_row, int B, int D, float init_sigma) {
-  const int b = blockIdx.x, d = threadIdx.x;
-  const int R = 2 * B;
-  const float x = init_lat[(long long)b * D + d] * init_sigma;
-  lat[(long long)b * D + d] = x;
+// Token assembly at the start of the reverse process for one chain of `Bc` motions starting at b0
+// (mld_denoiser.py:143-196: tokens [latent, time, text]; rows token-major s*Rc + r with Rc = 2*Bc and the
+// unconditional half first, mld.py:224-231,325):
+//   X0[r]          = init_latents[b] * init_sigma + pe[0]        (both CFG halves share the latent)
+//   X0[Rc + r]     = T1[step 0]                                   (time MLP + pe[1], precomputed)
+//   X0[2Rc + r]    = TP[b0 + b] (uncond) / TP[B + b0 + b] (cond)  (text projection + pe[2])
+// grid = Bc, block = 256 (= latent width).
+__global__ __launch_bounds__(256) void init_chain_kernel(const float* __restrict__ init_lat, float* __restrict__ lat,
+                                                         float* __restrict__ X0, const float* __restrict__ pe0,
+                                                         const float* __restrict__ t1_row, const float* __restrict__ TP,
+                                                         int B, int b0, int Bc, float init_sigma) {
+  const int b = blockIdx.x, d = threadIdx.x, Rc = 2 * Bc;
+  const float x = init_lat[(long long)b * 256 + d] * init_sigma;
+  lat[(long long)b * 256 + d] = x;
   const float tok = x + pe0[d];
-  X0[(long long)b * D + d] = tok;
-  X0[(long long)(B + b) * D + d] = tok;
+  X0[(long long)b * 256 + d] = tok;
+  X0[(long long)(Bc + b) * 256 + d] = tok;
   const float tt = t1_row[d];
-  X0[(long long)(R + b) * D + d] = tt;
-  X0[(long long)(R + B + b) * D + d] = tt;
+  X0[(long long)(Rc + b) * 256 + d] = tt;
+  X0[(long long)(Rc + Bc + b) * 256 + d] = tt;
+  X0[(long long)(2 * Rc + b) * 256 + d] = TP[(long long)(b0 + b) * 256 + d];
+  X0[(long long)(2 * Rc + Bc + b) * 256 + d] = TP[(long long)(B + b0 + b) * 256 + d];
 }
 
 struct DdimCoef { float sqrt_at, sqrt_1mat, sqrt_ap, sqrt_1map; };   // DDIM eta=0 coefficients of one step

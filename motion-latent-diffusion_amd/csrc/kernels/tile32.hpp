@@ -52,70 +52,33 @@ constexpr int kT32Stride = 260;                         // LDS row stride (float
 constexpr int kT32LdsFloats = (32 + 64) * kT32Stride;   // A tile + W tile
 constexpr int kT32LdsBytes = kT32LdsFloats * 4;         // 99,840 B -> one workgroup per CU
 
-// One wave assembles one 256-wide row; lane l owns columns 4l..4l+3.
-__device__ __forceinline__ F4 assemble_row(const ASrc& s, int row, int M, int col0, int lane, bool write_back) {
-  F4 v;
-  if (s.attn_R > 0) {
-    // nn.MultiheadAttention over the 3 tokens of one sample (cross_attention.py:265-266):
-    // head = lane >> 4 (64 dims = 16 lanes x 4), q pre-scaled by 1/sqrt(64), softmax over 3 keys.
-    const int R = s.attn_R;
-    const int tok = row / R, smp = row - tok * R;
-    const float* q = s.base + (long long)row * 768 + lane * 4;
-    const F4 qv = ld4(q);
-    F4 kv[3], vv[3];
+// Four independent wave reductions in lockstep (the shuffles of different rows interleave, so the cost
+// is one dependent chain, not four).
+__device__ __forceinline__ void sum64x4(float (&v)[4]) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const float* kr = s.base + (long long)(j * R + smp) * 768 + 256 + lane * 4;
-      kv[j] = ld4(kr);
-      vv[j] = ld4(kr + 256);
-    }
-    float sc[3];
+  for (int m = 1; m < 64; m <<= 1) {
+    float t[4];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float d = qv.x * kv[j].x;
-      d = fmaf(qv.y, kv[j].y, d);
-      d = fmaf(qv.z, kv[j].z, d);
-      d = fmaf(qv.w, kv[j].w, d);
-      sc[j] = sum16(d) * 0.125f;
-    }
-    const float m = fmaxf(sc[0], fmaxf(sc[1], sc[2]));
-    const float e0 = expf(sc[0] - m), e1 = expf(sc[1] - m), e2 = expf(sc[2] - m);
-    const float inv = 1.0f / (e0 + e1 + e2);
-    const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
-    v.x = p0 * vv[0].x + p1 * vv[1].x + p2 * vv[2].x;
-    v.y = p0 * vv[0].y + p1 * vv[1].y + p2 * vv[2].y;
-    v.z = p0 * vv[0].z + p1 * vv[1].z + p2 * vv[2].z;
-    v.w = p0 * vv[0].w + p1 * vv[1].w + p2 * vv[2].w;
-    return v;
+    for (int i = 0; i < 4; ++i) t[i] = wave_xor(v[i], m);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += t[i];
   }
-  if (s.nsplit == 0) return ld4(s.base + (long long)row * s.ld + col0 + lane * 4);
-  // ---- combine: sum of slabs + bias + residual, then optional LayerNorm (all in this wave)
-  v = ld4(s.base + (long long)row * 256 + lane * 4);
-  for (int z = 1; z < s.nsplit; ++z) {
-    const F4 t = ld4(s.base + z * s.pstride + (long long)row * 256 + lane * 4);
-    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-  }
-  if (s.bias) {
-    const F4 t = ld4(s.bias + lane * 4);
-    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-  }
-  if (s.res) {
-    const F4 t = ld4(s.res + (long long)row * s.ldres + lane * 4);
-    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-  }
-  if (s.gamma) {
-    const float mean = sum64(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
-    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-    const float var = sum64(a * a + b * b + c * c + d * d) * (1.0f / 256.0f);
-    const float rs = rsqrtf(var + kLnEps);
-    const F4 gm = ld4(s.gamma + lane * 4), bt = ld4(s.beta + lane * 4);
-    v = F4{a * rs * gm.x + bt.x, b * rs * gm.y + bt.y, c * rs * gm.z + bt.z, d * rs * gm.w + bt.w};
-  }
-  if (write_back && s.out) st4(s.out + (long long)row * s.ldout + lane * 4, v);
-  return v;
 }
+__device__ __forceinline__ void sum16x12(float (&v)[12]) {
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) {
+    float t[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) t[i] = wave_xor(v[i], m);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] += t[i];
+  }
+}
+__device__ __forceinline__ F4 f4add(F4 a, F4 b) { return F4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 
 // grid = (ceil(M/32), N/64, K/256); block = 512 (8 waves: wave w -> column tile w&3, row tile w>>2).
+// A prologue: each wave assembles 4 rows (w, w+8, w+16, w+24 of the tile); lane l owns columns 4l..4l+3.
+// EVERY global load of the workgroup is issued before the first dependent instruction.
 __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
@@ -131,7 +94,7 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
   const int acol = (second ? z - p.nz0 : z) * 256;
   const int wcol = z * 256;
 
-  // ---- issue everything: 8 weight rows + 4 A rows per wave, one coalesced 1 KiB row per instruction
+  // ---- weights: 8 rows per wave, one coalesced 1 KiB row per instruction
   F4 wreg[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -139,13 +102,99 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
     n = n < p.N ? n : p.N - 1;
     wreg[i] = ld4(p.W + (long long)n * p.ldw + wcol + lane * 4);
   }
-  F4 areg[4];
+  int rows[4];
+  bool live[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int row = m0 + wave + i * 8;
-    const bool live = row < p.M;
-    row = live ? row : p.M - 1;
-    areg[i] = assemble_row(src, row, p.M, acol, lane, live && blockIdx.y == 0);
+    const int row = m0 + wave + i * 8;
+    live[i] = row < p.M;
+    rows[i] = live[i] ? row : p.M - 1;
+  }
+  F4 areg[4];
+  if (src.attn_R > 0) {
+    // nn.MultiheadAttention over the 3 tokens of one sample (cross_attention.py:265-266): head = lane >> 4
+    // (64 dims = 16 lanes x 4), q pre-scaled by 1/sqrt(64), softmax over the 3 keys, all in registers.
+    const int R = src.attn_R;
+    F4 q[4], k[4][3], v[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tok = rows[i] / R, smp = rows[i] - tok * R;
+      q[i] = ld4(src.base + (long long)rows[i] * 768 + lane * 4);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float* kr = src.base + (long long)(j * R + smp) * 768 + 256 + lane * 4;
+        k[i][j] = ld4(kr);
+        v[i][j] = ld4(kr + 256);
+      }
+    }
+    float sc[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float d = q[i].x * k[i][j].x;
+        d = fmaf(q[i].y, k[i][j].y, d);
+        d = fmaf(q[i].z, k[i][j].z, d);
+        d = fmaf(q[i].w, k[i][j].w, d);
+        sc[i * 3 + j] = d;
+      }
+    sum16x12(sc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float s0 = sc[i * 3] * 0.125f, s1 = sc[i * 3 + 1] * 0.125f, s2 = sc[i * 3 + 2] * 0.125f;
+      const float m = fmaxf(s0, fmaxf(s1, s2));
+      const float e0 = expf(s0 - m), e1 = expf(s1 - m), e2 = expf(s2 - m);
+      const float inv = 1.0f / (e0 + e1 + e2);
+      const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
+      areg[i].x = p0 * v[i][0].x + p1 * v[i][1].x + p2 * v[i][2].x;
+      areg[i].y = p0 * v[i][0].y + p1 * v[i][1].y + p2 * v[i][2].y;
+      areg[i].z = p0 * v[i][0].z + p1 * v[i][1].z + p2 * v[i][2].z;
+      areg[i].w = p0 * v[i][0].w + p1 * v[i][1].w + p2 * v[i][2].w;
+    }
+  } else if (src.nsplit == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) areg[i] = ld4(src.base + (long long)rows[i] * src.ld + acol + lane * 4);
+  } else {
+    // ---- combine: sum of <= 4 slabs + bias + residual, then optional LayerNorm; one wave owns a row
+    F4 sl[4][4], rs[4];
+    const F4 zero = F4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        sl[i][s] = s < src.nsplit ? ld4(src.base + s * src.pstride + (long long)rows[i] * 256 + lane * 4) : zero;
+      rs[i] = src.res ? ld4(src.res + (long long)rows[i] * src.ldres + lane * 4) : zero;
+    }
+    const F4 bias = src.bias ? ld4(src.bias + lane * 4) : zero;
+    F4 gm = zero, bt = zero;
+    if (src.gamma) { gm = ld4(src.gamma + lane * 4); bt = ld4(src.beta + lane * 4); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)   // same association as the first version: ((s0+s1)+s2)+s3, +bias, +res
+      areg[i] = f4add(f4add(f4add(f4add(f4add(sl[i][0], sl[i][1]), sl[i][2]), sl[i][3]), bias), rs[i]);
+    if (src.gamma) {
+      float s[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[i] = areg[i].x + areg[i].y + areg[i].z + areg[i].w;
+      sum64x4(s);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float mean = s[i] * (1.0f / 256.0f);
+        areg[i] = F4{areg[i].x - mean, areg[i].y - mean, areg[i].z - mean, areg[i].w - mean};
+        s[i] = areg[i].x * areg[i].x + areg[i].y * areg[i].y + areg[i].z * areg[i].z + areg[i].w * areg[i].w;
+      }
+      sum64x4(s);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float rstd = rsqrtf(s[i] * (1.0f / 256.0f) + kLnEps);
+        areg[i] = F4{areg[i].x * rstd * gm.x + bt.x, areg[i].y * rstd * gm.y + bt.y, areg[i].z * rstd * gm.z + bt.z,
+                     areg[i].w * rstd * gm.w + bt.w};
+      }
+    }
+    if (src.out && blockIdx.y == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (live[i]) st4(src.out + (long long)rows[i] * src.ldout + lane * 4, areg[i]);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * kT32Stride + lane * 4, wreg[i]);

@@ -95,12 +95,16 @@ struct mldhip_engine {
   // decode
   float *cv1, *cvec, *LNO, *feats_int, *joints_int, *zbuf;
   float *Po, *Pf, *Ps;   // denoiser split-K slabs: out-proj [1], FFN2 [4], skip-linear [2], each [6*max_batch][256]
+  float* TP;             // text projection rows [2*max_batch][256] (+pe[2]), gathered per chain
+  int nchains = 1;       // independent sub-batch chains of the reverse loop (parallel graph branches)
 
   int launches[3] = {0, 0, 0};
   int phase = 0;
 
 #if !defined(MLDHIP_SIM)
   hipStream_t cap_stream = nullptr;
+  hipStream_t side[7] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[7] = {};
   std::map<GraphKey, hipGraphExec_t> graphs;
 #endif
 
@@ -362,95 +366,108 @@ ASrc combine_src(const float* slabs, int nsplit, long long pstride, const float*
   return s;
 }
 
-struct DenBufs { long long slab; };
+// One chain's slice of the denoiser workspace: rows [row0, row0 + 3R) of every row-indexed buffer.
+struct DenView {
+  float *X0, *QKV, *FF, *H1, *Ha, *Po, *Pf, *Ps, *S[8], *lat;
+  int R;            // samples in this chain's CFG batch (uncond half first)
+};
+
+DenView den_view(E* e, int row0, int b0, int R) {
+  DenView v;
+  const size_t D = e->cfg.latent_dim, F = e->cfg.ff_size, r0 = (size_t)row0;
+  v.X0 = e->X0 + r0 * D; v.QKV = e->QKV + r0 * 3 * D; v.FF = e->FF + r0 * F; v.H1 = e->H1 + r0 * D; v.Ha = e->Ha + r0 * D;
+  v.Po = e->Po + r0 * D; v.Pf = e->Pf + r0 * D; v.Ps = e->Ps + r0 * D;
+  for (int i = 0; i < 8; ++i) v.S[i] = e->S[i] ? e->S[i] + r0 * D : nullptr;
+  v.lat = e->lat + (size_t)b0 * D;
+  v.R = R;
+  return v;
+}
+long long den_slab(const E* e) { return (long long)6 * e->cfg.max_batch * 256; }
 
 // QKV projection; `x` describes how the layer input rows are obtained (and where they are written back).
-void den_qkv(Ctx& c, const EncLayerP& L, const ASrc& x, int M) {
-  E* e = c.e;
+void den_qkv(Ctx& c, const DenView& v, const EncLayerP& L, const ASrc& x) {
   Tile32Args a;
-  a.src[0] = x; a.nz0 = 1; a.W = L.in_w; a.ldw = 256; a.bias = L.in_b; a.Y = e->QKV; a.ldy = 768; a.M = M; a.N = 768;
+  a.src[0] = x; a.nz0 = 1; a.W = L.in_w; a.ldw = 256; a.bias = L.in_b; a.Y = v.QKV; a.ldy = 768; a.M = 3 * v.R; a.N = 768;
   tile32(c, a, 1);
 }
 // out-projection of the 3-token self-attention (computed while the A tile is assembled) -> raw slab Po
-void den_outproj(Ctx& c, const EncLayerP& L, int R) {
-  E* e = c.e;
+void den_outproj(Ctx& c, const DenView& v, const EncLayerP& L) {
   Tile32Args a;
-  a.src[0].base = e->QKV; a.src[0].attn_R = R;
-  a.nz0 = 1; a.W = L.out_w; a.ldw = 256; a.P = e->Po; a.pstride = 0; a.M = 3 * R; a.N = 256;
+  a.src[0].base = v.QKV; a.src[0].attn_R = v.R;
+  a.nz0 = 1; a.W = L.out_w; a.ldw = 256; a.P = v.Po; a.pstride = 0; a.M = 3 * v.R; a.N = 256;
   tile32(c, a, 1);
 }
 // h1 = LN1(x + out_proj) assembled on load (written to H1), FF = gelu(h1 W1^T + b1)
-void den_ffn1(Ctx& c, const EncLayerP& L, const float* xn, int M) {
-  E* e = c.e;
+void den_ffn1(Ctx& c, const DenView& v, const EncLayerP& L, const float* xn) {
+  const int F = c.e->cfg.ff_size;
   Tile32Args a;
-  a.src[0] = combine_src(e->Po, 1, 0, L.out_b, xn, L.n1_w, L.n1_b, e->H1);
-  a.nz0 = 1; a.W = L.l1_w; a.ldw = 256; a.bias = L.l1_b; a.act = 1; a.Y = e->FF; a.ldy = e->cfg.ff_size; a.M = M; a.N = e->cfg.ff_size;
+  a.src[0] = combine_src(v.Po, 1, 0, L.out_b, xn, L.n1_w, L.n1_b, v.H1);
+  a.nz0 = 1; a.W = L.l1_w; a.ldw = 256; a.bias = L.l1_b; a.act = 1; a.Y = v.FF; a.ldy = F; a.M = 3 * v.R; a.N = F;
   tile32(c, a, 1);
 }
 // FFN2 as ff_size/256 K-slices -> raw slabs Pf; bias, residual and norm2 are applied by whoever reads them
-void den_ffn2(Ctx& c, const EncLayerP& L, int M) {
-  E* e = c.e;
-  const int F = e->cfg.ff_size;
+void den_ffn2(Ctx& c, const DenView& v, const EncLayerP& L) {
+  const int F = c.e->cfg.ff_size;
   Tile32Args a;
-  a.src[0] = plain_src(e->FF, F);
-  a.nz0 = F / 256; a.W = L.l2_w; a.ldw = F; a.P = e->Pf; a.pstride = (long long)6 * e->cfg.max_batch * 256; a.M = M; a.N = 256;
+  a.src[0] = plain_src(v.FF, F);
+  a.nz0 = F / 256; a.W = L.l2_w; a.ldw = F; a.P = v.Pf; a.pstride = den_slab(c.e); a.M = 3 * v.R; a.N = 256;
   tile32(c, a, F / 256);
 }
-ASrc den_layer_output(E* e, const EncLayerP& L, float* write_back) {   // LN2(sum Pf + b2 + h1)
-  return combine_src(e->Pf, e->cfg.ff_size / 256, (long long)6 * e->cfg.max_batch * 256, L.l2_b, e->H1, L.n2_w, L.n2_b, write_back);
+ASrc den_layer_output(E* e, const DenView& v, const EncLayerP& L, float* write_back) {   // LN2(sum Pf + b2 + h1)
+  return combine_src(v.Pf, e->cfg.ff_size / 256, den_slab(e), L.l2_b, v.H1, L.n2_w, L.n2_b, write_back);
 }
 
 // SkipTransformerEncoder over the 3-token sequences (cross_attention.py:41-64).  Leaves the last layer's
 // FFN2 slabs in Pf and its norm1 output in H1; the caller applies norm2 + encoder.norm (FinalArgs).
-void denoiser_body(Ctx& c, int R) {
+void denoiser_body(Ctx& c, const DenView& v) {
   E* e = c.e;
-  const int nb = (e->cfg.num_layers - 1) / 2, M = 3 * R, L = e->cfg.num_layers;
-  const long long slab = (long long)6 * e->cfg.max_batch * 256;
-  ASrc x = plain_src(e->X0, 256);
-  const float* xn = e->X0;                 // where the (normalised) layer input lives, for the norm1 residual
+  const int nb = (e->cfg.num_layers - 1) / 2, L = e->cfg.num_layers;
+  ASrc x = plain_src(v.X0, 256);
+  const float* xn = v.X0;                  // where the (normalised) layer input lives, for the norm1 residual
   for (int l = 0; l < L; ++l) {
     const EncLayerP& P_ = e->den[l];
-    den_qkv(c, P_, x, M);
-    den_outproj(c, P_, R);
-    den_ffn1(c, P_, xn, M);
-    den_ffn2(c, P_, M);
+    den_qkv(c, v, P_, x);
+    den_outproj(c, v, P_);
+    den_ffn1(c, v, P_, xn);
+    den_ffn2(c, v, P_);
     if (l + 1 == L) break;
     if (l < nb) {
       // next layer input = LN2(...), kept in S[l] for the skip connection (written by the next QKV prologue)
-      x = den_layer_output(e, P_, e->S[l]);
-      xn = e->S[l];
+      x = den_layer_output(e, v, P_, v.S[l]);
+      xn = v.S[l];
     } else {
       // Linear(cat[x, skip]) as two K slices (cross_attention.py:56-58): slice 0 assembles x = LN2(...) on load,
       // slice 1 reads the stored skip activation; the sum + bias is assembled by the next QKV prologue.
       const int i = l - nb;
       Tile32Args a;
-      a.src[0] = den_layer_output(e, P_, nullptr);
-      a.src[1] = plain_src(e->S[nb - 1 - i], 256);
+      a.src[0] = den_layer_output(e, v, P_, nullptr);
+      a.src[1] = plain_src(v.S[nb - 1 - i], 256);
       a.nz0 = 1;
       a.W = P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".weight"); a.ldw = 512;
-      a.P = e->Ps; a.pstride = slab; a.M = M; a.N = 256;
+      a.P = v.Ps; a.pstride = den_slab(e); a.M = 3 * v.R; a.N = 256;
       tile32(c, a, 2);
-      x = combine_src(e->Ps, 2, slab, P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".bias"), nullptr, nullptr, nullptr, e->Ha);
-      xn = e->Ha;
+      x = combine_src(v.Ps, 2, den_slab(e), P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".bias"), nullptr, nullptr,
+                      nullptr, v.Ha);
+      xn = v.Ha;
     }
   }
 }
 
-FinalArgs den_final_args(E* e) {
+FinalArgs den_final_args(E* e, const DenView& v) {
   const EncLayerP& L = e->den.back();
   FinalArgs f;
-  f.P = e->Pf; f.nsplit = e->cfg.ff_size / 256; f.pstride = (long long)6 * e->cfg.max_batch * 256;
-  f.b2 = L.l2_b; f.H1 = e->H1; f.g2 = L.n2_w; f.be2 = L.n2_b;
+  f.P = v.Pf; f.nsplit = e->cfg.ff_size / 256; f.pstride = den_slab(e);
+  f.b2 = L.l2_b; f.H1 = v.H1; f.g2 = L.n2_w; f.be2 = L.n2_b;
   f.gf = P(e, "denoiser.encoder.norm.weight"); f.bef = P(e, "denoiser.encoder.norm.bias");
   return f;
 }
 
-void text_projection(Ctx& c, const float* text_emb, int R) {
+// emb_proj = Sequential(ReLU, Linear) (mld_denoiser.py:65-68) for `rows` text rows -> dst[rows][D]; the
+// bias already holds + pe[2] (token 2 of the sequence).
+void text_projection(Ctx& c, const float* text_emb, int rows, float* dst) {
   E* e = c.e;
   const int D = e->cfg.latent_dim, TD = e->cfg.text_dim;
-  // emb_proj = Sequential(ReLU, Linear) (mld_denoiser.py:65-68); bias already holds + pe[2]
-  GemmArgs g = lin_args(text_emb, TD, TD, P(e, "denoiser.emb_proj.1.weight"), e->text_bias,
-                        e->X0 + (size_t)2 * R * D, D, R, D);
+  GemmArgs g = lin_args(text_emb, TD, TD, P(e, "denoiser.emb_proj.1.weight"), e->text_bias, dst, D, rows, D);
   g.relu_in = 1;
   gemm(c, g);
 }
@@ -570,27 +587,58 @@ void joints_body(Ctx& c, const float* feats, int B, int T, float* joints) {
   check_launch(c, "feats2joints");
 }
 
-// Everything mld.py:232-240,264 does after the text encoder, as one stream-ordered sequence.
+// Everything mld.py:232-240,264 does after the text encoder.  The reverse loop is latency bound (a few
+// hundred rows per launch), and samples never interact, so the batch is cut into `nchains` sub-batches
+// whose 50-step chains run on parallel branches (side streams forked from / joined to `stream`; inside
+// a capture they become parallel branches of the hipGraph).  The MFMA-bound decode runs on the whole batch.
 int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* init_lat, int B, int T,
                    float* lat_out, float* feats_out, float* joints_out) {
   Ctx c{e, stream};
-  const int D = e->cfg.latent_dim, R = 2 * B, n = e->cfg.num_inference_steps;
+  const int D = e->cfg.latent_dim, n = e->cfg.num_inference_steps;
   e->launches[0] = e->launches[1] = e->launches[2] = 0;
   e->phase = 0;
-  text_projection(c, text, R);
-  MLD_LAUNCH(init_x0_kernel, dim3(B), dim3(D), 0, stream, init_lat, e->lat, e->X0, P(e, "denoiser.query_pos.pe"),
-             (const float*)e->T1, B, D, 1.0f /* DDIM init_noise_sigma */);
-  count(c);
-  check_launch(c, "init_x0");
-  for (int s = 0; s < n; ++s) {
-    denoiser_body(c, R);
-    const float* t1n = (s + 1 < n) ? e->T1 + (size_t)(s + 1) * D : nullptr;
-    MLD_LAUNCH(den_final_step_kernel, dim3(B), dim3(256), 0, stream, den_final_args(e), e->lat, e->X0,
-               P(e, "denoiser.query_pos.pe"), t1n, B, e->cfg.guidance_scale, ddim_coef(e, e->timesteps[s]));
-    count(c);
-    check_launch(c, "den_final_step");
-    if (c.rc) return c.rc;
+  text_projection(c, text, 2 * B, e->TP);
+  int nch = std::min(e->nchains, B);
+  const int Bc = (B + nch - 1) / nch;
+  nch = (B + Bc - 1) / Bc;
+#if !defined(MLDHIP_SIM)
+  if (nch > 1) {
+    hipError_t s = hipEventRecord(e->ev_fork, stream);
+    for (int ch = 1; ch < nch && s == hipSuccess; ++ch) s = hipStreamWaitEvent(e->side[ch - 1], e->ev_fork, 0);
+    if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "fork: %s", hipGetErrorString(s));
   }
+#endif
+  int rc = 0;
+  for (int ch = 0; ch < nch; ++ch) {
+    const int b0 = ch * Bc, bc = std::min(Bc, B - b0);
+#if !defined(MLDHIP_SIM)
+    Ctx cc{e, ch == 0 ? stream : e->side[ch - 1]};
+#else
+    Ctx cc{e, stream};
+#endif
+    const DenView v = den_view(e, 6 * b0, b0, 2 * bc);
+    MLD_LAUNCH(init_chain_kernel, dim3(bc), dim3(256), 0, cc.stream, init_lat + (size_t)b0 * D, v.lat, v.X0,
+               P(e, "denoiser.query_pos.pe"), (const float*)e->T1, (const float*)e->TP, B, b0, bc, 1.0f /* init_noise_sigma */);
+    count(cc);
+    check_launch(cc, "init_chain");
+    for (int s = 0; s < n && !cc.rc; ++s) {
+      denoiser_body(cc, v);
+      const float* t1n = (s + 1 < n) ? e->T1 + (size_t)(s + 1) * D : nullptr;
+      MLD_LAUNCH(den_final_step_kernel, dim3(bc), dim3(256), 0, cc.stream, den_final_args(e, v), v.lat, v.X0,
+                 P(e, "denoiser.query_pos.pe"), t1n, bc, e->cfg.guidance_scale, ddim_coef(e, e->timesteps[s]));
+      count(cc);
+      check_launch(cc, "den_final_step");
+    }
+    if (cc.rc && !rc) rc = cc.rc;
+#if !defined(MLDHIP_SIM)
+    if (ch > 0) {   // join (also on error paths, so a capture can always be closed)
+      hipError_t s = hipEventRecord(e->ev_join[ch - 1], e->side[ch - 1]);
+      if (s == hipSuccess) s = hipStreamWaitEvent(stream, e->ev_join[ch - 1], 0);
+      if (s != hipSuccess && !rc) rc = e->fail(MLDHIP_EHIP, "join: %s", hipGetErrorString(s));
+    }
+#endif
+  }
+  if (rc) return rc;
   if (lat_out) {
     hipError_t s = hipMemcpyAsync(lat_out, e->lat, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream);
     if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "latents copy: %s", hipGetErrorString(s));
@@ -668,6 +716,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   auto* e = new mldhip_engine();
   if (const char* m = std::getenv("MLDHIP_GEMM")) g_staged_gemm = std::strcmp(m, "direct") != 0;
   if (const char* m = std::getenv("MLDHIP_SMALL_M")) g_small_m = std::atoi(m);
+  e->nchains = 2;
+  if (const char* m = std::getenv("MLDHIP_CHAINS")) e->nchains = std::max(1, std::min(8, std::atoi(m)));
   e->cfg = *cfg;
   e->device = device;
   declare_params(e);
@@ -685,7 +735,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   for (int i = 0; i < 8; ++i) want(&e->S[i], (i < (int)(L - 1) / 2) ? rows * D : 0);
   want(&e->QKV, rows * 3 * D); want(&e->AO, rows * D); want(&e->FF, rows * F);
   want(&e->lat, Bm * D); want(&e->zbuf, Bm * D);
-  want(&e->Po, 6 * Bm * D); want(&e->Pf, 4 * 6 * Bm * D); want(&e->Ps, 2 * 6 * Bm * D);
+  want(&e->Po, 6 * Bm * D); want(&e->Pf, 4 * 6 * Bm * D); want(&e->Ps, 2 * 6 * Bm * D); want(&e->TP, 2 * Bm * D);
   want(&e->T1, n * D); want(&e->temb0, n * TD); want(&e->tmid, n * D);
   want(&e->text_bias, D); want(&e->time_b2pe, D); want(&e->t1_one, D); want(&e->temb0_one, TD + D);
   want(&e->cv1, L * Bm * D); want(&e->cvec, L * Bm * D);
@@ -697,6 +747,11 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   if (hipMalloc((void**)&e->lens_dev, Bm * sizeof(int32_t)) != hipSuccess) { e->err = "hipMalloc(lens) failed"; return fail_create(MLDHIP_EHIP); }
 #if !defined(MLDHIP_SIM)
   if (hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return fail_create(MLDHIP_EHIP); }
+  for (int i = 0; i < 7; ++i) {
+    if (hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) != hipSuccess) { e->err = "side stream/event create failed"; return fail_create(MLDHIP_EHIP); }
+  }
+  if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) { e->err = "event create failed"; return fail_create(MLDHIP_EHIP); }
   // the decoder attention keeps K and V of one (sample, head) in LDS: up to 2*18*16*68*4 = 153 KiB
   const int big = 2 * 18 * 16 * 68 * 4;
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -716,6 +771,8 @@ void mldhip_destroy(mldhip_handle* e) {
 #if !defined(MLDHIP_SIM)
   for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
   if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+  for (int i = 0; i < 7; ++i) { if (e->side[i]) (void)hipStreamDestroy(e->side[i]); if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]); }
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
 #endif
   if (e->arena) (void)hipFree(e->arena);
   if (e->ws) (void)hipFree(e->ws);
@@ -855,13 +912,14 @@ int mldhip_denoiser_forward(mldhip_handle* e, const float* sample_dev, int32_t t
   HIP_TRY(e, hipMemcpyAsync(e->temb0_one, host.data(), TD * sizeof(float), hipMemcpyHostToDevice, stream));
   HIP_TRY(e, hipStreamSynchronize(stream));   // `host` is a stack temporary
   time_mlp(c, e->temb0_one, e->temb0_one + TD, e->t1_one, 1);
-  text_projection(c, text_emb_dev, R);
+  const DenView v = den_view(e, 0, 0, R);
+  text_projection(c, text_emb_dev, R, e->X0 + (size_t)2 * R * D);
   // token 0 rows: sample + pe[0]; token 1 rows: the time-MLP row (pe[1] already folded in)
   MLD_LAUNCH(add_rows_kernel, dim3((R * D + 255) / 256), dim3(256), 0, stream, e->X0, sample_dev, P(e, "denoiser.query_pos.pe"), R, D);
   MLD_LAUNCH(bcast_rows_kernel, dim3((R * D + 255) / 256), dim3(256), 0, stream, e->X0 + (size_t)R * D, (const float*)e->t1_one, R, D);
   check_launch(c, "assemble");
-  denoiser_body(c, R);
-  MLD_LAUNCH(den_final_rows_kernel, dim3(R), dim3(256), 0, stream, den_final_args(e), out_dev);
+  denoiser_body(c, v);
+  MLD_LAUNCH(den_final_rows_kernel, dim3(R), dim3(256), 0, stream, den_final_args(e, v), out_dev);
   check_launch(c, "final_norm");
   return c.rc;
 }
@@ -930,21 +988,22 @@ int mldhip_profile_kernel(mldhip_handle* e, const char* name, int32_t B, int32_t
   int saved_phase = e->phase;
   e->phase = dec ? 1 : 0;
   const EncLayerP& DL = e->den[mid];
+  const DenView v = den_view(e, 0, 0, R);
   for (int it = 0; it < iters && !c.rc; ++it) {
     if (n == "den_qkv") {            // with the LN2-on-load prologue of a typical layer (sums the 4 FFN2 slabs)
-      den_qkv(c, DL, den_layer_output(e, e->den[mid - 1], e->S[mid - 1]), (int)M);
+      den_qkv(c, v, DL, den_layer_output(e, v, e->den[mid - 1], v.S[mid - 1]));
       *flops_per_launch = 2.0 * M * D * 3 * D;
     } else if (n == "den_outproj") {
-      den_outproj(c, DL, R);
+      den_outproj(c, v, DL);
       *flops_per_launch = 2.0 * M * D * D + 4.0 * M * 3 * D;
     } else if (n == "den_ffn1") {
-      den_ffn1(c, DL, e->S[mid - 1], (int)M);
+      den_ffn1(c, v, DL, v.S[mid - 1]);
       *flops_per_launch = 2.0 * M * D * F;
     } else if (n == "den_ffn2") {
-      den_ffn2(c, DL, (int)M);
+      den_ffn2(c, v, DL);
       *flops_per_launch = 2.0 * M * D * F;
     } else if (n == "den_final") {
-      MLD_LAUNCH(den_final_step_kernel, dim3(B), dim3(256), 0, c.stream, den_final_args(e), e->zbuf, e->LNO,
+      MLD_LAUNCH(den_final_step_kernel, dim3(B), dim3(256), 0, c.stream, den_final_args(e, v), e->zbuf, e->LNO,
                  P(e, "denoiser.query_pos.pe"), (const float*)e->T1, B, e->cfg.guidance_scale, ddim_coef(e, e->timesteps[0]));
       check_launch(c, "den_final_step");
       *flops_per_launch = 0.0;

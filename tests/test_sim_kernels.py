@@ -111,7 +111,24 @@ def test_full_sample_sim(eng, ow):
     assert np.abs(feats - fr).max() < 1e-4
     assert np.abs(joints - jr).max() < 1e-4
     den, dec, jn = eng.launch_counts()
-    assert den == 2 + 2 * (9 * 4 + 4 + 1) and dec == 2 + 1 + 9 * 5 + 4 + 2 and jn == 1
+    # text projection + per chain (default 2 chains -> one motion each): init + steps * (9 layers * 4 + 4 skip + 1 final)
+    assert den == 1 + 2 * (1 + 2 * (9 * 4 + 4 + 1)) and dec == 2 + 1 + 9 * 5 + 4 + 2 and jn == 1
+
+
+@pytest.mark.parametrize("nch", [1, 3])
+def test_chain_split_is_exact_sim(monkeypatch, ow, nch):
+    """Sub-batch chains (parallel graph branches on the GPU) must not change any value."""
+    ops, bd, bv = ow
+    monkeypatch.setenv("MLDHIP_CHAINS", str(nch))
+    e = simlib.sim_engine(max_batch=4, max_frames=24, num_inference_steps=2)
+    b = syn.make_batch(3, [20, 13, 7])
+    mean, std = syn.make_mean_std()
+    joints = np.zeros((3, 20, 22, 3), np.float32)
+    e.sample(b.text_emb, b.init_latents, b.lengths, None, None, joints)
+    jr = O.sample(ops, bd, bv, b.text_emb, b.init_latents, b.lengths, mean, std, steps=2)
+    assert np.abs(joints - jr).max() < 1e-4
+    assert e.launch_counts()[0] == 1 + nch * (1 + 2 * 41)
+    e.close()
 
 
 def test_abi_errors_sim(eng):
