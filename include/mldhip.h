@@ -141,6 +141,12 @@ int mldhip_get_alphas_cumprod(mldhip_handle* h, float* out_host, int32_t n);
 int mldhip_profile_kernel(mldhip_handle* h, const char* name, int32_t B, int32_t T, int32_t iters,
                           double* flops_per_launch, void* stream);
 
+/* Measurement hook: one traced launch of a den_* kernel; writes 8 uint64 timestamps per wave (64 per
+ * workgroup) to out_host: start, loads landed, LDS written, barrier passed, MFMAs done, stores drained
+ * (shader clock) and start/end on the 100 MHz realtime counter.  Returns workgroup slots copied. */
+int mldhip_profile_trace(mldhip_handle* h, const char* name, int32_t B, int32_t T, uint64_t* out_host,
+                         int64_t cap_u64, void* stream);
+
 /* Per-phase kernel launch counts of the last sample() (denoise loop, decode, joints). */
 int mldhip_get_launch_counts(mldhip_handle* h, int32_t* out_host /*[3]*/);
 

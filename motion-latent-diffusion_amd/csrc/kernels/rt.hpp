@@ -81,4 +81,25 @@ __device__ __forceinline__ void st4(float* p, F4 v) { *reinterpret_cast<F4*>(p) 
 
 constexpr float kLnEps = 1e-5f;
 
+// shader-clock timestamp pinned in program order (phase tracing of a kernel; measurement only)
+__device__ __forceinline__ unsigned long long clock_pinned() {
+#if defined(MLDHIP_SIM)
+  return 0ull;
+#else
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const unsigned long long t = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+#endif
+}
+__device__ __forceinline__ unsigned long long realtime_100mhz() {
+#if defined(MLDHIP_SIM)
+  return 0ull;
+#else
+  return __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
 }  // namespace mld

@@ -46,6 +46,7 @@ struct Tile32Args {
   float* P = nullptr;            // partial epilogue when non-null: P[z][M][N] = acc (raw)
   long long pstride = 0;
   int M = 0, N = 0;
+  unsigned long long* trace = nullptr;   // measurement only: 8 timestamps per wave (see mldhip_profile_trace)
 };
 
 constexpr int kT32Stride = 260;                         // LDS row stride (floats): 256 + 4 pad
@@ -79,6 +80,7 @@ __device__ __forceinline__ F4 f4add(F4 a, F4 b) { return F4{a.x + b.x, a.y + b.y
 // grid = (ceil(M/32), N/64, K/256); block = 512 (8 waves: wave w -> column tile w&3, row tile w>>2).
 // A prologue: each wave assembles 4 rows (w, w+8, w+16, w+24 of the tile); lane l owns columns 4l..4l+3.
 // EVERY global load of the workgroup is issued before the first dependent instruction.
+template <bool TRACE>
 __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
@@ -93,6 +95,9 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
   const ASrc& src = second ? p.src[1] : p.src[0];
   const int acol = (second ? z - p.nz0 : z) * 256;
   const int wcol = z * 256;
+  unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, rt0 = 0;
+  constexpr bool tracing = TRACE;
+  if constexpr (tracing) { rt0 = realtime_100mhz(); ts[0] = clock_pinned(); }
 
   // ---- weights: 8 rows per wave, one coalesced 1 KiB row per instruction
   F4 wreg[8];
@@ -196,11 +201,14 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
         if (live[i]) st4(src.out + (long long)rows[i] * src.ldout + lane * 4, areg[i]);
     }
   }
+  if constexpr (tracing) ts[1] = clock_pinned();      // every load landed, prologue math done
 #pragma unroll
   for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * kT32Stride + lane * 4, wreg[i]);
 #pragma unroll
   for (int i = 0; i < 4; ++i) st4(As + (wave + i * 8) * kT32Stride + lane * 4, areg[i]);
+  if constexpr (tracing) ts[2] = clock_pinned();      // tile parked in LDS (this wave)
   __syncthreads();
+  if constexpr (tracing) ts[3] = clock_pinned();      // barrier passed
 
   // ---- 64 MFMAs per wave: one 16x16 tile over K = 256, two accumulators to hide the MFMA latency
   const int r = lane & 15, g = lane >> 4;
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
     acc1 = mfma_f32_16x16x4(a1.w, b1.w, acc1);
   }
   const f32x4 acc = acc0 + acc1;
+  if constexpr (tracing) { asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); ts[4] = clock_pinned(); }   // MFMAs retired
   const int col = n0 + ct * 16 + r;
   if (col >= p.N) return;
   if (p.P) {
@@ -242,6 +251,16 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
         else if (p.act == 2) v = silu(v);
         p.Y[(long long)row * p.ldy + col] = v;
       }
+    }
+  }
+  if constexpr (tracing) {
+    ts[5] = clock_pinned();                 // epilogue stores issued and drained
+    if (lane == 0) {
+      const long long wg = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+      unsigned long long* o = p.trace + (wg * 8 + wave) * 8;
+      for (int i = 0; i < 6; ++i) o[i] = ts[i];
+      o[6] = rt0;
+      o[7] = realtime_100mhz();
     }
   }
 }

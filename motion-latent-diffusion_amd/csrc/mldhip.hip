@@ -95,6 +95,8 @@ struct mldhip_engine {
   // decode
   float *cv1, *cvec, *LNO, *feats_int, *joints_int, *zbuf;
   float *Po, *Pf, *Ps;   // denoiser split-K slabs: out-proj [1], FFN2 [4], skip-linear [2], each [6*max_batch][256]
+  unsigned long long* trace_buf = nullptr;   // measurement only (mldhip_profile_trace)
+  unsigned long long* trace_on = nullptr;    // non-null while a traced launch is being built
   float* TP;             // text projection rows [2*max_batch][256] (+pe[2]), gathered per chain
   int nchains = 1;       // independent sub-batch chains of the reverse loop (parallel graph branches)
 
@@ -346,9 +348,15 @@ GemmArgs lin_args(const float* A, int lda, int K, const float* W, const float* b
 }
 
 // ---- denoiser layer pipeline on the tile32 kernels (4 launches per encoder layer) ----------------
-void tile32(Ctx& c, const Tile32Args& a, int nz) {
+void tile32(Ctx& c, const Tile32Args& a_, int nz) {
+  Tile32Args a = a_;
+  a.trace = c.e->trace_on;
   dim3 grid((a.M + 31) / 32, (a.N + 63) / 64, nz);
-  MLD_LAUNCH(gemm_tile32_kernel, grid, dim3(512), kT32LdsBytes, c.stream, a);
+  if (a.trace) {
+    MLD_LAUNCH((gemm_tile32_kernel<true>), grid, dim3(512), kT32LdsBytes, c.stream, a);
+  } else {
+    MLD_LAUNCH((gemm_tile32_kernel<false>), grid, dim3(512), kT32LdsBytes, c.stream, a);
+  }
   count(c);
   check_launch(c, "gemm_tile32");
 }
@@ -757,7 +765,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<18>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
+  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
+  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
   (void)hipFuncSetAttribute((const void*)gemm_kernel<1, 4, 2, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<1, 4, 2, 4>());
   (void)hipFuncSetAttribute((const void*)gemm_kernel<2, 2, 2, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<2, 2, 2, 4>());
   (void)hipGetLastError();
@@ -777,6 +786,7 @@ void mldhip_destroy(mldhip_handle* e) {
   if (e->arena) (void)hipFree(e->arena);
   if (e->ws) (void)hipFree(e->ws);
   if (e->lens_dev) (void)hipFree(e->lens_dev);
+  if (e->trace_buf) (void)hipFree(e->trace_buf);
   delete e;
 }
 
@@ -1036,6 +1046,26 @@ int mldhip_profile_kernel(mldhip_handle* e, const char* name, int32_t B, int32_t
   }
   e->phase = saved_phase;
   return c.rc;
+}
+
+int mldhip_profile_trace(mldhip_handle* e, const char* name, int32_t B, int32_t T, uint64_t* out_host, int64_t cap_u64, void* stream_) {
+  // Runs ONE traced launch of a den_* kernel (after 3 untraced warm-ups) and copies back 8 timestamps per
+  // wave: [0] start [1] loads landed + prologue [2] LDS written [3] barrier passed [4] MFMAs done
+  // [5] stores drained (shader clock), [6]/[7] start/end on the 100 MHz realtime counter.
+  if (!e || !name || !out_host) return MLDHIP_EINVAL;
+  constexpr int64_t kMax = 512 * 8 * 8;
+  if (!e->trace_buf && hipMalloc((void**)&e->trace_buf, kMax * sizeof(uint64_t)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(trace)");
+  double fl = 0;
+  if (int rc = mldhip_profile_kernel(e, name, B, T, 3, &fl, stream_)) return rc;
+  HIP_TRY(e, hipMemsetAsync(e->trace_buf, 0, kMax * sizeof(uint64_t), (hipStream_t)stream_));
+  e->trace_on = e->trace_buf;
+  int rc = mldhip_profile_kernel(e, name, B, T, 1, &fl, stream_);
+  e->trace_on = nullptr;
+  if (rc) return rc;
+  HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream_));
+  const int64_t n = std::min<int64_t>(cap_u64, kMax);
+  HIP_TRY(e, hipMemcpy(out_host, e->trace_buf, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return (int)(n / 64);
 }
 
 int mldhip_get_timesteps(mldhip_handle* e, int32_t* out, int32_t n) {

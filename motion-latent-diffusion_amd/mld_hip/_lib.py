@@ -51,6 +51,7 @@ _SYMBOLS = {
     "mldhip_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mldhip_feats2joints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mldhip_profile_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
+    "mldhip_profile_trace": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.c_int64, C.c_void_p]),
     "mldhip_get_timesteps": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]),
     "mldhip_get_alphas_cumprod": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
     "mldhip_get_launch_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
@@ -184,6 +185,13 @@ class Engine:
         fl = C.c_double(0.0)
         self._check(self.lib.mldhip_profile_kernel(self._h, name.encode(), B, T, iters, C.byref(fl), stream))
         return fl.value
+
+    def profile_trace(self, name: str, B: int, T: int, stream: int = 0) -> np.ndarray:
+        """[workgroups, 8 waves, 8] uint64 timestamps of one traced den_* launch (measurement only)."""
+        cap = 512 * 64
+        buf = (C.c_uint64 * cap)()
+        n = self._check(self.lib.mldhip_profile_trace(self._h, name.encode(), B, T, buf, cap, stream))
+        return np.ctypeslib.as_array(buf).reshape(-1, 8, 8)[:n].copy()
 
     def timesteps(self) -> np.ndarray:
         n = self.cfg.num_inference_steps
