@@ -46,23 +46,12 @@ def algorithmic_gflop(B, T, D=256, F=1024, L=9, NF=263, steps=STEPS_DDIM):
 
 def pack_and_broadcast_weights(rank, world, dev):
     """Rank 0 builds the synthetic checkpoint; ONE broadcast ships it (RCCL over xGMI when world > 1)."""
-    sd_d, sd_v = syn.make_denoiser_state_dict(), syn.make_vae_state_dict()      # cheap: gives keys/shapes everywhere
-    mean, std = syn.make_mean_std()
-    items = [("denoiser." + k, v) for k, v in sd_d.items()] + [("vae." + k, v) for k, v in sd_v.items()] + \
-            [("mean", mean), ("std", std)]
-    total = sum(v.size for _, v in items)
-    if rank == 0:
-        blob = torch.from_numpy(np.concatenate([v.ravel() for _, v in items])).to(dev)
-    else:
-        blob = torch.empty(total, dtype=torch.float32, device=dev)
-    if world > 1:
-        import torch.distributed as dist
-        dist.broadcast(blob, src=0)
-    out, off = {}, 0
-    for k, v in items:
-        out[k] = blob[off:off + v.size].view(*v.shape)
-        off += v.size
-    return out, total * 4
+    from mld_hip import dp
+    template = {**{"denoiser." + k: v for k, v in syn.make_denoiser_state_dict().items()},
+                **{"vae." + k: v for k, v in syn.make_vae_state_dict().items()}}
+    template["mean"], template["std"] = syn.make_mean_std()
+    state = dp.broadcast_state(template if rank == 0 else {}, template, dev, src=0)
+    return state, sum(v.size for v in template.values()) * 4
 
 
 def time_kernel(eng, name, B, T, iters, stream):

@@ -1,0 +1,64 @@
+"""``HipMldDenoiser`` -- drop-in for ``mld.models.architectures.mld_denoiser.MldDenoiser`` (text condition).
+
+Same constructor keywords (mld_denoiser.py:18-38), same ``forward(sample, timestep,
+encoder_hidden_states, lengths=None) -> (sample,)`` contract (mld_denoiser.py:135-228), same
+``state_dict`` keys; the arithmetic runs in libmldhip's HIP kernels.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import synthetic as syn
+from ._module import HipModule
+
+
+class HipMldDenoiser(HipModule):
+    _prefix = "denoiser."
+
+    def __init__(self, ablation, nfeats: int = 263, condition: str = "text", latent_dim: list = [1, 256],
+                 ff_size: int = 1024, num_layers: int = 6, num_heads: int = 4, dropout: float = 0.1,
+                 normalize_before: bool = False, activation: str = "gelu", flip_sin_to_cos: bool = True,
+                 return_intermediate_dec: bool = False, position_embedding: str = "learned", arch: str = "trans_enc",
+                 freq_shift: int = 0, guidance_scale: float = 7.5, guidance_uncondp: float = 0.1,
+                 text_encoded_dim: int = 768, nclasses: int = 10, **kwargs) -> None:
+        super().__init__()
+        abl = ablation if isinstance(ablation, dict) else vars(ablation) if not hasattr(ablation, "get") else ablation
+        get = (lambda k, d=None: abl.get(k, d)) if hasattr(abl, "get") else (lambda k, d=None: getattr(ablation, k, d))
+        unsupported = []
+        if condition not in ("text",):
+            unsupported.append(f"condition={condition!r} (action / text_uncond: SURVEY.md §8f row 3)")
+        if arch != "trans_enc" or not get("SKIP_CONNECT", False):
+            unsupported.append(f"arch={arch!r}/SKIP_CONNECT={get('SKIP_CONNECT')} (only the skip trans_enc of config_mld_humanml3d)")
+        if get("VAE_TYPE", "mld") == "no":
+            unsupported.append("VAE_TYPE='no' (raw-motion diffusion: SURVEY.md §8f row 2)")
+        if get("DIFF_PE_TYPE", "mld") != "mld" or position_embedding != "learned":
+            unsupported.append("only DIFF_PE_TYPE='mld' with learned positional embeddings")
+        if normalize_before or activation != "gelu" or not flip_sin_to_cos or freq_shift != 0:
+            unsupported.append("post-norm / gelu / flip_sin_to_cos=True / freq_shift=0 expected")
+        if list(latent_dim) != [1, 256] or num_heads * 64 != 256 or num_layers % 2 == 0:
+            unsupported.append(f"latent_dim={latent_dim}, num_heads={num_heads}, num_layers={num_layers}")
+        if unsupported:
+            raise NotImplementedError("HipMldDenoiser: " + "; ".join(unsupported))
+        self.latent_dim = latent_dim[-1]
+        self.text_encoded_dim = text_encoded_dim
+        self.condition = condition
+        self.arch = arch
+        self.num_layers = num_layers
+        self.ff_size = ff_size
+        dims = syn.ModelDims(latent_dim=self.latent_dim, latent_size=latent_dim[0], ff_size=ff_size, num_layers=num_layers,
+                             num_heads=num_heads, nfeats=nfeats, text_dim=text_encoded_dim)
+        self._register_tree(syn.make_denoiser_state_dict(seed=0, dims=dims))
+
+    def forward(self, sample, timestep, encoder_hidden_states, lengths=None, **kwargs):
+        """sample [R, 1, D], timestep int / 0-d tensor, encoder_hidden_states [R, 1, text_dim] -> ([R, 1, D],)."""
+        sample = self._check(sample, "sample")
+        text = self._check(encoder_hidden_states, "encoder_hidden_states")
+        if sample.dim() != 3 or sample.shape[1] != 1 or sample.shape[2] != self.latent_dim:
+            raise ValueError(f"sample must be [R, 1, {self.latent_dim}], got {tuple(sample.shape)}")
+        if text.shape[0] != sample.shape[0] or text.shape[-1] != self.text_encoded_dim or text.numel() != sample.shape[0] * self.text_encoded_dim:
+            raise ValueError(f"encoder_hidden_states must be [R, 1, {self.text_encoded_dim}], got {tuple(text.shape)}")
+        t = int(timestep.reshape(-1)[0].item()) if torch.is_tensor(timestep) else int(timestep)
+        eng = self.sync_weights()
+        out = torch.empty_like(sample)
+        eng.denoiser_forward(sample, t, text, sample.shape[0], out, self._stream())
+        return (out,)

@@ -1,0 +1,149 @@
+"""``MLD`` -- the orchestrator of the sampling path with the reference's call surface
+(mld/models/modeltype/mld.py:33-143 construct, :216-265 forward, :267-275 gen_from_latent,
+:290-360 _diffusion_reverse), minus Lightning/training/metrics (out of scope).
+
+Two execution paths, same results:
+  fused   -- every network part is a Hip* drop-in: ONE ``mldhip_sample`` call (hipGraph replay of the
+             50-step loop + decode + joints); this is what bench.py measures.
+  modular -- the reference's own Python loop over ``denoiser`` / ``scheduler.step`` / ``vae.decode``; used
+             when a part was swapped for something else, and by the parity tests of the per-op entry points.
+"""
+from __future__ import annotations
+
+import inspect
+from collections import OrderedDict
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import engine as _engine
+from .config import instantiate_from_config
+from .denoiser import HipMldDenoiser
+from .scheduler import HipDDIMScheduler
+from .vae import HipMldVae
+
+
+def remove_padding(tensors, lengths):
+    """mld/utils/temos_utils.py:24-28."""
+    return [t[:n] for t, n in zip(tensors, lengths)]
+
+
+class MLD(nn.Module):
+    def __init__(self, cfg, datamodule, text_encoder: Optional[nn.Module] = None, engine_key: Optional[str] = None, **kwargs):
+        super().__init__()
+        self.cfg = cfg
+        self.stage = cfg.TRAIN.get("STAGE", "diffusion")
+        self.condition = cfg.model.condition
+        self.nfeats = cfg.DATASET.NFEATS
+        self.njoints = cfg.DATASET.NJOINTS
+        self.latent_dim = cfg.model.latent_dim
+        self.guidance_scale = cfg.model.guidance_scale
+        self.datamodule = datamodule
+        self.vae_type = cfg.model.motion_vae.target.split(".")[-1].lower().replace("hip", "").replace("vae", "")
+        if self.condition != "text" or self.stage not in ("diffusion", "vae_diffusion"):
+            raise NotImplementedError(f"mld_hip.MLD covers text-to-motion sampling (condition={self.condition!r}, stage={self.stage!r})")
+        self._engine_key = engine_key
+        if engine_key is None:
+            _engine.configure(num_inference_steps=cfg.model.scheduler.num_inference_timesteps)
+        self.text_encoder = text_encoder if text_encoder is not None else instantiate_from_config(cfg.model.text_encoder)
+        self.vae = instantiate_from_config(cfg.model.motion_vae)
+        self.denoiser = instantiate_from_config(cfg.model.denoiser)
+        self.scheduler = instantiate_from_config(cfg.model.scheduler)
+        for m in (self.vae, self.denoiser):
+            if engine_key is not None and hasattr(m, "use_engine"):
+                m.use_engine(engine_key)
+        self.sample_mean = False
+        self.fact = None
+        self.do_classifier_free_guidance = self.guidance_scale > 1.0
+        self.feats2joints = datamodule.feats2joints
+        self.times: List[float] = []
+
+    # ------------------------------------------------------------------ checkpoint contract (base.py:96-127)
+    def load_state_dict(self, state_dict, strict: bool = True):
+        new = OrderedDict(("text_encoder." + k, v) for k, v in self.text_encoder.state_dict().items())
+        for k, v in state_dict.items():
+            if "text_encoder" not in k and not k.startswith("t2m_"):      # evaluator nets are not part of sampling
+                new[k] = v
+        return super().load_state_dict(new, strict)
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def fused(self) -> bool:
+        return (isinstance(self.denoiser, HipMldDenoiser) and isinstance(self.vae, HipMldVae)
+                and isinstance(self.scheduler, HipDDIMScheduler) and self.do_classifier_free_guidance)
+
+    def _engine(self):
+        eng = self.denoiser.sync_weights()
+        self.vae.sync_weights()
+        want = self.scheduler.engine_config(self.cfg.model.scheduler.num_inference_timesteps)
+        for k in ("num_train_timesteps", "num_inference_steps", "steps_offset", "set_alpha_to_one"):
+            if getattr(eng.cfg, k) != want[k]:
+                raise RuntimeError(f"engine/scheduler mismatch on {k}: engine {getattr(eng.cfg, k)}, scheduler {want[k]}; "
+                                   "create the engine with mld_hip.engine.configure(**scheduler.engine_config(n)) first")
+        if abs(eng.cfg.guidance_scale - self.guidance_scale) > 1e-6:
+            raise RuntimeError("engine guidance_scale differs from cfg.model.guidance_scale")
+        return eng
+
+    # ------------------------------------------------------------------ fused path
+    @torch.no_grad()
+    def sample(self, text_emb: torch.Tensor, lengths: List[int], init_latents: Optional[torch.Tensor] = None):
+        """text_emb [2B, 1, 768] (uncond half first) -> (joints [B,T,22,3], feats [B,T,nfeats], latents [B,1,D]) on device."""
+        lengths = [int(x) for x in lengths]
+        B, T = len(lengths), max(lengths)
+        dev = text_emb.device
+        text_emb = text_emb.float().contiguous()
+        if init_latents is None:
+            init_latents = torch.randn((B, self.latent_dim[0], self.latent_dim[-1]), device=dev, dtype=torch.float)   # mld.py:303
+        init_latents = init_latents.float().contiguous()
+        eng = self._engine()
+        dm_eng = self.datamodule._engine(dev) if hasattr(self.datamodule, "_engine") else eng
+        if dm_eng is not eng:
+            raise RuntimeError("datamodule and network parts are bound to different engines")
+        _engine.finalize_if_dirty(eng, _engine.current_stream_handle(text_emb))
+        lat = torch.empty(B, self.latent_dim[0], self.latent_dim[-1], device=dev)
+        feats = torch.empty(B, T, self.nfeats, device=dev)
+        joints = torch.empty(B, T, self.njoints, 3, device=dev)
+        eng.sample(text_emb, init_latents, lengths, lat, feats, joints, _engine.current_stream_handle(text_emb))
+        return joints, feats, lat
+
+    # ------------------------------------------------------------------ reference surface
+    @torch.no_grad()
+    def forward(self, batch, init_latents: Optional[torch.Tensor] = None):
+        texts, lengths = list(batch["text"]), list(batch["length"])
+        if self.do_classifier_free_guidance:
+            texts = [""] * len(texts) + texts                                   # mld.py:224-230: uncond first
+        text_emb = self.text_encoder(texts)
+        if self.fused:
+            joints, _, _ = self.sample(text_emb, lengths, init_latents)
+        else:
+            z = self._diffusion_reverse(text_emb, lengths, init_latents)
+            feats = self.vae.decode(z, lengths)
+            joints = self.feats2joints(feats.detach())
+        return remove_padding(joints.detach().cpu(), lengths)                   # mld.py:264-265
+
+    @torch.no_grad()
+    def gen_from_latent(self, batch):
+        feats = self.vae.decode(batch["latent"], batch["length"])
+        return remove_padding(self.feats2joints(feats.detach()).cpu(), batch["length"])
+
+    @torch.no_grad()
+    def _diffusion_reverse(self, encoder_hidden_states, lengths=None, init_latents: Optional[torch.Tensor] = None):
+        """The reference's Python loop (mld.py:290-360) over the drop-in parts -> [latent_size, B, D]."""
+        bsz = encoder_hidden_states.shape[0] // (2 if self.do_classifier_free_guidance else 1)
+        latents = init_latents if init_latents is not None else torch.randn(
+            (bsz, self.latent_dim[0], self.latent_dim[-1]), device=encoder_hidden_states.device, dtype=torch.float)
+        latents = latents * self.scheduler.init_noise_sigma
+        self.scheduler.set_timesteps(self.cfg.model.scheduler.num_inference_timesteps)
+        extra = {}
+        if "eta" in set(inspect.signature(self.scheduler.step).parameters.keys()):
+            extra["eta"] = self.cfg.model.scheduler.eta
+        for t in self.scheduler.timesteps.tolist():
+            x = torch.cat([latents] * 2) if self.do_classifier_free_guidance else latents
+            noise_pred = self.denoiser(sample=x, timestep=t, encoder_hidden_states=encoder_hidden_states,
+                                       lengths=(list(lengths) * 2 if lengths is not None else None))[0]
+            if self.do_classifier_free_guidance:
+                u, c = noise_pred.chunk(2)
+                noise_pred = u + self.guidance_scale * (c - u)
+            latents = self.scheduler.step(noise_pred, t, latents, **extra).prev_sample
+        return latents.permute(1, 0, 2)

@@ -1,0 +1,76 @@
+"""``HipDDIMScheduler`` -- drop-in for ``diffusers.DDIMScheduler`` as the reference uses it
+(configs/modules/scheduler.yaml:1-14; call sites mld.py:81-83,310-320,345-346).
+
+Third-party arithmetic restated from the published algorithm (diffusers is not installed; SURVEY.md App.
+A.3, parity unpinned): float32 tables, scaled_linear betas, steps_offset, set_alpha_to_one=False, eta=0.
+The tables are host logic; ``step`` is four elementwise torch ops on whatever device the sample lives
+(PyTorch-ROCm plumbing for the per-op path).  The fused ``MLD.sample`` never calls ``step``: the same
+coefficients are computed inside libmldhip and applied by the step-final kernel.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+
+class SchedulerOutput(SimpleNamespace):
+    pass
+
+
+class HipDDIMScheduler:
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
+                 beta_schedule: str = "linear", clip_sample: bool = True, set_alpha_to_one: bool = True,
+                 steps_offset: int = 0, prediction_type: str = "epsilon", **kwargs):
+        if beta_schedule != "scaled_linear":
+            raise NotImplementedError(f"beta_schedule={beta_schedule!r}: the MLD configs use 'scaled_linear'")
+        if clip_sample:
+            raise NotImplementedError("clip_sample=True is not used by any MLD config")
+        if prediction_type != "epsilon":
+            raise NotImplementedError("PREDICT_EPSILON=False (prediction_type='sample') is not shipped by any MLD config")
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                      beta_schedule=beta_schedule, clip_sample=clip_sample, set_alpha_to_one=set_alpha_to_one,
+                                      steps_offset=steps_offset, prediction_type=prediction_type)
+        self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    def engine_config(self, num_inference_steps: int):
+        """Fields of mldhip_config that must agree with this scheduler for the fused path."""
+        c = self.config
+        return dict(num_train_timesteps=c.num_train_timesteps, num_inference_steps=num_inference_steps,
+                    steps_offset=c.steps_offset, set_alpha_to_one=int(c.set_alpha_to_one),
+                    beta_start=c.beta_start, beta_end=c.beta_end)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.config.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+        self.timesteps = torch.from_numpy(ts).to(device) if device is not None else torch.from_numpy(ts)
+
+    def step(self, model_output, timestep, sample, eta: float = 0.0, **kwargs):
+        if eta != 0.0:
+            raise NotImplementedError("eta > 0 draws noise inside the scheduler; MLD uses eta = 0 (scheduler.yaml:4)")
+        if self.num_inference_steps is None:
+            raise ValueError("call set_timesteps() first")
+        t = int(timestep)
+        prev = t - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+        sa, sb = float(a_t ** 0.5), float((1 - a_t) ** 0.5)
+        pa, pb = float(a_p ** 0.5), float((1 - a_p) ** 0.5)
+        x0 = (sample - sb * model_output) / sa
+        return SchedulerOutput(prev_sample=pa * x0 + pb * model_output, pred_original_sample=x0)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        a = self.alphas_cumprod.to(original_samples.device)[timesteps].reshape(-1, *([1] * (original_samples.dim() - 1)))
+        return a.sqrt() * original_samples + (1 - a).sqrt() * noise

@@ -131,6 +131,12 @@ def main():
     ts = sch.set_timesteps(50)
     np.savez_compressed(os.path.join(OUT, "ddim_table.npz"), timesteps=ts, alphas_cumprod=sch.alphas_cumprod,
                         coeffs=np.array([sch.coeffs(t) for t in ts], np.float32))
+    # ---- 6. checkpoint key contract: names + shapes of the reference modules' state_dicts
+    import json
+    keys = {"denoiser": {k: list(v.shape) for k, v in den.state_dict().items()},
+            "vae": {k: list(v.shape) for k, v in vae.state_dict().items()}}
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

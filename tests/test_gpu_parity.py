@@ -232,3 +232,36 @@ def test_error_behaviour(eng, dev):
     with pytest.raises(_lib.MldHipError):
         fresh.load_tensor("denoiser.encoder.norm.weight", np.zeros(255, np.float32))   # wrong shape
     fresh.close()
+
+
+def test_mld_module_surface_on_gpu(dev):
+    """The reference-shaped Python surface (YAML targets -> drop-in modules -> MLD.forward) on the real engine."""
+    from mld_hip import config as C
+    from mld_hip import engine as E
+    from mld_hip.datamodule import HipDataModule
+    from mld_hip.mld import MLD
+    from mld_hip.text_encoder import SyntheticTextEncoder
+
+    cfg = C.load_config()
+    E.configure(max_batch=8, max_frames=196)
+    model = MLD(cfg, HipDataModule(cfg), text_encoder=SyntheticTextEncoder()).to(dev).eval()
+    assert model.fused
+    texts = ["a man kicks with something or someone with his left leg.", "A person is skipping rope.", "a person walks backward slowly."]
+    lengths = [50, 100, 100]                                   # demo/example.txt
+    lat0 = _cuda(syn.make_batch(3, lengths).init_latents, dev)
+    joints = model({"text": texts, "length": lengths}, init_latents=lat0)
+    assert [tuple(j.shape) for j in joints] == [(50, 22, 3), (100, 22, 3), (100, 22, 3)] and not joints[0].is_cuda
+    ops = O.NumpyOps(np.float32)
+    emb = model.text_encoder([""] * 3 + texts)
+    mean, std = syn.make_mean_std()
+    jr = O.sample(ops, O.to_backend(ops, syn.make_denoiser_state_dict()), O.to_backend(ops, syn.make_vae_state_dict()),
+                  emb.cpu().numpy(), lat0.cpu().numpy(), lengths, mean, std)
+    for i, n in enumerate(lengths):
+        assert np.abs(joints[i].numpy() - jr[i, :n]).max() < 1e-3
+    # per-op drop-ins in the reference's own loop (mld.py:290-360) agree with the fused graph
+    z = model._diffusion_reverse(emb, lengths, init_latents=lat0)
+    feats = model.vae.decode(z.contiguous(), lengths)
+    j2 = model.feats2joints(feats).cpu().numpy()
+    for i, n in enumerate(lengths):
+        assert np.abs(j2[i, :n] - joints[i].numpy()).max() < 1e-3
+    E.drop_engines()

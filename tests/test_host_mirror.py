@@ -1,0 +1,190 @@
+"""Host-side mirror of the reference's plugin surface (config merge, drop-in modules, MLD orchestrator),
+exercised on CPU through the TEST-ONLY simulator engine (injected; the package itself has no CPU path)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import simlib
+from mld_hip import config as C
+from mld_hip import engine as E
+from mld_hip import synthetic as syn
+from mld_hip.datamodule import HipDataModule
+from mld_hip.denoiser import HipMldDenoiser
+from mld_hip.mld import MLD
+from mld_hip.scheduler import HipDDIMScheduler
+from mld_hip.text_encoder import SyntheticTextEncoder
+from mld_hip.vae import HipMldVae
+from oracle import mld_oracle as O
+
+REF = "/root/reference"
+
+
+# ------------------------------------------------------------------------------------------ config
+def test_config_merge_order_and_interpolation():
+    cfg = C.load_config()
+    assert cfg.model.target == "modules_hip"
+    d = cfg.model.denoiser
+    assert d.target == "mld_hip.denoiser.HipMldDenoiser"
+    assert d.params.latent_dim == [1, 256] and d.params.condition == "text" and d.params.guidance_scale == 7.5
+    assert d.params.nfeats == 263 and d.params.num_layers == 9
+    abl = d.params.ablation
+    assert abl.SKIP_CONNECT is True and abl.PE_TYPE == "mld" and abl.DIFF_PE_TYPE == "mld"   # experiment overrides base
+    assert abl.PREDICT_EPSILON is True and abl.MLP_DIST is False                             # base survives
+    assert cfg.model.scheduler.num_inference_timesteps == 50 and cfg.model.scheduler.eta == 0.0
+    assert cfg.model.scheduler.params.steps_offset == 1 and cfg.model.scheduler.params.set_alpha_to_one is False
+    assert cfg.model.text_encoder.params.modelpath == cfg.model.clip_path                     # from assets.yaml
+    over = C.load_config(overrides={"model.guidance_scale": 3.0})
+    assert over.model.denoiser.params.guidance_scale == 3.0                                   # interpolation sees override
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+def test_hot_path_params_equal_the_reference_yamls():
+    """Same `params:` blocks as configs/modules/*.yaml and same experiment keys (only targets differ)."""
+    import yaml
+    mine = C.load_config()
+    for part, fn in (("denoiser", "denoiser.yaml"), ("motion_vae", "motion_vae.yaml"), ("scheduler", "scheduler.yaml")):
+        ref = yaml.safe_load(open(os.path.join(REF, "configs", "modules", fn)))[part]
+        got = yaml.safe_load(open(os.path.join(C.CONFIG_DIR, "modules_hip", fn)))[part]
+        assert ref["params"] == got["params"], part
+        for k in ("num_inference_timesteps", "eta"):
+            if k in ref:
+                assert ref[k] == got[k]
+    ref_exp = yaml.safe_load(open(os.path.join(REF, "configs", "config_mld_humanml3d.yaml")))
+    for k in ("latent_dim", "ff_size", "num_layers", "num_head", "guidance_scale", "guidance_uncondp", "condition", "vae"):
+        assert ref_exp["model"][k] == mine.model[k], k
+    assert ref_exp["TRAIN"]["ABLATION"] == {k: mine.TRAIN.ABLATION[k] for k in ref_exp["TRAIN"]["ABLATION"]}
+    assert ref_exp["TEST"]["CHECKPOINTS"] == mine.TEST.CHECKPOINTS
+
+
+def test_instantiate_from_config_contract():
+    with pytest.raises(KeyError):
+        C.instantiate_from_config({"params": {}})
+    s = C.instantiate_from_config(C.load_config().model.scheduler)
+    assert isinstance(s, HipDDIMScheduler) and s.init_noise_sigma == 1.0
+
+
+# ------------------------------------------------------------------------------------------ scheduler
+def test_scheduler_matches_oracle_tables():
+    s = HipDDIMScheduler(**C.load_config().model.scheduler.params)
+    o = O.DDIMSchedule()
+    s.set_timesteps(50)
+    np.testing.assert_array_equal(s.timesteps.numpy(), o.set_timesteps(50))
+    np.testing.assert_allclose(s.alphas_cumprod.numpy(), o.alphas_cumprod, rtol=3e-6)
+    x, e = torch.randn(3, 1, 256), torch.randn(3, 1, 256)
+    for t in (981, 501, 1):
+        np.testing.assert_allclose(s.step(e, t, x, eta=0.0).prev_sample.numpy(), o.step(e.numpy(), t, x.numpy()), atol=2e-6)
+    with pytest.raises(NotImplementedError):
+        s.step(e, 1, x, eta=0.5)
+    import inspect
+    assert "eta" in inspect.signature(s.step).parameters            # the reference probes for it (mld.py:318-320)
+    assert s.config.num_train_timesteps == 1000
+
+
+# ------------------------------------------------------------------------------------------ modules
+def test_state_dict_keys_match_the_reference_modules(golden_dir):
+    keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
+    cfg = C.load_config()
+    den = C.instantiate_from_config(cfg.model.denoiser)
+    vae = C.instantiate_from_config(cfg.model.motion_vae)
+    assert {k: list(v.shape) for k, v in den.state_dict().items()} == keys["denoiser"]
+    assert {k: list(v.shape) for k, v in vae.state_dict().items()} == keys["vae"]
+    # strict load of a foreign checkpoint works and survives a round trip
+    sd = {k: torch.randn(*s) for k, s in keys["denoiser"].items()}
+    den.load_state_dict(sd, strict=True)
+    assert torch.equal(den.state_dict()["encoder.norm.weight"], sd["encoder.norm.weight"])
+    with pytest.raises(RuntimeError):
+        den.load_state_dict({k: v for k, v in sd.items() if k != "encoder.norm.weight"}, strict=True)
+
+
+def test_unsupported_configurations_fail_loudly():
+    abl = dict(SKIP_CONNECT=True, VAE_TYPE="mld", DIFF_PE_TYPE="mld", PE_TYPE="mld", MLP_DIST=False)
+    with pytest.raises(NotImplementedError):
+        HipMldDenoiser(ablation=abl, condition="action", num_layers=9)
+    with pytest.raises(NotImplementedError):
+        HipMldDenoiser(ablation={**abl, "VAE_TYPE": "no"}, num_layers=9)
+    with pytest.raises(NotImplementedError):
+        HipMldVae(ablation=abl, nfeats=263, arch="all_encoder")
+    d = HipMldDenoiser(ablation=abl, num_layers=9)
+    with pytest.raises(RuntimeError):                      # CPU tensors, no injected engine: no CPU path
+        d(torch.zeros(2, 1, 256), 5, torch.zeros(2, 1, 768))
+
+
+@pytest.fixture(scope="module")
+def sim_key():
+    eng = simlib._lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=4, max_frames=40, num_inference_steps=2)
+    key = E.inject_engine(eng, "inject:hostmirror")
+    yield key
+    E._engines.pop(key, None)
+    eng.close()
+
+
+def _cfg2():
+    return C.load_config(overrides={"model.scheduler.num_inference_timesteps": 2})
+
+
+def test_modules_forward_through_the_engine(sim_key):
+    cfg = _cfg2()
+    den = C.instantiate_from_config(cfg.model.denoiser).use_engine(sim_key)
+    vae = C.instantiate_from_config(cfg.model.motion_vae).use_engine(sim_key)
+    ops = O.NumpyOps(np.float32)
+    b = syn.make_batch(2, [20, 13])
+    x = torch.from_numpy(np.concatenate([b.init_latents] * 2))
+    out = den(sample=x, timestep=torch.tensor(981), encoder_hidden_states=torch.from_numpy(b.text_emb), lengths=[20, 13] * 2)
+    assert isinstance(out, tuple) and out[0].shape == (4, 1, 256)
+    ref = O.denoiser_forward(ops, O.to_backend(ops, syn.make_denoiser_state_dict()), x.numpy(), 981, b.text_emb)
+    assert np.abs(out[0].numpy() - ref).max() < 5e-5
+    z = torch.randn(1, 2, 256)
+    feats = vae.decode(z, [20, 13])
+    fr = O.vae_decode(ops, O.to_backend(ops, syn.make_vae_state_dict()), z.permute(1, 0, 2).numpy(), [20, 13])
+    assert feats.shape == (2, 20, 263) and np.abs(feats.numpy() - fr).max() < 5e-5
+    # weights are re-uploaded after load_state_dict
+    sd = den.state_dict()
+    sd["encoder.norm.bias"] = sd["encoder.norm.bias"] + 1.0
+    den.load_state_dict(sd)
+    out2 = den(sample=x, timestep=981, encoder_hidden_states=torch.from_numpy(b.text_emb))[0]
+    assert np.abs((out2 - out[0]).numpy() - 1.0).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        vae.encode(torch.zeros(1, 4, 263), [4])
+
+
+def test_mld_forward_fused_and_modular_agree_with_oracle(sim_key):
+    cfg = _cfg2()
+    dm = HipDataModule(cfg, engine_key=sim_key)
+    enc = SyntheticTextEncoder()
+    model = MLD(cfg, dm, text_encoder=enc, engine_key=sim_key).eval()
+    texts, lengths = ["a man kicks with his left leg.", "a person walks backward slowly."], [24, 17]
+    lat0 = torch.from_numpy(syn.make_batch(2, lengths).init_latents)
+    assert model.fused
+    joints = model({"text": texts, "length": lengths}, init_latents=lat0)
+    assert [tuple(j.shape) for j in joints] == [(24, 22, 3), (17, 22, 3)]
+    # oracle on the same embeddings / noise
+    ops = O.NumpyOps(np.float32)
+    emb = enc([""] * 2 + texts).numpy()
+    assert (emb[0] == emb[1]).all()
+    mean, std = syn.make_mean_std()
+    jr = O.sample(ops, O.to_backend(ops, syn.make_denoiser_state_dict()), O.to_backend(ops, syn.make_vae_state_dict()),
+                  emb, lat0.numpy(), lengths, mean, std, steps=2)
+    for i, n in enumerate(lengths):
+        assert np.abs(joints[i].numpy() - jr[i, :n]).max() < 1e-4
+    # the reference-style Python loop over the drop-in parts gives the same motions
+    z = model._diffusion_reverse(torch.from_numpy(emb), lengths, init_latents=lat0)
+    assert z.shape == (1, 2, 256)
+    feats = model.vae.decode(z.contiguous(), lengths)
+    j2 = model.feats2joints(feats)
+    assert np.abs(j2.numpy() - jr).max() < 1e-4
+    # checkpoint contract: denoiser.* / vae.* keys, text_encoder.* re-injected, t2m_* ignored (base.py:117-127)
+    sd = {k: v for k, v in model.state_dict().items() if not k.startswith("text_encoder.")}
+    sd["t2m_textencoder.fake"] = torch.zeros(1)
+    model.load_state_dict(sd, strict=True)
+    assert all(k.split(".")[0] in ("denoiser", "vae", "text_encoder") for k in model.state_dict())
+
+
+def test_demo_example_parser(tmp_path):
+    from mld_hip.demo import load_example_input
+    p = tmp_path / "ex.txt"
+    p.write_text("50 a man kicks with something or someone with his left leg.\n100 A person is skipping rope.\n")
+    texts, lens = load_example_input(str(p))
+    assert lens == [50, 100] and texts[1] == "A person is skipping rope."
