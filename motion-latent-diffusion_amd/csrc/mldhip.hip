@@ -724,7 +724,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   auto* e = new mldhip_engine();
   if (const char* m = std::getenv("MLDHIP_GEMM")) g_staged_gemm = std::strcmp(m, "direct") != 0;
   if (const char* m = std::getenv("MLDHIP_SMALL_M")) g_small_m = std::atoi(m);
-  e->nchains = 2;
+  e->nchains = 1;   // measured: parallel chains do not shorten the sequential depth
   if (const char* m = std::getenv("MLDHIP_CHAINS")) e->nchains = std::max(1, std::min(8, std::atoi(m)));
   e->cfg = *cfg;
   e->device = device;

@@ -111,11 +111,11 @@ def test_full_sample_sim(eng, ow):
     assert np.abs(feats - fr).max() < 1e-4
     assert np.abs(joints - jr).max() < 1e-4
     den, dec, jn = eng.launch_counts()
-    # text projection + per chain (default 2 chains -> one motion each): init + steps * (9 layers * 4 + 4 skip + 1 final)
-    assert den == 1 + 2 * (1 + 2 * (9 * 4 + 4 + 1)) and dec == 2 + 1 + 9 * 5 + 4 + 2 and jn == 1
+    # text projection + per chain (default: one chain): init + steps * (9 layers * 4 + 4 skip + 1 final)
+    assert den == 1 + 1 * (1 + 2 * (9 * 4 + 4 + 1)) and dec == 2 + 1 + 9 * 5 + 4 + 2 and jn == 1
 
 
-@pytest.mark.parametrize("nch", [1, 3])
+@pytest.mark.parametrize("nch", [2, 3])
 def test_chain_split_is_exact_sim(monkeypatch, ow, nch):
     """Sub-batch chains (parallel graph branches on the GPU) must not change any value."""
     ops, bd, bv = ow
