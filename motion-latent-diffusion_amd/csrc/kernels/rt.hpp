@@ -51,12 +51,28 @@ __device__ __forceinline__ float wave_bcast(float v, int src_lane) {
 #endif
 }
 
-// sum / max over the 16 lanes that share (lane >> 4): the column axis of an MFMA C tile
+#if !defined(MLDHIP_SIM)
+// DPP lane permutes (VALU speed, no LDS crossbar): quad_perm / row_half_mirror / row_mirror.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+#endif
+
+// sum over the 16 lanes that share (lane >> 4): the column axis of an MFMA C tile (= one DPP "row").
+// Every lane of the row receives the total.
 __device__ __forceinline__ float sum16(float v) {
+#if defined(MLDHIP_SIM)
   v += wave_xor(v, 1);
   v += wave_xor(v, 2);
   v += wave_xor(v, 4);
   v += wave_xor(v, 8);
+#else
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror: lane i <-> 7-i inside each 8
+  v += dpp_mov<0x140>(v);   // row_mirror:      lane i <-> 15-i
+#endif
   return v;
 }
 // sum / max over the 4 lanes {l, l^16, l^32, l^48}: the row-group axis of an MFMA C tile
@@ -70,9 +86,36 @@ __device__ __forceinline__ float max_groups(float v) {
   v = fmaxf(v, wave_xor(v, 32));
   return v;
 }
-__device__ __forceinline__ float sum64(float v) { return sum_groups(sum16(v)); }
+// sum over all 64 lanes, result in every lane: 4 DPP adds inside each 16-lane row, then the four row
+// totals are read through SGPRs (v_readlane) -- no ds_bpermute on the dependent chain.
+__device__ __forceinline__ float sum64(float v) {
+  v = sum16(v);
+#if defined(MLDHIP_SIM)
+  return sum_groups(v);
+#else
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
+#endif
+}
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26), branch free: the epilogue of the FFN1 GEMMs
+// evaluates it 4-32 times per lane and libm's erff is a divergent multi-branch routine.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = 1.0f / fmaf(0.3275911f, ax, 1.0f);
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float y = 1.0f - p * t * expf(-ax * ax);
+  return copysignf(y, x);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
 struct alignas(16) F4 { float x, y, z, w; };

@@ -53,27 +53,14 @@ constexpr int kT32Stride = 260;                         // LDS row stride (float
 constexpr int kT32LdsFloats = (32 + 64) * kT32Stride;   // A tile + W tile
 constexpr int kT32LdsBytes = kT32LdsFloats * 4;         // 99,840 B -> one workgroup per CU
 
-// Four independent wave reductions in lockstep (the shuffles of different rows interleave, so the cost
-// is one dependent chain, not four).
+// Independent wave reductions issued back to back: the DPP chains of different rows interleave.
 __device__ __forceinline__ void sum64x4(float (&v)[4]) {
 #pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    float t[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] = wave_xor(v[i], m);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] += t[i];
-  }
+  for (int i = 0; i < 4; ++i) v[i] = sum64(v[i]);
 }
 __device__ __forceinline__ void sum16x12(float (&v)[12]) {
 #pragma unroll
-  for (int m = 1; m < 16; m <<= 1) {
-    float t[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) t[i] = wave_xor(v[i], m);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) v[i] += t[i];
-  }
+  for (int i = 0; i < 12; ++i) v[i] = sum16(v[i]);
 }
 __device__ __forceinline__ F4 f4add(F4 a, F4 b) { return F4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 
