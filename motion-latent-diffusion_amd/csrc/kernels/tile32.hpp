@@ -67,7 +67,10 @@ __device__ __forceinline__ F4 f4add(F4 a, F4 b) { return F4{a.x + b.x, a.y + b.y
 // grid = (ceil(M/32), N/64, K/256); block = 512 (8 waves: wave w -> column tile w&3, row tile w>>2).
 // A prologue: each wave assembles 4 rows (w, w+8, w+16, w+24 of the tile); lane l owns columns 4l..4l+3.
 // EVERY global load of the workgroup is issued before the first dependent instruction.
-template <bool TRACE>
+// NS0 = compile-time slab count of src[0] when it is a combine source (0: src[0] is plain / attention):
+// keeps every load unconditional and straight-line (a per-load `cond ? load : 0` makes hipcc branch and
+// wait per element -- cdna_hip_programming.md, "three .s-level traps" (c)).
+template <int NS0, bool TRACE>
 __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
@@ -94,6 +97,10 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
     n = n < p.N ? n : p.N - 1;
     wreg[i] = ld4(p.W + (long long)n * p.ldw + wcol + lane * 4);
   }
+  // epilogue bias of this wave's output column, fetched now so its latency hides behind everything else
+  const int ecol = n0 + (wave & 3) * 16 + (lane & 15);
+  float ebias = 0.f;
+  if (p.bias) ebias = p.bias[ecol < p.N ? ecol : p.N - 1];
   int rows[4];
   bool live[4];
 #pragma unroll
@@ -143,27 +150,35 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
       areg[i].z = p0 * v[i][0].z + p1 * v[i][1].z + p2 * v[i][2].z;
       areg[i].w = p0 * v[i][0].w + p1 * v[i][1].w + p2 * v[i][2].w;
     }
-  } else if (src.nsplit == 0) {
+  } else if (NS0 == 0 || second) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) areg[i] = ld4(src.base + (long long)rows[i] * src.ld + acol + lane * 4);
   } else {
-    // ---- combine: sum of <= 4 slabs + bias + residual, then optional LayerNorm; one wave owns a row
-    F4 sl[4][4], rs[4];
-    const F4 zero = F4{0.f, 0.f, 0.f, 0.f};
+    // ---- combine: sum of NS0 slabs + bias (+ residual), then optional LayerNorm; one wave owns a row.
+    constexpr int NS = NS0 > 0 ? NS0 : 1;
+    F4 sl[4][NS], rs[4];
+    const bool has_res = src.res != nullptr, has_ln = src.gamma != nullptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-        sl[i][s] = s < src.nsplit ? ld4(src.base + s * src.pstride + (long long)rows[i] * 256 + lane * 4) : zero;
-      rs[i] = src.res ? ld4(src.res + (long long)rows[i] * src.ldres + lane * 4) : zero;
+      for (int s = 0; s < NS; ++s) sl[i][s] = ld4(src.base + s * src.pstride + (long long)rows[i] * 256 + lane * 4);
+    if (has_res) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rs[i] = ld4(src.res + (long long)rows[i] * src.ldres + lane * 4);
     }
-    const F4 bias = src.bias ? ld4(src.bias + lane * 4) : zero;
-    F4 gm = zero, bt = zero;
-    if (src.gamma) { gm = ld4(src.gamma + lane * 4); bt = ld4(src.beta + lane * 4); }
+    const F4 bias = ld4(src.bias + lane * 4);
+    F4 gm = F4{1.f, 1.f, 1.f, 1.f}, bt = F4{0.f, 0.f, 0.f, 0.f};
+    if (has_ln) { gm = ld4(src.gamma + lane * 4); bt = ld4(src.beta + lane * 4); }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)   // same association as the first version: ((s0+s1)+s2)+s3, +bias, +res
-      areg[i] = f4add(f4add(f4add(f4add(f4add(sl[i][0], sl[i][1]), sl[i][2]), sl[i][3]), bias), rs[i]);
-    if (src.gamma) {
+    for (int i = 0; i < 4; ++i) {   // ((s0+s1)+s2)+s3, + bias, + res
+      F4 v = sl[i][0];
+#pragma unroll
+      for (int s = 1; s < NS; ++s) v = f4add(v, sl[i][s]);
+      v = f4add(v, bias);
+      if (has_res) v = f4add(v, rs[i]);
+      areg[i] = v;
+    }
+    if (has_ln) {
       float s[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) s[i] = areg[i].x + areg[i].y + areg[i].z + areg[i].w;
@@ -188,7 +203,6 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
         if (live[i]) st4(src.out + (long long)rows[i] * src.ldout + lane * 4, areg[i]);
     }
   }
-  if constexpr (tracing) ts[1] = clock_pinned();      // every load landed, prologue math done
 #pragma unroll
   for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * kT32Stride + lane * 4, wreg[i]);
 #pragma unroll
@@ -218,26 +232,32 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
   }
   const f32x4 acc = acc0 + acc1;
   if constexpr (tracing) { asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); ts[4] = clock_pinned(); }   // MFMAs retired
-  const int col = n0 + ct * 16 + r;
-  if (col >= p.N) return;
-  if (p.P) {
-    float* P = p.P + z * p.pstride;
+  // ---- epilogue: bias/activation in registers, tile transposed through LDS (the A panel is dead now),
+  //      then ONE 16-byte store per lane: a wave writes 4 rows x 256 contiguous bytes.
+  constexpr int CS = 68;                      // staging row stride (floats)
+  float* Cs = smem;                           // [32][68] over the A panel
+  __syncthreads();                            // every wave finished reading As / Ws
+  {
+    const bool direct = p.P == nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = m0 + rt * 16 + g * 4 + i;
-      if (row < p.M) P[(long long)row * p.N + col] = acc[i];
-    }
-  } else {
-    const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = m0 + rt * 16 + g * 4 + i;
-      if (row < p.M) {
-        float v = acc[i] + bv;
+      float v = acc[i];
+      if (direct) {
+        v += ebias;
         if (p.act == 1) v = gelu_erf(v);
         else if (p.act == 2) v = silu(v);
-        p.Y[(long long)row * p.ldy + col] = v;
       }
+      Cs[(rt * 16 + g * 4 + i) * CS + ct * 16 + r] = v;
+    }
+  }
+  __syncthreads();
+  {
+    const int orow = tid >> 4, oc4 = tid & 15;             // 32 rows x 16 float4
+    const int grow = m0 + orow, gcol = n0 + oc4 * 4;
+    if (grow < p.M && gcol < p.N) {
+      const F4 v = ld4(Cs + orow * CS + oc4 * 4);
+      float* dst = p.P ? p.P + z * p.pstride + (long long)grow * p.N + gcol : p.Y + (long long)grow * p.ldy + gcol;
+      st4(dst, v);
     }
   }
   if constexpr (tracing) {

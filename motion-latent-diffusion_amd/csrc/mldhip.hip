@@ -352,11 +352,20 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
   Tile32Args a = a_;
   a.trace = c.e->trace_on;
   dim3 grid((a.M + 31) / 32, (a.N + 63) / 64, nz);
-  if (a.trace) {
-    MLD_LAUNCH((gemm_tile32_kernel<true>), grid, dim3(512), kT32LdsBytes, c.stream, a);
-  } else {
-    MLD_LAUNCH((gemm_tile32_kernel<false>), grid, dim3(512), kT32LdsBytes, c.stream, a);
+  const int ns = a.src[0].attn_R > 0 ? 0 : a.src[0].nsplit;
+#define MLD_T32(NS)                                                                                        \
+  do {                                                                                                     \
+    if (a.trace) { MLD_LAUNCH((gemm_tile32_kernel<NS, true>), grid, dim3(512), kT32LdsBytes, c.stream, a); }  \
+    else { MLD_LAUNCH((gemm_tile32_kernel<NS, false>), grid, dim3(512), kT32LdsBytes, c.stream, a); }         \
+  } while (0)
+  switch (ns) {
+    case 0: MLD_T32(0); break;
+    case 1: MLD_T32(1); break;
+    case 2: MLD_T32(2); break;
+    case 4: MLD_T32(4); break;
+    default: c.rc = c.e->fail(MLDHIP_EINVAL, "tile32: unsupported slab count %d", ns); return;
   }
+#undef MLD_T32
   count(c);
   check_launch(c, "gemm_tile32");
 }
@@ -703,7 +712,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   if (cfg->latent_dim != 256 || cfg->latent_size != 1) return bad("this release supports latent_dim [1, 256] only");
   if (cfg->num_heads * 64 != cfg->latent_dim) return bad("head_dim must be 64");
   if (cfg->num_layers < 3 || cfg->num_layers % 2 == 0 || cfg->num_layers > 17) return bad("num_layers must be odd, 3..17 (SkipTransformer)");
-  if (cfg->ff_size % 64 || cfg->text_dim % 32) return bad("ff_size % 64 and text_dim % 32 must be 0");
+  if ((cfg->ff_size != 256 && cfg->ff_size != 512 && cfg->ff_size != 1024) || cfg->text_dim % 32) return bad("ff_size must be 256, 512 or 1024 and text_dim % 32 == 0");
   if (cfg->max_batch < 1 || cfg->max_frames < 1 || cfg->max_frames > 288) return bad("max_batch >= 1, 1 <= max_frames <= 288");
   if (cfg->nfeats < 67 || cfg->njoints != 22) return bad("HumanML3D layout expected: nfeats >= 67, njoints 22");
   if (cfg->num_inference_steps < 1 || cfg->num_train_timesteps % cfg->num_inference_steps) return bad("num_train_timesteps must be a multiple of num_inference_steps");
@@ -765,8 +774,11 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<18>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
-  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
+#define MLD_T32_ATTR(NS)                                                                                                    \
+  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
+  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
+  MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4)
+#undef MLD_T32_ATTR
   (void)hipFuncSetAttribute((const void*)gemm_kernel<1, 4, 2, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<1, 4, 2, 4>());
   (void)hipFuncSetAttribute((const void*)gemm_kernel<2, 2, 2, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<2, 2, 2, 4>());
   (void)hipGetLastError();
