@@ -203,6 +203,7 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
         if (live[i]) st4(src.out + (long long)rows[i] * src.ldout + lane * 4, areg[i]);
     }
   }
+  if constexpr (tracing) ts[1] = clock_pinned();      // every load landed, prologue math done
 #pragma unroll
   for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * kT32Stride + lane * 4, wreg[i]);
 #pragma unroll
@@ -232,32 +233,29 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
   }
   const f32x4 acc = acc0 + acc1;
   if constexpr (tracing) { asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); ts[4] = clock_pinned(); }   // MFMAs retired
-  // ---- epilogue: bias/activation in registers, tile transposed through LDS (the A panel is dead now),
-  //      then ONE 16-byte store per lane: a wave writes 4 rows x 256 contiguous bytes.
-  constexpr int CS = 68;                      // staging row stride (floats)
-  float* Cs = smem;                           // [32][68] over the A panel
-  __syncthreads();                            // every wave finished reading As / Ws
-  {
-    const bool direct = p.P == nullptr;
+  // ---- epilogue: direct stores (16 lanes write 64 contiguous bytes per row).  A coalesced variant that
+  //      transposed the tile through LDS was measured SLOWER (+0.7-1.8 k cycles: two barriers + an LDS
+  //      round trip cost more than the wider stores save; profiles/r01_v5).
+  const int col = n0 + ct * 16 + r;
+  if (col < p.N) {
+    if (p.P) {
+      float* P = p.P + z * p.pstride;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v = acc[i];
-      if (direct) {
-        v += ebias;
-        if (p.act == 1) v = gelu_erf(v);
-        else if (p.act == 2) v = silu(v);
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + rt * 16 + g * 4 + i;
+        if (row < p.M) P[(long long)row * p.N + col] = acc[i];
       }
-      Cs[(rt * 16 + g * 4 + i) * CS + ct * 16 + r] = v;
-    }
-  }
-  __syncthreads();
-  {
-    const int orow = tid >> 4, oc4 = tid & 15;             // 32 rows x 16 float4
-    const int grow = m0 + orow, gcol = n0 + oc4 * 4;
-    if (grow < p.M && gcol < p.N) {
-      const F4 v = ld4(Cs + orow * CS + oc4 * 4);
-      float* dst = p.P ? p.P + z * p.pstride + (long long)grow * p.N + gcol : p.Y + (long long)grow * p.ldy + gcol;
-      st4(dst, v);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + rt * 16 + g * 4 + i;
+        if (row < p.M) {
+          float v = acc[i] + ebias;
+          if (p.act == 1) v = gelu_erf(v);
+          else if (p.act == 2) v = silu(v);
+          p.Y[(long long)row * p.ldy + col] = v;
+        }
+      }
     }
   }
   if constexpr (tracing) {
