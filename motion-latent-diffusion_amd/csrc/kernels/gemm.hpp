@@ -138,26 +138,30 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
     static_assert(ROWS * 8 % NT == 0, "panel rows must tile the workgroup");
     const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
     F4 stage[NLD];
+    constexpr int NLA = BM * 8 / NT;          // staging slots that hold A rows (uniform across the workgroup)
+    static_assert(BM * 8 % NT == 0, "A panel must fill whole staging slots");
+    const float relu_lo = relu ? 0.f : -INFINITY;   // fmaxf(v, -inf) == v: ReLU-on-load without a branch
     auto gload = [&](int kc) {
+      // Straight-line: no per-load condition (a `cond ? load : other` makes hipcc branch and drain vmcnt
+      // per element, which serialised this prefetch in front of the MFMAs in the first version).
       const int k = kc * 32;
       const bool first = k < p.K1;
       const float* abase = first ? A : p.A2;
       const int ald = first ? p.lda : p.lda2;
       const int ak = first ? k : k - p.K1;
 #pragma unroll
-      for (int j = 0; j < NLD; ++j) {
+      for (int j = 0; j < NLA; ++j) {
         const int idx = tid + j * NT, row = idx >> 3, c4 = idx & 7;
-        if (row < BM) {
-          int m = bm0 + row;
-          m = m < p.M ? m : p.M - 1;
-          F4 v = ld4(abase + (long long)m * ald + ak + c4 * 4);
-          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          stage[j] = v;
-        } else {
-          int n = bn0 + row - BM;
-          n = n < p.N ? n : p.N - 1;
-          stage[j] = ld4(W + (long long)n * p.ldw + k + c4 * 4);
-        }
+        int m = bm0 + row;
+        m = m < p.M ? m : p.M - 1;
+        stage[j] = ld4(abase + (long long)m * ald + ak + c4 * 4);   // ReLU is applied in lstore: no use of the
+      }                                                               // loaded value before the MFMAs of this chunk
+#pragma unroll
+      for (int j = NLA; j < NLD; ++j) {
+        const int idx = tid + j * NT, row = idx >> 3, c4 = idx & 7;
+        int n = bn0 + row - BM;
+        n = n < p.N ? n : p.N - 1;
+        stage[j] = ld4(W + (long long)n * p.ldw + k + c4 * 4);
       }
     };
     auto lstore = [&](int buf) {
@@ -165,7 +169,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < NLD; ++j) {
         const int idx = tid + j * NT, row = idx >> 3, c4 = idx & 7;
-        st4(dst + row * kGemmLdsStride + c4 * 4, stage[j]);
+        F4 v = stage[j];
+        if (j < NLA) { v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo); }
+        st4(dst + row * kGemmLdsStride + c4 * 4, v);
       }
     };
     auto lfrags = [&](int buf) {
@@ -198,27 +204,45 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   if (SPLIT) acc[0][0] += acc2;
 
   if constexpr (!LN) {
+    // per-row facts once (validity, padded-frame mask), per-column facts once (bias), activation hoisted
+    bool rowok[MREP][4];
+    float rowmask[MREP][4];
 #pragma unroll
     for (int a = 0; a < MREP; ++a)
 #pragma unroll
-      for (int b = 0; b < NREP; ++b) {
-        const int col = n0 + b * 16 + r;
-        const float bv = (bias && col < p.N) ? bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = m0 + a * 16 + g * 4 + i;
-          if (row < p.M && col < p.N) {
-            float v = acc[a][b][i] + bv;
-            if (p.act == ACT_GELU) v = gelu_erf(v);
-            else if (p.act == ACT_SILU) v = silu(v);
-            if (p.lens) {
-              int grp = row / p.rows_per_group, t = row - grp * p.rows_per_group;
-              if (t >= p.lens[grp]) v = 0.f;
-            }
-            Y[(long long)row * p.ldy + col] = v;
-          }
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + a * 16 + g * 4 + i;
+        rowok[a][i] = row < p.M;
+        rowmask[a][i] = 1.f;
+        if (p.lens) {
+          const int rc = rowok[a][i] ? row : p.M - 1;
+          const int grp = rc / p.rows_per_group, t = rc - grp * p.rows_per_group;
+          rowmask[a][i] = t < p.lens[grp] ? 1.f : 0.f;
         }
       }
+    const int act = p.act;
+#pragma unroll
+    for (int b = 0; b < NREP; ++b) {
+      const int col = n0 + b * 16 + r;
+      const bool colok = col < p.N;
+      const float bv = (bias && colok) ? bias[col] : 0.f;
+#pragma unroll
+      for (int a = 0; a < MREP; ++a) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[a][b][i] + bv;
+        if (act == ACT_GELU) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+        } else if (act == ACT_SILU) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = silu(v[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (rowok[a][i] && colok) Y[(long long)(m0 + a * 16 + g * 4 + i) * p.ldy + col] = v[i] * rowmask[a][i];
+      }
+    }
     return;
   } else {
   // ---------------- residual + LayerNorm epilogue (full rows live in this workgroup) -------------
