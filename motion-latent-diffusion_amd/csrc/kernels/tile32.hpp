@@ -54,33 +54,41 @@ constexpr int kT32LdsFloats = (32 + 64) * kT32Stride;   // A tile + W tile
 constexpr int kT32LdsBytes = kT32LdsFloats * 4;         // 99,840 B -> one workgroup per CU
 
 // Independent wave reductions issued back to back: the DPP chains of different rows interleave.
-__device__ __forceinline__ void sum64x4(float (&v)[4]) {
+template <int N>
+__device__ __forceinline__ void sum64xn(float (&v)[N]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = sum64(v[i]);
+  for (int i = 0; i < N; ++i) v[i] = sum64(v[i]);
 }
-__device__ __forceinline__ void sum16x12(float (&v)[12]) {
+template <int N>
+__device__ __forceinline__ void sum16xn(float (&v)[N]) {
 #pragma unroll
-  for (int i = 0; i < 12; ++i) v[i] = sum16(v[i]);
+  for (int i = 0; i < N; ++i) v[i] = sum16(v[i]);
 }
 __device__ __forceinline__ F4 f4add(F4 a, F4 b) { return F4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 
-// grid = (ceil(M/32), N/64, K/256); block = 512 (8 waves: wave w -> column tile w&3, row tile w>>2).
-// A prologue: each wave assembles 4 rows (w, w+8, w+16, w+24 of the tile); lane l owns columns 4l..4l+3.
+// grid = (ceil(M/MT), N/64, K/256); block = 512 (8 waves).
+//   MT = 32: wave w -> column tile w&3, row tile w>>2, all of K (64 MFMAs per wave).
+//   MT = 16: wave w -> column tile w&3, K half w>>2 (32 MFMAs per wave), halves summed through LDS.  Used for
+//            the N = 256 GEMMs (out-proj, skip linear) which would otherwise run on 48 / 96 workgroups: twice
+//            the workgroups, half the A bytes and half the per-SIMD MFMA queue per workgroup.
+// A prologue: each wave assembles MT/8 rows (w, w+8, ... of the tile); lane l owns columns 4l..4l+3.
 // EVERY global load of the workgroup is issued before the first dependent instruction.
 // NS0 = compile-time slab count of src[0] when it is a combine source (0: src[0] is plain / attention):
 // keeps every load unconditional and straight-line (a per-load `cond ? load : 0` makes hipcc branch and
 // wait per element -- cdna_hip_programming.md, "three .s-level traps" (c)).
-template <int NS0, bool TRACE>
+template <int MT, int NS0, bool TRACE>
 __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
+  static_assert(MT == 16 || MT == 32, "row tile");
+  constexpr int RPW = MT / 8;                 // A rows assembled per wave
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
 #else
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #endif
-  float* As = smem;                          // [32][260]
-  float* Ws = smem + 32 * kT32Stride;        // [64][260]
+  float* As = smem;                          // [MT][260]
+  float* Ws = smem + MT * kT32Stride;        // [64][260]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 64, z = blockIdx.z;
+  const int m0 = blockIdx.x * MT, n0 = blockIdx.y * 64, z = blockIdx.z;
   const bool second = z >= p.nz0;
   const ASrc& src = second ? p.src[1] : p.src[0];
   const int acol = (second ? z - p.nz0 : z) * 256;
@@ -101,22 +109,22 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
   const int ecol = n0 + (wave & 3) * 16 + (lane & 15);
   float ebias = 0.f;
   if (p.bias) ebias = p.bias[ecol < p.N ? ecol : p.N - 1];
-  int rows[4];
-  bool live[4];
+  int rows[RPW];
+  bool live[RPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < RPW; ++i) {
     const int row = m0 + wave + i * 8;
     live[i] = row < p.M;
     rows[i] = live[i] ? row : p.M - 1;
   }
-  F4 areg[4];
+  F4 areg[RPW];
   if (src.attn_R > 0) {
     // nn.MultiheadAttention over the 3 tokens of one sample (cross_attention.py:265-266): head = lane >> 4
     // (64 dims = 16 lanes x 4), q pre-scaled by 1/sqrt(64), softmax over the 3 keys, all in registers.
     const int R = src.attn_R;
-    F4 q[4], k[4][3], v[4][3];
+    F4 q[RPW], k[RPW][3], v[RPW][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RPW; ++i) {
       const int tok = rows[i] / R, smp = rows[i] - tok * R;
       q[i] = ld4(src.base + (long long)rows[i] * 768 + lane * 4);
 #pragma unroll
@@ -126,9 +134,9 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
         v[i][j] = ld4(kr + 256);
       }
     }
-    float sc[12];
+    float sc[RPW * 3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RPW; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         float d = q[i].x * k[i][j].x;
@@ -137,9 +145,9 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
         d = fmaf(q[i].w, k[i][j].w, d);
         sc[i * 3 + j] = d;
       }
-    sum16x12(sc);
+    sum16xn<RPW * 3>(sc);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RPW; ++i) {
       const float s0 = sc[i * 3] * 0.125f, s1 = sc[i * 3 + 1] * 0.125f, s2 = sc[i * 3 + 2] * 0.125f;
       const float m = fmaxf(s0, fmaxf(s1, s2));
       const float e0 = expf(s0 - m), e1 = expf(s1 - m), e2 = expf(s2 - m);
@@ -152,25 +160,25 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
     }
   } else if (NS0 == 0 || second) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) areg[i] = ld4(src.base + (long long)rows[i] * src.ld + acol + lane * 4);
+    for (int i = 0; i < RPW; ++i) areg[i] = ld4(src.base + (long long)rows[i] * src.ld + acol + lane * 4);
   } else {
     // ---- combine: sum of NS0 slabs + bias (+ residual), then optional LayerNorm; one wave owns a row.
     constexpr int NS = NS0 > 0 ? NS0 : 1;
-    F4 sl[4][NS], rs[4];
+    F4 sl[RPW][NS], rs[RPW];
     const bool has_res = src.res != nullptr, has_ln = src.gamma != nullptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RPW; ++i)
 #pragma unroll
       for (int s = 0; s < NS; ++s) sl[i][s] = ld4(src.base + s * src.pstride + (long long)rows[i] * 256 + lane * 4);
     if (has_res) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rs[i] = ld4(src.res + (long long)rows[i] * src.ldres + lane * 4);
+      for (int i = 0; i < RPW; ++i) rs[i] = ld4(src.res + (long long)rows[i] * src.ldres + lane * 4);
     }
     const F4 bias = ld4(src.bias + lane * 4);
     F4 gm = F4{1.f, 1.f, 1.f, 1.f}, bt = F4{0.f, 0.f, 0.f, 0.f};
     if (has_ln) { gm = ld4(src.gamma + lane * 4); bt = ld4(src.beta + lane * 4); }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {   // ((s0+s1)+s2)+s3, + bias, + res
+    for (int i = 0; i < RPW; ++i) {   // ((s0+s1)+s2)+s3, + bias, + res
       F4 v = sl[i][0];
 #pragma unroll
       for (int s = 1; s < NS; ++s) v = f4add(v, sl[i][s]);
@@ -179,19 +187,19 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
       areg[i] = v;
     }
     if (has_ln) {
-      float s[4];
+      float s[RPW];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s[i] = areg[i].x + areg[i].y + areg[i].z + areg[i].w;
-      sum64x4(s);
+      for (int i = 0; i < RPW; ++i) s[i] = areg[i].x + areg[i].y + areg[i].z + areg[i].w;
+      sum64xn<RPW>(s);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RPW; ++i) {
         const float mean = s[i] * (1.0f / 256.0f);
         areg[i] = F4{areg[i].x - mean, areg[i].y - mean, areg[i].z - mean, areg[i].w - mean};
         s[i] = areg[i].x * areg[i].x + areg[i].y * areg[i].y + areg[i].z * areg[i].z + areg[i].w * areg[i].w;
       }
-      sum64x4(s);
+      sum64xn<RPW>(s);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RPW; ++i) {
         const float rstd = rsqrtf(s[i] * (1.0f / 256.0f) + kLnEps);
         areg[i] = F4{areg[i].x * rstd * gm.x + bt.x, areg[i].y * rstd * gm.y + bt.y, areg[i].z * rstd * gm.z + bt.z,
                      areg[i].w * rstd * gm.w + bt.w};
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
     }
     if (src.out && blockIdx.y == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < RPW; ++i)
         if (live[i]) st4(src.out + (long long)rows[i] * src.ldout + lane * 4, areg[i]);
     }
   }
@@ -207,19 +215,22 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * kT32Stride + lane * 4, wreg[i]);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) st4(As + (wave + i * 8) * kT32Stride + lane * 4, areg[i]);
+  for (int i = 0; i < RPW; ++i) st4(As + (wave + i * 8) * kT32Stride + lane * 4, areg[i]);
   if constexpr (tracing) ts[2] = clock_pinned();      // tile parked in LDS (this wave)
   __syncthreads();
   if constexpr (tracing) ts[3] = clock_pinned();      // barrier passed
 
-  // ---- 64 MFMAs per wave: one 16x16 tile over K = 256, two accumulators to hide the MFMA latency
+  // ---- one 16x16 tile per wave; two accumulators hide the MFMA dependent latency
   const int r = lane & 15, g = lane >> 4;
-  const int ct = wave & 3, rt = wave >> 2;
-  const float* ap = As + (rt * 16 + r) * kT32Stride + g * 8;
-  const float* wp = Ws + (ct * 16 + r) * kT32Stride + g * 8;
+  const int ct = wave & 3;
+  const int rt = MT == 32 ? (wave >> 2) : 0;          // row tile (MT = 32)
+  const int kh = MT == 16 ? (wave >> 2) : 0;          // K half   (MT = 16)
+  constexpr int KCH = MT == 32 ? 8 : 4;               // 32-wide K chunks per wave
+  const float* ap = As + (rt * 16 + r) * kT32Stride + g * 8 + kh * 128;
+  const float* wp = Ws + (ct * 16 + r) * kT32Stride + g * 8 + kh * 128;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kc = 0; kc < 8; ++kc) {
+  for (int kc = 0; kc < KCH; ++kc) {
     const F4 a0 = ld4(ap + kc * 32), a1 = ld4(ap + kc * 32 + 4);
     const F4 b0 = ld4(wp + kc * 32), b1 = ld4(wp + kc * 32 + 4);
     acc0 = mfma_f32_16x16x4(a0.x, b0.x, acc0);
@@ -231,13 +242,21 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
     acc0 = mfma_f32_16x16x4(a1.z, b1.z, acc0);
     acc1 = mfma_f32_16x16x4(a1.w, b1.w, acc1);
   }
-  const f32x4 acc = acc0 + acc1;
+  f32x4 acc = acc0 + acc1;
+  if constexpr (MT == 16) {
+    // combine the two K halves: upper waves park their tile in LDS (the W panel is dead after a barrier)
+    __syncthreads();
+    float* red = Ws;                                   // [4 col tiles][64 lanes][4]
+    if (kh == 1) *reinterpret_cast<f32x4*>(red + (ct * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (kh == 0) acc += *reinterpret_cast<const f32x4*>(red + (ct * 64 + lane) * 4);
+  }
   if constexpr (tracing) { asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); ts[4] = clock_pinned(); }   // MFMAs retired
   // ---- epilogue: direct stores (16 lanes write 64 contiguous bytes per row).  A coalesced variant that
   //      transposed the tile through LDS was measured SLOWER (+0.7-1.8 k cycles: two barriers + an LDS
   //      round trip cost more than the wider stores save; profiles/r01_v5).
   const int col = n0 + ct * 16 + r;
-  if (col < p.N) {
+  if (col < p.N && kh == 0) {
     if (p.P) {
       float* P = p.P + z * p.pstride;
 #pragma unroll

@@ -98,6 +98,7 @@ struct mldhip_engine {
   unsigned long long* trace_buf = nullptr;   // measurement only (mldhip_profile_trace)
   unsigned long long* trace_on = nullptr;    // non-null while a traced launch is being built
   float* TP;             // text projection rows [2*max_batch][256] (+pe[2]), gathered per chain
+  bool tile16 = true;    // MLDHIP_TILE16=0 disables the 16-row K-split tiles (A/B runs)
   int nchains = 1;       // independent sub-batch chains of the reverse loop (parallel graph branches)
 
   int launches[3] = {0, 0, 0};
@@ -348,23 +349,31 @@ GemmArgs lin_args(const float* A, int lda, int K, const float* W, const float* b
 }
 
 // ---- denoiser layer pipeline on the tile32 kernels (4 launches per encoder layer) ----------------
+constexpr int t32_lds_bytes(int mt) { return (mt + 64) * kT32Stride * 4; }
+
 void tile32(Ctx& c, const Tile32Args& a_, int nz) {
   Tile32Args a = a_;
   a.trace = c.e->trace_on;
-  dim3 grid((a.M + 31) / 32, (a.N + 63) / 64, nz);
+  // 16-row K-split tiles for the narrow (N = 256) GEMMs: more workgroups, fewer bytes and MFMAs per CU
+  const bool mt16 = a.N <= 256 && ((a.M + 15) / 16) * ((a.N + 63) / 64) * nz <= 256 && c.e->tile16;
+  const int mt = mt16 ? 16 : 32;
+  dim3 grid((a.M + mt - 1) / mt, (a.N + 63) / 64, nz);
   const int ns = a.src[0].attn_R > 0 ? 0 : a.src[0].nsplit;
-#define MLD_T32(NS)                                                                                        \
-  do {                                                                                                     \
-    if (a.trace) { MLD_LAUNCH((gemm_tile32_kernel<NS, true>), grid, dim3(512), kT32LdsBytes, c.stream, a); }  \
-    else { MLD_LAUNCH((gemm_tile32_kernel<NS, false>), grid, dim3(512), kT32LdsBytes, c.stream, a); }         \
+#define MLD_T32(MT, NS)                                                                                          \
+  do {                                                                                                           \
+    if (a.trace) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, true>), grid, dim3(512), t32_lds_bytes(MT), c.stream, a); }  \
+    else { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false>), grid, dim3(512), t32_lds_bytes(MT), c.stream, a); }         \
   } while (0)
-  switch (ns) {
-    case 0: MLD_T32(0); break;
-    case 1: MLD_T32(1); break;
-    case 2: MLD_T32(2); break;
-    case 4: MLD_T32(4); break;
-    default: c.rc = c.e->fail(MLDHIP_EINVAL, "tile32: unsupported slab count %d", ns); return;
+#define MLD_T32_NS(MT)                                                                                           \
+  switch (ns) {                                                                                                  \
+    case 0: MLD_T32(MT, 0); break;                                                                               \
+    case 1: MLD_T32(MT, 1); break;                                                                               \
+    case 2: MLD_T32(MT, 2); break;                                                                               \
+    case 4: MLD_T32(MT, 4); break;                                                                               \
+    default: c.rc = c.e->fail(MLDHIP_EINVAL, "tile32: unsupported slab count %d", ns); return;                   \
   }
+  if (mt16) { MLD_T32_NS(16) } else { MLD_T32_NS(32) }
+#undef MLD_T32_NS
 #undef MLD_T32
   count(c);
   check_launch(c, "gemm_tile32");
@@ -733,6 +742,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   auto* e = new mldhip_engine();
   if (const char* m = std::getenv("MLDHIP_GEMM")) g_staged_gemm = std::strcmp(m, "direct") != 0;
   if (const char* m = std::getenv("MLDHIP_SMALL_M")) g_small_m = std::atoi(m);
+  if (const char* m = std::getenv("MLDHIP_TILE16")) e->tile16 = std::atoi(m) != 0;
   e->nchains = 1;   // measured: parallel chains do not shorten the sequential depth
   if (const char* m = std::getenv("MLDHIP_CHAINS")) e->nchains = std::max(1, std::min(8, std::atoi(m)));
   e->cfg = *cfg;
@@ -775,8 +785,10 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<18>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
 #define MLD_T32_ATTR(NS)                                                                                                    \
-  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
-  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
+  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<32, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
+  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<32, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);  \
+  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
+  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
   MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4)
 #undef MLD_T32_ATTR
   (void)hipFuncSetAttribute((const void*)gemm_kernel<1, 4, 2, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<1, 4, 2, 4>());
