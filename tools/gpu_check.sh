@@ -10,7 +10,6 @@ TAG=${1:-r01}
   echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -25
   echo "== bench"; timeout 900 python bench.py --steps 20 --warmup 3 2>gpurun_out/bench_${TAG}.err | tee gpurun_out/bench_${TAG}.json
   tail -5 gpurun_out/bench_${TAG}.err
-  for nch in 1 2 4 8; do echo "== bench chains=$nch"; MLDHIP_CHAINS=$nch timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_${TAG}_chains$nch.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k:v['avg_us'] for k,v in d['kernels'].items()})"; done
 } 2>&1 | tee gpurun_out/check_${TAG}.log
 echo "== rocprofv3" | tee -a gpurun_out/check_${TAG}.log
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG} -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}.log 2>&1
