@@ -42,6 +42,7 @@ struct GemmArgs {
 };
 
 struct Frag { float v[8]; };
+struct alignas(8) uint2_t { unsigned x, y; };
 
 template <int REP>
 __device__ __forceinline__ void load_frags(Frag (&f)[REP], const float* base, int ld, int row0, int nrows,
@@ -73,8 +74,12 @@ constexpr int gemm_lds_bytes() { return 2 * (WM * MREP * 16 + WN * NREP * 16) * 
 //                 flight while chunk k's MFMAs run; one barrier per chunk.  (The register-direct form
 //                 reached only ~50 of 157 TF on the decoder: fragment-shaped loads saturate the TA path,
 //                 cdna_hip_programming.md "x through LDS in full lines".)
-template <int WM, int WN, int MREP, int NREP, bool LN, bool STAGED = false>
+// PREC (staged path only): 0 = exact fp32 MFMA, 1 = split-bf16 ("bf16x3", rt.hpp): operands are split into
+//                 bf16 hi/lo planes while they are written to LDS (same LDS footprint as fp32), 3 bf16 MFMAs
+//                 per tile per K chunk.
+template <int WM, int WN, int MREP, int NREP, bool LN, bool STAGED = false, int PREC = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
+  static_assert(PREC == 0 || STAGED, "split-bf16 needs the LDS-staged main loop");
   constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
   constexpr bool SPLIT = (MREP * NREP == 1);   // one tile per wave: split the k-chain over 2 accumulators
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -171,7 +176,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         const int idx = tid + j * NT, row = idx >> 3, c4 = idx & 7;
         F4 v = stage[j];
         if (j < NLA) { v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo); }
-        st4(dst + row * kGemmLdsStride + c4 * 4, v);
+        if constexpr (PREC == 0) {
+          st4(dst + row * kGemmLdsStride + c4 * 4, v);
+        } else {
+          // row image: [32 x bf16 hi | 32 x bf16 lo | pad]; this thread owns k = 4*c4 .. 4*c4+3
+          unsigned h0, l0, h1, l1;
+          split_bf16_pair(v.x, v.y, h0, l0);
+          split_bf16_pair(v.z, v.w, h1, l1);
+          unsigned* rowp = reinterpret_cast<unsigned*>(dst + row * kGemmLdsStride);
+          *reinterpret_cast<uint2_t*>(rowp + c4 * 2) = uint2_t{h0, h1};
+          *reinterpret_cast<uint2_t*>(rowp + 16 + c4 * 2) = uint2_t{l0, l1};
+        }
       }
     };
     auto lfrags = [&](int buf) {
@@ -190,13 +205,45 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         fb0[t].v[4] = b.x; fb0[t].v[5] = b.y; fb0[t].v[6] = b.z; fb0[t].v[7] = b.w;
       }
     };
+    U4 ahi[MREP], alo[MREP], bhi[NREP], blo[NREP];
+    auto lfrags_bf16 = [&](int buf) {
+      const float* as = smem + buf * ROWS * kGemmLdsStride + (wm * MREP * 16 + r) * kGemmLdsStride;
+      const float* ws = smem + buf * ROWS * kGemmLdsStride + (BM + wn * NREP * 16 + r) * kGemmLdsStride;
+#pragma unroll
+      for (int t = 0; t < MREP; ++t) {
+        const U4* rp = reinterpret_cast<const U4*>(as + t * 16 * kGemmLdsStride);
+        ahi[t] = rp[g];
+        alo[t] = rp[4 + g];
+      }
+#pragma unroll
+      for (int t = 0; t < NREP; ++t) {
+        const U4* rp = reinterpret_cast<const U4*>(ws + t * 16 * kGemmLdsStride);
+        bhi[t] = rp[g];
+        blo[t] = rp[4 + g];
+      }
+    };
+    auto compute_bf16 = [&]() {
+#pragma unroll
+      for (int a = 0; a < MREP; ++a)
+#pragma unroll
+        for (int b = 0; b < NREP; ++b) {
+          acc[a][b] = mfma_bf16_16x16x32(alo[a], bhi[b], acc[a][b]);
+          acc[a][b] = mfma_bf16_16x16x32(ahi[a], blo[b], acc[a][b]);
+          acc[a][b] = mfma_bf16_16x16x32(ahi[a], bhi[b], acc[a][b]);
+        }
+    };
     gload(0);
     lstore(0);
     __syncthreads();
     for (int kc = 0; kc < KC; ++kc) {
       if (kc + 1 < KC) gload(kc + 1);          // in flight while this chunk's MFMAs run
-      lfrags(kc & 1);
-      compute(fa0, fb0);
+      if constexpr (PREC == 0) {
+        lfrags(kc & 1);
+        compute(fa0, fb0);
+      } else {
+        lfrags_bf16(kc & 1);
+        compute_bf16();
+      }
       if (kc + 1 < KC) lstore((kc + 1) & 1);   // that buffer was last read in iteration kc-1 (barrier passed)
       __syncthreads();
     }

@@ -317,9 +317,13 @@ bool g_staged_gemm = true;   // MLDHIP_GEMM=direct selects the first-version reg
 
 void gemm(Ctx& c, const GemmArgs& a, int nz = 1) {
   const bool small = a.M <= g_small_m;
+  const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_DECODE && c.e->phase == 1;   // decoder GEMMs only
   if (small) {
     dim3 grid((a.M + 15) / 16, (a.N + 63) / 64, nz);
     MLD_LAUNCH((gemm_kernel<1, 4, 1, 1, false>), grid, dim3(256), 0, c.stream, a);
+  } else if (x3) {
+    dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);
+    MLD_LAUNCH((gemm_kernel<2, 2, 2, 4, false, true, 1>), grid, dim3(256), (gemm_lds_bytes<2, 2, 2, 4>()), c.stream, a);
   } else if (g_staged_gemm) {
     dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);
     MLD_LAUNCH((gemm_kernel<2, 2, 2, 4, false, true>), grid, dim3(256), (gemm_lds_bytes<2, 2, 2, 4>()), c.stream, a);
@@ -333,7 +337,10 @@ void gemm(Ctx& c, const GemmArgs& a, int nz = 1) {
 
 void gemm_ln(Ctx& c, const GemmArgs& a) {   // N == 256; full rows per workgroup (32 x 256 tile)
   dim3 grid((a.M + 31) / 32, 1, 1);
-  if (g_staged_gemm) {
+  const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_DECODE && c.e->phase == 1;
+  if (x3) {
+    MLD_LAUNCH((gemm_kernel<1, 4, 2, 4, true, true, 1>), grid, dim3(256), (gemm_lds_bytes<1, 4, 2, 4>()), c.stream, a);
+  } else if (g_staged_gemm) {
     MLD_LAUNCH((gemm_kernel<1, 4, 2, 4, true, true>), grid, dim3(256), (gemm_lds_bytes<1, 4, 2, 4>()), c.stream, a);
   } else {
     MLD_LAUNCH((gemm_kernel<1, 4, 2, 4, true>), grid, dim3(256), 0, c.stream, a);
@@ -727,7 +734,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   if (cfg->num_inference_steps < 1 || cfg->num_train_timesteps % cfg->num_inference_steps) return bad("num_train_timesteps must be a multiple of num_inference_steps");
   if ((cfg->num_inference_steps - 1) * (cfg->num_train_timesteps / cfg->num_inference_steps) + cfg->steps_offset >= cfg->num_train_timesteps)
     return bad("steps_offset pushes the first timestep past num_train_timesteps");
-  if (cfg->precision != MLDHIP_PREC_F32) return bad("unsupported precision");
+  if (cfg->precision != MLDHIP_PREC_F32 && cfg->precision != MLDHIP_PREC_BF16X3_DECODE) return bad("unsupported precision");
 #if !defined(MLDHIP_SIM)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_last_error = "no HIP device visible (libmldhip has no CPU path)"; return MLDHIP_ENODEV; }
@@ -792,6 +799,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4)
 #undef MLD_T32_ATTR
   (void)hipFuncSetAttribute((const void*)gemm_kernel<1, 4, 2, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<1, 4, 2, 4>());
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<1, 4, 2, 4, true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<1, 4, 2, 4>());
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<2, 2, 2, 4, false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<2, 2, 2, 4>());
   (void)hipFuncSetAttribute((const void*)gemm_kernel<2, 2, 2, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<2, 2, 2, 4>());
   (void)hipGetLastError();
 #endif

@@ -78,7 +78,36 @@ static void compute_mfma(WaveState& w, int slot) {
   }
 }
 
-int wave_arrive(const void* payload, int nbytes, bool is_mfma) {
+static float bf16_to_float(unsigned short h) {
+  unsigned u = unsigned(h) << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+static void compute_mfma_bf16(WaveState& w, int slot) {
+  float A[16][32], B[32][16];
+  for (int l = 0; l < 64; ++l) {
+    const unsigned* p = reinterpret_cast<const unsigned*>(w.buf[slot][l]);
+    for (int j = 0; j < 8; ++j) {
+      const unsigned short ah = (p[j >> 1] >> (16 * (j & 1))) & 0xFFFFu, bh = (p[4 + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
+      A[l & 15][(l >> 4) * 8 + j] = bf16_to_float(ah);
+      B[(l >> 4) * 8 + j][l & 15] = bf16_to_float(bh);
+    }
+  }
+  for (int l = 0; l < 64; ++l) {
+    const float* cp = reinterpret_cast<const float*>(w.buf[slot][l]) + 8;
+    const int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+      const int row = (l >> 4) * 4 + r;
+      float d = cp[r];
+      for (int k = 0; k < 32; ++k) d = fmaf(A[row][k], B[k][col], d);   // products of bf16 are exact in fp32
+      w.res[slot][l][r] = d;
+    }
+  }
+}
+
+int wave_arrive(const void* payload, int nbytes, int is_mfma) {
   BlockState& b = g_blk;
   WaveState& w = b.waves[b.cur->wave];
   unsigned my = w.gen;
@@ -88,7 +117,8 @@ int wave_arrive(const void* payload, int nbytes, bool is_mfma) {
   if (w.count == w.alive) {
     if (is_mfma) {
       if (w.alive != 64) { std::fprintf(stderr, "hipsim: MFMA issued by a partial wave\n"); std::abort(); }
-      compute_mfma(w, slot);
+      if (is_mfma == 1) compute_mfma(w, slot);
+      else compute_mfma_bf16(w, slot);
     }
     w.count = 0;
     w.gen++;

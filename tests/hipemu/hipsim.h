@@ -62,11 +62,11 @@ void sync_threads();
 
 // ---- wave-level rendezvous: every live lane of the wave must call the same op ----
 // Deposits `nbytes` of payload, waits for the whole wave, returns the slot index used.
-int wave_arrive(const void* payload, int nbytes, bool is_mfma_f32_16x16x4);
+int wave_arrive(const void* payload, int nbytes, int mfma_kind /*0 none, 1 f32 16x16x4, 2 bf16 16x16x32*/);
 
 inline float shfl_xor(float v, int mask) {
   BlockState& b = blk();
-  int slot = wave_arrive(&v, 4, false);
+  int slot = wave_arrive(&v, 4, 0);
   WaveState& w = b.waves[b.cur->wave];
   float r;
   std::memcpy(&r, w.buf[slot][(b.cur->lane ^ mask) & 63], 4);
@@ -74,7 +74,7 @@ inline float shfl_xor(float v, int mask) {
 }
 inline float shfl(float v, int src) {
   BlockState& b = blk();
-  int slot = wave_arrive(&v, 4, false);
+  int slot = wave_arrive(&v, 4, 0);
   WaveState& w = b.waves[b.cur->wave];
   float r;
   std::memcpy(&r, w.buf[slot][src & 63], 4);
@@ -86,7 +86,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 inline f32x4 mfma_f32_16x16x4(float a, float bb, f32x4 c) {
   BlockState& b = blk();
   float payload[6] = {a, bb, c[0], c[1], c[2], c[3]};
-  int slot = wave_arrive(payload, 24, true);
+  int slot = wave_arrive(payload, 24, 1);
+  WaveState& w = b.waves[b.cur->wave];
+  const float* r = w.res[slot][b.cur->lane];
+  f32x4 d = {r[0], r[1], r[2], r[3]};
+  return d;
+}
+
+// v_mfma_f32_16x16x32_bf16: 8 bf16 of A and of B per lane (k = 8*(l>>4)+j), fp32 accumulate
+inline f32x4 mfma_bf16_16x16x32(const unsigned (&a)[4], const unsigned (&bq)[4], f32x4 c) {
+  BlockState& b = blk();
+  unsigned payload[12];
+  for (int i = 0; i < 4; ++i) { payload[i] = a[i]; payload[4 + i] = bq[i]; }
+  float cf[4] = {c[0], c[1], c[2], c[3]};
+  std::memcpy(&payload[8], cf, 16);
+  int slot = wave_arrive(payload, 48, 2);
   WaveState& w = b.waves[b.cur->wave];
   const float* r = w.res[slot][b.cur->lane];
   f32x4 d = {r[0], r[1], r[2], r[3]};

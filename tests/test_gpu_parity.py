@@ -265,3 +265,22 @@ def test_mld_module_surface_on_gpu(dev):
     for i, n in enumerate(lengths):
         assert np.abs(j2[i, :n] - joints[i].numpy()).max() < 1e-3
     E.drop_engines()
+
+
+def test_split_bf16_decode_mode_meets_the_joint_tolerance(dev, golden_dir):
+    """precision = BF16X3_DECODE: decoder GEMMs on 3 bf16 MFMAs per K chunk; must still satisfy the 1e-3 contract."""
+    e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=1)
+    _load(e)
+    g = _gold(golden_dir, "pipeline_b64.npz")
+    b = syn.make_batch(64)
+    lat, feats, joints, _ = _run_sample(e, dev, b)
+    err_f = np.abs(feats.cpu().numpy()[:, -1] - g["feats_frame_last"]).max()
+    err_j = np.abs(joints.cpu().numpy()[:, ::4] - g["joints_every4"]).max()
+    print("bf16x3 decode: feats err %.3e joints err %.3e" % (err_f, err_j))
+    assert err_f < 5e-4 and err_j < 1e-3
+    gd = _gold(golden_dir, "vae_decode_b3.npz")
+    f3 = torch.empty(3, 100, 263, device=dev)
+    e.vae_decode(_cuda(gd["z"], dev), [int(x) for x in gd["lengths"]], f3)
+    torch.cuda.synchronize()
+    assert np.abs(f3.cpu().numpy() - gd["feats"]).max() < 3e-4
+    e.close()
