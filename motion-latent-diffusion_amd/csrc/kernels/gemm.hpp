@@ -142,11 +142,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
     constexpr int NT = WM * WN * 64, ROWS = BM + BN, NLD = ROWS * 8 / NT;
     static_assert(ROWS * 8 % NT == 0, "panel rows must tile the workgroup");
     const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
-    F4 stage[NLD];
+    // 4-deep register prefetch ring: chunks k+1..k+4 are in flight while chunk k is multiplied.  With one chunk
+    // of look-ahead only ~48 KB per CU was outstanding against a latency x bandwidth product of ~250 KB
+    // (1.5-2 us x ~56 B/clk/CU), which left the first staged version latency bound (profiles/r01_v7).
+    F4 st0[NLD], st1[NLD], st2[NLD], st3[NLD];
     constexpr int NLA = BM * 8 / NT;          // staging slots that hold A rows (uniform across the workgroup)
     static_assert(BM * 8 % NT == 0, "A panel must fill whole staging slots");
     const float relu_lo = relu ? 0.f : -INFINITY;   // fmaxf(v, -inf) == v: ReLU-on-load without a branch
-    auto gload = [&](int kc) {
+    auto gload = [&](F4(&stage)[NLD], int kc) {
       // Straight-line: no per-load condition (a `cond ? load : other` makes hipcc branch and drain vmcnt
       // per element, which serialised this prefetch in front of the MFMAs in the first version).
       const int k = kc * 32;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         stage[j] = ld4(W + (long long)n * p.ldw + k + c4 * 4);
       }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, F4(&stage)[NLD]) {
       float* dst = smem + buf * ROWS * kGemmLdsStride;
 #pragma unroll
       for (int j = 0; j < NLD; ++j) {
@@ -232,19 +235,35 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
           acc[a][b] = mfma_bf16_16x16x32(ahi[a], bhi[b], acc[a][b]);
         }
     };
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kc = 0; kc < KC; ++kc) {
-      if (kc + 1 < KC) gload(kc + 1);          // in flight while this chunk's MFMAs run
+    auto mma = [&](int buf) {
       if constexpr (PREC == 0) {
-        lfrags(kc & 1);
+        lfrags(buf);
         compute(fa0, fb0);
       } else {
-        lfrags_bf16(kc & 1);
+        lfrags_bf16(buf);
         compute_bf16();
       }
-      if (kc + 1 < KC) lstore((kc + 1) & 1);   // that buffer was last read in iteration kc-1 (barrier passed)
+    };
+    // KC is a multiple of 4 for every staged GEMM of the path (K = 256, 512, 1024).
+    gload(st0, 0);
+    if (1 < KC) gload(st1, 1);
+    if (2 < KC) gload(st2, 2);
+    if (3 < KC) gload(st3, 3);
+    lstore(0, st0);
+    if (4 < KC) gload(st0, 4);
+    __syncthreads();
+    for (int kc = 0; kc < KC; kc += 4) {
+      mma(0);                                                     // chunk kc   (buffer 0)
+      if (kc + 1 < KC) { lstore(1, st1); if (kc + 5 < KC) gload(st1, kc + 5); }
+      __syncthreads();
+      if (kc + 1 < KC) mma(1);                                    // chunk kc+1 (buffer 1)
+      if (kc + 2 < KC) { lstore(0, st2); if (kc + 6 < KC) gload(st2, kc + 6); }
+      __syncthreads();
+      if (kc + 2 < KC) mma(0);                                    // chunk kc+2
+      if (kc + 3 < KC) { lstore(1, st3); if (kc + 7 < KC) gload(st3, kc + 7); }
+      __syncthreads();
+      if (kc + 3 < KC) mma(1);                                    // chunk kc+3
+      if (kc + 4 < KC) { lstore(0, st0); if (kc + 8 < KC) gload(st0, kc + 8); }
       __syncthreads();
     }
   }
