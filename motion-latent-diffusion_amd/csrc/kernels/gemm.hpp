@@ -77,7 +77,10 @@ constexpr int gemm_lds_bytes() { return 2 * (WM * MREP * 16 + WN * NREP * 16) * 
 // PREC (staged path only): 0 = exact fp32 MFMA, 1 = split-bf16 ("bf16x3", rt.hpp): operands are split into
 //                 bf16 hi/lo planes while they are written to LDS (same LDS footprint as fp32), 3 bf16 MFMAs
 //                 per tile per K chunk.
-template <int WM, int WN, int MREP, int NREP, bool LN, bool STAGED = false, int PREC = 0>
+// KCS (staged path only): K / 32, compile time, so that the whole chunk pipeline is straight-line code: any
+//                 runtime branch around a prefetch load makes hipcc's vmcnt bookkeeping conservative and the
+//                 ring drains at every LDS store (seen in the ISA as vmcnt(5)..vmcnt(0) ladders).
+template <int WM, int WN, int MREP, int NREP, bool LN, bool STAGED = false, int PREC = 0, int KCS = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   static_assert(PREC == 0 || STAGED, "split-bf16 needs the LDS-staged main loop");
   constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
@@ -244,26 +247,33 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         compute_bf16();
       }
     };
-    // KC is a multiple of 4 for every staged GEMM of the path (K = 256, 512, 1024).
+    static_assert(KCS >= 4 && KCS % 4 == 0, "staged GEMMs take K in {256, 512, 1024}");
     gload(st0, 0);
-    if (1 < KC) gload(st1, 1);
-    if (2 < KC) gload(st2, 2);
-    if (3 < KC) gload(st3, 3);
+    gload(st1, 1);
+    gload(st2, 2);
+    gload(st3, 3);
     lstore(0, st0);
-    if (4 < KC) gload(st0, 4);
+    if constexpr (4 < KCS) gload(st0, 4);
     __syncthreads();
-    for (int kc = 0; kc < KC; kc += 4) {
-      mma(0);                                                     // chunk kc   (buffer 0)
-      if (kc + 1 < KC) { lstore(1, st1); if (kc + 5 < KC) gload(st1, kc + 5); }
+#pragma unroll
+    for (int kc = 0; kc < KCS; kc += 4) {
+      mma(0);                                                       // chunk kc   (buffer 0)
+      lstore(1, st1);
+      if (kc + 5 < KCS) gload(st1, kc + 5);                         // kc is a constant after unrolling
       __syncthreads();
-      if (kc + 1 < KC) mma(1);                                    // chunk kc+1 (buffer 1)
-      if (kc + 2 < KC) { lstore(0, st2); if (kc + 6 < KC) gload(st2, kc + 6); }
+      mma(1);                                                       // chunk kc+1 (buffer 1)
+      lstore(0, st2);
+      if (kc + 6 < KCS) gload(st2, kc + 6);
       __syncthreads();
-      if (kc + 2 < KC) mma(0);                                    // chunk kc+2
-      if (kc + 3 < KC) { lstore(1, st3); if (kc + 7 < KC) gload(st3, kc + 7); }
+      mma(0);                                                       // chunk kc+2
+      lstore(1, st3);
+      if (kc + 7 < KCS) gload(st3, kc + 7);
       __syncthreads();
-      if (kc + 3 < KC) mma(1);                                    // chunk kc+3
-      if (kc + 4 < KC) { lstore(0, st0); if (kc + 8 < KC) gload(st0, kc + 8); }
+      mma(1);                                                       // chunk kc+3
+      if (kc + 4 < KCS) {
+        lstore(0, st0);
+        if (kc + 8 < KCS) gload(st0, kc + 8);
+      }
       __syncthreads();
     }
   }

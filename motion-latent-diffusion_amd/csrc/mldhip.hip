@@ -315,21 +315,39 @@ int check_launch(Ctx& c, const char* what) {
 int g_small_m = 256;         // MLDHIP_SMALL_M: row count up to which the 16x64 one-tile-per-wave shape is used (tiny one-off GEMMs)
 bool g_staged_gemm = true;   // MLDHIP_GEMM=direct selects the first-version register-direct main loop (A/B runs)
 
+// staged (LDS, prefetch ring) launch of one tile shape; K / 32 is a template parameter
+template <int WM, int WN, int MREP, int NREP, bool LN, int PREC>
+void launch_staged(Ctx& c, const GemmArgs& a, dim3 grid) {
+  const int kcs = (a.K1 + a.K2) / 32;
+  constexpr int lds = gemm_lds_bytes<WM, WN, MREP, NREP>();
+  switch (kcs) {
+    case 8: MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 8>), grid, dim3(WM * WN * 64), lds, c.stream, a); break;
+    case 16: MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 16>), grid, dim3(WM * WN * 64), lds, c.stream, a); break;
+    case 32: MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 32>), grid, dim3(WM * WN * 64), lds, c.stream, a); break;
+    default: c.rc = c.e->fail(MLDHIP_EINVAL, "staged GEMM: K=%d not in {256,512,1024}", a.K1 + a.K2);
+  }
+}
+template <int WM, int WN, int MREP, int NREP, bool LN, int PREC>
+void staged_attrs() {
+#if !defined(MLDHIP_SIM)
+  constexpr int lds = gemm_lds_bytes<WM, WN, MREP, NREP>();
+#endif
+}
+
 void gemm(Ctx& c, const GemmArgs& a, int nz = 1) {
-  const bool small = a.M <= g_small_m;
+  const int K = a.K1 + a.K2;
+  const bool small = a.M <= g_small_m || (K != 256 && K != 512 && K != 1024);
   const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_DECODE && c.e->phase == 1;   // decoder GEMMs only
   if (small) {
     dim3 grid((a.M + 15) / 16, (a.N + 63) / 64, nz);
     MLD_LAUNCH((gemm_kernel<1, 4, 1, 1, false>), grid, dim3(256), 0, c.stream, a);
-  } else if (x3) {
-    dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);
-    MLD_LAUNCH((gemm_kernel<2, 2, 2, 4, false, true, 1>), grid, dim3(256), (gemm_lds_bytes<2, 2, 2, 4>()), c.stream, a);
-  } else if (g_staged_gemm) {
-    dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);
-    MLD_LAUNCH((gemm_kernel<2, 2, 2, 4, false, true>), grid, dim3(256), (gemm_lds_bytes<2, 2, 2, 4>()), c.stream, a);
-  } else {
+  } else if (!g_staged_gemm) {
     dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);
     MLD_LAUNCH((gemm_kernel<2, 2, 2, 4, false>), grid, dim3(256), 0, c.stream, a);
+  } else {
+    dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);
+    if (x3) launch_staged<2, 2, 2, 4, false, 1>(c, a, grid);
+    else launch_staged<2, 2, 2, 4, false, 0>(c, a, grid);
   }
   count(c);
   check_launch(c, "gemm");
@@ -338,12 +356,12 @@ void gemm(Ctx& c, const GemmArgs& a, int nz = 1) {
 void gemm_ln(Ctx& c, const GemmArgs& a) {   // N == 256; full rows per workgroup (32 x 256 tile)
   dim3 grid((a.M + 31) / 32, 1, 1);
   const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_DECODE && c.e->phase == 1;
-  if (x3) {
-    MLD_LAUNCH((gemm_kernel<1, 4, 2, 4, true, true, 1>), grid, dim3(256), (gemm_lds_bytes<1, 4, 2, 4>()), c.stream, a);
-  } else if (g_staged_gemm) {
-    MLD_LAUNCH((gemm_kernel<1, 4, 2, 4, true, true>), grid, dim3(256), (gemm_lds_bytes<1, 4, 2, 4>()), c.stream, a);
-  } else {
+  if (!g_staged_gemm) {
     MLD_LAUNCH((gemm_kernel<1, 4, 2, 4, true>), grid, dim3(256), 0, c.stream, a);
+  } else if (x3) {
+    launch_staged<1, 4, 2, 4, true, 1>(c, a, grid);
+  } else {
+    launch_staged<1, 4, 2, 4, true, 0>(c, a, grid);
   }
   count(c);
   check_launch(c, "gemm_ln");
@@ -797,11 +815,9 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
   MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4)
+  staged_attrs<2, 2, 2, 4, false, 0>(); staged_attrs<2, 2, 2, 4, false, 1>();
+  staged_attrs<1, 4, 2, 4, true, 0>(); staged_attrs<1, 4, 2, 4, true, 1>();
 #undef MLD_T32_ATTR
-  (void)hipFuncSetAttribute((const void*)gemm_kernel<1, 4, 2, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<1, 4, 2, 4>());
-  (void)hipFuncSetAttribute((const void*)gemm_kernel<1, 4, 2, 4, true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<1, 4, 2, 4>());
-  (void)hipFuncSetAttribute((const void*)gemm_kernel<2, 2, 2, 4, false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<2, 2, 2, 4>());
-  (void)hipFuncSetAttribute((const void*)gemm_kernel<2, 2, 2, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<2, 2, 2, 4>());
   (void)hipGetLastError();
 #endif
   *out = e;
