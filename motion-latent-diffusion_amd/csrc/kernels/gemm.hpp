@@ -39,6 +39,7 @@ struct GemmArgs {
   const float* g1 = nullptr; const float* b1 = nullptr;
   const float* cvec = nullptr; int ldcvec = 0;           // + cvec[row / rows_per_group] then LN(g2,b2)
   const float* g2 = nullptr; const float* b2 = nullptr;
+  unsigned long long* trace = nullptr;   // measurement only (staged kernels): 8 timestamps per wave
 };
 
 struct Frag { float v[8]; };
@@ -80,7 +81,7 @@ constexpr int gemm_lds_bytes() { return 2 * (WM * MREP * 16 + WN * NREP * 16) * 
 // KCS (staged path only): K / 32, compile time, so that the whole chunk pipeline is straight-line code: any
 //                 runtime branch around a prefetch load makes hipcc's vmcnt bookkeeping conservative and the
 //                 ring drains at every LDS store (seen in the ISA as vmcnt(5)..vmcnt(0) ladders).
-template <int WM, int WN, int MREP, int NREP, bool LN, bool STAGED = false, int PREC = 0, int KCS = 0>
+template <int WM, int WN, int MREP, int NREP, bool LN, bool STAGED = false, int PREC = 0, int KCS = 0, bool TRACE = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   static_assert(PREC == 0 || STAGED, "split-bf16 needs the LDS-staged main loop");
   constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
@@ -99,6 +100,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   const int KC = K / 32;
   const bool relu = p.relu_in != 0;
 
+  unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, rt0 = 0;
+  if constexpr (TRACE) { rt0 = realtime_100mhz(); ts[0] = clock_pinned(); }
   f32x4 acc[MREP][NREP];
   f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -255,8 +258,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
     lstore(0, st0);
     if constexpr (4 < KCS) gload(st0, 4);
     __syncthreads();
+    if constexpr (TRACE) ts[1] = clock_pinned();            // first chunk in LDS
 #pragma unroll
     for (int kc = 0; kc < KCS; kc += 4) {
+      if constexpr (TRACE) { if (kc == 4) ts[2] = clock_pinned(); }   // 4 chunks done
       mma(0);                                                       // chunk kc   (buffer 0)
       lstore(1, st1);
       if (kc + 5 < KCS) gload(st1, kc + 5);                         // kc is a constant after unrolling
@@ -278,6 +283,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
     }
   }
   if (SPLIT) acc[0][0] += acc2;
+  if constexpr (TRACE) ts[3] = clock_pinned();              // main loop done
+  auto trace_out = [&]() {
+    if constexpr (TRACE) {
+      ts[4] = clock_pinned();                                // epilogue stores drained
+      const long long wg = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+      if (lane == 0 && wg < 512) {
+        unsigned long long* o = p.trace + (wg * 8 + wave) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = ts[i];
+        o[6] = rt0;
+        o[7] = realtime_100mhz();
+      }
+    }
+  };
 
   if constexpr (!LN) {
     // per-row facts once (validity, padded-frame mask), per-column facts once (bias), activation hoisted
@@ -319,6 +337,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
           if (rowok[a][i] && colok) Y[(long long)(m0 + a * 16 + g * 4 + i) * p.ldy + col] = v[i] * rowmask[a][i];
       }
     }
+    trace_out();
     return;
   } else {
   // ---------------- residual + LayerNorm epilogue (full rows live in this workgroup) -------------
@@ -419,6 +438,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         if (row < p.M) Y[(long long)row * p.ldy + col] = vals[a][b][i];
       }
     }
+  trace_out();
   }
 }
 

@@ -320,6 +320,13 @@ template <int WM, int WN, int MREP, int NREP, bool LN, int PREC>
 void launch_staged(Ctx& c, const GemmArgs& a, dim3 grid) {
   const int kcs = (a.K1 + a.K2) / 32;
   constexpr int lds = gemm_lds_bytes<WM, WN, MREP, NREP>();
+  if (c.e->trace_on) {   // measurement build of the same kernel (K = 256 shapes only)
+    GemmArgs t = a;
+    t.trace = c.e->trace_on;
+    if (kcs == 8) { MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 8, true>), grid, dim3(WM * WN * 64), lds, c.stream, t); }
+    else if (kcs == 32) { MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 32, true>), grid, dim3(WM * WN * 64), lds, c.stream, t); }
+    return;
+  }
   switch (kcs) {
     case 8: MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 8>), grid, dim3(WM * WN * 64), lds, c.stream, a); break;
     case 16: MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 16>), grid, dim3(WM * WN * 64), lds, c.stream, a); break;
