@@ -43,6 +43,27 @@ struct GemmArgs {
 };
 
 struct Frag { float v[8]; };
+
+// Copy a [BM][BN] fp32 tile parked in LDS (row stride BN + 4) to Y with 16-byte stores: one wave instruction
+// covers 1 KiB of contiguous output.  (Measured: 32 scattered 4-byte stores per lane -- 64-byte row fragments --
+// cost 13-26 k cycles per workgroup, more than the whole fp32 MFMA main loop; profiles/r01_v8_gemm_phase_trace.)
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void store_tile_from_lds(const float* Cs, float* Y, int ldy, int row0, int col0, int M, int N, int tid) {
+  constexpr int CST = BN + 4, V = BN / 4;
+  const bool vec_ok = (ldy & 3) == 0 && col0 + BN <= N && ((reinterpret_cast<unsigned long long>(Y) & 15) == 0);
+  if (vec_ok) {
+#pragma unroll
+    for (int j = 0; j < BM * V / NT; ++j) {
+      const int idx = tid + j * NT, row = idx / V, c4 = idx - row * V;
+      if (row0 + row < M) st4(Y + (long long)(row0 + row) * ldy + col0 + c4 * 4, ld4(Cs + row * CST + c4 * 4));
+    }
+  } else {   // ragged right edge / unaligned row stride (final_layer: N = ldy = 263): scalar, still row-contiguous
+    for (int idx = tid; idx < BM * BN; idx += NT) {
+      const int row = idx / BN, c = idx - row * BN;
+      if (row0 + row < M && col0 + c < N) Y[(long long)(row0 + row) * ldy + col0 + c] = Cs[row * CST + c];
+    }
+  }
+}
 struct alignas(8) uint2_t { unsigned x, y; };
 
 template <int REP>
@@ -315,6 +336,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         }
       }
     const int act = p.act;
+    float* Cs = nullptr;
+    if constexpr (STAGED) {
+#if defined(MLDHIP_SIM)
+      Cs = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
+#else
+      extern __shared__ __attribute__((aligned(16))) float smem_epi[];
+      Cs = smem_epi;
+#endif
+    }
 #pragma unroll
     for (int b = 0; b < NREP; ++b) {
       const int col = n0 + b * 16 + r;
@@ -333,9 +363,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
           for (int i = 0; i < 4; ++i) v[i] = silu(v[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (rowok[a][i] && colok) Y[(long long)(m0 + a * 16 + g * 4 + i) * p.ldy + col] = v[i] * rowmask[a][i];
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (STAGED) {
+            Cs[(wm * MREP * 16 + a * 16 + g * 4 + i) * (BN + 4) + wn * NREP * 16 + b * 16 + r] = v[i] * rowmask[a][i];
+          } else {
+            if (rowok[a][i] && colok) Y[(long long)(m0 + a * 16 + g * 4 + i) * p.ldy + col] = v[i] * rowmask[a][i];
+          }
+        }
       }
+    }
+    if constexpr (STAGED) {
+      __syncthreads();
+      store_tile_from_lds<BM, BN, WM * WN * 64>(Cs, Y, p.ldy, blockIdx.x * BM, blockIdx.y * BN, p.M, p.N, tid);
     }
     trace_out();
     return;
@@ -427,6 +466,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         }
       }
   }
+  if constexpr (STAGED) {
+#if defined(MLDHIP_SIM)
+    float* Cs = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
+#else
+    extern __shared__ __attribute__((aligned(16))) float smem_epi[];
+    float* Cs = smem_epi;
+#endif
+#pragma unroll
+    for (int a = 0; a < MREP; ++a)
+#pragma unroll
+      for (int b = 0; b < NREP; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          Cs[(wm * MREP * 16 + a * 16 + g * 4 + i) * (BN + 4) + wn * NREP * 16 + b * 16 + r] = vals[a][b][i];
+    __syncthreads();
+    store_tile_from_lds<BM, BN, WM * WN * 64>(Cs, Y, p.ldy, blockIdx.x * BM, 0, p.M, p.N, tid);
+  } else {
 #pragma unroll
   for (int a = 0; a < MREP; ++a)
 #pragma unroll
@@ -438,6 +494,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         if (row < p.M) Y[(long long)row * p.ldy + col] = vals[a][b][i];
       }
     }
+  }
   trace_out();
   }
 }
