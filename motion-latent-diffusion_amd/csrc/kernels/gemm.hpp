@@ -319,23 +319,40 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   };
 
   if constexpr (!LN) {
-    // per-row facts once (validity, padded-frame mask), per-column facts once (bias), activation hoisted
+    // All epilogue loads are unconditional (clamped indices) and issued as one batch: a `cond ? load : 0`
+    // becomes a branch + vmcnt(0) per load in hipcc's output (four serialised bias latencies before this).
+    float bv[NREP];
+#pragma unroll
+    for (int b = 0; b < NREP; ++b) {
+      const int col = n0 + b * 16 + r;
+      bv[b] = bias[col < p.N ? col : p.N - 1];
+    }
     bool rowok[MREP][4];
     float rowmask[MREP][4];
 #pragma unroll
     for (int a = 0; a < MREP; ++a)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = m0 + a * 16 + g * 4 + i;
-        rowok[a][i] = row < p.M;
+        rowok[a][i] = m0 + a * 16 + g * 4 + i < p.M;
         rowmask[a][i] = 1.f;
-        if (p.lens) {
-          const int rc = rowok[a][i] ? row : p.M - 1;
-          const int grp = rc / p.rows_per_group, t = rc - grp * p.rows_per_group;
-          rowmask[a][i] = t < p.lens[grp] ? 1.f : 0.f;
-        }
       }
-    const int act = p.act;
+    if (p.lens) {                      // padded-frame zeroing (final_layer only): one block, loads batched
+      int lim[MREP][4], tt[MREP][4];
+#pragma unroll
+      for (int a = 0; a < MREP; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = m0 + a * 16 + g * 4 + i;
+          const int rc = row < p.M ? row : p.M - 1;
+          const int grp = rc / p.rows_per_group;
+          tt[a][i] = rc - grp * p.rows_per_group;
+          lim[a][i] = p.lens[grp];
+        }
+#pragma unroll
+      for (int a = 0; a < MREP; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rowmask[a][i] = tt[a][i] < lim[a][i] ? 1.f : 0.f;
+    }
     float* Cs = nullptr;
     if constexpr (STAGED) {
 #if defined(MLDHIP_SIM)
@@ -345,33 +362,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
       Cs = smem_epi;
 #endif
     }
+    auto finish = [&](auto actfn) {
 #pragma unroll
-    for (int b = 0; b < NREP; ++b) {
-      const int col = n0 + b * 16 + r;
-      const bool colok = col < p.N;
-      const float bv = (bias && colok) ? bias[col] : 0.f;
+      for (int b = 0; b < NREP; ++b) {
+        const int col = n0 + b * 16 + r;
+        const bool colok = col < p.N;
 #pragma unroll
-      for (int a = 0; a < MREP; ++a) {
-        float v[4];
+        for (int a = 0; a < MREP; ++a)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = acc[a][b][i] + bv;
-        if (act == ACT_GELU) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
-        } else if (act == ACT_SILU) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = silu(v[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if constexpr (STAGED) {
-            Cs[(wm * MREP * 16 + a * 16 + g * 4 + i) * (BN + 4) + wn * NREP * 16 + b * 16 + r] = v[i] * rowmask[a][i];
-          } else {
-            if (rowok[a][i] && colok) Y[(long long)(m0 + a * 16 + g * 4 + i) * p.ldy + col] = v[i] * rowmask[a][i];
+          for (int i = 0; i < 4; ++i) {
+            const float v = actfn(acc[a][b][i] + bv[b]) * rowmask[a][i];
+            if constexpr (STAGED) {
+              Cs[(wm * MREP * 16 + a * 16 + g * 4 + i) * (BN + 4) + wn * NREP * 16 + b * 16 + r] = v;
+            } else {
+              if (rowok[a][i] && colok) Y[(long long)(m0 + a * 16 + g * 4 + i) * p.ldy + col] = v;
+            }
           }
-        }
       }
-    }
+    };
+    if (p.act == ACT_GELU) finish([](float x) { return gelu_erf(x); });
+    else if (p.act == ACT_SILU) finish([](float x) { return silu(x); });
+    else finish([](float x) { return x; });
     if constexpr (STAGED) {
       __syncthreads();
       store_tile_from_lds<BM, BN, WM * WN * 64>(Cs, Y, p.ldy, blockIdx.x * BM, blockIdx.y * BN, p.M, p.N, tid);
@@ -382,26 +393,57 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   // ---------------- residual + LayerNorm epilogue (full rows live in this workgroup) -------------
   __shared__ float red[4][BM][WN];
   const int nstage = p.cvec ? 2 : 1;
+  // ---- every epilogue operand is fetched up front, unconditionally (bias / residual / affine / cross-attn vector)
+  float bv[NREP], gm1[NREP], bt1[NREP], gm2[NREP], bt2[NREP];
+#pragma unroll
+  for (int b = 0; b < NREP; ++b) {
+    const int col = n0 + b * 16 + r;
+    bv[b] = bias[col];
+    gm1[b] = p.g1[col];
+    bt1[b] = p.b1[col];
+    gm2[b] = 1.f;
+    bt2[b] = 0.f;
+  }
+  int rowc[MREP][4];
+#pragma unroll
+  for (int a = 0; a < MREP; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + a * 16 + g * 4 + i;
+      rowc[a][i] = row < p.M ? row : p.M - 1;
+    }
+  float resv[MREP][NREP][4];
+#pragma unroll
+  for (int a = 0; a < MREP; ++a)
+#pragma unroll
+    for (int b = 0; b < NREP; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) resv[a][b][i] = p.res[(long long)rowc[a][i] * p.ldres + n0 + b * 16 + r];
+  float cvv[MREP][NREP][4];
+  if (nstage == 2) {
+#pragma unroll
+    for (int b = 0; b < NREP; ++b) {
+      gm2[b] = p.g2[n0 + b * 16 + r];
+      bt2[b] = p.b2[n0 + b * 16 + r];
+    }
+#pragma unroll
+    for (int a = 0; a < MREP; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long grp = rowc[a][i] / p.rows_per_group;      // one division per row, not per element
+#pragma unroll
+        for (int b = 0; b < NREP; ++b) cvv[a][b][i] = p.cvec[grp * p.ldcvec + n0 + b * 16 + r];
+      }
+  }
   float vals[MREP][NREP][4];
 #pragma unroll
   for (int a = 0; a < MREP; ++a)
 #pragma unroll
-    for (int b = 0; b < NREP; ++b) {
-      const int col = n0 + b * 16 + r;
-      const float bv = bias ? bias[col] : 0.f;
+    for (int b = 0; b < NREP; ++b)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int row = m0 + a * 16 + g * 4 + i;
-        row = row < p.M ? row : p.M - 1;
-        float v = acc[a][b][i] + bv;
-        if (p.res) v += p.res[(long long)row * p.ldres + col];
-        vals[a][b][i] = v;
-      }
-    }
+      for (int i = 0; i < 4; ++i) vals[a][b][i] = acc[a][b][i] + bv[b] + resv[a][b][i];
   const float inv_n = 1.0f / float(BN);
   for (int st = 0; st < nstage; ++st) {
-    const float* gam = st == 0 ? p.g1 : p.g2;
-    const float* bet = st == 0 ? p.b1 : p.b2;
     float mean[MREP][4], rstd[MREP][4];
     // pass 1: mean
 #pragma unroll
@@ -452,16 +494,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
     for (int a = 0; a < MREP; ++a)
 #pragma unroll
       for (int b = 0; b < NREP; ++b) {
-        const int col = n0 + b * 16 + r;
-        const float gm = gam[col], bt = bet[col];
+        const float gm = st == 0 ? gm1[b] : gm2[b], bt = st == 0 ? bt1[b] : bt2[b];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float v = (vals[a][b][i] - mean[a][i]) * rstd[a][i] * gm + bt;
-          if (st == 0 && nstage == 2) {
-            int row = m0 + a * 16 + g * 4 + i;
-            row = row < p.M ? row : p.M - 1;
-            v += p.cvec[(long long)(row / p.rows_per_group) * p.ldcvec + col];
-          }
+          if (st == 0 && nstage == 2) v += cvv[a][b][i];
           vals[a][b][i] = v;
         }
       }
