@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="disable hipGraph replay (debug)")
-    ap.add_argument("--precision", choices=["f32", "bf16x3_decode", "bf16x3_all"], default=os.environ.get("MLD_BENCH_PRECISION", "f32"),
+    ap.add_argument("--precision", choices=["f32", "bf16x3_decode"], default=os.environ.get("MLD_BENCH_PRECISION", "f32"),
                     help="f32: exact-fp32 MFMA everywhere; bf16x3_decode: split-bf16 MFMA in the VAE-decoder GEMMs")
     a = ap.parse_args()
 
@@ -104,7 +104,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    prec = {"f32": 0, "bf16x3_decode": 1, "bf16x3_all": 2}[a.precision]
+    prec = {"f32": 0, "bf16x3_decode": 1}[a.precision]
     eng = _lib.Engine(device=local, max_batch=BATCH, max_frames=FRAMES, use_graph=0 if a.eager else 1, precision=prec)
     weights, weight_bytes = pack_and_broadcast_weights(rank, world, dev)
     eng.load_state_dict(weights)
@@ -147,8 +147,7 @@ def main():
         "metric": "motions/sec (50-step DDIM + VAE decode), HumanML3D bs64", "value": round(value, 2),
         "unit": "motions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {0: "f32", 1: "f32 (reverse loop, attention, norms) + split-bf16 x3 MFMA, fp32 accumulate (decoder GEMMs)",
-                  2: "split-bf16 x3 MFMA with fp32 accumulate (all GEMMs); fp32 attention, norms, scheduler, joints"}[prec],
+        "dtype": {0: "f32", 1: "f32 (reverse loop, attention, norms) + split-bf16 x3 MFMA, fp32 accumulate (decoder GEMMs)"}[prec],
         "data": "synthetic",
         "config": {"workload": "config_mld_humanml3d.yaml, bs=64 per GPU, T=196, 50-step DDIM, CFG 7.5, VAE decode + feats2joints",
                    "global_batch": BATCH * world, "parallelism": f"dp{world}", "graph": not a.eager, "precision": a.precision,

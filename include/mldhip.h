@@ -44,9 +44,10 @@ enum { MLDHIP_F32 = 0 };   /* dtype codes for mldhip_load_tensor */
 
 enum {                     /* arithmetic mode of the matrix kernels */
   MLDHIP_PREC_F32 = 0,            /* exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere: the parity mode */
-  MLDHIP_PREC_BF16X3_DECODE = 1,  /* VAE-decoder GEMMs on split-bf16 (3 x v_mfma_f32_16x16x32_bf16, fp32 accumulate,
-                                     ~1e-5 relative per product); reverse loop, attention, LayerNorm, joints stay fp32 */
-  MLDHIP_PREC_BF16X3_ALL = 2      /* split-bf16 GEMMs in the reverse loop as well (attention, norms, DDIM stay fp32) */
+  MLDHIP_PREC_BF16X3_DECODE = 1   /* VAE-decoder GEMMs on split-bf16 (3 x v_mfma_f32_16x16x32_bf16, fp32 accumulate,
+                                     ~1e-5 relative per product); reverse loop, attention, LayerNorm, joints stay fp32.
+                                     (Split-bf16 in the reverse loop was measured and rejected: joint error 1.1e-3 at
+                                     T=196 -- over the 1e-3 contract -- and no faster; profiles/r01_v9.) */
 };
 
 /* Mirrors the keys of configs/config_mld_humanml3d.yaml + configs/modules/{denoiser,motion_vae,

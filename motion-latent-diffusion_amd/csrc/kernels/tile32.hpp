@@ -15,7 +15,6 @@
 // Row layout: token-major, row = s*R + r (s = token 0..2, r = sample), 256 floats per row.
 #pragma once
 #include "elementwise.hpp"
-#include "gemm.hpp"
 #include "rt.hpp"
 
 namespace mld {
@@ -77,9 +76,7 @@ __device__ __forceinline__ F4 f4add(F4 a, F4 b) { return F4{a.x + b.x, a.y + b.y
 // NS0 = compile-time slab count of src[0] when it is a combine source (0: src[0] is plain / attention):
 // keeps every load unconditional and straight-line (a per-load `cond ? load : 0` makes hipcc branch and
 // wait per element -- cdna_hip_programming.md, "three .s-level traps" (c)).
-// PREC: 0 = exact fp32 MFMA; 1 = split-bf16 (operands split into bf16 hi/lo planes when the tile is parked in
-//       LDS: row image [256 x bf16 hi | 256 x bf16 lo], same footprint; 3 bf16 MFMAs per 32-wide K chunk).
-template <int MT, int NS0, bool TRACE, int PREC = 0>
+template <int MT, int NS0, bool TRACE>
 __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
   static_assert(MT == 16 || MT == 32, "row tile");
   constexpr int RPW = MT / 8;                 // A rows assembled per wave
@@ -215,25 +212,10 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
     }
   }
   if constexpr (tracing) ts[1] = clock_pinned();      // every load landed, prologue math done
-  if constexpr (PREC == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * kT32Stride + lane * 4, wreg[i]);
+  for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * kT32Stride + lane * 4, wreg[i]);
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) st4(As + (wave + i * 8) * kT32Stride + lane * 4, areg[i]);
-  } else {
-    auto park = [&](float* rowp, F4 v) {     // this lane owns k = 4*lane .. 4*lane+3 of the row
-      unsigned h0, l0, h1, l1;
-      split_bf16_pair(v.x, v.y, h0, l0);
-      split_bf16_pair(v.z, v.w, h1, l1);
-      unsigned* u = reinterpret_cast<unsigned*>(rowp);
-      *reinterpret_cast<uint2_t*>(u + lane * 2) = uint2_t{h0, h1};
-      *reinterpret_cast<uint2_t*>(u + 128 + lane * 2) = uint2_t{l0, l1};
-    };
-#pragma unroll
-    for (int i = 0; i < 8; ++i) park(Ws + (wave + i * 8) * kT32Stride, wreg[i]);
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) park(As + (wave + i * 8) * kT32Stride, areg[i]);
-  }
+  for (int i = 0; i < RPW; ++i) st4(As + (wave + i * 8) * kT32Stride + lane * 4, areg[i]);
   if constexpr (tracing) ts[2] = clock_pinned();      // tile parked in LDS (this wave)
   __syncthreads();
   if constexpr (tracing) ts[3] = clock_pinned();      // barrier passed
@@ -247,32 +229,18 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
   const float* ap = As + (rt * 16 + r) * kT32Stride + g * 8 + kh * 128;
   const float* wp = Ws + (ct * 16 + r) * kT32Stride + g * 8 + kh * 128;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (PREC == 0) {
 #pragma unroll
-    for (int kc = 0; kc < KCH; ++kc) {
-      const F4 a0 = ld4(ap + kc * 32), a1 = ld4(ap + kc * 32 + 4);
-      const F4 b0 = ld4(wp + kc * 32), b1 = ld4(wp + kc * 32 + 4);
-      acc0 = mfma_f32_16x16x4(a0.x, b0.x, acc0);
-      acc1 = mfma_f32_16x16x4(a0.y, b0.y, acc1);
-      acc0 = mfma_f32_16x16x4(a0.z, b0.z, acc0);
-      acc1 = mfma_f32_16x16x4(a0.w, b0.w, acc1);
-      acc0 = mfma_f32_16x16x4(a1.x, b1.x, acc0);
-      acc1 = mfma_f32_16x16x4(a1.y, b1.y, acc1);
-      acc0 = mfma_f32_16x16x4(a1.z, b1.z, acc0);
-      acc1 = mfma_f32_16x16x4(a1.w, b1.w, acc1);
-    }
-  } else {
-    // hi plane: 16-byte chunk (kc*4 + g) of the row; lo plane 512 bytes further
-    const U4* ar = reinterpret_cast<const U4*>(As + (rt * 16 + r) * kT32Stride) + kh * 16 + g;
-    const U4* wr = reinterpret_cast<const U4*>(Ws + (ct * 16 + r) * kT32Stride) + kh * 16 + g;
-#pragma unroll
-    for (int kc = 0; kc < KCH; ++kc) {
-      const U4 ahi = ar[kc * 4], alo = ar[32 + kc * 4];
-      const U4 bhi = wr[kc * 4], blo = wr[32 + kc * 4];
-      acc1 = mfma_bf16_16x16x32(alo, bhi, acc1);
-      acc1 = mfma_bf16_16x16x32(ahi, blo, acc1);
-      acc0 = mfma_bf16_16x16x32(ahi, bhi, acc0);
-    }
+  for (int kc = 0; kc < KCH; ++kc) {
+    const F4 a0 = ld4(ap + kc * 32), a1 = ld4(ap + kc * 32 + 4);
+    const F4 b0 = ld4(wp + kc * 32), b1 = ld4(wp + kc * 32 + 4);
+    acc0 = mfma_f32_16x16x4(a0.x, b0.x, acc0);
+    acc1 = mfma_f32_16x16x4(a0.y, b0.y, acc1);
+    acc0 = mfma_f32_16x16x4(a0.z, b0.z, acc0);
+    acc1 = mfma_f32_16x16x4(a0.w, b0.w, acc1);
+    acc0 = mfma_f32_16x16x4(a1.x, b1.x, acc0);
+    acc1 = mfma_f32_16x16x4(a1.y, b1.y, acc1);
+    acc0 = mfma_f32_16x16x4(a1.z, b1.z, acc0);
+    acc1 = mfma_f32_16x16x4(a1.w, b1.w, acc1);
   }
   f32x4 acc = acc0 + acc1;
   if constexpr (MT == 16) {

@@ -391,11 +391,9 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
   const int mt = mt16 ? 16 : 32;
   dim3 grid((a.M + mt - 1) / mt, (a.N + 63) / 64, nz);
   const int ns = a.src[0].attn_R > 0 ? 0 : a.src[0].nsplit;
-  const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_ALL;
 #define MLD_T32(MT, NS)                                                                                          \
   do {                                                                                                           \
     if (a.trace) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, true>), grid, dim3(512), t32_lds_bytes(MT), c.stream, a); }  \
-    else if (x3) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, 1>), grid, dim3(512), t32_lds_bytes(MT), c.stream, a); } \
     else { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false>), grid, dim3(512), t32_lds_bytes(MT), c.stream, a); }         \
   } while (0)
 #define MLD_T32_NS(MT)                                                                                           \
@@ -761,7 +759,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   if (cfg->num_inference_steps < 1 || cfg->num_train_timesteps % cfg->num_inference_steps) return bad("num_train_timesteps must be a multiple of num_inference_steps");
   if ((cfg->num_inference_steps - 1) * (cfg->num_train_timesteps / cfg->num_inference_steps) + cfg->steps_offset >= cfg->num_train_timesteps)
     return bad("steps_offset pushes the first timestep past num_train_timesteps");
-  if (cfg->precision < MLDHIP_PREC_F32 || cfg->precision > MLDHIP_PREC_BF16X3_ALL) return bad("unsupported precision");
+  if (cfg->precision != MLDHIP_PREC_F32 && cfg->precision != MLDHIP_PREC_BF16X3_DECODE) return bad("unsupported precision");
 #if !defined(MLDHIP_SIM)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_last_error = "no HIP device visible (libmldhip has no CPU path)"; return MLDHIP_ENODEV; }
@@ -822,9 +820,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<32, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<32, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);  \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
-  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);   \
-  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<32, NS, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
-  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
+  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
   MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4)
   staged_attrs<2, 2, 2, 4, false, 0>(); staged_attrs<2, 2, 2, 4, false, 1>();
   staged_attrs<1, 4, 2, 4, true, 0>(); staged_attrs<1, 4, 2, 4, true, 1>();
