@@ -88,9 +88,9 @@ void mldhip_destroy(mldhip_handle* h);
 /* Replaces: model.load_state_dict(ckpt["state_dict"], strict=True) (demo.py:129-150) plus the
  * datamodule's Mean.npy/Std.npy (mld/data/get_data.py:38-40).  `key` is the checkpoint key
  * ("denoiser.encoder.input_blocks.0.self_attn.in_proj_weight", "vae.final_layer.bias", ...) or
- * "mean" / "std".  Keys the sampling path never reads (vae.encoder.*, vae.skel_embedding.*,
- * vae.global_motion_token, vae.query_pos_encoder.pe, denoiser.mem_pos.pe, text_encoder.*, t2m_*)
- * are accepted and ignored (returns 1).  `src_is_device` != 0 when `data` is a device pointer. */
+ * "mean" / "std".  Keys the engine never reads (denoiser.mem_pos.pe, text_encoder.*, t2m_*) are accepted
+ * and ignored (returns 1).  Weight groups (denoiser.*, VAE decoder, VAE encoder, mean/std) are each
+ * all-or-nothing; ops of an absent group return MLDHIP_ESTATE.  `src_is_device` != 0 when `data` is a device pointer. */
 int mldhip_load_tensor(mldhip_handle* h, const char* key, const void* data, const int64_t* shape,
                        int32_t ndim, int32_t dtype, int32_t src_is_device);
 
@@ -124,6 +124,14 @@ int mldhip_denoiser_forward(mldhip_handle* h, const float* sample_dev, int32_t t
  * z [latent_size, B, D] (== [B, D] for latent_size 1) -> feats [B, Tmax, nfeats]. */
 int mldhip_vae_decode(mldhip_handle* h, const float* z_dev, const int32_t* lengths_host, int32_t B,
                       float* feats_out_dev, void* stream);
+
+/* Replaces: MldVae.encode(features, lengths) (mld/models/architectures/mld_vae.py:124-184) -- scope row 8f.1.
+ * feats [B, T, nfeats] zero padded (T >= max(lengths)); mu / logvar [B, D] are the Normal's parameters
+ * (dist.loc, log of dist.scale^2); when eps_dev [B, D] (the N(0,1) draw of rsample) is given,
+ * latent_out = mu + exp(logvar)^0.5 * eps.  Needs the optional weight group vae.encoder.*, vae.skel_embedding.*,
+ * vae.global_motion_token, vae.query_pos_encoder.pe. */
+int mldhip_vae_encode(mldhip_handle* h, const float* feats_dev, const int32_t* lengths_host, int32_t B, int32_t T,
+                      const float* eps_dev, float* latent_out_dev, float* mu_out_dev, float* logvar_out_dev, void* stream);
 
 /* Replaces: DDIMScheduler.step(model_output, t, sample, eta=0).prev_sample (call site
  * mld.py:345-346).  n elements, in/out may alias. */

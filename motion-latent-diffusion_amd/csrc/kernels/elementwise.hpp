@@ -85,6 +85,53 @@ __global__ __launch_bounds__(256) void bcast_rows_kernel(float* __restrict__ dst
     dst[i] = vec[i % D];
 }
 
+// dst[r][0..KP) = src[r][0..K) followed by zeros (K = 263 features -> KP = 288 so MFMA K chunks stay full)
+__global__ __launch_bounds__(256) void pad_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int K, int KP) {
+  const long long n = (long long)rows * KP;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / KP;
+    const int c = int(i - r * KP);
+    dst[i] = c < K ? src[r * K + c] : 0.f;
+  }
+}
+
+// Encoder token assembly (mld_vae.py:143-160): X[b*(T+2) + s] = (s < 2 ? global_motion_token[s] : emb[b*T + s-2]) + pe[s]
+__global__ __launch_bounds__(256) void enc_tokens_kernel(const float* __restrict__ emb, const float* __restrict__ tok,
+                                                         const float* __restrict__ pe, float* __restrict__ X, int B, int T, int D) {
+  const int S = T + 2;
+  const long long n4 = (long long)B * S * D / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4;
+    const int d = int(e % D);
+    const long long row = e / D;
+    const int s = int(row % S), b = int(row / S);
+    const F4 a = s < 2 ? ld4(tok + (long long)s * D + d) : ld4(emb + ((long long)b * T + s - 2) * D + d);
+    const F4 p = ld4(pe + (long long)s * D + d);
+    st4(X + e, F4{a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w});
+  }
+}
+
+// Encoder head (mld_vae.py:176-183): mu / logvar = final-norm of token rows 0 / 1 of each sample; the
+// reparameterised draw uses an injected N(0,1) tensor: latent = mu + exp(logvar)^0.5 * eps.  grid = B, block = 256.
+__global__ __launch_bounds__(256) void enc_finish_kernel(const float* __restrict__ H, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ eps,
+                                                         float* __restrict__ latent, float* __restrict__ mu, float* __restrict__ logvar, int S) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x, d = threadIdx.x;
+  float out[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float x = H[((long long)b * S + s) * 256 + d];
+    const float mean = block_sum_256(x, sh, d) * (1.0f / 256.0f);
+    const float xc = x - mean;
+    const float var = block_sum_256(xc * xc, sh, d) * (1.0f / 256.0f);
+    out[s] = xc * rsqrtf(var + kLnEps) * gamma[d] + beta[d];
+  }
+  mu[(long long)b * 256 + d] = out[0];
+  logvar[(long long)b * 256 + d] = out[1];
+  if (eps) latent[(long long)b * 256 + d] = out[0] + sqrtf(expf(out[1])) * eps[(long long)b * 256 + d];
+}
+
 // ----------------------------------------------------------------------------------------------
 // feats -> joints: HumanML3DDataModule.feats2joints + recover_from_ric
 // (HumanML3D.py:41-45, motion_process.py:362-381,415-432, quaternion.py:16-20,54-73).

@@ -70,7 +70,7 @@ struct mldhip_engine {
   int device = 0;
   std::string err;
   bool finalized = false;
-  bool group_ready[3] = {false, false, false};
+  bool group_ready[4] = {false, false, false, false};   // denoiser, vae decoder, mean/std, vae encoder
 
   // ---- parameters
   std::vector<Param> params;
@@ -79,6 +79,7 @@ struct mldhip_engine {
   size_t arena_floats = 0;
   std::vector<EncLayerP> den;      // execution order
   std::vector<DecLayerP> dec;
+  std::vector<EncLayerP> venc;     // VAE encoder layers (same layer type as the denoiser's)
   size_t dec_layer_stride = 0;     // floats between consecutive decoder layers' tensors
 
   // ---- schedule
@@ -97,6 +98,9 @@ struct mldhip_engine {
   float *Po, *Pf, *Ps;   // denoiser split-K slabs: out-proj [1], FFN2 [4], skip-linear [2], each [6*max_batch][256]
   unsigned long long* trace_buf = nullptr;   // measurement only (mldhip_profile_trace)
   unsigned long long* trace_on = nullptr;    // non-null while a traced launch is being built
+  float* WskelP = nullptr;   // skel_embedding.weight padded to [D][KP]
+  int32_t* lens2_dev = nullptr;  // lengths + 2 (encoder key-padding mask incl. the two distribution tokens)
+  std::vector<int32_t> lens2_host;
   float* TP;             // text projection rows [2*max_batch][256] (+pe[2]), gathered per chain
   bool tile16 = true;    // MLDHIP_TILE16=0 disables the 16-row K-split tiles (A/B runs)
   int nchains = 1;       // independent sub-batch chains of the reverse loop (parallel graph branches)
@@ -150,7 +154,9 @@ size_t add_param(E* e, const std::string& key, std::vector<int64_t> shape) {
   p.numel = 1;
   for (auto s : shape) p.numel *= size_t(s);
   p.offset = e->arena_floats;
-  p.group = key.rfind("denoiser.", 0) == 0 ? 0 : key.rfind("vae.", 0) == 0 ? 1 : 2;
+  const bool enc = key.rfind("vae.encoder.", 0) == 0 || key.rfind("vae.skel_embedding.", 0) == 0 ||
+                   key.rfind("vae.global_motion_token", 0) == 0 || key.rfind("vae.query_pos_encoder.", 0) == 0;
+  p.group = key.rfind("denoiser.", 0) == 0 ? 0 : enc ? 3 : key.rfind("vae.", 0) == 0 ? 1 : 2;
   e->arena_floats += align_up(p.numel);
   e->index[key] = int(e->params.size());
   e->params.push_back(p);
@@ -213,6 +219,20 @@ void declare_params(E* e) {
   for (int i = 0; i < nb; ++i) lin("vae.decoder.linear_blocks." + std::to_string(i), D, 2 * D);
   norm("vae.decoder.norm");
   lin("vae.final_layer", NF, D);
+  // VAE encoder (mld_vae.py:75-83,108-111) -- scope row 8f.1; an optional weight group
+  add_param(e, "vae.global_motion_token", {2 * (int64_t)c.latent_size, D});
+  add_param(e, "vae.query_pos_encoder.pe", {500, 1, D});
+  lin("vae.skel_embedding", D, NF);
+  for (auto& b : block_names(nb)) {
+    std::string p = "vae.encoder." + b;
+    mha(p + ".self_attn");
+    lin(p + ".linear1", F, D);
+    lin(p + ".linear2", D, F);
+    norm(p + ".norm1");
+    norm(p + ".norm2");
+  }
+  for (int i = 0; i < nb; ++i) lin("vae.encoder.linear_blocks." + std::to_string(i), D, 2 * D);
+  norm("vae.encoder.norm");
   add_param(e, "mean", {NF});
   add_param(e, "std", {NF});
 }
@@ -233,6 +253,18 @@ void bind_layers(E* e) {
     L.n1_w = P(e, p + ".norm1.weight"); L.n1_b = P(e, p + ".norm1.bias");
     L.n2_w = P(e, p + ".norm2.weight"); L.n2_b = P(e, p + ".norm2.bias");
     e->den.push_back(L);
+  }
+  e->venc.clear();
+  for (auto& b : block_names(nb)) {
+    std::string p = "vae.encoder." + b;
+    EncLayerP L;
+    L.in_w = P(e, p + ".self_attn.in_proj_weight"); L.in_b = P(e, p + ".self_attn.in_proj_bias");
+    L.out_w = P(e, p + ".self_attn.out_proj.weight"); L.out_b = P(e, p + ".self_attn.out_proj.bias");
+    L.l1_w = P(e, p + ".linear1.weight"); L.l1_b = P(e, p + ".linear1.bias");
+    L.l2_w = P(e, p + ".linear2.weight"); L.l2_b = P(e, p + ".linear2.bias");
+    L.n1_w = P(e, p + ".norm1.weight"); L.n1_b = P(e, p + ".norm1.bias");
+    L.n2_w = P(e, p + ".norm2.weight"); L.n2_b = P(e, p + ".norm2.bias");
+    e->venc.push_back(L);
   }
   for (auto& b : block_names(nb)) {
     std::string p = "vae.decoder." + b;
@@ -544,17 +576,18 @@ void time_mlp(Ctx& c, const float* temb0, float* mid, float* out, int n) {
 // One decoder layer over M = B*T frame rows with memory = the sample's latent (cross_attention.py:323-345).
 int pick_nkt(int T) { return T <= 64 ? 4 : T <= 112 ? 7 : T <= 208 ? 13 : 18; }
 
-void dec_attention(Ctx& c, int B, int T) {
+void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr) {
+  if (!lens) lens = c.e->lens_dev;
   E* e = c.e;
   const int H = e->cfg.num_heads;
   const int nkt = pick_nkt(T);
   const size_t shmem = (size_t)2 * nkt * 16 * 68 * sizeof(float);
   dim3 grid(B * H), block(256);
   switch (nkt) {
-    case 4: MLD_LAUNCH((attn_decode_kernel<4>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)e->lens_dev, T, H); break;
-    case 7: MLD_LAUNCH((attn_decode_kernel<7>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)e->lens_dev, T, H); break;
-    case 13: MLD_LAUNCH((attn_decode_kernel<13>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)e->lens_dev, T, H); break;
-    default: MLD_LAUNCH((attn_decode_kernel<18>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)e->lens_dev, T, H); break;
+    case 4: MLD_LAUNCH((attn_decode_kernel<4>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
+    case 7: MLD_LAUNCH((attn_decode_kernel<7>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
+    case 13: MLD_LAUNCH((attn_decode_kernel<13>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
+    default: MLD_LAUNCH((attn_decode_kernel<18>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
   }
   count(c);
   check_launch(c, "attn_decode");
@@ -630,6 +663,58 @@ void decode_body(Ctx& c, const float* z, int B, int T, float* feats_out) {
   GemmArgs f = lin_args(e->LNO, D, D, P(e, "vae.final_layer.weight"), P(e, "vae.final_layer.bias"), feats_out, NF, M, NF);
   f.lens = e->lens_dev; f.rows_per_group = T;   // output[~mask.T] = 0 (mld_vae.py:245)
   gemm(c, f);
+}
+
+
+// One post-norm encoder layer over M = B*S token rows with a key-padding mask (cross_attention.py:259-272),
+// on the decoder's kernels: packed in-proj GEMM, masked MFMA attention, out-proj + res + norm1, FFN.
+void venc_layer(Ctx& c, const EncLayerP& L, const float* xin, float* xout, int B, int S) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim, F = e->cfg.ff_size, M = B * S;
+  gemm(c, lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
+  dec_attention(c, B, S, e->lens2_dev);
+  GemmArgs o = lin_args(e->AO, D, D, L.out_w, L.out_b, e->H1, D, M, D);
+  o.res = xin; o.ldres = D; o.g1 = L.n1_w; o.b1 = L.n1_b;
+  gemm_ln(c, o);
+  GemmArgs f1 = lin_args(e->H1, D, D, L.l1_w, L.l1_b, e->FF, F, M, F);
+  f1.act = ACT_GELU;
+  gemm(c, f1);
+  GemmArgs f2 = lin_args(e->FF, F, F, L.l2_w, L.l2_b, xout, D, M, D);
+  f2.res = e->H1; f2.ldres = D; f2.g1 = L.n2_w; f2.b1 = L.n2_b;
+  gemm_ln(c, f2);
+}
+
+// MldVae.encode (mld_vae.py:124-184): feats [B,T,nfeats] -> mu, logvar (and latent = mu + exp(logvar)^0.5 * eps).
+void encode_body(Ctx& c, const float* feats, int B, int T, const float* eps, float* latent, float* mu, float* logvar) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim, NF = e->cfg.nfeats, KP = (NF + 31) / 32 * 32, nb = (e->cfg.num_layers - 1) / 2;
+  const int S = T + 2, M = B * S;
+  // skel_embedding: K = 263 is padded to 288 so the MFMA K chunks stay full (zeros contribute nothing)
+  MLD_LAUNCH(pad_cols_kernel, dim3(std::min(4096, (B * T * KP + 255) / 256)), dim3(256), 0, c.stream, feats, e->FF, B * T, NF, KP);
+  count(c);
+  check_launch(c, "pad_cols");
+  {
+    GemmArgs g = lin_args(e->FF, KP, KP, e->WskelP, P(e, "vae.skel_embedding.bias"), e->LNO, D, B * T, D);
+    gemm(c, g);
+  }
+  MLD_LAUNCH(enc_tokens_kernel, dim3(std::min(4096, (M * D / 4 + 255) / 256)), dim3(256), 0, c.stream, (const float*)e->LNO,
+             P(e, "vae.global_motion_token"), P(e, "vae.query_pos_encoder.pe"), e->X0, B, T, D);
+  count(c);
+  check_launch(c, "enc_tokens");
+  const float* x = e->X0;
+  for (int l = 0; l < nb; ++l) {
+    venc_layer(c, e->venc[l], x, e->S[l], B, S);
+    x = e->S[l];
+  }
+  venc_layer(c, e->venc[nb], x, e->Ha, B, S);
+  for (int i = 0; i < nb; ++i) {
+    skip_linear(c, "vae.encoder", i, e->Ha, e->S[nb - 1 - i], e->Hb, M);
+    venc_layer(c, e->venc[nb + 1 + i], e->Hb, e->Ha, B, S);
+  }
+  MLD_LAUNCH(enc_finish_kernel, dim3(B), dim3(256), 0, c.stream, (const float*)e->Ha, P(e, "vae.encoder.norm.weight"),
+             P(e, "vae.encoder.norm.bias"), eps, latent, mu, logvar, S);
+  count(c);
+  check_launch(c, "enc_finish");
 }
 
 void joints_body(Ctx& c, const float* feats, int B, int T, float* joints) {
@@ -786,7 +871,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   // ---- workspace carve
   const size_t D = cfg->latent_dim, F = cfg->ff_size, TD = cfg->text_dim, NF = cfg->nfeats;
   const size_t Bm = cfg->max_batch, Tm = cfg->max_frames, n = cfg->num_inference_steps, L = cfg->num_layers;
-  const size_t rows = std::max(Bm * Tm, 6 * Bm);
+  const size_t rows = std::max(Bm * (Tm + 2), 6 * Bm);   // decoder: B*T frame rows; encoder: B*(T+2) token rows
+  const size_t KP = (NF + 31) / 32 * 32;                 // feature width padded to the MFMA K chunk
   size_t off = 0;
   std::vector<std::pair<float**, size_t>> carve;
   auto want = [&](float** p, size_t nfl) { carve.push_back({p, off}); off += align_up(nfl); };
@@ -798,12 +884,13 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   want(&e->T1, n * D); want(&e->temb0, n * TD); want(&e->tmid, n * D);
   want(&e->text_bias, D); want(&e->time_b2pe, D); want(&e->t1_one, D); want(&e->temb0_one, TD + D);
   want(&e->cv1, L * Bm * D); want(&e->cvec, L * Bm * D);
+  want(&e->WskelP, D * KP);
   want(&e->feats_int, Bm * Tm * NF); want(&e->joints_int, Bm * Tm * cfg->njoints * 3);
   e->ws_floats = off;
   if (hipMalloc((void**)&e->ws, off * sizeof(float)) != hipSuccess) { e->err = "hipMalloc(workspace) failed"; return fail_create(MLDHIP_EHIP); }
   if (hipMemset(e->ws, 0, off * sizeof(float)) != hipSuccess) { e->err = "hipMemset(workspace) failed"; return fail_create(MLDHIP_EHIP); }
   for (auto& cv : carve) *cv.first = e->ws + cv.second;
-  if (hipMalloc((void**)&e->lens_dev, Bm * sizeof(int32_t)) != hipSuccess) { e->err = "hipMalloc(lens) failed"; return fail_create(MLDHIP_EHIP); }
+  if (hipMalloc((void**)&e->lens_dev, Bm * sizeof(int32_t)) != hipSuccess || hipMalloc((void**)&e->lens2_dev, Bm * sizeof(int32_t)) != hipSuccess) { e->err = "hipMalloc(lens) failed"; return fail_create(MLDHIP_EHIP); }
 #if !defined(MLDHIP_SIM)
   if (hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return fail_create(MLDHIP_EHIP); }
   for (int i = 0; i < 7; ++i) {
@@ -842,6 +929,7 @@ void mldhip_destroy(mldhip_handle* e) {
   if (e->arena) (void)hipFree(e->arena);
   if (e->ws) (void)hipFree(e->ws);
   if (e->lens_dev) (void)hipFree(e->lens_dev);
+  if (e->lens2_dev) (void)hipFree(e->lens2_dev);
   if (e->trace_buf) (void)hipFree(e->trace_buf);
   delete e;
 }
@@ -852,7 +940,7 @@ int mldhip_load_tensor(mldhip_handle* e, const char* key, const void* data, cons
   if (dtype != MLDHIP_F32) return e->fail(MLDHIP_EINVAL, "tensor %s: only float32 tensors are accepted", key);
   auto it = e->index.find(key);
   if (it == e->index.end()) {
-    static const char* ignorable[] = {"vae.encoder.", "vae.skel_embedding.", "vae.global_motion_token", "vae.query_pos_encoder.",
+    static const char* ignorable[] = {
                                       "denoiser.mem_pos.", "text_encoder.", "t2m_", "vae.dist_layer."};
     for (auto p : ignorable)
       if (std::strncmp(key, p, std::strlen(p)) == 0) return 1;
@@ -891,12 +979,12 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
   // A group (denoiser / vae decoder / mean+std) must be loaded completely or not at all; ops of an
   // absent group fail with MLDHIP_ESTATE, sample() needs all three.
-  int have[3] = {0, 0, 0}, total[3] = {0, 0, 0};
+  int have[4] = {0, 0, 0, 0}, total[4] = {0, 0, 0, 0};
   for (auto& p : e->params) { total[p.group]++; have[p.group] += p.loaded; }
   for (auto& p : e->params)
     if (!p.loaded && have[p.group] != 0) return e->fail(MLDHIP_ENOKEY, "missing tensor %s (strict load)", p.key.c_str());
-  if (have[0] + have[1] + have[2] == 0) return e->fail(MLDHIP_ENOKEY, "no tensors loaded");
-  for (int g = 0; g < 3; ++g) e->group_ready[g] = have[g] == total[g];
+  if (have[0] + have[1] + have[2] + have[3] == 0) return e->fail(MLDHIP_ENOKEY, "no tensors loaded");
+  for (int g = 0; g < 4; ++g) e->group_ready[g] = have[g] == total[g];
   hipStream_t stream = (hipStream_t)stream_;
   bind_layers(e);
   Ctx c{e, stream};
@@ -913,6 +1001,11 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
     HIP_TRY(e, hipMemcpy(e->temb0, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
     time_mlp(c, e->temb0, e->tmid, e->T1, n);
     if (c.rc) return c.rc;
+  }
+  if (e->group_ready[3]) {
+    const int NF = e->cfg.nfeats, KP = (NF + 31) / 32 * 32;
+    MLD_LAUNCH(pad_cols_kernel, dim3((D * KP + 255) / 256), dim3(256), 0, stream, P(e, "vae.skel_embedding.weight"), e->WskelP, D, NF, KP);
+    if (check_launch(c, "pad_cols")) return c.rc;
   }
   HIP_TRY(e, hipStreamSynchronize(stream));
 #if !defined(MLDHIP_SIM)
@@ -1002,6 +1095,25 @@ int mldhip_vae_decode(mldhip_handle* e, const float* z_dev, const int32_t* lengt
   Ctx c{e, stream};
   e->phase = 1;
   decode_body(c, z_dev, B, T, feats_out_dev);
+  return c.rc;
+}
+
+int mldhip_vae_encode(mldhip_handle* e, const float* feats_dev, const int32_t* lengths_host, int32_t B, int32_t T,
+                      const float* eps_dev, float* latent_out_dev, float* mu_out_dev, float* logvar_out_dev, void* stream_) {
+  if (!e) return MLDHIP_EINVAL;
+  if (!e->finalized || !e->group_ready[3]) return e->fail(MLDHIP_ESTATE, "vae_encode before finalize / vae.encoder.* not loaded");
+  if (!feats_dev || !mu_out_dev || !logvar_out_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
+  if (eps_dev && !latent_out_dev) return e->fail(MLDHIP_EINVAL, "eps given but latent_out is NULL");
+  int Tm = 0;
+  if (int rc = validate_lengths(e, lengths_host, B, &Tm)) return rc;
+  if (T < Tm || T > e->cfg.max_frames || T + 2 > 288) return e->fail(MLDHIP_EINVAL, "T=%d must satisfy max(lengths) <= T <= min(max_frames, 286)", T);
+  hipStream_t stream = (hipStream_t)stream_;
+  e->lens2_host.assign(lengths_host, lengths_host + B);
+  for (auto& v : e->lens2_host) v += 2;                       // the two distribution tokens are always attended to
+  HIP_TRY(e, hipMemcpyAsync(e->lens2_dev, e->lens2_host.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  Ctx c{e, stream};
+  e->phase = 1;
+  encode_body(c, feats_dev, B, T, eps_dev, latent_out_dev, mu_out_dev, logvar_out_dev);
   return c.rc;
 }
 

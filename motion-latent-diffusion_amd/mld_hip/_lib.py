@@ -48,6 +48,8 @@ _SYMBOLS = {
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "mldhip_denoiser_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mldhip_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p]),
+    "mldhip_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "mldhip_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mldhip_feats2joints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mldhip_profile_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
@@ -173,6 +175,11 @@ class Engine:
     def vae_decode(self, z, lengths: Sequence[int], feats_out, stream: int = 0):
         lens = (C.c_int32 * len(lengths))(*[int(x) for x in lengths])
         self._check(self.lib.mldhip_vae_decode(self._h, _ptr(z), lens, len(lengths), _ptr(feats_out), stream))
+
+    def vae_encode(self, feats, lengths: Sequence[int], T: int, eps, latent_out, mu_out, logvar_out, stream: int = 0):
+        lens = (C.c_int32 * len(lengths))(*[int(x) for x in lengths])
+        self._check(self.lib.mldhip_vae_encode(self._h, _ptr(feats), lens, len(lengths), int(T), _ptr(eps), _ptr(latent_out),
+                                               _ptr(mu_out), _ptr(logvar_out), stream))
 
     def ddim_step(self, eps, timestep: int, sample, prev_sample, n: int, stream: int = 0):
         self._check(self.lib.mldhip_ddim_step(self._h, _ptr(eps), int(timestep), _ptr(sample), _ptr(prev_sample), n, stream))

@@ -1,12 +1,12 @@
 """``HipMldVae`` -- drop-in for ``mld.models.architectures.mld_vae.MldVae`` (arch encoder_decoder, PE mld).
 
-``decode(z, lengths)`` (mld_vae.py:186-248) runs on the HIP engine.  ``encode`` is the next row of the
-scope table and raises until it lands; the encoder weights are still part of the
-``state_dict`` so a released checkpoint loads with ``strict=True``.
+``decode(z, lengths)`` (mld_vae.py:186-248) and ``encode(features, lengths)`` (mld_vae.py:124-184; scope row
+SURVEY.md §8f.1) run on the HIP engine.  ``encode`` returns ``(latent, Normal(mu, std))`` like the reference;
+the N(0,1) draw of ``rsample`` comes from torch's generator on the tensor's device unless ``eps=`` is injected.
 """
 from __future__ import annotations
 
-from typing import List
+from typing import List, Optional
 
 import torch
 
@@ -52,9 +52,26 @@ class HipMldVae(HipModule):
         eng.vae_decode(z, lengths, feats, self._stream())
         return feats
 
-    def encode(self, features, lengths=None):
-        raise NotImplementedError("HipMldVae.encode (mld_vae.py:124-184) is not on the sampling path; it is the next "
-                                  "scope row (SURVEY.md §8f.1).  Use the reference MldVae for reconstruction.")
+    def encode(self, features: torch.Tensor, lengths: Optional[List[int]] = None, eps: Optional[torch.Tensor] = None):
+        """features [B, T, nfeats] (zero padded) -> (latent [latent_size, B, D], torch.distributions.Normal(mu, std))."""
+        features = self._check(features, "features")
+        if features.dim() != 3 or features.shape[2] != self.nfeats:
+            raise ValueError(f"features must be [B, T, {self.nfeats}], got {tuple(features.shape)}")
+        B, T = features.shape[0], features.shape[1]
+        lengths = [T] * B if lengths is None else [int(x) for x in lengths]      # reference: len(feature) per sample
+        if len(lengths) != B or max(lengths) > T:
+            raise ValueError("lengths must have one entry per sample and not exceed the padded length")
+        eng = self.sync_weights()
+        dev = features.device
+        if eps is None:
+            eps = torch.randn(B, self.latent_dim, device=dev, dtype=torch.float32)   # the draw of Normal.rsample()
+        eps = self._check(eps.reshape(B, self.latent_dim), "eps")
+        lat = torch.empty(B, self.latent_dim, device=dev)
+        mu = torch.empty_like(lat)
+        logvar = torch.empty_like(lat)
+        eng.vae_encode(features, lengths, T, eps, lat, mu, logvar, self._stream())
+        dist = torch.distributions.Normal(mu.unsqueeze(0), logvar.exp().pow(0.5).unsqueeze(0))
+        return lat.unsqueeze(0), dist
 
     def forward(self, features, lengths=None):
         raise NotImplementedError("MldVae.forward is a stub in the reference too (mld_vae.py:114-122); use decode().")

@@ -131,6 +131,18 @@ def main():
     ts = sch.set_timesteps(50)
     np.savez_compressed(os.path.join(OUT, "ddim_table.npz"), timesteps=ts, alphas_cumprod=sch.alphas_cumprod,
                         coeffs=np.array([sch.coeffs(t) for t in ts], np.float32))
+    # ---- 5b. VAE encode (scope row 8f.1): mu / std of the reference's Normal, ragged B=3
+    fe = syn._rng(9, "golden_feats").standard_normal((3, 100, 263)).astype(np.float32)
+    for i, n in enumerate(b3.lengths):
+        fe[i, n:] = 0
+    with torch.no_grad():
+        _, dist = vae.encode(torch.from_numpy(fe), b3.lengths)
+    mu_r, std_r = dist.loc.permute(1, 0, 2).numpy(), dist.scale.permute(1, 0, 2).numpy()
+    _, mu_o, lv_o = O.vae_encode(ops, bv, fe, b3.lengths)
+    np.savez_compressed(os.path.join(OUT, "vae_encode_b3.npz"), feats=fe, lengths=np.array(b3.lengths), mu=mu_r, std=std_r,
+                        oracle_diff_mu=np.abs(mu_r - mu_o).max(), oracle_diff_std=np.abs(std_r - np.sqrt(np.exp(lv_o))).max())
+    print("vae_encode_b3 oracle-vs-reference:", np.abs(mu_r - mu_o).max(), np.abs(std_r - np.sqrt(np.exp(lv_o))).max())
+
     # ---- 6. checkpoint key contract: names + shapes of the reference modules' state_dicts
     import json
     keys = {"denoiser": {k: list(v.shape) for k, v in den.state_dict().items()},

@@ -17,6 +17,7 @@ names (all citations relative to /root/reference):
   Transformer{Encoder,Decoder}Layer.forward_post  cross_attention.py:259-272, 323-345
   PositionEmbeddingLearned1D mld/models/operator/position_encoding.py:138-159
   MldVae.decode              mld/models/architectures/mld_vae.py:186-248
+  MldVae.encode              mld/models/architectures/mld_vae.py:124-184   (scope row 8f.1)
   lengths_to_mask            mld/utils/temos_utils.py:10-17
   feats2joints               mld/data/HumanML3D.py:41-45
   recover_from_ric           mld/data/humanml/scripts/motion_process.py:362-381,415-432
@@ -423,6 +424,29 @@ def vae_decode(ops, sd, z, lengths: Sequence[int], nhead=4):
                            lambda p, x: decoder_layer(ops, sd, p, x, z, nhead, valid))
     feats = linear(ops, out, sd["final_layer.weight"], sd["final_layer.bias"])
     return ops.where(valid[:, :, None], feats, ops.zeros_like(feats))                    # :245
+
+
+def vae_encode(ops, sd, feats, lengths: Sequence[int], eps=None, nhead=4):
+    """MldVae.encode, PE mld / MLP_DIST false (mld_vae.py:124-184).
+
+    feats [B, T, nfeats] (zero padded), lengths -> (latent [B,1,D], mu [B,1,D], logvar [B,1,D]).
+    Tokens: [mu token, logvar token, frame 0 .. frame T-1] (global_motion_token rows first, :143-154), learned
+    PE over the T+2 positions, SkipTransformerEncoder with key-padding mask (tokens always valid), first two
+    output rows are mu / logvar; rsample = mu + exp(logvar)^0.5 * eps with the N(0,1) draw injected.
+    """
+    b, t = feats.shape[0], feats.shape[1]
+    valid = ops.mask_from_lengths([int(x) + 2 for x in lengths], t + 2)            # aug_mask: 2 tokens + frames
+    x = linear(ops, feats, sd["skel_embedding.weight"], sd["skel_embedding.bias"])   # [B,T,D]
+    tok = sd["global_motion_token"][None, :, :] + ops.zeros_like(x[:, :1, :])        # [B,2,D] (tile)
+    xseq = ops.cat([tok, x], 1)
+    xseq = xseq + ops.swap(sd["query_pos_encoder.pe"][: t + 2], 0, 1)
+    out = skip_transformer(ops, sd, "encoder", xseq, nhead,
+                           lambda p, h: encoder_layer(ops, sd, p, h, nhead, valid))
+    mu, logvar = out[:, 0:1, :], out[:, 1:2, :]
+    if eps is None:
+        return mu, mu, logvar
+    std = ops.sqrt(ops.exp(logvar))                                                  # logvar.exp().pow(0.5)
+    return mu + std * eps, mu, logvar
 
 
 def feats2joints(ops, feats, mean, std, njoints=22):

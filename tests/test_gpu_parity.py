@@ -284,3 +284,26 @@ def test_split_bf16_decode_mode_meets_the_joint_tolerance(dev, golden_dir):
     torch.cuda.synchronize()
     assert np.abs(f3.cpu().numpy() - gd["feats"]).max() < 3e-4
     e.close()
+
+
+def test_vae_encode_vs_reference_golden(eng, dev, golden_dir, oracle_weights):
+    """Scope row 8f.1: MldVae.encode vs the reference's own Normal(mu, std) on the frozen inputs."""
+    ops, _, bv = oracle_weights
+    g = _gold(golden_dir, "vae_encode_b3.npz")
+    lengths = [int(x) for x in g["lengths"]]
+    eps = syn._rng(12, "eps").standard_normal((3, 256)).astype(np.float32)
+    lat, mu, lv = (torch.empty(3, 256, device=dev) for _ in range(3))
+    eng.vae_encode(_cuda(g["feats"], dev), lengths, 100, _cuda(eps, dev), lat, mu, lv)
+    torch.cuda.synchronize()
+    assert np.abs(mu.cpu().numpy() - g["mu"][:, 0]).max() < 1e-4
+    assert np.abs(np.sqrt(np.exp(lv.cpu().numpy())) - g["std"][:, 0]).max() < 2e-4
+    lr, _, _ = O.vae_encode(ops, bv, g["feats"], lengths, eps[:, None, :])
+    assert np.abs(lat.cpu().numpy() - lr[:, 0]).max() < 5e-4
+    # full-size batch: encode -> decode round trip stays finite and deterministic
+    b = 64
+    f = syn._rng(13, "f64").standard_normal((b, 196, 263)).astype(np.float32)
+    z = torch.empty(b, 256, device=dev); m2 = torch.empty_like(z); l2 = torch.empty_like(z)
+    eng.vae_encode(_cuda(f, dev), [196] * b, 196, None, None, m2, l2)
+    eng.vae_encode(_cuda(f, dev), [196] * b, 196, None, None, z, l2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(m2).all() and torch.equal(m2, z)

@@ -146,8 +146,16 @@ def test_modules_forward_through_the_engine(sim_key):
     den.load_state_dict(sd)
     out2 = den(sample=x, timestep=981, encoder_hidden_states=torch.from_numpy(b.text_emb))[0]
     assert np.abs((out2 - out[0]).numpy() - 1.0).max() < 1e-5
-    with pytest.raises(NotImplementedError):
-        vae.encode(torch.zeros(1, 4, 263), [4])
+    # encode (scope row 8f.1): (latent, Normal) like the reference, eps injectable
+    fe = torch.randn(2, 20, 263)
+    fe[1, 13:] = 0
+    eps = torch.randn(2, 256)
+    latent, dist = vae.encode(fe, [20, 13], eps=eps)
+    lr, mr, lvr = O.vae_encode(ops, O.to_backend(ops, syn.make_vae_state_dict()), fe.numpy(), [20, 13], eps.numpy()[:, None, :])
+    assert latent.shape == (1, 2, 256) and isinstance(dist, torch.distributions.Normal)
+    assert np.abs(dist.loc[0].numpy() - mr[:, 0]).max() < 5e-5
+    assert np.abs(dist.scale[0].numpy() - np.sqrt(np.exp(lvr[:, 0]))).max() < 5e-5
+    assert np.abs(latent[0].numpy() - lr[:, 0]).max() < 1e-4
 
 
 def test_mld_forward_fused_and_modular_agree_with_oracle(sim_key):

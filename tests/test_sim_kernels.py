@@ -36,12 +36,11 @@ def test_schedule_tables(eng):
 def test_ignored_and_required_keys():
     e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=2, max_frames=16)
     n_required = len(e.missing_keys())
-    assert n_required == (126 - 1) + (1 + 9 * 18 + 8 + 2 + 2) + 2      # denoiser sans mem_pos, vae decoder path, mean/std
+    # denoiser sans mem_pos, vae decoder, mean/std, vae encoder (token, pe, skel_embedding, 9 layers, skips, norm)
+    assert n_required == (126 - 1) + (1 + 9 * 18 + 8 + 2 + 2) + 2 + (1 + 1 + 2 + 9 * 12 + 8 + 2)
     ignored = simlib.load_synthetic_weights(e, finalize=False)
     assert e.missing_keys() == []
-    assert "denoiser.mem_pos.pe" in ignored and "vae.skel_embedding.weight" in ignored
-    assert all(k.startswith(("vae.encoder.", "vae.skel_embedding.", "vae.global_motion_token",
-                             "vae.query_pos_encoder.", "denoiser.mem_pos.")) for k in ignored)
+    assert ignored == ["denoiser.mem_pos.pe"]                  # the only checkpoint tensor no kernel reads
     e.finalize()
     e.close()
 
@@ -77,6 +76,22 @@ def test_vae_decode_ragged_sim(eng, ow):
     assert np.isfinite(feats).all()
     assert np.abs(feats - ref).max() < 5e-5
     assert (feats[1, 13:] == 0).all() and (feats[2, 1:] == 0).all()
+
+
+def test_vae_encode_sim(eng, ow):
+    """Scope row 8f.1: MldVae.encode on the decoder's kernels (T+2 tokens, key-padding mask, padded K = 263)."""
+    ops, _, bv = ow
+    lengths, T = [20, 13, 1], 22                      # padded length > max(lengths) is legal
+    fe = syn._rng(9, "f").standard_normal((3, T, 263)).astype(np.float32)
+    for i, n in enumerate(lengths):
+        fe[i, n:] = 0
+    eps = syn._rng(10, "e").standard_normal((3, 1, 256)).astype(np.float32)
+    lat, mu, lv = (np.zeros((3, 1, 256), np.float32) for _ in range(3))
+    eng.vae_encode(fe, lengths, T, eps, lat, mu, lv)
+    lr, mr, lvr = O.vae_encode(ops, bv, fe, lengths, eps)
+    assert np.abs(mu - mr).max() < 5e-5 and np.abs(lv - lvr).max() < 5e-5 and np.abs(lat - lr).max() < 1e-4
+    with pytest.raises(_lib.MldHipError):
+        eng.vae_encode(fe, [30, 13, 1], T, eps, lat, mu, lv)     # a length beyond the padded T
 
 
 def test_feats2joints_sim(eng, ow):
