@@ -167,8 +167,15 @@ def main():
             kern[name] = {"avg_us": round(ms * 1e3, 2), "gflop": round(fl / 1e9, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 3),
                           "launches_per_sample": cnt, "share_ms": round(ms * cnt, 3)}
         dom = max(kern, key=lambda k: kern[k]["share_ms"])
+        traffic = None
+        try:   # PMC counters cannot be collected from inside this process: read the committed rocprofv3 --pmc summary
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            traffic = pmc[dom]["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": FP32_MFMA_PEAK_TF,
-                           "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TF, 4), "traffic": traffic,
+                           "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, L2<->fabric bytes per launch)",
                            "avg_us": kern[dom]["avg_us"], "gflop_per_launch": kern[dom]["gflop"]}
         out["kernels"] = kern
         out["whole_job"] = {"algorithmic_gflop_per_batch": round(gf_total, 1), "denoise_gflop_per_step": round(gf_den, 3),
