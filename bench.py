@@ -80,6 +80,38 @@ def cpu_baseline(seed, threads, timeout=420):
         return {"error": repr(ex)[:200]}, None
 
 
+def bench_a2m(local, dev, stream, warmup, steps, B=256, T=60):
+    """BASELINE config 5 shape (config_mld_humanact12.yaml: action condition, 15-layer denoiser, ActorVae decoder,
+    bs=256, T=60), same timing rule; a secondary line, never the headline `value`.  fp32 like the headline (the fp8
+    denoiser GEMMs BASELINE.json muses about cannot meet the parity tolerance: DESIGN.md §7)."""
+    eng = _lib.Engine(device=local, max_batch=B, max_frames=T, condition=_lib.COND_ACTION, nclasses=12,
+                      vae_arch=_lib.VAE_ACTOR, vae_num_layers=6, num_layers=15, nfeats=150)
+    dims = syn.ModelDims(num_layers=15, nfeats=150)
+    eng.load_state_dict(syn.make_denoiser_state_dict(seed=3, dims=dims, condition="action", nclasses=12), "denoiser.")
+    eng.load_state_dict(syn.make_actor_vae_state_dict(), "vae.")
+    eng.finalize()
+    acts, lat0, lens = syn.make_action_batch(B, nframes=T)
+    x0 = torch.from_numpy(lat0).to(dev)
+    feats = torch.empty(B, T, 150, device=dev)
+    for _ in range(warmup):
+        eng.sample_action(acts, x0, lens, None, feats, stream.cuda_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.sample_action(acts, x0, lens, None, feats, stream.cuda_stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _, den15, _ = algorithmic_gflop(B, T, L=15, NF=150)     # 15-layer skip denoiser, per step
+    _, _, dec6 = algorithmic_gflop(B, T, L=6, NF=150)       # 6 decoder layers ...
+    gflop = den15 * STEPS_DDIM + dec6 - (6 - 1) / 2 * 2.0 * B * T * 512 * 256 / 1e9   # ... minus the skip linears ActorVae lacks
+    out = {"workload": "config_mld_humanact12.yaml (action-to-motion), bs=256, T=60, 50-step DDIM, CFG 7.5, ActorVae decode -> feats",
+           "value": round(B * steps / dt, 2), "unit": "motions/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+           "dtype": "f32", "algorithmic_gflop_per_batch": round(gflop, 1),
+           "achieved_tflops": round(gflop / 1e3 / (dt / steps), 2), "launches_per_step": eng.launch_counts()}
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="disable hipGraph replay (debug)")
+    ap.add_argument("--no-a2m", action="store_true", help="skip the secondary action-to-motion (config 5) measurement")
     ap.add_argument("--precision", choices=["f32", "bf16x3_decode"], default=os.environ.get("MLD_BENCH_PRECISION", "f32"),
                     help="f32: exact-fp32 MFMA everywhere; bf16x3_decode: split-bf16 MFMA in the VAE-decoder GEMMs")
     a = ap.parse_args()
@@ -216,6 +249,8 @@ def main():
                 alt["max_abs_joints_vs_oracle"] = float(np.abs(j2.cpu().numpy() - cj).max())
             out["alt_mode"] = alt
             eng2.close()
+        if world == 1 and not a.eager and not a.no_a2m:
+            out["other_workloads"] = [bench_a2m(local, dev, stream, max(2, a.warmup), max(3, a.steps // 2))]
         print(json.dumps(out))
     if dist:
         dist.barrier()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MLDHIP_ABI_VERSION 1
+#define MLDHIP_ABI_VERSION 2
 
 enum {
   MLDHIP_OK = 0,
@@ -73,7 +73,15 @@ typedef struct mldhip_config {
   float guidance_scale;         /* model.guidance_scale = 7.5 */
   int32_t precision;            /* MLDHIP_PREC_* */
   int32_t use_graph;            /* 1: capture sample() into a hipGraph and replay it */
+  /* ---- ABI 2: the action-conditioned variant (configs/config_mld_humanact12.yaml, modules_humanact12/) */
+  int32_t condition;            /* MLDHIP_COND_TEXT | MLDHIP_COND_ACTION (denoiser.params.condition) */
+  int32_t nclasses;             /* rows of emb_proj.action_embedding (12 HumanAct12, 40 UESTC); action only */
+  int32_t vae_arch;             /* MLDHIP_VAE_MLD (MldVae, skip enc-dec) | MLDHIP_VAE_ACTOR (ActorVae decoder) */
+  int32_t vae_num_layers;       /* ActorVae: layers of seqTransDecoder (6); 0 = num_layers */
 } mldhip_config;
+
+enum { MLDHIP_COND_TEXT = 0, MLDHIP_COND_ACTION = 1 };
+enum { MLDHIP_VAE_MLD = 0, MLDHIP_VAE_ACTOR = 1 };
 
 typedef struct mldhip_engine mldhip_handle;
 
@@ -120,7 +128,23 @@ int mldhip_sample(mldhip_handle* h, const float* text_emb_dev, const float* init
 int mldhip_denoiser_forward(mldhip_handle* h, const float* sample_dev, int32_t timestep,
                             const float* text_emb_dev, int32_t R, float* out_dev, void* stream);
 
-/* Replaces: MldVae.decode(z, lengths) (mld/models/architectures/mld_vae.py:186-248).
+/* Action-conditioned sampling (BASELINE config 5).  Replaces: the sampling core of MLD.a2m_eval
+ * (mld/models/modeltype/mld.py:716-735: cond = cat(zeros_like(actions), actions); _diffusion_reverse;
+ * vae.decode) for an engine created with condition = MLDHIP_COND_ACTION.
+ *   actions_host      [B] int32 class labels in [0, nclasses)
+ *   feats_out_dev     [B, Tmax, nfeats]  (rot6d/xyz features; joints need SMPL, which is out of scope) */
+int mldhip_sample_action(mldhip_handle* h, const int32_t* actions_host, const float* init_latents_dev,
+                         const int32_t* lengths_host, int32_t B, float* latents_out_dev, float* feats_out_dev,
+                         void* stream);
+
+/* Replaces: MldDenoiser.forward with condition 'action' (mld_denoiser.py:69-77,171-178 -> EmbedAction,
+ * mld_denoiser.py:249-260).  actions_host [R] labels; as in the reference's eval mode with
+ * guidance_scale > 1 the FIRST R/2 rows get the zero (unconditional) embedding whatever their label. */
+int mldhip_denoiser_forward_action(mldhip_handle* h, const float* sample_dev, int32_t timestep,
+                                   const int32_t* actions_host, int32_t R, float* out_dev, void* stream);
+
+/* Replaces: MldVae.decode(z, lengths) (mld/models/architectures/mld_vae.py:186-248); with
+ * vae_arch = MLDHIP_VAE_ACTOR: ActorVae.decode (mld/models/architectures/actor_vae.py:72-74,209-235).
  * z [latent_size, B, D] (== [B, D] for latent_size 1) -> feats [B, Tmax, nfeats]. */
 int mldhip_vae_decode(mldhip_handle* h, const float* z_dev, const int32_t* lengths_host, int32_t B,
                       float* feats_out_dev, void* stream);

@@ -79,6 +79,17 @@ __global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ dst, 
     dst[i] = a[i] + vec[i % D];
 }
 
+// EmbedAction in eval mode (mld_denoiser.py:249-260) + the token-2 positional row:
+//   dst[r] = (r < nuncond ? 0 : table[labels[r]]) + pe2        grid = rows, block = 256 (= latent width)
+__global__ __launch_bounds__(256) void action_rows_kernel(float* __restrict__ dst, const float* __restrict__ table,
+                                                          const float* __restrict__ pe2, const int* __restrict__ labels,
+                                                          int nuncond) {
+  const int r = blockIdx.x, d = threadIdx.x;
+  float v = pe2[d];
+  if (r >= nuncond) v = table[(long long)labels[r] * 256 + d] + v;
+  dst[(long long)r * 256 + d] = v;
+}
+
 __global__ __launch_bounds__(256) void bcast_rows_kernel(float* __restrict__ dst, const float* __restrict__ vec, int rows, int D) {
   const long long n = (long long)rows * D;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)

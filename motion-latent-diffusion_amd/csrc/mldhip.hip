@@ -99,6 +99,7 @@ struct mldhip_engine {
   unsigned long long* trace_buf = nullptr;   // measurement only (mldhip_profile_trace)
   unsigned long long* trace_on = nullptr;    // non-null while a traced launch is being built
   float* WskelP = nullptr;   // skel_embedding.weight padded to [D][KP]
+  int32_t* labels_dev = nullptr; // action labels of the CFG batch [2*max_batch] (uncond half first, ignored there)
   int32_t* lens2_dev = nullptr;  // lengths + 2 (encoder key-padding mask incl. the two distribution tokens)
   std::vector<int32_t> lens2_host;
   float* TP;             // text projection rows [2*max_batch][256] (+pe[2]), gathered per chain
@@ -136,11 +137,18 @@ using E = mldhip_engine;
     if (_s != hipSuccess) return (e)->fail(MLDHIP_EHIP, "%s failed: %s", #call, hipGetErrorString(_s)); \
   } while (0)
 
+bool is_action(const E* e) { return e->cfg.condition == MLDHIP_COND_ACTION; }
+bool is_actor(const E* e) { return e->cfg.vae_arch == MLDHIP_VAE_ACTOR; }
+int time_width(const E* e) { return is_action(e) ? e->cfg.latent_dim : e->cfg.text_dim; }   // mld_denoiser.py:57-77
+int vae_layers(const E* e) { return is_actor(e) ? (e->cfg.vae_num_layers > 0 ? e->cfg.vae_num_layers : e->cfg.num_layers) : e->cfg.num_layers; }
+std::string actor_layer(int i) { return "vae.decoder.seqTransDecoder.layers." + std::to_string(i); }
+
 constexpr size_t kAlign = 64;   // floats
 size_t align_up(size_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
 
 std::vector<std::string> block_names(int num_block) {
   std::vector<std::string> v;
+  if (num_block < 0) return v;
   for (int i = 0; i < num_block; ++i) v.push_back("input_blocks." + std::to_string(i));
   v.push_back("middle_block");
   for (int i = 0; i < num_block; ++i) v.push_back("output_blocks." + std::to_string(i));
@@ -183,9 +191,10 @@ void declare_params(E* e) {
     add_param(e, p + ".bias", {D});
   };
   // denoiser (mld_denoiser.py:40-133)
-  lin("denoiser.time_embedding.linear_1", D, TD);
+  lin("denoiser.time_embedding.linear_1", D, time_width(e));
   lin("denoiser.time_embedding.linear_2", D, D);
-  lin("denoiser.emb_proj.1", D, TD);
+  if (is_action(e)) add_param(e, "denoiser.emb_proj.action_embedding", {(int64_t)c.nclasses, D});   // EmbedAction
+  else lin("denoiser.emb_proj.1", D, TD);
   add_param(e, "denoiser.query_pos.pe", {500, 1, D});
   for (auto& b : block_names(nb)) {
     std::string p = "denoiser.encoder." + b;
@@ -197,10 +206,33 @@ void declare_params(E* e) {
   }
   for (int i = 0; i < nb; ++i) lin("denoiser.encoder.linear_blocks." + std::to_string(i), D, 2 * D);
   norm("denoiser.encoder.norm");
-  // VAE decoder (mld_vae.py:85-112)
-  add_param(e, "vae.query_pos_decoder.pe", {500, 1, D});
   size_t first = 0, second = 0;
   int li = 0;
+  if (is_actor(e)) {
+    // ActorVae decoder (actor_vae.py:176-207): sinusoidal PE buffer, stock decoder layers, final_layer.  Its
+    // encoder (training / reconstruction only) is not on the sampling path: vae.encoder.* keys are ignored.
+    add_param(e, "vae.decoder.sequence_pos_encoding.pe", {5000, 1, D});
+    for (int i = 0; i < vae_layers(e); ++i) {
+      std::string p = actor_layer(i);
+      size_t start = e->arena_floats;
+      mha(p + ".self_attn");
+      mha(p + ".multihead_attn");
+      lin(p + ".linear1", F, D);
+      lin(p + ".linear2", D, F);
+      norm(p + ".norm1");
+      norm(p + ".norm2");
+      norm(p + ".norm3");
+      if (i == 0) first = start;
+      if (i == 1) second = start;
+    }
+    e->dec_layer_stride = second - first;
+    lin("vae.decoder.final_layer", NF, D);
+    add_param(e, "mean", {NF});
+    add_param(e, "std", {NF});
+    return;
+  }
+  // VAE decoder (mld_vae.py:85-112)
+  add_param(e, "vae.query_pos_decoder.pe", {500, 1, D});
   for (auto& b : block_names(nb)) {
     std::string p = "vae.decoder." + b;
     size_t start = e->arena_floats;
@@ -255,7 +287,7 @@ void bind_layers(E* e) {
     e->den.push_back(L);
   }
   e->venc.clear();
-  for (auto& b : block_names(nb)) {
+  for (auto& b : block_names(is_actor(e) ? -1 : nb)) {
     std::string p = "vae.encoder." + b;
     EncLayerP L;
     L.in_w = P(e, p + ".self_attn.in_proj_weight"); L.in_b = P(e, p + ".self_attn.in_proj_bias");
@@ -266,8 +298,10 @@ void bind_layers(E* e) {
     L.n2_w = P(e, p + ".norm2.weight"); L.n2_b = P(e, p + ".norm2.bias");
     e->venc.push_back(L);
   }
-  for (auto& b : block_names(nb)) {
-    std::string p = "vae.decoder." + b;
+  std::vector<std::string> dec_names;
+  if (is_actor(e)) for (int i = 0; i < vae_layers(e); ++i) dec_names.push_back(actor_layer(i));
+  else for (auto& b : block_names(nb)) dec_names.push_back("vae.decoder." + b);
+  for (auto& p : dec_names) {
     DecLayerP L;
     L.in_w = P(e, p + ".self_attn.in_proj_weight"); L.in_b = P(e, p + ".self_attn.in_proj_bias");
     L.out_w = P(e, p + ".self_attn.out_proj.weight"); L.out_b = P(e, p + ".self_attn.out_proj.bias");
@@ -565,7 +599,7 @@ void text_projection(Ctx& c, const float* text_emb, int rows, float* dst) {
 // time-MLP rows for `n` timestep embeddings already in `temb0` -> out[n, D] (+pe[1] folded in the bias)
 void time_mlp(Ctx& c, const float* temb0, float* mid, float* out, int n) {
   E* e = c.e;
-  const int D = e->cfg.latent_dim, TD = e->cfg.text_dim;
+  const int D = e->cfg.latent_dim, TD = time_width(e);
   GemmArgs a = lin_args(temb0, TD, TD, P(e, "denoiser.time_embedding.linear_1.weight"),
                         P(e, "denoiser.time_embedding.linear_1.bias"), mid, D, n, D);
   a.act = ACT_SILU;
@@ -628,7 +662,7 @@ void skip_linear(Ctx& c, const std::string& prefix, int i, const float* x, const
 void decode_body(Ctx& c, const float* z, int B, int T, float* feats_out) {
   E* e = c.e;
   const int D = e->cfg.latent_dim, NF = e->cfg.nfeats, nb = (e->cfg.num_layers - 1) / 2, M = B * T;
-  const int L = e->cfg.num_layers;
+  const int L = vae_layers(e);
   // cross-attention with ONE memory token: softmax == 1, so the sub-layer adds
   // out_proj(v_proj(z_b)) to every frame of sample b (exact).  All layers at once.
   {
@@ -641,10 +675,24 @@ void decode_body(Ctx& c, const float* z, int B, int T, float* feats_out) {
     gemm(c, o, L);
   }
   {
+    // time queries = zeros + PE rows (learned: mld_vae.py:216-222; sinusoidal: actor_vae.py:221-222)
     MLD_LAUNCH(init_queries_kernel, dim3(std::min(2048, (M * D / 4 + 255) / 256)), dim3(256), 0, c.stream, e->X0,
-               P(e, "vae.query_pos_decoder.pe"), B, T, D);
+               P(e, is_actor(e) ? "vae.decoder.sequence_pos_encoding.pe" : "vae.query_pos_decoder.pe"), B, T, D);
     count(c);
     check_launch(c, "init_queries");
+  }
+  if (is_actor(e)) {
+    // ActorAgnosticDecoder (actor_vae.py:224-235): plain stack, no skip links, no final LayerNorm
+    const float* xin = e->X0;
+    for (int l = 0; l < L; ++l) {
+      float* xout = (l & 1) ? e->Hb : e->Ha;
+      dec_layer(c, l, xin, xout, B, T);
+      xin = xout;
+    }
+    GemmArgs f = lin_args(xin, D, D, P(e, "vae.decoder.final_layer.weight"), P(e, "vae.decoder.final_layer.bias"), feats_out, NF, M, NF);
+    f.lens = e->lens_dev; f.rows_per_group = T;   // output[~mask.T] = 0 (actor_vae.py:231)
+    gemm(c, f);
+    return;
   }
   const float* x = e->X0;
   for (int l = 0; l < nb; ++l) {
@@ -734,13 +782,26 @@ void joints_body(Ctx& c, const float* feats, int B, int T, float* joints) {
 // hundred rows per launch), and samples never interact, so the batch is cut into `nchains` sub-batches
 // whose 50-step chains run on parallel branches (side streams forked from / joined to `stream`; inside
 // a capture they become parallel branches of the hipGraph).  The MFMA-bound decode runs on the whole batch.
+// rows of token 2 for an action CFG batch of R rows -> dst[R][D] (labels already in labels_dev)
+void action_rows(Ctx& c, int R, int nuncond, float* dst) {
+  E* e = c.e;
+  MLD_LAUNCH(action_rows_kernel, dim3(R), dim3(256), 0, c.stream, dst, P(e, "denoiser.emb_proj.action_embedding"),
+             P(e, "denoiser.query_pos.pe") + 2 * e->cfg.latent_dim, (const int*)e->labels_dev, nuncond);
+  count(c);
+  check_launch(c, "action_rows");
+}
+
+// `text` == nullptr selects the action condition (labels_dev holds the 2B labels).
 int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* init_lat, int B, int T,
                    float* lat_out, float* feats_out, float* joints_out) {
   Ctx c{e, stream};
   const int D = e->cfg.latent_dim, n = e->cfg.num_inference_steps;
+  // guidance_scale <= 1: the reference runs the conditional batch alone (mld.py:300,316-340); u + 1*(c-u) is that batch
+  const float guidance = e->cfg.guidance_scale > 1.0f ? e->cfg.guidance_scale : 1.0f;
   e->launches[0] = e->launches[1] = e->launches[2] = 0;
   e->phase = 0;
-  text_projection(c, text, 2 * B, e->TP);
+  if (text) text_projection(c, text, 2 * B, e->TP);
+  else action_rows(c, 2 * B, B, e->TP);
   int nch = std::min(e->nchains, B);
   const int Bc = (B + nch - 1) / nch;
   nch = (B + Bc - 1) / Bc;
@@ -768,7 +829,7 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
       denoiser_body(cc, v);
       const float* t1n = (s + 1 < n) ? e->T1 + (size_t)(s + 1) * D : nullptr;
       MLD_LAUNCH(den_final_step_kernel, dim3(bc), dim3(256), 0, cc.stream, den_final_args(e, v), v.lat, v.X0,
-                 P(e, "denoiser.query_pos.pe"), t1n, bc, e->cfg.guidance_scale, ddim_coef(e, e->timesteps[s]));
+                 P(e, "denoiser.query_pos.pe"), t1n, bc, guidance, ddim_coef(e, e->timesteps[s]));
       count(cc);
       check_launch(cc, "den_final_step");
     }
@@ -827,6 +888,7 @@ void mldhip_default_config(mldhip_config* c) {
   c->num_train_timesteps = 1000; c->num_inference_steps = 50; c->steps_offset = 1; c->set_alpha_to_one = 0;
   c->beta_start = 0.00085f; c->beta_end = 0.012f; c->guidance_scale = 7.5f;
   c->precision = MLDHIP_PREC_F32; c->use_graph = 1;
+  c->condition = MLDHIP_COND_TEXT; c->nclasses = 0; c->vae_arch = MLDHIP_VAE_MLD; c->vae_num_layers = 0;
 }
 
 const char* mldhip_last_error(mldhip_handle* h) { return h ? h->err.c_str() : g_last_error.c_str(); }
@@ -840,7 +902,12 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   if (cfg->num_layers < 3 || cfg->num_layers % 2 == 0 || cfg->num_layers > 17) return bad("num_layers must be odd, 3..17 (SkipTransformer)");
   if ((cfg->ff_size != 256 && cfg->ff_size != 512 && cfg->ff_size != 1024) || cfg->text_dim % 32) return bad("ff_size must be 256, 512 or 1024 and text_dim % 32 == 0");
   if (cfg->max_batch < 1 || cfg->max_frames < 1 || cfg->max_frames > 288) return bad("max_batch >= 1, 1 <= max_frames <= 288");
-  if (cfg->nfeats < 67 || cfg->njoints != 22) return bad("HumanML3D layout expected: nfeats >= 67, njoints 22");
+  if (cfg->condition != MLDHIP_COND_TEXT && cfg->condition != MLDHIP_COND_ACTION) return bad("condition must be text or action");
+  if (cfg->vae_arch != MLDHIP_VAE_MLD && cfg->vae_arch != MLDHIP_VAE_ACTOR) return bad("vae_arch must be mld or actor");
+  if (cfg->condition == MLDHIP_COND_ACTION && (cfg->nclasses < 1 || cfg->nclasses > 4096)) return bad("action condition needs 1 <= nclasses <= 4096");
+  if (cfg->vae_num_layers < 0 || cfg->vae_num_layers > 17) return bad("vae_num_layers must be 0..17");
+  if (cfg->vae_arch == MLDHIP_VAE_MLD && (cfg->nfeats < 67 || cfg->njoints != 22)) return bad("HumanML3D layout expected: nfeats >= 67, njoints 22");
+  if (cfg->nfeats < 1 || cfg->nfeats > 1024) return bad("nfeats must be 1..1024");
   if (cfg->num_inference_steps < 1 || cfg->num_train_timesteps % cfg->num_inference_steps) return bad("num_train_timesteps must be a multiple of num_inference_steps");
   if ((cfg->num_inference_steps - 1) * (cfg->num_train_timesteps / cfg->num_inference_steps) + cfg->steps_offset >= cfg->num_train_timesteps)
     return bad("steps_offset pushes the first timestep past num_train_timesteps");
@@ -869,8 +936,9 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   auto fail_create = [&](int code) { g_last_error = e->err; mldhip_destroy(e); return code; };
   if (hipMalloc((void**)&e->arena, e->arena_floats * sizeof(float)) != hipSuccess) { e->err = "hipMalloc(weights) failed"; return fail_create(MLDHIP_EHIP); }
   // ---- workspace carve
-  const size_t D = cfg->latent_dim, F = cfg->ff_size, TD = cfg->text_dim, NF = cfg->nfeats;
+  const size_t D = cfg->latent_dim, F = cfg->ff_size, TD = std::max(cfg->text_dim, cfg->latent_dim), NF = cfg->nfeats;
   const size_t Bm = cfg->max_batch, Tm = cfg->max_frames, n = cfg->num_inference_steps, L = cfg->num_layers;
+  const size_t Lv = std::max<size_t>(L, vae_layers(e));
   const size_t rows = std::max(Bm * (Tm + 2), 6 * Bm);   // decoder: B*T frame rows; encoder: B*(T+2) token rows
   const size_t KP = (NF + 31) / 32 * 32;                 // feature width padded to the MFMA K chunk
   size_t off = 0;
@@ -883,14 +951,15 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   want(&e->Po, 6 * Bm * D); want(&e->Pf, 4 * 6 * Bm * D); want(&e->Ps, 2 * 6 * Bm * D); want(&e->TP, 2 * Bm * D);
   want(&e->T1, n * D); want(&e->temb0, n * TD); want(&e->tmid, n * D);
   want(&e->text_bias, D); want(&e->time_b2pe, D); want(&e->t1_one, D); want(&e->temb0_one, TD + D);
-  want(&e->cv1, L * Bm * D); want(&e->cvec, L * Bm * D);
+  want(&e->cv1, Lv * Bm * D); want(&e->cvec, Lv * Bm * D);
   want(&e->WskelP, D * KP);
   want(&e->feats_int, Bm * Tm * NF); want(&e->joints_int, Bm * Tm * cfg->njoints * 3);
   e->ws_floats = off;
   if (hipMalloc((void**)&e->ws, off * sizeof(float)) != hipSuccess) { e->err = "hipMalloc(workspace) failed"; return fail_create(MLDHIP_EHIP); }
   if (hipMemset(e->ws, 0, off * sizeof(float)) != hipSuccess) { e->err = "hipMemset(workspace) failed"; return fail_create(MLDHIP_EHIP); }
   for (auto& cv : carve) *cv.first = e->ws + cv.second;
-  if (hipMalloc((void**)&e->lens_dev, Bm * sizeof(int32_t)) != hipSuccess || hipMalloc((void**)&e->lens2_dev, Bm * sizeof(int32_t)) != hipSuccess) { e->err = "hipMalloc(lens) failed"; return fail_create(MLDHIP_EHIP); }
+  if (hipMalloc((void**)&e->lens_dev, Bm * sizeof(int32_t)) != hipSuccess || hipMalloc((void**)&e->lens2_dev, Bm * sizeof(int32_t)) != hipSuccess ||
+      hipMalloc((void**)&e->labels_dev, 2 * Bm * sizeof(int32_t)) != hipSuccess) { e->err = "hipMalloc(lens) failed"; return fail_create(MLDHIP_EHIP); }
 #if !defined(MLDHIP_SIM)
   if (hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return fail_create(MLDHIP_EHIP); }
   for (int i = 0; i < 7; ++i) {
@@ -930,6 +999,7 @@ void mldhip_destroy(mldhip_handle* e) {
   if (e->ws) (void)hipFree(e->ws);
   if (e->lens_dev) (void)hipFree(e->lens_dev);
   if (e->lens2_dev) (void)hipFree(e->lens2_dev);
+  if (e->labels_dev) (void)hipFree(e->labels_dev);
   if (e->trace_buf) (void)hipFree(e->trace_buf);
   delete e;
 }
@@ -944,6 +1014,7 @@ int mldhip_load_tensor(mldhip_handle* e, const char* key, const void* data, cons
                                       "denoiser.mem_pos.", "text_encoder.", "t2m_", "vae.dist_layer."};
     for (auto p : ignorable)
       if (std::strncmp(key, p, std::strlen(p)) == 0) return 1;
+    if (is_actor(e) && std::strncmp(key, "vae.encoder.", 12) == 0) return 1;   // ActorVae encoder: not on the sampling path
     return e->fail(MLDHIP_EINVAL, "unexpected key %s", key);
   }
   Param& p = e->params[it->second];
@@ -984,16 +1055,16 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
   for (auto& p : e->params)
     if (!p.loaded && have[p.group] != 0) return e->fail(MLDHIP_ENOKEY, "missing tensor %s (strict load)", p.key.c_str());
   if (have[0] + have[1] + have[2] + have[3] == 0) return e->fail(MLDHIP_ENOKEY, "no tensors loaded");
-  for (int g = 0; g < 4; ++g) e->group_ready[g] = have[g] == total[g];
+  for (int g = 0; g < 4; ++g) e->group_ready[g] = total[g] > 0 && have[g] == total[g];
   hipStream_t stream = (hipStream_t)stream_;
   bind_layers(e);
   Ctx c{e, stream};
-  const int D = e->cfg.latent_dim, TD = e->cfg.text_dim, n = e->cfg.num_inference_steps;
+  const int D = e->cfg.latent_dim, TD = time_width(e), n = e->cfg.num_inference_steps;
   if (e->group_ready[0]) {
     // PE-folded biases: token 1 (time) gets pe[1], token 2 (text) gets pe[2] (mld_denoiser.py:187,196)
     const float* pe = P(e, "denoiser.query_pos.pe");
     MLD_LAUNCH(add_rows_kernel, dim3(1), dim3(256), 0, stream, e->time_b2pe, P(e, "denoiser.time_embedding.linear_2.bias"), pe + D, 1, D);
-    MLD_LAUNCH(add_rows_kernel, dim3(1), dim3(256), 0, stream, e->text_bias, P(e, "denoiser.emb_proj.1.bias"), pe + 2 * D, 1, D);
+    if (!is_action(e)) MLD_LAUNCH(add_rows_kernel, dim3(1), dim3(256), 0, stream, e->text_bias, P(e, "denoiser.emb_proj.1.bias"), pe + 2 * D, 1, D);
     if (check_launch(c, "add_rows")) return c.rc;
     // time-MLP output for every scheduler timestep (sample independent; embeddings.py:245-305)
     std::vector<float> host((size_t)n * TD);
@@ -1016,17 +1087,29 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
   return MLDHIP_OK;
 }
 
-int mldhip_sample(mldhip_handle* e, const float* text_emb_dev, const float* init_latents_dev, const int32_t* lengths_host,
-                  int32_t B, float* latents_out_dev, float* feats_out_dev, float* joints_out_dev, void* stream_) {
-  if (!e) return MLDHIP_EINVAL;
+}  // extern "C"
+
+namespace {
+// shared body of mldhip_sample / mldhip_sample_action (text_emb_dev == nullptr <=> action labels given)
+int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* actions_host, const float* init_latents_dev,
+                const int32_t* lengths_host, int32_t B, float* latents_out_dev, float* feats_out_dev, float* joints_out_dev,
+                void* stream_) {
   if (!e->finalized) return e->fail(MLDHIP_ESTATE, "mldhip_sample before mldhip_finalize_weights");
   if (!e->group_ready[0] || !e->group_ready[1] || (joints_out_dev && !e->group_ready[2]))
     return e->fail(MLDHIP_ESTATE, "mldhip_sample needs denoiser.*, vae.decoder.* (and mean/std for joints) loaded");
-  if (!text_emb_dev || !init_latents_dev) return e->fail(MLDHIP_EINVAL, "null input pointer");
+  if (!init_latents_dev) return e->fail(MLDHIP_EINVAL, "null input pointer");
   int T = 0;
   if (int rc = validate_lengths(e, lengths_host, B, &T)) return rc;
   hipStream_t stream = (hipStream_t)stream_;
   HIP_TRY(e, hipMemcpyAsync(e->lens_dev, lengths_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  if (actions_host) {
+    for (int i = 0; i < B; ++i)
+      if (actions_host[i] < 0 || actions_host[i] >= e->cfg.nclasses)
+        return e->fail(MLDHIP_EINVAL, "actions[%d]=%d outside [0, nclasses=%d)", i, actions_host[i], e->cfg.nclasses);
+    // cond = cat(zeros_like(actions), actions) (mld.py:722-725); the first half is never read (null embedding)
+    HIP_TRY(e, hipMemsetAsync(e->labels_dev, 0, (size_t)B * sizeof(int32_t), stream));
+    HIP_TRY(e, hipMemcpyAsync(e->labels_dev + B, actions_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  }
 #if !defined(MLDHIP_SIM)
   if (e->cfg.use_graph) {
     GraphKey key{B, T, text_emb_dev, init_latents_dev, latents_out_dev, feats_out_dev, joints_out_dev};
@@ -1054,25 +1137,54 @@ int mldhip_sample(mldhip_handle* e, const float* text_emb_dev, const float* init
 #endif
   return enqueue_sample(e, stream, text_emb_dev, init_latents_dev, B, T, latents_out_dev, feats_out_dev, joints_out_dev);
 }
+}  // namespace
 
-int mldhip_denoiser_forward(mldhip_handle* e, const float* sample_dev, int32_t timestep, const float* text_emb_dev,
-                            int32_t R, float* out_dev, void* stream_) {
+extern "C" {
+
+int mldhip_sample(mldhip_handle* e, const float* text_emb_dev, const float* init_latents_dev, const int32_t* lengths_host,
+                  int32_t B, float* latents_out_dev, float* feats_out_dev, float* joints_out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  if (is_action(e)) return e->fail(MLDHIP_ESTATE, "engine was created with the action condition: use mldhip_sample_action");
+  if (joints_out_dev && is_actor(e)) return e->fail(MLDHIP_ESTATE, "joints of the ActorVae feature layout need SMPL (out of scope)");
+  if (!text_emb_dev) return e->fail(MLDHIP_EINVAL, "null input pointer");
+  return sample_impl(e, text_emb_dev, nullptr, init_latents_dev, lengths_host, B, latents_out_dev, feats_out_dev, joints_out_dev, stream_);
+}
+
+int mldhip_sample_action(mldhip_handle* e, const int32_t* actions_host, const float* init_latents_dev, const int32_t* lengths_host,
+                         int32_t B, float* latents_out_dev, float* feats_out_dev, void* stream_) {
+  if (!e) return MLDHIP_EINVAL;
+  if (!is_action(e)) return e->fail(MLDHIP_ESTATE, "engine was created with the text condition: use mldhip_sample");
+  if (!actions_host) return e->fail(MLDHIP_EINVAL, "null input pointer");
+  return sample_impl(e, nullptr, actions_host, init_latents_dev, lengths_host, B, latents_out_dev, feats_out_dev, nullptr, stream_);
+}
+
+}  // extern "C"
+
+namespace {
+int denoiser_forward_impl(mldhip_handle* e, const float* sample_dev, int32_t timestep, const float* text_emb_dev,
+                          const int32_t* actions_host, int32_t R, float* out_dev, void* stream_) {
   if (!e->finalized || !e->group_ready[0]) return e->fail(MLDHIP_ESTATE, "denoiser_forward before finalize / denoiser.* not loaded");
-  if (!sample_dev || !text_emb_dev || !out_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
+  if (!sample_dev || !out_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
   if (R < 1 || R > 2 * e->cfg.max_batch) return e->fail(MLDHIP_EINVAL, "R=%d outside [1, 2*max_batch]", R);
   if (timestep < 0 || timestep >= e->cfg.num_train_timesteps) return e->fail(MLDHIP_EINVAL, "timestep %d out of range", timestep);
   hipStream_t stream = (hipStream_t)stream_;
   Ctx c{e, stream};
-  const int D = e->cfg.latent_dim, TD = e->cfg.text_dim;
+  const int D = e->cfg.latent_dim, TD = time_width(e);
   e->phase = 0;
+  if (actions_host) {
+    for (int i = 0; i < R; ++i)
+      if (actions_host[i] < 0 || actions_host[i] >= e->cfg.nclasses)
+        return e->fail(MLDHIP_EINVAL, "actions[%d]=%d outside [0, nclasses=%d)", i, actions_host[i], e->cfg.nclasses);
+    HIP_TRY(e, hipMemcpyAsync(e->labels_dev, actions_host, (size_t)R * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  }
   std::vector<float> host(TD);
   timestep_sincos(float(timestep), TD, host.data());
   HIP_TRY(e, hipMemcpyAsync(e->temb0_one, host.data(), TD * sizeof(float), hipMemcpyHostToDevice, stream));
   HIP_TRY(e, hipStreamSynchronize(stream));   // `host` is a stack temporary
   time_mlp(c, e->temb0_one, e->temb0_one + TD, e->t1_one, 1);
   const DenView v = den_view(e, 0, 0, R);
-  text_projection(c, text_emb_dev, R, e->X0 + (size_t)2 * R * D);
+  if (text_emb_dev) text_projection(c, text_emb_dev, R, e->X0 + (size_t)2 * R * D);
+  else action_rows(c, R, e->cfg.guidance_scale > 1.0f ? R / 2 : 0, e->X0 + (size_t)2 * R * D);   // mld_denoiser.py:253-257
   // token 0 rows: sample + pe[0]; token 1 rows: the time-MLP row (pe[1] already folded in)
   MLD_LAUNCH(add_rows_kernel, dim3((R * D + 255) / 256), dim3(256), 0, stream, e->X0, sample_dev, P(e, "denoiser.query_pos.pe"), R, D);
   MLD_LAUNCH(bcast_rows_kernel, dim3((R * D + 255) / 256), dim3(256), 0, stream, e->X0 + (size_t)R * D, (const float*)e->t1_one, R, D);
@@ -1081,6 +1193,25 @@ int mldhip_denoiser_forward(mldhip_handle* e, const float* sample_dev, int32_t t
   MLD_LAUNCH(den_final_rows_kernel, dim3(R), dim3(256), 0, stream, den_final_args(e, v), out_dev);
   check_launch(c, "final_norm");
   return c.rc;
+}
+}  // namespace
+
+extern "C" {
+
+int mldhip_denoiser_forward(mldhip_handle* e, const float* sample_dev, int32_t timestep, const float* text_emb_dev,
+                            int32_t R, float* out_dev, void* stream_) {
+  if (!e) return MLDHIP_EINVAL;
+  if (is_action(e)) return e->fail(MLDHIP_ESTATE, "engine was created with the action condition: use mldhip_denoiser_forward_action");
+  if (!text_emb_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
+  return denoiser_forward_impl(e, sample_dev, timestep, text_emb_dev, nullptr, R, out_dev, stream_);
+}
+
+int mldhip_denoiser_forward_action(mldhip_handle* e, const float* sample_dev, int32_t timestep, const int32_t* actions_host,
+                                   int32_t R, float* out_dev, void* stream_) {
+  if (!e) return MLDHIP_EINVAL;
+  if (!is_action(e)) return e->fail(MLDHIP_ESTATE, "engine was created with the text condition: use mldhip_denoiser_forward");
+  if (!actions_host) return e->fail(MLDHIP_EINVAL, "null pointer");
+  return denoiser_forward_impl(e, sample_dev, timestep, nullptr, actions_host, R, out_dev, stream_);
 }
 
 int mldhip_vae_decode(mldhip_handle* e, const float* z_dev, const int32_t* lengths_host, int32_t B, float* feats_out_dev,
@@ -1138,6 +1269,7 @@ int mldhip_ddim_step(mldhip_handle* e, const float* eps_dev, int32_t timestep, c
 
 int mldhip_feats2joints(mldhip_handle* e, const float* feats_dev, int32_t B, int32_t T, float* joints_out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  if (is_actor(e) || e->cfg.nfeats < 67) return e->fail(MLDHIP_ESTATE, "feats2joints implements the HumanML3D layout only (SMPL-based layouts are out of scope)");
   if (!e->finalized || !e->group_ready[2]) return e->fail(MLDHIP_ESTATE, "feats2joints before finalize / mean,std not loaded");
   if (!feats_dev || !joints_out_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
   if (B < 1 || T < 1 || T > 512) return e->fail(MLDHIP_EINVAL, "B >= 1 and 1 <= T <= 512 required");

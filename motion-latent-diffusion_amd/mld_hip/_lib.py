@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libmldhip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MldHipError(RuntimeError):
@@ -32,7 +32,12 @@ class Config(C.Structure):
         ("num_train_timesteps", C.c_int32), ("num_inference_steps", C.c_int32), ("steps_offset", C.c_int32),
         ("set_alpha_to_one", C.c_int32), ("beta_start", C.c_float), ("beta_end", C.c_float),
         ("guidance_scale", C.c_float), ("precision", C.c_int32), ("use_graph", C.c_int32),
+        ("condition", C.c_int32), ("nclasses", C.c_int32), ("vae_arch", C.c_int32), ("vae_num_layers", C.c_int32),
     ]
+
+
+COND_TEXT, COND_ACTION = 0, 1      # MLDHIP_COND_*
+VAE_MLD, VAE_ACTOR = 0, 1          # MLDHIP_VAE_*
 
 
 _SYMBOLS = {
@@ -47,6 +52,10 @@ _SYMBOLS = {
     "mldhip_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "mldhip_denoiser_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mldhip_sample_action": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "mldhip_denoiser_forward_action": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_void_p,
+                                                 C.c_void_p]),
     "mldhip_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p]),
     "mldhip_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -171,6 +180,19 @@ class Engine:
 
     def denoiser_forward(self, sample, timestep: int, text_emb, R: int, out, stream: int = 0):
         self._check(self.lib.mldhip_denoiser_forward(self._h, _ptr(sample), int(timestep), _ptr(text_emb), R, _ptr(out), stream))
+
+    def sample_action(self, actions: Sequence[int], init_latents, lengths: Sequence[int], latents_out=None, feats_out=None,
+                      stream: int = 0):
+        lens = (C.c_int32 * len(lengths))(*[int(x) for x in lengths])
+        acts = (C.c_int32 * len(actions))(*[int(x) for x in actions])
+        if len(actions) != len(lengths):
+            raise ValueError("actions and lengths must have one entry per motion")
+        self._check(self.lib.mldhip_sample_action(self._h, acts, _ptr(init_latents), lens, len(lengths), _ptr(latents_out),
+                                                  _ptr(feats_out), stream))
+
+    def denoiser_forward_action(self, sample, timestep: int, actions: Sequence[int], out, stream: int = 0):
+        acts = (C.c_int32 * len(actions))(*[int(x) for x in actions])
+        self._check(self.lib.mldhip_denoiser_forward_action(self._h, _ptr(sample), int(timestep), acts, len(actions), _ptr(out), stream))
 
     def vae_decode(self, z, lengths: Sequence[int], feats_out, stream: int = 0):
         lens = (C.c_int32 * len(lengths))(*[int(x) for x in lengths])

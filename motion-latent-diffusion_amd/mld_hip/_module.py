@@ -19,9 +19,11 @@ class _Node(nn.Module):
 
 class HipModule(nn.Module):
     _prefix = ""            # "denoiser." / "vae."  (Lightning checkpoint prefixes, base.py:96-127)
+    _variant = "text"       # engine registry variant (mld_hip.engine)
 
     def __init__(self):
         super().__init__()
+        self._arch: Dict[str, object] = {}           # mldhip_config fields this module's weights imply
         self._engine_key: Optional[str] = None      # set by tests to an injected (simulator) engine
         self._synced_sig = None
 
@@ -48,7 +50,12 @@ class HipModule(nn.Module):
     def engine(self):
         if self._engine_key is not None:
             return _engine.get_engine(self._engine_key)
-        return _engine.get_engine(next(self.parameters()).device)
+        return _engine.get_engine(next(self.parameters()).device, self._variant)
+
+    def _set_arch(self, variant: str, **fields):
+        self._variant = variant
+        self._arch = dict(fields)
+        _engine.configure(variant, **fields)
 
     def _signature(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -56,6 +63,7 @@ class HipModule(nn.Module):
     def sync_weights(self):
         """Upload parameters to the engine if they changed since the last upload; finalize lazily."""
         eng = self.engine
+        _engine.check_arch(eng, type(self).__name__, **self._arch)
         sig = (id(eng), self._signature())
         if sig != self._synced_sig:
             for name, p in self.named_parameters():

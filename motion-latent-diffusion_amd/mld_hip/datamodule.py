@@ -17,7 +17,11 @@ class HipDataModule:
     name = "humanml3d"
 
     def __init__(self, cfg=None, mean: Optional[np.ndarray] = None, std: Optional[np.ndarray] = None,
-                 nfeats: int = 263, njoints: int = 22, engine_key: Optional[str] = None):
+                 nfeats: int = 263, njoints: int = 22, engine_key: Optional[str] = None, name: str = "humanml3d",
+                 nclasses: int = 12):
+        """name 'humanml3d' (263-d features, 22 joints) or 'humanact12' (rot6d 25x6 = 150-d features, 12 classes;
+        mld/data/HumanAct12.py) -- the latter only carries shapes: its feats2joints needs SMPL."""
+        self.name, self.nclasses = name, nclasses
         self.nfeats, self.njoints = nfeats, njoints
         if mean is None or std is None:
             root = None
@@ -47,8 +51,11 @@ class HipDataModule:
             self._loaded_on = eng
         return eng
 
-    def feats2joints(self, features: torch.Tensor) -> torch.Tensor:
+    def feats2joints(self, features: torch.Tensor, mask=None) -> torch.Tensor:
         """[B, T, nfeats] -> [B, T, njoints, 3] (HumanML3D.py:41-45 + recover_from_ric), on the tensor's device."""
+        if self.name != "humanml3d":
+            raise NotImplementedError(f"feats2joints of '{self.name}' maps rot6d features through the SMPL body model "
+                                      "(mld/transforms/rots2joints/smplh.py); SMPL is an external asset and out of scope")
         if features.dtype != torch.float32:
             raise TypeError("feats2joints expects float32 features (recover_from_ric's index_put needs fp32)")
         f = features.contiguous()

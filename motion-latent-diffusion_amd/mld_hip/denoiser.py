@@ -1,4 +1,4 @@
-"""``HipMldDenoiser`` -- drop-in for ``mld.models.architectures.mld_denoiser.MldDenoiser`` (text condition).
+"""``HipMldDenoiser`` -- drop-in for ``mld.models.architectures.mld_denoiser.MldDenoiser`` (text and action conditions).
 
 Same constructor keywords (mld_denoiser.py:18-38), same ``forward(sample, timestep,
 encoder_hidden_states, lengths=None) -> (sample,)`` contract (mld_denoiser.py:135-228), same
@@ -25,8 +25,8 @@ class HipMldDenoiser(HipModule):
         abl = ablation if isinstance(ablation, dict) else vars(ablation) if not hasattr(ablation, "get") else ablation
         get = (lambda k, d=None: abl.get(k, d)) if hasattr(abl, "get") else (lambda k, d=None: getattr(ablation, k, d))
         unsupported = []
-        if condition not in ("text",):
-            unsupported.append(f"condition={condition!r} (action / text_uncond: SURVEY.md §8f row 3)")
+        if condition not in ("text", "action"):
+            unsupported.append(f"condition={condition!r} (text_uncond is a training-only ablation)")
         if arch != "trans_enc" or not get("SKIP_CONNECT", False):
             unsupported.append(f"arch={arch!r}/SKIP_CONNECT={get('SKIP_CONNECT')} (only the skip trans_enc of config_mld_humanml3d)")
         if get("VAE_TYPE", "mld") == "no":
@@ -45,16 +45,36 @@ class HipMldDenoiser(HipModule):
         self.arch = arch
         self.num_layers = num_layers
         self.ff_size = ff_size
+        self.nclasses = nclasses
+        self.guidance_scale = guidance_scale
         dims = syn.ModelDims(latent_dim=self.latent_dim, latent_size=latent_dim[0], ff_size=ff_size, num_layers=num_layers,
                              num_heads=num_heads, nfeats=nfeats, text_dim=text_encoded_dim)
-        self._register_tree(syn.make_denoiser_state_dict(seed=0, dims=dims))
+        self._register_tree(syn.make_denoiser_state_dict(seed=0, dims=dims, condition=condition, nclasses=nclasses))
+        from . import _lib
+        if condition == "action":
+            self._set_arch("action", condition=_lib.COND_ACTION, nclasses=int(nclasses), num_layers=int(num_layers),
+                           ff_size=int(ff_size), guidance_scale=float(guidance_scale))
+        else:
+            self._set_arch("text", condition=_lib.COND_TEXT, num_layers=int(num_layers), ff_size=int(ff_size),
+                           text_dim=int(text_encoded_dim))
 
     def forward(self, sample, timestep, encoder_hidden_states, lengths=None, **kwargs):
-        """sample [R, 1, D], timestep int / 0-d tensor, encoder_hidden_states [R, 1, text_dim] -> ([R, 1, D],)."""
+        """sample [R, 1, D], timestep int / 0-d tensor, encoder_hidden_states [R, 1, text_dim] (text) or [R, 1] class
+        labels (action; the first R/2 rows are the unconditional half when guidance_scale > 1) -> ([R, 1, D],)."""
         sample = self._check(sample, "sample")
-        text = self._check(encoder_hidden_states, "encoder_hidden_states")
         if sample.dim() != 3 or sample.shape[1] != 1 or sample.shape[2] != self.latent_dim:
             raise ValueError(f"sample must be [R, 1, {self.latent_dim}], got {tuple(sample.shape)}")
+        if self.condition == "action":
+            # EmbedAction: idx = input[:, 0].long() (mld_denoiser.py:250); labels cross to the host like lengths do
+            acts = encoder_hidden_states.reshape(encoder_hidden_states.shape[0], -1)[:, 0].long().cpu().tolist()
+            if len(acts) != sample.shape[0]:
+                raise ValueError(f"encoder_hidden_states must hold one action label per row of sample ({sample.shape[0]}), got {len(acts)}")
+            t = int(timestep.reshape(-1)[0].item()) if torch.is_tensor(timestep) else int(timestep)
+            eng = self.sync_weights()
+            out = torch.empty_like(sample)
+            eng.denoiser_forward_action(sample, t, acts, out, self._stream())
+            return (out,)
+        text = self._check(encoder_hidden_states, "encoder_hidden_states")
         if text.shape[0] != sample.shape[0] or text.shape[-1] != self.text_encoded_dim or text.numel() != sample.shape[0] * self.text_encoded_dim:
             raise ValueError(f"encoder_hidden_states must be [R, 1, {self.text_encoded_dim}], got {tuple(text.shape)}")
         t = int(timestep.reshape(-1)[0].item()) if torch.is_tensor(timestep) else int(timestep)

@@ -1,6 +1,10 @@
 """Per-device engine registry: HipMldDenoiser, HipMldVae, HipDDIMScheduler and the datamodule stub that are
 instantiated separately from YAML (as the reference does, mld.py:56-83) all talk to ONE ``libmldhip``
-handle per device, because the fused ``sample()`` needs every weight group in one place."""
+handle per (device, model variant), because the fused ``sample()`` needs every weight group in one place.
+
+Variants: "text" = config_mld_humanml3d (MldDenoiser text condition + MldVae), "action" = config_mld_humanact12
+(MldDenoiser action condition + ActorVae).  Modules push their architecture fields with ``configure(variant, ...)``
+when constructed and verify them against the live engine before every use (``check_arch``)."""
 from __future__ import annotations
 
 from typing import Dict, Optional
@@ -8,12 +12,25 @@ from typing import Dict, Optional
 from . import _lib
 
 _engines: Dict[object, "_lib.Engine"] = {}
-_defaults = dict(max_batch=64, max_frames=196)
+_defaults = {
+    "text": dict(max_batch=64, max_frames=196),
+    "action": dict(max_batch=64, max_frames=60, condition=_lib.COND_ACTION, vae_arch=_lib.VAE_ACTOR, num_layers=15,
+                   vae_num_layers=6, nclasses=12, nfeats=150),
+}
 
 
-def configure(**cfg):
-    """Set engine capacity / scheduler fields used for engines created later (e.g. max_batch=128)."""
-    _defaults.update(cfg)
+def configure(variant: str = "text", **cfg):
+    """Set engine capacity / scheduler / architecture fields for engines of `variant` created later."""
+    _defaults[variant].update(cfg)
+
+
+def check_arch(engine, who: str, **want):
+    """Raise when a live engine was created with other architecture fields than module `who` needs."""
+    bad = {k: (getattr(engine.cfg, k), v) for k, v in want.items()
+           if (abs(getattr(engine.cfg, k) - v) > 1e-6 if isinstance(v, float) else getattr(engine.cfg, k) != v)}
+    if bad:
+        raise RuntimeError(f"{who}: engine/module mismatch " + ", ".join(f"{k}: engine {a} vs module {b}" for k, (a, b) in bad.items())
+                           + "; construct the modules before the first use of the engine, or call mld_hip.engine.drop_engines()")
 
 
 def device_index(device) -> int:
@@ -25,10 +42,12 @@ def device_index(device) -> int:
     return d.index if d.index is not None else torch.cuda.current_device()
 
 
-def get_engine(device, **cfg) -> "_lib.Engine":
-    key = device if isinstance(device, str) and device.startswith("inject:") else device_index(device)
+def get_engine(device, variant: str = "text", **cfg) -> "_lib.Engine":
+    if isinstance(device, str) and device.startswith("inject:"):
+        return _engines[device]
+    key = (device_index(device), variant)
     if key not in _engines:
-        _engines[key] = _lib.Engine(device=key if isinstance(key, int) else 0, **{**_defaults, **cfg})
+        _engines[key] = _lib.Engine(device=key[0], **{**_defaults[variant], **cfg})
         _engines[key]._dirty = True
     return _engines[key]
 

@@ -21,7 +21,7 @@ from . import engine as _engine
 from .config import instantiate_from_config
 from .denoiser import HipMldDenoiser
 from .scheduler import HipDDIMScheduler
-from .vae import HipMldVae
+from .vae import HipActorVae, HipMldVae
 
 
 def remove_padding(tensors, lengths):
@@ -41,12 +41,15 @@ class MLD(nn.Module):
         self.guidance_scale = cfg.model.guidance_scale
         self.datamodule = datamodule
         self.vae_type = cfg.model.motion_vae.target.split(".")[-1].lower().replace("hip", "").replace("vae", "")
-        if self.condition != "text" or self.stage not in ("diffusion", "vae_diffusion"):
-            raise NotImplementedError(f"mld_hip.MLD covers text-to-motion sampling (condition={self.condition!r}, stage={self.stage!r})")
+        if self.condition not in ("text", "action") or self.stage not in ("diffusion", "vae_diffusion"):
+            raise NotImplementedError(f"mld_hip.MLD covers text-/action-to-motion sampling (condition={self.condition!r}, stage={self.stage!r})")
         self._engine_key = engine_key
         if engine_key is None:
-            _engine.configure(num_inference_steps=cfg.model.scheduler.num_inference_timesteps)
-        self.text_encoder = text_encoder if text_encoder is not None else instantiate_from_config(cfg.model.text_encoder)
+            _engine.configure(self.condition, num_inference_steps=cfg.model.scheduler.num_inference_timesteps,
+                              guidance_scale=float(self.guidance_scale))
+        # the reference builds CLIP for every condition (mld.py:60); the action path never calls it, so it is skipped there
+        self.text_encoder = text_encoder if (text_encoder is not None or self.condition != "text") \
+            else instantiate_from_config(cfg.model.text_encoder)
         self.vae = instantiate_from_config(cfg.model.motion_vae)
         self.denoiser = instantiate_from_config(cfg.model.denoiser)
         self.scheduler = instantiate_from_config(cfg.model.scheduler)
@@ -61,7 +64,8 @@ class MLD(nn.Module):
 
     # ------------------------------------------------------------------ checkpoint contract (base.py:96-127)
     def load_state_dict(self, state_dict, strict: bool = True):
-        new = OrderedDict(("text_encoder." + k, v) for k, v in self.text_encoder.state_dict().items())
+        te = self.text_encoder.state_dict() if self.text_encoder is not None else {}
+        new = OrderedDict(("text_encoder." + k, v) for k, v in te.items())
         for k, v in state_dict.items():
             if "text_encoder" not in k and not k.startswith("t2m_"):      # evaluator nets are not part of sampling
                 new[k] = v
@@ -70,7 +74,7 @@ class MLD(nn.Module):
     # ------------------------------------------------------------------ helpers
     @property
     def fused(self) -> bool:
-        return (isinstance(self.denoiser, HipMldDenoiser) and isinstance(self.vae, HipMldVae)
+        return (isinstance(self.denoiser, HipMldDenoiser) and isinstance(self.vae, (HipMldVae, HipActorVae))
                 and isinstance(self.scheduler, HipDDIMScheduler) and self.do_classifier_free_guidance)
 
     def _engine(self):
@@ -107,6 +111,38 @@ class MLD(nn.Module):
         eng.sample(text_emb, init_latents, lengths, lat, feats, joints, _engine.current_stream_handle(text_emb))
         return joints, feats, lat
 
+    @torch.no_grad()
+    def sample_action(self, actions, lengths: List[int], init_latents: Optional[torch.Tensor] = None, device=None):
+        """Action labels [B] / [B, 1] -> (feats [B, T, nfeats], latents [B, 1, D]) on device: ONE mldhip_sample_action call."""
+        lengths = [int(x) for x in lengths]
+        acts = [int(a) for a in (actions.reshape(-1).tolist() if torch.is_tensor(actions) else list(actions))]
+        B, T = len(lengths), max(lengths)
+        dev = init_latents.device if init_latents is not None else (device or next(self.denoiser.parameters()).device)
+        if init_latents is None:
+            init_latents = torch.randn((B, self.latent_dim[0], self.latent_dim[-1]), device=dev, dtype=torch.float)   # mld.py:303
+        init_latents = init_latents.float().contiguous()
+        eng = self._engine()
+        lat = torch.empty(B, self.latent_dim[0], self.latent_dim[-1], device=dev)
+        feats = torch.empty(B, T, self.nfeats, device=dev)
+        eng.sample_action(acts, init_latents, lengths, lat, feats, _engine.current_stream_handle(init_latents))
+        return feats, lat
+
+    @torch.no_grad()
+    def a2m_eval(self, batch, init_latents: Optional[torch.Tensor] = None):
+        """Sampling core of MLD.a2m_eval (mld.py:710-735): batch["action"] [B, 1] labels, batch["length"] -> rs_set with
+        ``m_action`` / ``m_rst`` (features [B, T, nfeats]) / ``m_lens``.  The joints entries of the reference's rs_set go
+        through SMPL (mld/transforms/rots2joints/smplh.py) and are not produced here."""
+        actions, lengths = batch["action"], list(batch["length"])
+        if self.fused:
+            feats, _ = self.sample_action(actions, lengths, init_latents,
+                                          device=actions.device if torch.is_tensor(actions) and actions.is_cuda else None)
+        else:
+            a = actions if torch.is_tensor(actions) else torch.tensor(actions)
+            cond = torch.cat((torch.zeros_like(a), a)) if self.do_classifier_free_guidance else a      # mld.py:716-717
+            z = self._diffusion_reverse(cond.reshape(-1, 1), lengths, init_latents)
+            feats = self.vae.decode(z.contiguous(), lengths)
+        return {"m_action": actions, "m_rst": feats, "m_lens": lengths}
+
     # ------------------------------------------------------------------ reference surface
     @torch.no_grad()
     def forward(self, batch, init_latents: Optional[torch.Tensor] = None):
@@ -131,8 +167,9 @@ class MLD(nn.Module):
     def _diffusion_reverse(self, encoder_hidden_states, lengths=None, init_latents: Optional[torch.Tensor] = None):
         """The reference's Python loop (mld.py:290-360) over the drop-in parts -> [latent_size, B, D]."""
         bsz = encoder_hidden_states.shape[0] // (2 if self.do_classifier_free_guidance else 1)
+        dev = init_latents.device if init_latents is not None else encoder_hidden_states.device
         latents = init_latents if init_latents is not None else torch.randn(
-            (bsz, self.latent_dim[0], self.latent_dim[-1]), device=encoder_hidden_states.device, dtype=torch.float)
+            (bsz, self.latent_dim[0], self.latent_dim[-1]), device=dev, dtype=torch.float)
         latents = latents * self.scheduler.init_noise_sigma
         self.scheduler.set_timesteps(self.cfg.model.scheduler.num_inference_timesteps)
         extra = {}

@@ -99,13 +99,23 @@ def _skip_transformer(sd, seed, prefix, dims: ModelDims, decoder: bool):
     _norm(sd, seed, f"{prefix}.norm", d)
 
 
-def make_denoiser_state_dict(seed: int = 0, dims: ModelDims = ModelDims()) -> Dict[str, np.ndarray]:
-    """Synthetic ``MldDenoiser`` weights (text condition, trans_enc + skip, learned PE)."""
+def make_denoiser_state_dict(seed: int = 0, dims: ModelDims = ModelDims(), condition: str = "text",
+                             nclasses: int = 12) -> Dict[str, np.ndarray]:
+    """Synthetic ``MldDenoiser`` weights (trans_enc + skip, learned PE).
+
+    condition 'text'  : 768-wide timestep embedding + ReLU/Linear text projection (mld_denoiser.py:57-68)
+    condition 'action': latent-wide timestep embedding + ``EmbedAction`` table (mld_denoiser.py:69-77,231-246)
+    """
     sd: Dict[str, np.ndarray] = {}
     d = dims.latent_dim
-    _linear(sd, seed, "time_embedding.linear_1", d, dims.text_dim)
-    _linear(sd, seed, "time_embedding.linear_2", d, d)
-    _linear(sd, seed, "emb_proj.1", d, dims.text_dim)
+    if condition == "action":
+        _linear(sd, seed, "time_embedding.linear_1", d, d)
+        _linear(sd, seed, "time_embedding.linear_2", d, d)
+        sd["emb_proj.action_embedding"] = _xavier(seed, "emb_proj.action_embedding", (nclasses, d))
+    else:
+        _linear(sd, seed, "time_embedding.linear_1", d, dims.text_dim)
+        _linear(sd, seed, "time_embedding.linear_2", d, d)
+        _linear(sd, seed, "emb_proj.1", d, dims.text_dim)
     sd["query_pos.pe"] = _rng(seed, "query_pos.pe").uniform(0, 1, (MAX_PE, 1, d)).astype(np.float32)
     sd["mem_pos.pe"] = _rng(seed, "mem_pos.pe").uniform(0, 1, (MAX_PE, 1, d)).astype(np.float32)
     _skip_transformer(sd, seed, "encoder", dims, decoder=False)
@@ -125,6 +135,53 @@ def make_vae_state_dict(seed: int = 1, dims: ModelDims = ModelDims()) -> Dict[st
     _linear(sd, seed, "skel_embedding", d, dims.nfeats)
     _linear(sd, seed, "final_layer", dims.nfeats, d)
     return sd
+
+
+def sinusoidal_pe(d_model: int, max_len: int = 5000) -> np.ndarray:
+    """PositionalEncoding buffer (mld/models/operator/position_encoding_layer.py:15-23), [max_len, 1, d]."""
+    pos = np.arange(max_len, dtype=np.float32)[:, None]
+    div = np.exp(np.arange(0, d_model, 2, dtype=np.float32) * np.float32(-np.log(10000.0) / d_model)).astype(np.float32)
+    pe = np.zeros((max_len, d_model), np.float32)
+    pe[:, 0::2] = np.sin(pos * div)
+    pe[:, 1::2] = np.cos(pos * div)
+    return pe[:, None, :]
+
+
+def make_actor_vae_state_dict(seed: int = 2, dims: ModelDims = ModelDims(nfeats=150), num_layers: int = 6) -> Dict[str, np.ndarray]:
+    """Synthetic ``ActorVae`` weights (mld/models/architectures/actor_vae.py:21-70,77-125,176-207): stock
+    nn.TransformerEncoder/DecoderLayer stacks, sinusoidal PE buffers, mu/logvar tokens."""
+    sd: Dict[str, np.ndarray] = {}
+    d, ff = dims.latent_dim, dims.ff_size
+    sd["encoder.mu_token"] = _rng(seed, "encoder.mu_token").standard_normal(d).astype(np.float32)
+    sd["encoder.logvar_token"] = _rng(seed, "encoder.logvar_token").standard_normal(d).astype(np.float32)
+    _linear(sd, seed, "encoder.skel_embedding", d, dims.nfeats)
+    sd["encoder.sequence_pos_encoding.pe"] = sinusoidal_pe(d)
+    for i in range(num_layers):
+        p = f"encoder.seqTransEncoder.layers.{i}"
+        _mha(sd, seed, p + ".self_attn", d)
+        _linear(sd, seed, p + ".linear1", ff, d, xavier=True)
+        _linear(sd, seed, p + ".linear2", d, ff, xavier=True)
+        _norm(sd, seed, p + ".norm1", d)
+        _norm(sd, seed, p + ".norm2", d)
+    sd["decoder.sequence_pos_encoding.pe"] = sinusoidal_pe(d)
+    for i in range(num_layers):
+        p = f"decoder.seqTransDecoder.layers.{i}"
+        _mha(sd, seed, p + ".self_attn", d)
+        _mha(sd, seed, p + ".multihead_attn", d)
+        _linear(sd, seed, p + ".linear1", ff, d, xavier=True)
+        _linear(sd, seed, p + ".linear2", d, ff, xavier=True)
+        for n in ("norm1", "norm2", "norm3"):
+            _norm(sd, seed, f"{p}.{n}", d)
+    _linear(sd, seed, "decoder.final_layer", dims.nfeats, d)
+    return sd
+
+
+def make_action_batch(batch: int, nframes: int = 60, nclasses: int = 12, seed: int = 1234, dims: ModelDims = ModelDims()):
+    """HumanAct12-shaped sampler inputs: labels uniform in [0, nclasses), N(0,1) start noise, fixed length."""
+    g = _rng(seed, f"abatch{batch}")
+    actions = g.integers(0, nclasses, size=batch).astype(np.int32)
+    lat = g.standard_normal((batch, dims.latent_size, dims.latent_dim)).astype(np.float32)
+    return actions, lat, [nframes] * batch
 
 
 def make_mean_std(nfeats: int = NFEATS) -> Tuple[np.ndarray, np.ndarray]:

@@ -40,6 +40,8 @@ class HipMldVae(HipModule):
         dims = syn.ModelDims(latent_dim=self.latent_dim, latent_size=self.latent_size, ff_size=ff_size, num_layers=num_layers,
                              num_heads=num_heads, nfeats=nfeats)
         self._register_tree(syn.make_vae_state_dict(seed=1, dims=dims))
+        from . import _lib
+        self._set_arch("text", vae_arch=_lib.VAE_MLD, num_layers=int(num_layers), ff_size=int(ff_size), nfeats=int(nfeats))
 
     def decode(self, z: torch.Tensor, lengths: List[int]):
         """z [latent_size(=1), B, D], lengths list[int] -> feats [B, max(lengths), nfeats], zeros at padded frames."""
@@ -75,3 +77,39 @@ class HipMldVae(HipModule):
 
     def forward(self, features, lengths=None):
         raise NotImplementedError("MldVae.forward is a stub in the reference too (mld_vae.py:114-122); use decode().")
+
+
+class HipActorVae(HipModule):
+    """Drop-in for ``mld.models.architectures.actor_vae.ActorVae`` on the sampling path: ``decode(z, lengths)``
+    (actor_vae.py:72-74 -> ActorAgnosticDecoder.forward, :209-235).  The state_dict carries the encoder tensors too
+    (so reference checkpoints load strictly) but ``encode`` -- reconstruction / VAE-stage training only -- is not built."""
+    _prefix = "vae."
+
+    def __init__(self, ablation, nfeats: int, latent_dim: list = [1, 256], ff_size: int = 1024, num_layers: int = 7,
+                 num_heads: int = 4, dropout: float = 0.1, is_vae: bool = True, activation: str = "gelu",
+                 position_embedding: str = "learned", **kwargs) -> None:
+        super().__init__()
+        if list(latent_dim) != [1, 256] or num_heads * 64 != 256 or activation != "gelu" or not is_vae:
+            raise NotImplementedError(f"HipActorVae: latent_dim={latent_dim}, num_heads={num_heads}, activation={activation!r}, is_vae={is_vae}")
+        self.latent_size, self.latent_dim, self.nfeats = latent_dim[0], latent_dim[-1], nfeats
+        dims = syn.ModelDims(latent_dim=self.latent_dim, ff_size=ff_size, num_heads=num_heads, nfeats=nfeats)
+        self._register_tree(syn.make_actor_vae_state_dict(seed=2, dims=dims, num_layers=num_layers))
+        from . import _lib
+        self._set_arch("action", vae_arch=_lib.VAE_ACTOR, vae_num_layers=int(num_layers), ff_size=int(ff_size), nfeats=int(nfeats))
+
+    def decode(self, z: torch.Tensor, lengths: List[int]):
+        """z [1, B, D], lengths list[int] -> feats [B, max(lengths), nfeats], zeros at padded frames."""
+        z = self._check(z, "z")
+        lengths = [int(x) for x in lengths]
+        if z.dim() != 3 or z.shape[0] != self.latent_size or z.shape[1] != len(lengths) or z.shape[2] != self.latent_dim:
+            raise ValueError(f"z must be [{self.latent_size}, {len(lengths)}, {self.latent_dim}], got {tuple(z.shape)}")
+        eng = self.sync_weights()
+        feats = torch.empty(len(lengths), max(lengths), self.nfeats, dtype=torch.float32, device=z.device)
+        eng.vae_decode(z, lengths, feats, self._stream())
+        return feats
+
+    def encode(self, features, lengths=None):
+        raise NotImplementedError("ActorVae.encode is used by the VAE training stage / reconstruction only (out of scope, DESIGN.md §9)")
+
+    def forward(self, features, lengths=None):
+        raise NotImplementedError("ActorVae.forward is a stub in the reference too (actor_vae.py:57-65); use decode().")

@@ -153,5 +153,76 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
+@torch.no_grad()
+def main_action():
+    """Fixtures for the action-conditioned variant (BASELINE config 5, config_mld_humanact12.yaml + modules_humanact12):
+    MldDenoiser(condition='action', num_layers=15, nclasses=12) and ActorVae(num_layers=6, nfeats=150) imported from
+    the reference; a2m_eval's conditioning (mld.py:716-726) + the restated DDIM orchestrated below."""
+    import json
+    sys.path.insert(0, REF)
+    from mld.models.architectures.actor_vae import ActorVae
+    from mld.models.architectures.mld_denoiser import MldDenoiser
+
+    class Abl:
+        SKIP_CONNECT = True
+        VAE_TYPE = "actor"
+        PE_TYPE = "mld"
+        DIFF_PE_TYPE = "mld"
+        MLP_DIST = False
+
+    dims = syn.ModelDims(num_layers=15, nfeats=150)
+    den = MldDenoiser(ablation=Abl, nfeats=150, condition="action", latent_dim=[1, 256], ff_size=1024, num_layers=15,
+                      num_heads=4, nclasses=12, guidance_scale=7.5).eval()
+    vae = ActorVae(ablation=Abl, nfeats=150, latent_dim=[1, 256], ff_size=1024, num_layers=6, num_heads=4).eval()
+    sdd = syn.make_denoiser_state_dict(seed=3, dims=dims, condition="action", nclasses=12)
+    sdv = syn.make_actor_vae_state_dict()
+    den.load_state_dict({k: torch.from_numpy(v) for k, v in sdd.items()}, strict=True)
+    vae.load_state_dict({k: torch.from_numpy(v) for k, v in sdv.items()}, strict=True)
+    ops = O.NumpyOps(np.float32)
+    bd, bv = O.to_backend(ops, sdd), O.to_backend(ops, sdv)
+
+    # single ops, B=4 (denoiser CFG batch R=8; ragged decode)
+    acts, lat0, lens = syn.make_action_batch(4, nframes=60)
+    cond = np.concatenate([np.zeros_like(acts), acts])
+    x = np.concatenate([lat0, lat0])
+    ref = den(sample=torch.from_numpy(x), timestep=torch.tensor(981),
+              encoder_hidden_states=torch.from_numpy(cond[:, None].astype(np.float32)), lengths=lens * 2)[0].numpy()
+    mine = O.denoiser_forward_action(ops, bd, x, 981, cond)
+    z = syn._rng(5, "az").standard_normal((4, 1, 256)).astype(np.float32)
+    lens2 = [60, 45, 60, 12]
+    fr = vae.decode(torch.from_numpy(z).permute(1, 0, 2), lens2).numpy()
+    fm = O.actor_decode(ops, bv, z, lens2)
+    np.savez_compressed(os.path.join(OUT, "action_ops_b4.npz"), sample=x, cond=cond.astype(np.int32), out_t981=ref, z=z,
+                        lengths=np.array(lens2), feats=fr, oracle_diff_den=np.abs(ref - mine).max(),
+                        oracle_diff_feats=np.abs(fr - fm).max())
+    print("action ops oracle-vs-reference:", np.abs(ref - mine).max(), np.abs(fr - fm).max())
+
+    # full pipeline at config 5's shape: B=256, T=60, 50 steps (every 8th sample of feats kept)
+    acts, lat0, lens = syn.make_action_batch(256, nframes=60)
+    sch = O.DDIMSchedule()
+    lat = torch.from_numpy(lat0)
+    cond = torch.from_numpy(np.concatenate([np.zeros_like(acts), acts])[:, None].astype(np.float32))
+    for t in sch.set_timesteps(50):
+        eps = den(sample=torch.cat([lat] * 2), timestep=torch.tensor(int(t)), encoder_hidden_states=cond, lengths=lens * 2)[0]
+        u, c = eps.chunk(2)
+        eps = u + 7.5 * (c - u)
+        sa, sb, pa, pb = (float(v) for v in sch.coeffs(t))
+        lat = pa * ((lat - sb * eps) / sa) + pb * eps
+    feats = vae.decode(lat.permute(1, 0, 2), lens).numpy()
+    fo, lo = O.sample_action(ops, bd, bv, acts, lat0, lens, return_intermediates=True)
+    np.savez_compressed(os.path.join(OUT, "action_b256.npz"), latents=lat.numpy(), feats_every8=feats[::8],
+                        oracle_diff_latents=np.abs(lat.numpy() - lo).max(), oracle_diff_feats=np.abs(feats - fo).max())
+    print("action_b256 oracle-vs-reference:", np.abs(lat.numpy() - lo).max(), np.abs(feats - fo).max())
+
+    kp = os.path.join(OUT, "state_dict_keys.json")
+    keys = json.load(open(kp))
+    keys["denoiser_action"] = {k: list(v.shape) for k, v in den.state_dict().items()}
+    keys["actor_vae"] = {k: list(v.shape) for k, v in vae.state_dict().items()}
+    with open(kp, "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
-    main()
+    if "--action-only" not in sys.argv:
+        main()
+    main_action()

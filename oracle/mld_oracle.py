@@ -18,6 +18,7 @@ names (all citations relative to /root/reference):
   PositionEmbeddingLearned1D mld/models/operator/position_encoding.py:138-159
   MldVae.decode              mld/models/architectures/mld_vae.py:186-248
   MldVae.encode              mld/models/architectures/mld_vae.py:124-184   (scope row 8f.1)
+  action variant (cfg 5)     mld_denoiser.py:69-77,231-279 (EmbedAction); actor_vae.py:176-235 (ActorAgnosticDecoder)
   lengths_to_mask            mld/utils/temos_utils.py:10-17
   feats2joints               mld/data/HumanML3D.py:41-45
   recover_from_ric           mld/data/humanml/scripts/motion_process.py:362-381,415-432
@@ -324,6 +325,26 @@ def timestep_embedding(ops, t, dim, flip_sin_to_cos=True, freq_shift=0.0, max_pe
     return emb
 
 
+def denoiser_forward_action(ops, sd, sample, timestep, actions, nhead=4, guidance_scale=7.5):
+    """MldDenoiser.forward, action condition (mld_denoiser.py:69-77,135-228) with EmbedAction in eval mode
+    (mld_denoiser.py:249-260): rows of the embedding table, the FIRST half of the batch replaced by zeros when
+    guidance_scale > 1 (the unconditional half of the CFG batch).  sample [R,1,D], actions int [R] -> [R,1,D]."""
+    d = sample.shape[-1]
+    temb0 = timestep_embedding(ops, [float(timestep)], d)
+    temb = linear(ops, silu(ops, linear(ops, temb0, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])),
+                  sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+    temb = temb[None, :, :] + ops.zeros_like(sample)
+    idx = [int(a) for a in np.asarray(actions).reshape(-1)]
+    emb = ops.stack([sd["emb_proj.action_embedding"][i] for i in idx], 0)[:, None, :]            # [R,1,D]
+    if guidance_scale > 1.0:
+        half = len(idx) // 2
+        emb = ops.cat([ops.zeros_like(emb[:half]), emb[half:]], 0)
+    xseq = ops.cat([sample, temb, emb], 1)
+    xseq = xseq + ops.swap(sd["query_pos.pe"][: xseq.shape[1]], 0, 1)
+    out = skip_transformer(ops, sd, "encoder", xseq, nhead, lambda p, x: encoder_layer(ops, sd, p, x, nhead))
+    return out[:, : sample.shape[1], :]
+
+
 def denoiser_forward(ops, sd, sample, timestep, text_emb, nhead=4):
     """MldDenoiser.forward, text condition / trans_enc / skip / learned PE
     (mld_denoiser.py:135-228).  sample [R,1,D], timestep scalar, text_emb [R,1,768] -> [R,1,D].
@@ -424,6 +445,38 @@ def vae_decode(ops, sd, z, lengths: Sequence[int], nhead=4):
                            lambda p, x: decoder_layer(ops, sd, p, x, z, nhead, valid))
     feats = linear(ops, out, sd["final_layer.weight"], sd["final_layer.bias"])
     return ops.where(valid[:, :, None], feats, ops.zeros_like(feats))                    # :245
+
+
+def actor_decode(ops, sd, z, lengths: Sequence[int], nhead=4):
+    """ActorVae.decode -> ActorAgnosticDecoder.forward (actor_vae.py:209-235): sinusoidal-PE time queries,
+    stock post-norm nn.TransformerDecoderLayer stack (same sub-layer order as cross_attention.py:323-345), NO
+    final LayerNorm, final_layer, zero padded frames.  z [B,1,D] -> feats [B, max(lengths), nfeats]."""
+    b, tmax = len(lengths), int(max(lengths))
+    valid = ops.mask_from_lengths(lengths, tmax)
+    x = ops.swap(sd["decoder.sequence_pos_encoding.pe"][:tmax], 0, 1) + ops.zeros_like(z[:, :1, :])
+    i = 0
+    while f"decoder.seqTransDecoder.layers.{i}.linear1.weight" in sd:
+        x = decoder_layer(ops, sd, f"decoder.seqTransDecoder.layers.{i}", x, z, nhead, valid)
+        i += 1
+    feats = linear(ops, x, sd["decoder.final_layer.weight"], sd["decoder.final_layer.bias"])
+    return ops.where(valid[:, :, None], feats, ops.zeros_like(feats))
+
+
+def sample_action(ops, sd_den, sd_vae, actions, init_latents, lengths, guidance_scale=7.5, steps=50, nhead=4,
+                  return_intermediates=False):
+    """MLD.a2m_eval's sampling core (mld.py:710-735): cond = cat(zeros_like(actions), actions), reverse diffusion,
+    ActorVae decode.  Returns feats [B, T, nfeats] (joints need SMPL, unavailable: compared at feature level)."""
+    sch = DDIMSchedule()
+    lat = init_latents * sch.init_noise_sigma
+    acts = np.asarray(actions).reshape(-1)
+    cond = np.concatenate([np.zeros_like(acts), acts])
+    for t in sch.set_timesteps(steps):
+        eps = denoiser_forward_action(ops, sd_den, ops.cat([lat, lat], 0), t, cond, nhead, guidance_scale)
+        b = lat.shape[0]
+        u, c = eps[:b], eps[b:]
+        lat = sch.step(u + guidance_scale * (c - u), t, lat)
+    feats = actor_decode(ops, sd_vae, lat, lengths, nhead)
+    return (feats, lat) if return_intermediates else feats
 
 
 def vae_encode(ops, sd, feats, lengths: Sequence[int], eps=None, nhead=4):

@@ -42,3 +42,26 @@ def load_synthetic_weights(eng, finalize=True):
     if finalize:
         eng.finalize()
     return ign_d + ign_v
+
+
+ACTION_CFG = dict(condition=_lib.COND_ACTION, nclasses=12, vae_arch=_lib.VAE_ACTOR, vae_num_layers=6, num_layers=15, nfeats=150)
+
+
+def action_weights():
+    """(denoiser, ActorVae) synthetic state dicts of the HumanAct12 variant (the fixtures' seeds)."""
+    dims = syn.ModelDims(num_layers=15, nfeats=150)
+    return (syn.make_denoiser_state_dict(seed=3, dims=dims, condition="action", nclasses=12), syn.make_actor_vae_state_dict())
+
+
+def load_action_weights(eng, finalize=True):
+    sdd, sdv = action_weights()
+    ign = eng.load_state_dict(sdd, "denoiser.") + eng.load_state_dict(sdv, "vae.")
+    if finalize:
+        eng.finalize()
+    return ign
+
+
+def sim_action_engine(**cfg):
+    eng = _lib.Engine(lib=sim_library(), use_graph=0, **{**ACTION_CFG, **cfg})
+    load_action_weights(eng)
+    return eng

@@ -307,3 +307,83 @@ def test_vae_encode_vs_reference_golden(eng, dev, golden_dir, oracle_weights):
     eng.vae_encode(_cuda(f, dev), [196] * b, 196, None, None, z, l2)
     torch.cuda.synchronize()
     assert torch.isfinite(m2).all() and torch.equal(m2, z)
+
+
+# ------------------------------------------------------------------ action-conditioned variant (BASELINE config 5)
+ACTION_CFG = dict(condition=_lib.COND_ACTION, nclasses=12, vae_arch=_lib.VAE_ACTOR, vae_num_layers=6, num_layers=15, nfeats=150)
+
+
+def _action_weights():
+    dims = syn.ModelDims(num_layers=15, nfeats=150)
+    return (syn.make_denoiser_state_dict(seed=3, dims=dims, condition="action", nclasses=12), syn.make_actor_vae_state_dict())
+
+
+@pytest.fixture(scope="module")
+def aeng(dev):
+    e = _lib.Engine(device=0, max_batch=256, max_frames=60, **ACTION_CFG)
+    sdd, sdv = _action_weights()
+    e.load_state_dict(sdd, "denoiser.")
+    e.load_state_dict(sdv, "vae.")
+    e.finalize()
+    yield e
+    e.close()
+
+
+def test_action_denoiser_and_actor_decode_vs_golden(aeng, dev, golden_dir):
+    """Single ops of the HumanAct12 variant against the reference modules' outputs (oracle/make_golden.py main_action)."""
+    g = _gold(golden_dir, "action_ops_b4.npz")
+    out = torch.empty(8, 1, 256, device=dev)
+    aeng.denoiser_forward_action(_cuda(g["sample"], dev), 981, g["cond"].tolist(), out)
+    lens = g["lengths"].tolist()
+    feats = torch.full((4, max(lens), 150), 7.0, device=dev)
+    aeng.vae_decode(_cuda(g["z"], dev), lens, feats)
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - g["out_t981"]).max() < 1e-4
+    f = feats.cpu().numpy()
+    assert np.abs(f - g["feats"]).max() < 1e-4
+    for i, n in enumerate(lens):
+        assert np.all(f[i, n:] == 0)
+
+
+def test_action_pipeline_b256_vs_golden(aeng, dev, golden_dir):
+    """Config 5 at full size (B=256, T=60, 50 steps, guidance 7.5) against the reference-generated fixture; graph replay
+    is deterministic and a second label set changes the result (the labels are read at replay time, not baked in)."""
+    g = _gold(golden_dir, "action_b256.npz")
+    acts, lat0, lens = syn.make_action_batch(256, nframes=60)
+    lat = torch.empty(256, 1, 256, device=dev)
+    feats = torch.empty(256, 60, 150, device=dev)
+    x0 = _cuda(lat0, dev)
+    aeng.sample_action(acts, x0, lens, lat, feats)
+    torch.cuda.synchronize()
+    l1, f1 = lat.cpu().numpy(), feats.cpu().numpy()
+    assert np.abs(l1 - g["latents"]).max() < 5e-3          # |latents| ~ 70
+    assert np.abs(f1[::8] - g["feats_every8"]).max() < 1e-3
+    aeng.sample_action(acts, x0, lens, lat, feats)
+    torch.cuda.synchronize()
+    assert np.array_equal(f1, feats.cpu().numpy())
+    aeng.sample_action((acts + 1) % 12, x0, lens, lat, feats)
+    torch.cuda.synchronize()
+    assert np.abs(feats.cpu().numpy() - f1).max() > 1e-2
+    den, dec, _ = aeng.launch_counts()
+    assert den == 2 + 50 * (15 * 4 + 7 + 1) and dec == 2 + 1 + 6 * 5 + 1
+
+
+def test_action_mld_module_surface_on_gpu(dev):
+    from mld_hip import config as C
+    from mld_hip import engine as E
+    from mld_hip.datamodule import HipDataModule
+    from mld_hip.mld import MLD
+
+    cfg = C.load_config(os.path.join(C.CONFIG_DIR, "config_mld_humanact12.yaml"))
+    E.configure("action", max_batch=8, max_frames=60)
+    model = MLD(cfg, HipDataModule(cfg, nfeats=150, njoints=25, name="humanact12")).to(dev).eval()
+    sdd, sdv = _action_weights()
+    model.denoiser.load_state_dict({k: torch.from_numpy(v) for k, v in sdd.items()}, strict=True)
+    model.vae.load_state_dict({k: torch.from_numpy(v) for k, v in sdv.items()}, strict=True)
+    acts, lat0, _ = syn.make_action_batch(5, 60)
+    lengths = [60, 41, 60, 60, 17]
+    rs = model.a2m_eval({"action": _cuda(acts.astype(np.int64), dev)[:, None], "length": lengths}, init_latents=_cuda(lat0, dev))
+    ops = O.NumpyOps(np.float32)
+    fr = O.sample_action(ops, O.to_backend(ops, sdd), O.to_backend(ops, sdv), acts, lat0, lengths)
+    assert rs["m_rst"].is_cuda and np.abs(rs["m_rst"].cpu().numpy() - fr).max() < 1e-3
+    E.drop_engines()

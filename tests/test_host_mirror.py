@@ -16,7 +16,7 @@ from mld_hip.denoiser import HipMldDenoiser
 from mld_hip.mld import MLD
 from mld_hip.scheduler import HipDDIMScheduler
 from mld_hip.text_encoder import SyntheticTextEncoder
-from mld_hip.vae import HipMldVae
+from mld_hip.vae import HipActorVae, HipMldVae
 from oracle import mld_oracle as O
 
 REF = "/root/reference"
@@ -102,7 +102,7 @@ def test_state_dict_keys_match_the_reference_modules(golden_dir):
 def test_unsupported_configurations_fail_loudly():
     abl = dict(SKIP_CONNECT=True, VAE_TYPE="mld", DIFF_PE_TYPE="mld", PE_TYPE="mld", MLP_DIST=False)
     with pytest.raises(NotImplementedError):
-        HipMldDenoiser(ablation=abl, condition="action", num_layers=9)
+        HipMldDenoiser(ablation=abl, condition="text_uncond", num_layers=9)
     with pytest.raises(NotImplementedError):
         HipMldDenoiser(ablation={**abl, "VAE_TYPE": "no"}, num_layers=9)
     with pytest.raises(NotImplementedError):
@@ -188,6 +188,76 @@ def test_mld_forward_fused_and_modular_agree_with_oracle(sim_key):
     sd["t2m_textencoder.fake"] = torch.zeros(1)
     model.load_state_dict(sd, strict=True)
     assert all(k.split(".")[0] in ("denoiser", "vae", "text_encoder") for k in model.state_dict())
+
+
+# ------------------------------------------------------------------------------------------ action variant (config 5)
+A2M_CFG = os.path.join(C.CONFIG_DIR, "config_mld_humanact12.yaml")
+
+
+def test_action_config_and_reference_yaml_parity():
+    cfg = C.load_config(A2M_CFG)
+    assert cfg.model.condition == "action" and cfg.model.denoiser.target == "mld_hip.denoiser.HipMldDenoiser"
+    assert cfg.model.denoiser.params.num_layers == 15 and cfg.model.denoiser.params.nclasses == 12
+    assert cfg.model.motion_vae.target == "mld_hip.vae.HipActorVae" and cfg.model.motion_vae.params.num_layers == 6
+    assert cfg.model.motion_vae.params.nfeats == 150
+    if not os.path.isdir(REF):
+        pytest.skip("reference tree not present")
+    import yaml
+    for part, fn in (("denoiser", "denoiser.yaml"), ("motion_vae", "motion_vae.yaml"), ("scheduler", "scheduler.yaml")):
+        ref = yaml.safe_load(open(os.path.join(REF, "configs", "modules_humanact12", fn)))[part]
+        got = yaml.safe_load(open(os.path.join(C.CONFIG_DIR, "modules_hip_humanact12", fn)))[part]
+        assert ref["params"] == got["params"], part
+    ref_exp = yaml.safe_load(open(os.path.join(REF, "configs", "config_mld_humanact12.yaml")))
+    for k in ("latent_dim", "ff_size", "num_layers", "num_head", "guidance_scale", "guidance_uncondp", "condition", "vae"):
+        assert ref_exp["model"][k] == cfg.model[k], k
+    assert ref_exp["TRAIN"]["ABLATION"] == {k: cfg.TRAIN.ABLATION[k] for k in ref_exp["TRAIN"]["ABLATION"]}
+
+
+def test_action_state_dict_keys_match_the_reference_modules(golden_dir):
+    keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
+    cfg = C.load_config(A2M_CFG)
+    den = C.instantiate_from_config(cfg.model.denoiser)
+    vae = C.instantiate_from_config(cfg.model.motion_vae)
+    assert isinstance(vae, HipActorVae)
+    assert {k: list(v.shape) for k, v in den.state_dict().items()} == keys["denoiser_action"]
+    assert {k: list(v.shape) for k, v in vae.state_dict().items()} == keys["actor_vae"]
+    with pytest.raises(NotImplementedError):
+        vae.encode(torch.zeros(1, 8, 150), [8])
+
+
+def test_action_mld_fused_and_modular_agree_with_oracle():
+    eng = simlib.sim_action_engine(max_batch=4, max_frames=24, num_inference_steps=2)
+    key = E.inject_engine(eng, "inject:hostmirror_a2m")
+    try:
+        cfg = C.load_config(A2M_CFG, overrides={"model.scheduler.num_inference_timesteps": 2})
+        dm = HipDataModule(cfg, nfeats=150, njoints=25, name="humanact12", engine_key=key)
+        model = MLD(cfg, dm, engine_key=key).eval()
+        assert model.fused and model.text_encoder is None and model.vae_type == "actor"
+        sdd, sdv = simlib.action_weights()
+        model.denoiser.load_state_dict({k: torch.from_numpy(v) for k, v in sdd.items()}, strict=True)
+        model.vae.load_state_dict({k: torch.from_numpy(v) for k, v in sdv.items()}, strict=True)
+        acts, lat0, _ = syn.make_action_batch(3, 16)
+        lengths = [16, 9, 16]
+        batch = {"action": torch.from_numpy(acts.astype(np.int64))[:, None], "length": lengths}
+        rs = model.a2m_eval(batch, init_latents=torch.from_numpy(lat0))
+        assert rs["m_rst"].shape == (3, 16, 150) and rs["m_lens"] == lengths
+        ops = O.NumpyOps(np.float32)
+        fr = O.sample_action(ops, O.to_backend(ops, sdd), O.to_backend(ops, sdv), acts, lat0, lengths, steps=2)
+        assert np.abs(rs["m_rst"].numpy() - fr).max() < 1e-4
+        # the reference-style loop over the per-op drop-ins (cond = cat(zeros, actions), mld.py:716-717)
+        a = batch["action"]
+        z = model._diffusion_reverse(torch.cat((torch.zeros_like(a), a)), lengths, init_latents=torch.from_numpy(lat0))
+        f2 = model.vae.decode(z.contiguous(), lengths)
+        assert np.abs(f2.numpy() - fr).max() < 1e-4
+        with pytest.raises(NotImplementedError):
+            model.feats2joints(f2)                                  # SMPL layout: out of scope, fails loudly
+        # a text-variant module must refuse an action engine instead of mis-loading
+        with pytest.raises(RuntimeError):
+            C.instantiate_from_config(C.load_config().model.denoiser).use_engine(key)(
+                torch.zeros(2, 1, 256), 5, torch.zeros(2, 1, 768))
+    finally:
+        E._engines.pop(key, None)
+        eng.close()
 
 
 def test_demo_example_parser(tmp_path):

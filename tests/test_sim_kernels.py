@@ -159,3 +159,74 @@ def test_abi_errors_sim(eng):
         _lib.Engine(lib=simlib.sim_library(), latent_dim=512)
     with pytest.raises(_lib.MldHipError):
         _lib.Engine(lib=simlib.sim_library(), num_layers=8)
+
+
+# ------------------------------------------------------------------ action-conditioned variant (BASELINE config 5)
+@pytest.fixture(scope="module")
+def aeng():
+    e = simlib.sim_action_engine(max_batch=4, max_frames=24, num_inference_steps=2)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def aow():
+    ops = O.NumpyOps(np.float32)
+    sdd, sdv = simlib.action_weights()
+    return ops, O.to_backend(ops, sdd), O.to_backend(ops, sdv)
+
+
+def test_action_required_keys_sim():
+    e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=2, max_frames=16, **simlib.ACTION_CFG)
+    # denoiser: time MLP 4 + table 1 + pe 1 + 15 layers * 12 + 7 skip linears * 2 + norm 2; ActorVae decoder: pe + 6 * 18 + final 2; mean/std
+    assert len(e.missing_keys()) == (4 + 1 + 1 + 15 * 12 + 14 + 2) + (1 + 6 * 18 + 2) + 2
+    ignored = simlib.load_action_weights(e, finalize=False)
+    assert e.missing_keys() == ["mean", "std"]                 # optional group (no joints on this layout)
+    assert "denoiser.mem_pos.pe" in ignored and all(k == "denoiser.mem_pos.pe" or k.startswith("vae.encoder.") for k in ignored)
+    e.finalize()
+    with pytest.raises(_lib.MldHipError):                      # text entry point on an action engine
+        e.sample(np.zeros((4, 1, 768), np.float32), np.zeros((2, 1, 256), np.float32), [8, 8], None, None, None)
+    with pytest.raises(_lib.MldHipError):                      # label out of range
+        e.sample_action([0, 12], np.zeros((2, 1, 256), np.float32), [8, 8], None, None)
+    e.close()
+
+
+def test_action_denoiser_forward_sim(aeng, aow):
+    ops, bd, _ = aow
+    acts, lat0, _ = syn.make_action_batch(2, 16)
+    x = np.concatenate([lat0, lat0])
+    cond = np.concatenate([np.zeros_like(acts), acts])
+    out = np.zeros((4, 1, 256), np.float32)
+    aeng.denoiser_forward_action(x, 981, cond, out)
+    ref = O.denoiser_forward_action(ops, bd, x, 981, cond)
+    assert np.abs(out - ref).max() < 5e-5
+    # the unconditional half ignores its labels (EmbedAction zeroes it, mld_denoiser.py:253-257)
+    out2 = np.zeros_like(out)
+    aeng.denoiser_forward_action(x, 981, np.concatenate([acts[::-1], acts]), out2)
+    np.testing.assert_array_equal(out, out2)
+
+
+def test_actor_decode_ragged_sim(aeng, aow):
+    ops, _, bv = aow
+    z = syn._rng(5, "az").standard_normal((3, 1, 256)).astype(np.float32)
+    lens = [24, 9, 17]
+    feats = np.full((3, 24, 150), 7.0, np.float32)
+    aeng.vae_decode(z, lens, feats)
+    ref = O.actor_decode(ops, bv, z, lens)
+    assert np.abs(feats - ref).max() < 5e-5
+    assert np.all(feats[1, 9:] == 0) and np.all(feats[2, 17:] == 0)
+
+
+def test_action_full_sample_sim(aeng, aow):
+    ops, bd, bv = aow
+    acts, lat0, _ = syn.make_action_batch(3, 16)
+    lens = [16, 16, 11]
+    lat = np.zeros((3, 1, 256), np.float32)
+    feats = np.zeros((3, 16, 150), np.float32)
+    aeng.sample_action(acts, lat0, lens, lat, feats)
+    fr, lr = O.sample_action(ops, bd, bv, acts, lat0, lens, steps=2, return_intermediates=True)
+    assert np.abs(lat - lr).max() < 5e-4
+    assert np.abs(feats - fr).max() < 1e-4
+    den, dec, _ = aeng.launch_counts()
+    # label gather + init + steps * (15 layers * 4 + 7 skip + 1 final); decode: 2 cross-attn + queries + 6 * 5 + final
+    assert den == 1 + 1 + 2 * (15 * 4 + 7 + 1) and dec == 2 + 1 + 6 * 5 + 1
