@@ -83,7 +83,7 @@ def cpu_baseline(seed, threads, timeout=420):
 def bench_a2m(local, dev, stream, warmup, steps, B=256, T=60):
     """BASELINE config 5 shape (config_mld_humanact12.yaml: action condition, 15-layer denoiser, ActorVae decoder,
     bs=256, T=60), same timing rule; a secondary line, never the headline `value`.  fp32 like the headline (the fp8
-    denoiser GEMMs BASELINE.json muses about cannot meet the parity tolerance: DESIGN.md §7)."""
+    denoiser GEMMs BASELINE.json muses about cannot meet the parity tolerance: DESIGN.md §3 point 9, §7)."""
     eng = _lib.Engine(device=local, max_batch=B, max_frames=T, condition=_lib.COND_ACTION, nclasses=12,
                       vae_arch=_lib.VAE_ACTOR, vae_num_layers=6, num_layers=15, nfeats=150)
     dims = syn.ModelDims(num_layers=15, nfeats=150)
