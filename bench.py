@@ -112,6 +112,39 @@ def bench_a2m(local, dev, stream, warmup, steps, B=256, T=60):
     return out
 
 
+def bench_novae(local, dev, stream, B=64, T=196, steps=1000):
+    """BASELINE config 4 shape (config_novae_humanml3d.yaml: raw-motion diffusion, trans_dec denoiser d=512, DDPM x1000,
+    bs=64, T=196): ONE full 1000-step batch, timed like the headline (a secondary line, never `value`).  MFMA-bound:
+    1.29 TFLOP per step, noise from the in-kernel Philox stream."""
+    eng = _lib.Engine(device=local, max_batch=B, max_frames=T, latent_dim=512, vae_arch=_lib.VAE_NONE, denoiser_arch=_lib.ARCH_TRANS_DEC,
+                      scheduler_type=_lib.SCHED_DDPM, num_inference_steps=steps, steps_offset=0)
+    eng.load_state_dict(syn.make_novae_denoiser_state_dict(), "denoiser.")
+    mean, std = syn.make_mean_std()
+    eng.load_tensor("mean", mean)
+    eng.load_tensor("std", std)
+    eng.finalize()
+    b = syn.make_batch(B, None, seed=1234, max_len=T)
+    text = torch.from_numpy(b.text_emb).to(dev)
+    x0 = torch.randn(B, T, 263, device=dev)
+    joints = torch.empty(B, T, 22, 3, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.sample_novae(text, x0, b.lengths, None, 1234, None, joints, stream.cuda_stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lin = lambda m, k, n: 2.0 * m * k * n
+    m = 2 * B * T
+    gf_step = (9 * (lin(m, 512, 1536) + 3 * lin(m, 512, 512) + 2 * lin(m, 512, 1024) + 4.0 * m * T * 512 + 4.0 * m * 2 * 512)
+               + lin(m, 263, 512) + lin(m, 512, 263)) / 1e9
+    out = {"workload": "config_novae_humanml3d.yaml (raw-motion diffusion, trans_dec d=512), bs=64, T=196, 1000-step DDPM, CFG 7.5 -> joints",
+           "value": round(B / dt, 3), "unit": "motions/s", "ms_per_step": round(dt * 1e3, 1), "steps": 1, "ms_per_ddpm_step": round(dt * 1e3 / steps, 3),
+           "dtype": "f32", "algorithmic_gflop_per_ddpm_step": round(gf_step, 1), "achieved_tflops": round(gf_step * steps / 1e3 / dt, 2),
+           "frac_of_fp32_mfma_peak": round(gf_step * steps / 1e3 / dt / FP32_MFMA_PEAK_TF, 4), "finite": bool(torch.isfinite(joints).all().item()),
+           "launches_per_step": eng.launch_counts()}
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +153,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="disable hipGraph replay (debug)")
     ap.add_argument("--no-a2m", action="store_true", help="skip the secondary action-to-motion (config 5) measurement")
+    ap.add_argument("--no-novae", action="store_true", help="skip the secondary diffusion-only (config 4, 1000-step DDPM) measurement")
     ap.add_argument("--precision", choices=["f32", "bf16x3_decode"], default=os.environ.get("MLD_BENCH_PRECISION", "f32"),
                     help="f32: exact-fp32 MFMA everywhere; bf16x3_decode: split-bf16 MFMA in the VAE-decoder GEMMs")
     a = ap.parse_args()
@@ -251,6 +285,8 @@ def main():
             eng2.close()
         if world == 1 and not a.eager and not a.no_a2m:
             out["other_workloads"] = [bench_a2m(local, dev, stream, max(2, a.warmup), max(3, a.steps // 2))]
+            if not a.no_novae:
+                out["other_workloads"].append(bench_novae(local, dev, stream))
         print(json.dumps(out))
     if dist:
         dist.barrier()

@@ -78,10 +78,16 @@ typedef struct mldhip_config {
   int32_t nclasses;             /* rows of emb_proj.action_embedding (12 HumanAct12, 40 UESTC); action only */
   int32_t vae_arch;             /* MLDHIP_VAE_MLD (MldVae, skip enc-dec) | MLDHIP_VAE_ACTOR (ActorVae decoder) */
   int32_t vae_num_layers;       /* ActorVae: layers of seqTransDecoder (6); 0 = num_layers */
+  /* ---- the diffusion-only variant (configs/config_novae_humanml3d.yaml, modules_novae/): latent_dim 512,
+   * vae_arch NONE, denoiser_arch TRANS_DEC, scheduler_type DDPM with num_inference_steps 1000, steps_offset 0 */
+  int32_t denoiser_arch;        /* MLDHIP_ARCH_TRANS_ENC (skip encoder, mld_denoiser.py:98-119) | MLDHIP_ARCH_TRANS_DEC (:120-133) */
+  int32_t scheduler_type;       /* MLDHIP_SCHED_DDIM | MLDHIP_SCHED_DDPM (variance_type fixed_small) */
 } mldhip_config;
 
 enum { MLDHIP_COND_TEXT = 0, MLDHIP_COND_ACTION = 1 };
-enum { MLDHIP_VAE_MLD = 0, MLDHIP_VAE_ACTOR = 1 };
+enum { MLDHIP_VAE_MLD = 0, MLDHIP_VAE_ACTOR = 1, MLDHIP_VAE_NONE = 2 /* model.vae_type 'no': latents are raw motion */ };
+enum { MLDHIP_ARCH_TRANS_ENC = 0, MLDHIP_ARCH_TRANS_DEC = 1 };
+enum { MLDHIP_SCHED_DDIM = 0, MLDHIP_SCHED_DDPM = 1 };
 
 typedef struct mldhip_engine mldhip_handle;
 
@@ -142,6 +148,37 @@ int mldhip_sample_action(mldhip_handle* h, const int32_t* actions_host, const fl
  * guidance_scale > 1 the FIRST R/2 rows get the zero (unconditional) embedding whatever their label. */
 int mldhip_denoiser_forward_action(mldhip_handle* h, const float* sample_dev, int32_t timestep,
                                    const int32_t* actions_host, int32_t R, float* out_dev, void* stream);
+
+/* Diffusion-only sampling (BASELINE config 4).  Replaces: MLD.forward after the text encoder with vae_type 'no'
+ * (mld/models/modeltype/mld.py:232-242,264; _diffusion_reverse :290-360 with latents = raw motion [B,Tmax,nfeats]):
+ * num_inference_steps x (trans_dec denoiser on the 2B-row CFG batch, guidance, DDPM ancestral step), identity
+ * "decode", feats2joints.
+ *   text_emb_dev      [2B, 1, text_dim]   unconditional half first
+ *   init_latents_dev  [B, Tmax, nfeats]   the torch.randn of mld.py:296-301 (injected), Tmax = max(lengths)
+ *   step_noise_dev    [steps, B, Tmax, nfeats] the N(0,1) draw of every scheduler.step (injected; the reference takes
+ *                     it from torch's global generator), or NULL: drawn in-kernel from Philox4x32-10(seed, step, element)
+ *   feats_out_dev     [B, Tmax, nfeats] (padded frames hold the scheduler's noise, as in the reference; may be NULL)
+ *   joints_out_dev    [B, Tmax, njoints, 3] (may be NULL) */
+int mldhip_sample_novae(mldhip_handle* h, const float* text_emb_dev, const float* init_latents_dev,
+                        const int32_t* lengths_host, int32_t B, const float* step_noise_dev, uint64_t seed,
+                        float* feats_out_dev, float* joints_out_dev, void* stream);
+
+/* Replaces: MldDenoiser.forward, diffusion_only + arch trans_dec (mld_denoiser.py:144-146,208-221).
+ * sample [R, T, nfeats], text [R, 1, text_dim], lengths_host [R] (rows t >= len of the output are zero; all T frames
+ * are attended to, the reference passes no key-padding mask here) -> out [R, T, nfeats]. */
+int mldhip_denoiser_forward_novae(mldhip_handle* h, const float* sample_dev, int32_t timestep, const float* text_emb_dev,
+                                  const int32_t* lengths_host, int32_t R, int32_t T, float* out_dev, void* stream);
+
+/* Replaces: DDPMScheduler.step(model_output, t, sample).prev_sample (call site mld.py:345-346), variance_type
+ * fixed_small.  noise_dev [n] = the step's N(0,1) draw, or NULL for the Philox stream (seed, step_index).
+ * n elements, in/out may alias. */
+int mldhip_ddpm_step(mldhip_handle* h, const float* eps_dev, int32_t timestep, const float* sample_dev,
+                     const float* noise_dev, uint64_t seed, int32_t step_index, float* prev_sample_dev, int64_t n,
+                     void* stream);
+
+/* The engine's counter-based Gaussian stream: out[i] = N(0,1) of (seed, step_index, i) -- what mldhip_sample_novae
+ * uses when step_noise_dev is NULL (Philox4x32-10 + Box-Muller; restated in numpy in oracle/mld_oracle.py). */
+int mldhip_philox_normal(mldhip_handle* h, float* out_dev, int64_t n, uint64_t seed, int32_t step_index, void* stream);
 
 /* Replaces: MldVae.decode(z, lengths) (mld/models/architectures/mld_vae.py:186-248); with
  * vae_arch = MLDHIP_VAE_ACTOR: ActorVae.decode (mld/models/architectures/actor_vae.py:72-74,209-235).

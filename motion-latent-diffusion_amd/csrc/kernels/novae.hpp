@@ -1,0 +1,303 @@
+// Kernels of the no-VAE ("diffusion only") variant: raw-motion diffusion with the trans_dec denoiser
+// (configs/config_novae_humanml3d.yaml; mld_denoiser.py:208-221 -> TransformerDecoder, cross_attention.py:195-233,
+// layers :323-345) and the DDPM scheduler (configs/modules_novae/scheduler.yaml:16-29).
+//
+// Shapes (BASELINE config 4): d = 512, 4 heads x 128, ff 1024, 9 layers, R = 2B CFG rows x T frames: M = 25 088 rows.
+// 1.29 TFLOP per step, x1000 steps: the GEMMs (gemm.hpp, staged exact-fp32 MFMA) carry > 90 % of the time, so the
+// row-wise pieces here are plain HBM passes (each moves 100-150 MB per call, ~1 % of a step) -- not fused into the GEMM
+// epilogues on purpose in this first version.
+#pragma once
+#include "rt.hpp"
+
+namespace mld {
+
+// out[(h*B + b)*T + t][0:KP] = lat[b][t][0:NF] padded with zeros, h = 0,1 (torch.cat([latents] * 2), mld.py:324-326);
+// `dup` = 1 copies once (per-op entry point: the caller already passes R rows).
+__global__ __launch_bounds__(256) void dup_pad_rows_kernel(const float* __restrict__ lat, float* __restrict__ out,
+                                                           long long rows, int NF, int KP, int dup) {
+  const long long n = rows * KP;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / KP;
+    const int c = int(i - row * KP);
+    const float v = c < NF ? lat[row * NF + c] : 0.f;
+    for (int h = 0; h < dup; ++h) out[(h * rows + row) * KP + c] = v;
+  }
+}
+
+// H[row][:] += pe[row % T][:]   (PositionEmbeddingLearned1D over the frame axis, position_encoding.py:153-159)
+__global__ __launch_bounds__(256) void add_pe_mod_kernel(float* __restrict__ H, const float* __restrict__ pe, long long M, int T,
+                                                         int D) {
+  const long long n4 = M * D / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4, row = e / D;
+    const int d = int(e - row * D), t = int(row % T);
+    F4 a = ld4(H + e);
+    const F4 p = ld4(pe + (long long)t * D + d);
+    a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    st4(H + e, a);
+  }
+}
+
+// Y = LayerNorm(X + res) * gamma + beta over rows of width W (res may be null).  One wave per row, 4 rows per
+// workgroup; a lane owns W/256 float4 chunks (chunk c at column c*256 + lane*4: every wave load is one 1 KiB line).
+template <int W>
+__global__ __launch_bounds__(256) void add_layernorm_rows_kernel(const float* __restrict__ X, const float* __restrict__ res,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ Y, int M) {
+  constexpr int NC = W / 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int row = blockIdx.x * 4 + wave;
+  const bool live = row < M;
+  row = live ? row : M - 1;
+  F4 x[NC];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) x[c] = ld4(X + (long long)row * W + c * 256 + lane * 4);
+  if (res) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const F4 r = ld4(res + (long long)row * W + c * 256 + lane * 4);
+      x[c].x += r.x; x[c].y += r.y; x[c].z += r.z; x[c].w += r.w;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) s += (x[c].x + x[c].y) + (x[c].z + x[c].w);
+  const float mean = sum64(s) * (1.0f / W);
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    x[c].x -= mean; x[c].y -= mean; x[c].z -= mean; x[c].w -= mean;
+    q += (x[c].x * x[c].x + x[c].y * x[c].y) + (x[c].z * x[c].z + x[c].w * x[c].w);
+  }
+  const float rstd = rsqrtf(sum64(q) * (1.0f / W) + kLnEps);
+  if (!live) return;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const F4 gm = ld4(gamma + c * 256 + lane * 4), bt = ld4(beta + c * 256 + lane * 4);
+    F4 y;
+    y.x = x[c].x * rstd * gm.x + bt.x; y.y = x[c].y * rstd * gm.y + bt.y;
+    y.z = x[c].z * rstd * gm.z + bt.z; y.w = x[c].w * rstd * gm.w + bt.w;
+    st4(Y + (long long)row * W + c * 256 + lane * 4, y);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Self-attention over the T frames of one (sample, head) for head dims that do not leave room for K AND V in LDS
+// (HD = 128: 208 keys x 132 floats = 107 KiB per operand).  Same MFMA mapping as attn_decode_kernel (swapped QK^T,
+// P registers as the A operand of P.V) but K and V pass through ONE LDS buffer in turn, and a workgroup owns only
+// 4 query tiles (one per wave) so the scores of its queries stay in registers across the K -> V switch.
+//   grid = (samples * H, ceil(ceil(T/16) / 4)), block = 256, dynamic LDS = NKT*16*(HD+4)*4 bytes.
+// lens == nullptr: no key-padding mask (the trans_dec denoiser attends to all T frames, mld_denoiser.py:215).
+template <int NKT, int HD>
+__global__ __launch_bounds__(256) void attn_seq_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                       const int* __restrict__ lens, int T, int H) {
+  constexpr int ST = HD + 4, C4 = HD / 4, KPL = HD / 4;   // LDS row stride; float4 chunks per row; q/k dims per lane
+#if defined(MLDHIP_SIM)
+  float* KV = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
+#else
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* KV = smem;
+#endif
+  const int D = H * HD;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  int len = T;
+  if (lens) len = lens[b] < T ? lens[b] : T;
+  const int nkt = (len + 15) >> 4, nqt = (T + 15) >> 4;
+  const int qt = blockIdx.y * 4 + wave;
+  const bool active = qt < nqt;                       // idle waves still take part in the barriers
+  const float scale = rsqrtf((float)HD);
+
+  auto stage = [&](int col0) {                        // K (col0 = D) or V (col0 = 2D) rows of this (sample, head)
+    for (int idx = tid; idx < nkt * 16 * C4; idx += 256) {
+      const int key = idx / C4, c4 = idx - key * C4;
+      F4 v = F4{0.f, 0.f, 0.f, 0.f};                  // rows >= len are zero: P is 0 there and 0*garbage must not be NaN
+      if (key < len) v = ld4(qkv + (long long)(b * T + key) * 3 * D + col0 + h * HD + c4 * 4);
+      st4(KV + key * ST + c4 * 4, v);
+    }
+  };
+
+  stage(D);
+  __syncthreads();
+  f32x4 s[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float inv = 0.f;
+  if (active) {
+    int qrow = qt * 16 + r;
+    qrow = qrow < T ? qrow : T - 1;
+    const float* qp = qkv + (long long)(b * T + qrow) * 3 * D + h * HD + g * KPL;
+    float qf[KPL];
+#pragma unroll
+    for (int c = 0; c < KPL / 4; ++c) {
+      const F4 t = ld4(qp + c * 4);
+      qf[c * 4] = t.x * scale; qf[c * 4 + 1] = t.y * scale; qf[c * 4 + 2] = t.z * scale; qf[c * 4 + 3] = t.w * scale;
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < nkt) {
+        const float* kp = KV + (kt * 16 + r) * ST + g * KPL;
+#pragma unroll
+        for (int c = 0; c < KPL / 4; ++c) {
+          const F4 t = ld4(kp + c * 4);
+          s[kt] = mfma_f32_16x16x4(t.x, qf[c * 4], s[kt]);
+          s[kt] = mfma_f32_16x16x4(t.y, qf[c * 4 + 1], s[kt]);
+          s[kt] = mfma_f32_16x16x4(t.z, qf[c * 4 + 2], s[kt]);
+          s[kt] = mfma_f32_16x16x4(t.w, qf[c * 4 + 3], s[kt]);
+        }
+      }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool valid = (kt < nkt) && (kt * 16 + g * 4 + i < len);
+        s[kt][i] = valid ? s[kt][i] : -INFINITY;
+        m = fmaxf(m, s[kt][i]);
+      }
+    m = max_groups(m);
+    float den = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float e = expf(s[kt][i] - m);
+        s[kt][i] = e;
+        den += e;
+      }
+    den = sum_groups(den);
+    inv = 1.0f / den;
+  }
+  __syncthreads();                                    // every wave is done reading K
+  stage(2 * D);
+  __syncthreads();
+  if (!active) return;
+  f32x4 oacc[HD / 16];
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    if (kt < nkt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float pv = s[kt][i] * inv;
+        const float* vp = KV + (kt * 16 + g * 4 + i) * ST + r;
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) oacc[dt] = mfma_f32_16x16x4(pv, vp[dt * 16], oacc[dt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = qt * 16 + g * 4 + i;
+      if (q < T) o[(long long)(b * T + q) * D + h * HD + dt * 16 + r] = oacc[dt][i];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Cross-attention of the trans_dec denoiser: every frame row attends to the TWO memory tokens [time, text]
+// (mld_denoiser.py:170-172,214-215; cross_attention.py:336-339).  K/V of the time token are the same for all rows of
+// a step (kv_time[2*D]: k then v), those of the text token are per sample (kv_text[sample][2*D]).
+// One wave per row (D = 512: 8 contiguous dims per lane, a head = 16 lanes), 4 rows per workgroup.
+template <int D, int HD>
+__global__ __launch_bounds__(256) void cross2_kernel(const float* __restrict__ q, const float* __restrict__ kv_time,
+                                                     const float* __restrict__ kv_text, float* __restrict__ o, int M, int T) {
+  static_assert(D == 512 && HD == 128, "lane mapping below assumes 8 dims per lane and 16 lanes per head");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int row = blockIdx.x * 4 + wave;
+  const bool live = row < M;
+  row = live ? row : M - 1;
+  const int smp = row / T, c = lane * 8;
+  const float scale = rsqrtf((float)HD);
+  const F4 q0 = ld4(q + (long long)row * D + c), q1 = ld4(q + (long long)row * D + c + 4);
+  const F4 a0 = ld4(kv_time + c), a1 = ld4(kv_time + c + 4);
+  const F4 b0 = ld4(kv_text + (long long)smp * 2 * D + c), b1 = ld4(kv_text + (long long)smp * 2 * D + c + 4);
+  const F4 va0 = ld4(kv_time + D + c), va1 = ld4(kv_time + D + c + 4);
+  const F4 vb0 = ld4(kv_text + (long long)smp * 2 * D + D + c), vb1 = ld4(kv_text + (long long)smp * 2 * D + D + c + 4);
+  const float qs[8] = {q0.x * scale, q0.y * scale, q0.z * scale, q0.w * scale, q1.x * scale, q1.y * scale, q1.z * scale, q1.w * scale};
+  const float ka[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  const float kb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { sa = fmaf(qs[i], ka[i], sa); sb = fmaf(qs[i], kb[i], sb); }
+  sa = sum16(sa);
+  sb = sum16(sb);
+  const float m = fmaxf(sa, sb);
+  const float ea = expf(sa - m), eb = expf(sb - m);
+  const float inv = 1.0f / (ea + eb);
+  const float pa = ea * inv, pb = eb * inv;
+  if (!live) return;
+  F4 y0, y1;
+  y0.x = pa * va0.x + pb * vb0.x; y0.y = pa * va0.y + pb * vb0.y; y0.z = pa * va0.z + pb * vb0.z; y0.w = pa * va0.w + pb * vb0.w;
+  y1.x = pa * va1.x + pb * vb1.x; y1.y = pa * va1.y + pb * vb1.y; y1.z = pa * va1.z + pb * vb1.z; y1.w = pa * va1.w + pb * vb1.w;
+  st4(o + (long long)row * D + c, y0);
+  st4(o + (long long)row * D + c + 4, y1);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11) -> four N(0,1) draws per call through Box-Muller.  Counter-based, so the
+// noise of (seed, step, element) does not depend on launch geometry: the in-engine replacement for the
+// torch.randn(model_output.shape) inside DDPMScheduler.step (diffusers; call site mld.py:345-346).
+struct Philox4 { unsigned v[4]; };
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = unsigned(p1 >> 32) ^ c1 ^ k0, n1 = unsigned(p1), n2 = unsigned(p0 >> 32) ^ c3 ^ k1, n3 = unsigned(p0);
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox4{{c0, c1, c2, c3}};
+}
+__device__ __forceinline__ float u01(unsigned x) { return float(x >> 8) * (1.0f / 16777216.0f) + (0.5f / 16777216.0f); }   // (0, 1)
+__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned step, unsigned long long quad, float (&z)[4]) {
+  const Philox4 p = philox4x32_10(unsigned(quad), unsigned(quad >> 32), step, 0u, unsigned(seed), unsigned(seed >> 32));
+  const float r0 = sqrtf(-2.0f * logf(u01(p.v[0]))), t0 = 6.28318530717958647692f * u01(p.v[1]);
+  const float r1 = sqrtf(-2.0f * logf(u01(p.v[2]))), t1 = 6.28318530717958647692f * u01(p.v[3]);
+  z[0] = r0 * cosf(t0); z[1] = r0 * sinf(t0); z[2] = r1 * cosf(t1); z[3] = r1 * sinf(t1);
+}
+
+// out[n] = N(0,1) of (seed, step, element) -- exposed for tests / callers that want the engine's noise stream.
+__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, long long n, unsigned long long seed, unsigned step) {
+  const long long nq = (n + 3) / 4;
+  for (long long qd = (long long)blockIdx.x * blockDim.x + threadIdx.x; qd < nq; qd += (long long)gridDim.x * blockDim.x) {
+    float z[4];
+    philox_normal4(seed, step, (unsigned long long)qd, z);
+    for (int i = 0; i < 4; ++i)
+      if (qd * 4 + i < n) out[qd * 4 + i] = z[i];
+  }
+}
+
+// DDPM ancestral step, variance_type fixed_small, epsilon prediction, no clipping (diffusers DDPMScheduler.step as
+// restated in SURVEY.md App. A.3; third party, PARITY UNPINNED), with the classifier-free-guidance combine of
+// mld.py:339-342 folded in when eps_cond != nullptr:
+//   eps = eps_u + g (eps_c - eps_u);  x0 = (x - sqrt(1-ab_t) eps) / sqrt(ab_t);
+//   x' = c_x0 x0 + c_x x + sigma * z,   z = noise[i] (injected) or Philox(seed, step, i); sigma = 0 at t = 0.
+struct DdpmCoef { float sqrt_ab, sqrt_1mab, c_x0, c_x, sigma; };
+__global__ __launch_bounds__(256) void cfg_ddpm_step_kernel(const float* __restrict__ eps_u, const float* __restrict__ eps_c,
+                                                            const float* __restrict__ x, const float* __restrict__ noise,
+                                                            float* __restrict__ out, long long n, float guidance, DdpmCoef k,
+                                                            unsigned long long seed, unsigned step) {
+  const long long nq = (n + 3) / 4;
+  for (long long qd = (long long)blockIdx.x * blockDim.x + threadIdx.x; qd < nq; qd += (long long)gridDim.x * blockDim.x) {
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (k.sigma != 0.f && !noise) philox_normal4(seed, step, (unsigned long long)qd, z);
+    for (int i = 0; i < 4; ++i) {
+      const long long e = qd * 4 + i;
+      if (e >= n) break;
+      float ep = eps_u[e];
+      if (eps_c) ep = ep + guidance * (eps_c[e] - ep);
+      const float xv = x[e];
+      const float x0 = (xv - k.sqrt_1mab * ep) / k.sqrt_ab;
+      float y = k.c_x0 * x0 + k.c_x * xv;
+      if (k.sigma != 0.f) y += k.sigma * (noise ? noise[e] : z[i]);
+      out[e] = y;
+    }
+  }
+}
+
+}  // namespace mld

@@ -27,6 +27,7 @@
 #include "kernels/attention.hpp"
 #include "kernels/elementwise.hpp"
 #include "kernels/gemm.hpp"
+#include "kernels/novae.hpp"
 #include "kernels/rt.hpp"
 #include "kernels/tile32.hpp"
 
@@ -80,11 +81,14 @@ struct mldhip_engine {
   std::vector<EncLayerP> den;      // execution order
   std::vector<DecLayerP> dec;
   std::vector<EncLayerP> venc;     // VAE encoder layers (same layer type as the denoiser's)
+  std::vector<DecLayerP> ndec;     // no-VAE variant: denoiser.decoder.layers.* (TransformerDecoder, cross_attention.py:195-233)
+  size_t ndec_layer_stride = 0;
+  float *TKV = nullptr, *XKV = nullptr, *TKV_one = nullptr;   // memory-token K|V per layer: time [L][n][2D], text [L][2*max_batch][2D]
   size_t dec_layer_stride = 0;     // floats between consecutive decoder layers' tensors
 
   // ---- schedule
   std::vector<int32_t> timesteps;
-  std::vector<float> alphas_cumprod;
+  std::vector<float> alphas_cumprod, betas;
   float final_alpha_cumprod = 1.f;
 
   // ---- workspace
@@ -140,6 +144,9 @@ using E = mldhip_engine;
 bool is_action(const E* e) { return e->cfg.condition == MLDHIP_COND_ACTION; }
 bool is_actor(const E* e) { return e->cfg.vae_arch == MLDHIP_VAE_ACTOR; }
 int time_width(const E* e) { return is_action(e) ? e->cfg.latent_dim : e->cfg.text_dim; }   // mld_denoiser.py:57-77
+bool is_novae(const E* e) { return e->cfg.vae_arch == MLDHIP_VAE_NONE; }
+bool is_ddpm(const E* e) { return e->cfg.scheduler_type == MLDHIP_SCHED_DDPM; }
+int novae_kp(const E* e) { return (e->cfg.nfeats + 127) / 128 * 128; }   // feature width padded to 4 K chunks (263 -> 384)
 int vae_layers(const E* e) { return is_actor(e) ? (e->cfg.vae_num_layers > 0 ? e->cfg.vae_num_layers : e->cfg.num_layers) : e->cfg.num_layers; }
 std::string actor_layer(int i) { return "vae.decoder.seqTransDecoder.layers." + std::to_string(i); }
 
@@ -190,6 +197,35 @@ void declare_params(E* e) {
     add_param(e, p + ".weight", {D});
     add_param(e, p + ".bias", {D});
   };
+  if (is_novae(e)) {
+    // diffusion-only denoiser (mld_denoiser.py:50-53,57-68,88-91,120-133): no VAE tensors at all
+    lin("denoiser.pose_embd", D, NF);
+    lin("denoiser.pose_proj", NF, D);
+    lin("denoiser.time_embedding.linear_1", D, TD);
+    lin("denoiser.time_embedding.linear_2", D, D);
+    lin("denoiser.emb_proj.1", D, TD);
+    add_param(e, "denoiser.query_pos.pe", {500, 1, D});
+    add_param(e, "denoiser.mem_pos.pe", {500, 1, D});
+    size_t first = 0, second = 0;
+    for (int i = 0; i < c.num_layers; ++i) {
+      std::string p = "denoiser.decoder.layers." + std::to_string(i);
+      size_t start = e->arena_floats;
+      mha(p + ".self_attn");
+      mha(p + ".multihead_attn");
+      lin(p + ".linear1", F, D);
+      lin(p + ".linear2", D, F);
+      norm(p + ".norm1");
+      norm(p + ".norm2");
+      norm(p + ".norm3");
+      if (i == 0) first = start;
+      if (i == 1) second = start;
+    }
+    e->ndec_layer_stride = second - first;
+    norm("denoiser.decoder.norm");
+    add_param(e, "mean", {NF});
+    add_param(e, "std", {NF});
+    return;
+  }
   // denoiser (mld_denoiser.py:40-133)
   lin("denoiser.time_embedding.linear_1", D, time_width(e));
   lin("denoiser.time_embedding.linear_2", D, D);
@@ -271,10 +307,29 @@ void declare_params(E* e) {
 
 const float* P(E* e, const std::string& key) { return e->arena + e->params[e->index.at(key)].offset; }
 
+DecLayerP bind_dec_layer(E* e, const std::string& p) {
+  DecLayerP L;
+  L.in_w = P(e, p + ".self_attn.in_proj_weight"); L.in_b = P(e, p + ".self_attn.in_proj_bias");
+  L.out_w = P(e, p + ".self_attn.out_proj.weight"); L.out_b = P(e, p + ".self_attn.out_proj.bias");
+  L.cin_w = P(e, p + ".multihead_attn.in_proj_weight"); L.cin_b = P(e, p + ".multihead_attn.in_proj_bias");
+  L.cout_w = P(e, p + ".multihead_attn.out_proj.weight"); L.cout_b = P(e, p + ".multihead_attn.out_proj.bias");
+  L.l1_w = P(e, p + ".linear1.weight"); L.l1_b = P(e, p + ".linear1.bias");
+  L.l2_w = P(e, p + ".linear2.weight"); L.l2_b = P(e, p + ".linear2.bias");
+  L.n1_w = P(e, p + ".norm1.weight"); L.n1_b = P(e, p + ".norm1.bias");
+  L.n2_w = P(e, p + ".norm2.weight"); L.n2_b = P(e, p + ".norm2.bias");
+  L.n3_w = P(e, p + ".norm3.weight"); L.n3_b = P(e, p + ".norm3.bias");
+  return L;
+}
+
 void bind_layers(E* e) {
   const int nb = (e->cfg.num_layers - 1) / 2;
   e->den.clear();
   e->dec.clear();
+  e->ndec.clear();
+  if (is_novae(e)) {
+    for (int i = 0; i < e->cfg.num_layers; ++i) e->ndec.push_back(bind_dec_layer(e, "denoiser.decoder.layers." + std::to_string(i)));
+    return;
+  }
   for (auto& b : block_names(nb)) {
     std::string p = "denoiser.encoder." + b;
     EncLayerP L;
@@ -323,17 +378,36 @@ void build_schedule(E* e) {
   const float start = sqrtf(c.beta_start), stop = sqrtf(c.beta_end);
   const float step = (stop - start) / float(N - 1);
   e->alphas_cumprod.resize(N);
+  e->betas.resize(N);
   float prod = 1.f;
   for (int i = 0; i < N; ++i) {
     float y = (i == N - 1) ? stop : float(i) * step + start;
     float beta = y * y;
+    e->betas[i] = beta;
     prod = prod * (1.0f - beta);
     e->alphas_cumprod[i] = prod;
   }
   e->final_alpha_cumprod = c.set_alpha_to_one ? 1.0f : e->alphas_cumprod[0];
   const int n = c.num_inference_steps, ratio = N / n;
   e->timesteps.resize(n);
-  for (int i = 0; i < n; ++i) e->timesteps[i] = (n - 1 - i) * ratio + c.steps_offset;
+  // DDIM: steps_offset shifts the grid (scheduler.yaml:14); DDPM.set_timesteps has no offset
+  for (int i = 0; i < n; ++i) e->timesteps[i] = (n - 1 - i) * ratio + (is_ddpm(e) ? 0 : c.steps_offset);
+}
+
+// DDPM ancestral-step coefficients, variance_type fixed_small (third party, parity unpinned; float32 like diffusers).
+DdpmCoef ddpm_coef(const E* e, int t) {
+  const int prev = t - e->cfg.num_train_timesteps / e->cfg.num_inference_steps;
+  const float ab_t = e->alphas_cumprod[t], ab_p = prev >= 0 ? e->alphas_cumprod[prev] : 1.0f;
+  const bool unit = e->cfg.num_train_timesteps == e->cfg.num_inference_steps;   // ratio 1: table values (see oracle DDPMSchedule)
+  const float a_t = unit ? 1.0f - e->betas[t] : ab_t / ab_p, b_t = unit ? e->betas[t] : 1.0f - a_t;
+  const float bp_t = 1.0f - ab_t, bp_p = 1.0f - ab_p;
+  DdpmCoef k;
+  k.sqrt_ab = sqrtf(ab_t);
+  k.sqrt_1mab = sqrtf(bp_t);
+  k.c_x0 = sqrtf(ab_p) * b_t / bp_t;
+  k.c_x = sqrtf(a_t) * bp_p / bp_t;
+  k.sigma = t > 0 ? sqrtf(fmaxf(bp_p / bp_t * b_t, 1e-20f)) : 0.0f;
+  return k;
 }
 
 DdimCoef ddim_coef(const E* e, int t) {
@@ -395,22 +469,19 @@ void launch_staged(Ctx& c, const GemmArgs& a, dim3 grid) {
   }
   switch (kcs) {
     case 8: MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 8>), grid, dim3(WM * WN * 64), lds, c.stream, a); break;
+    case 12:   // K = 384: the 263-wide motion features padded to the chunk pipeline (pose_embd of the no-VAE denoiser)
+      if constexpr (!LN && PREC == 0) { MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 12>), grid, dim3(WM * WN * 64), lds, c.stream, a); }
+      else c.rc = c.e->fail(MLDHIP_EINVAL, "staged GEMM: K=384 is built for the plain fp32 tile only");
+      break;
     case 16: MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 16>), grid, dim3(WM * WN * 64), lds, c.stream, a); break;
     case 32: MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 32>), grid, dim3(WM * WN * 64), lds, c.stream, a); break;
-    default: c.rc = c.e->fail(MLDHIP_EINVAL, "staged GEMM: K=%d not in {256,512,1024}", a.K1 + a.K2);
+    default: c.rc = c.e->fail(MLDHIP_EINVAL, "staged GEMM: K=%d not in {256,384,512,1024}", a.K1 + a.K2);
   }
 }
-template <int WM, int WN, int MREP, int NREP, bool LN, int PREC>
-void staged_attrs() {
-#if !defined(MLDHIP_SIM)
-  constexpr int lds = gemm_lds_bytes<WM, WN, MREP, NREP>();
-#endif
-}
-
 void gemm(Ctx& c, const GemmArgs& a, int nz = 1) {
   const int K = a.K1 + a.K2;
-  const bool small = a.M <= g_small_m || (K != 256 && K != 512 && K != 1024);
-  const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_DECODE && c.e->phase == 1;   // decoder GEMMs only
+  const bool small = a.M <= g_small_m || (K != 256 && K != 384 && K != 512 && K != 1024);
+  const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_DECODE && c.e->phase == 1 && K != 384;   // decoder GEMMs only
   if (small) {
     dim3 grid((a.M + 15) / 16, (a.N + 63) / 64, nz);
     MLD_LAUNCH((gemm_kernel<1, 4, 1, 1, false>), grid, dim3(256), 0, c.stream, a);
@@ -778,6 +849,121 @@ void joints_body(Ctx& c, const float* feats, int B, int T, float* joints) {
   check_launch(c, "feats2joints");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Diffusion-only variant (BASELINE config 4): trans_dec denoiser on raw motion, d = 512 (kernels/novae.hpp).
+// Row layout: sample-major rows r*T + t of the CFG batch (r < R = 2B), 512 floats per row.
+void novae_ln(Ctx& c, const float* x, const float* res, const float* g, const float* b, float* y, int M) {
+  MLD_LAUNCH((add_layernorm_rows_kernel<512>), dim3((M + 3) / 4), dim3(256), 0, c.stream, x, res, g, b, y, M);
+  count(c);
+  check_launch(c, "add_layernorm_rows");
+}
+
+void novae_self_attention(Ctx& c, int R, int T) {
+  E* e = c.e;
+  const int H = e->cfg.num_heads, nkt = pick_nkt(T), nqt = (T + 15) / 16;
+  const size_t shmem = (size_t)nkt * 16 * 132 * sizeof(float);
+  dim3 grid(R * H, (nqt + 3) / 4), block(256);
+  const int* nolens = nullptr;    // the reference passes no key-padding mask to the trans_dec denoiser (mld_denoiser.py:215)
+  switch (nkt) {
+    case 4: MLD_LAUNCH((attn_seq_kernel<4, 128>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
+    case 7: MLD_LAUNCH((attn_seq_kernel<7, 128>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
+    case 13: MLD_LAUNCH((attn_seq_kernel<13, 128>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
+    default: MLD_LAUNCH((attn_seq_kernel<18, 128>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
+  }
+  count(c);
+  check_launch(c, "attn_seq");
+}
+
+// K|V of the memory tokens for all layers at once (blockIdx.z = layer): dst[l][rows][2D] = src · Wkv_l^T + bkv_l
+void novae_memory_kv(Ctx& c, const float* src, int rows, float* dst, long long dst_layer_stride) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim;
+  GemmArgs g = lin_args(src, D, D, e->ndec[0].cin_w + (size_t)D * D, e->ndec[0].cin_b + D, dst, 2 * D, rows, 2 * D);
+  g.sW = (long long)e->ndec_layer_stride; g.sBias = (long long)e->ndec_layer_stride; g.sY = dst_layer_stride;
+  gemm(c, g, e->cfg.num_layers);
+}
+
+// MldDenoiser.forward, trans_dec branch, for the M = R*T rows whose zero-padded features are in e->FF [M][KP].
+// tkv: K|V of the time token, layer l at tkv + l*tkv_stride; text-token K|V in e->XKV [L][2*max_batch][2D].
+void novae_denoiser_body(Ctx& c, int R, int T, const float* tkv, long long tkv_stride, float* eps_out) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim, F = e->cfg.ff_size, NF = e->cfg.nfeats, KP = novae_kp(e), M = R * T;
+  gemm(c, lin_args(e->FF, KP, KP, e->WskelP, P(e, "denoiser.pose_embd.bias"), e->X0, D, M, D));
+  MLD_LAUNCH(add_pe_mod_kernel, dim3(std::min(4096, (M * (D / 4) + 255) / 256)), dim3(256), 0, c.stream, e->X0,
+             P(e, "denoiser.query_pos.pe"), (long long)M, T, D);
+  count(c);
+  check_launch(c, "add_pe_mod");
+  for (int l = 0; l < e->cfg.num_layers && !c.rc; ++l) {
+    const DecLayerP& L = e->ndec[l];
+    gemm(c, lin_args(e->X0, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
+    novae_self_attention(c, R, T);
+    gemm(c, lin_args(e->AO, D, D, L.out_w, L.out_b, e->Ha, D, M, D));
+    novae_ln(c, e->Ha, e->X0, L.n1_w, L.n1_b, e->H1, M);
+    gemm(c, lin_args(e->H1, D, D, L.cin_w, L.cin_b, e->Hb, D, M, D));                    // cross-attention queries
+    MLD_LAUNCH((cross2_kernel<512, 128>), dim3((M + 3) / 4), dim3(256), 0, c.stream, (const float*)e->Hb, tkv + (size_t)l * tkv_stride,
+               (const float*)(e->XKV + (size_t)l * 2 * e->cfg.max_batch * 2 * D), e->AO, M, T);
+    count(c);
+    check_launch(c, "cross2");
+    gemm(c, lin_args(e->AO, D, D, L.cout_w, L.cout_b, e->Ha, D, M, D));
+    novae_ln(c, e->Ha, e->H1, L.n2_w, L.n2_b, e->X0, M);
+    GemmArgs f1 = lin_args(e->X0, D, D, L.l1_w, L.l1_b, e->FF, F, M, F);
+    f1.act = ACT_GELU;
+    gemm(c, f1);
+    gemm(c, lin_args(e->FF, F, F, L.l2_w, L.l2_b, e->Ha, D, M, D));
+    novae_ln(c, e->Ha, e->X0, L.n3_w, L.n3_b, e->X0, M);       // in place: a wave reads its whole row before writing it
+  }
+  novae_ln(c, e->X0, nullptr, P(e, "denoiser.decoder.norm.weight"), P(e, "denoiser.decoder.norm.bias"), e->H1, M);
+  GemmArgs f = lin_args(e->H1, D, D, P(e, "denoiser.pose_proj.weight"), P(e, "denoiser.pose_proj.bias"), eps_out, NF, M, NF);
+  f.lens = e->lens_dev; f.rows_per_group = T;                   // sample[~mask.T] = 0 (mld_denoiser.py:219-221)
+  gemm(c, f);
+}
+
+void novae_pad_input(Ctx& c, const float* x, long long rows, int dup) {
+  E* e = c.e;
+  const int KP = novae_kp(e);
+  MLD_LAUNCH(dup_pad_rows_kernel, dim3((unsigned)std::min<long long>(8192, (rows * KP + 255) / 256)), dim3(256), 0, c.stream, x, e->FF, rows,
+             e->cfg.nfeats, KP, dup);
+  count(c);
+  check_launch(c, "dup_pad_rows");
+}
+
+// text token of the memory: emb_proj(text) + mem_pos.pe[1] -> TP [rows][D], then its K|V for every layer -> XKV
+void novae_text_memory(Ctx& c, const float* text, int rows) {
+  E* e = c.e;
+  text_projection(c, text, rows, e->TP);
+  novae_memory_kv(c, e->TP, rows, e->XKV, (long long)2 * e->cfg.max_batch * 2 * e->cfg.latent_dim);
+}
+
+// MLD.forward after the text encoder with vae_type 'no' (mld.py:232-242,264,290-360).  lens_dev holds lengths ++ lengths.
+int enqueue_sample_novae(E* e, hipStream_t stream, const float* text, const float* init_lat, int B, int T, const float* step_noise,
+                         unsigned long long seed, float* feats_out, float* joints_out) {
+  Ctx c{e, stream};
+  const int D = e->cfg.latent_dim, NF = e->cfg.nfeats, n = e->cfg.num_inference_steps;
+  const long long nel = (long long)B * T * NF;
+  const float guidance = e->cfg.guidance_scale > 1.0f ? e->cfg.guidance_scale : 1.0f;
+  e->launches[0] = e->launches[1] = e->launches[2] = 0;
+  e->phase = 0;
+  HIP_TRY(e, hipMemcpyAsync(e->lat, init_lat, nel * sizeof(float), hipMemcpyDeviceToDevice, stream));   // init_noise_sigma = 1
+  novae_text_memory(c, text, 2 * B);
+  for (int s = 0; s < n && !c.rc; ++s) {
+    novae_pad_input(c, e->lat, (long long)B * T, 2);                                      // torch.cat([latents] * 2)
+    novae_denoiser_body(c, 2 * B, T, e->TKV + (size_t)s * 2 * D, (long long)n * 2 * D, e->feats_int);
+    MLD_LAUNCH(cfg_ddpm_step_kernel, dim3((unsigned)std::min<long long>(4096, (nel / 4 + 255) / 256)), dim3(256), 0, stream,
+               (const float*)e->feats_int, (const float*)(e->feats_int + nel), (const float*)e->lat,
+               step_noise ? step_noise + (size_t)s * nel : (const float*)nullptr, e->lat, nel, guidance,
+               ddpm_coef(e, e->timesteps[s]), seed, (unsigned)s);
+    count(c);
+    check_launch(c, "cfg_ddpm_step");
+  }
+  if (c.rc) return c.rc;
+  if (feats_out) HIP_TRY(e, hipMemcpyAsync(feats_out, e->lat, nel * sizeof(float), hipMemcpyDeviceToDevice, stream));   // "decode" = identity (mld.py:241-242)
+  if (joints_out) {
+    e->phase = 2;
+    joints_body(c, e->lat, B, T, joints_out);
+  }
+  return c.rc;
+}
+
 // Everything mld.py:232-240,264 does after the text encoder.  The reverse loop is latency bound (a few
 // hundred rows per launch), and samples never interact, so the batch is cut into `nchains` sub-batches
 // whose 50-step chains run on parallel branches (side streams forked from / joined to `stream`; inside
@@ -889,6 +1075,7 @@ void mldhip_default_config(mldhip_config* c) {
   c->beta_start = 0.00085f; c->beta_end = 0.012f; c->guidance_scale = 7.5f;
   c->precision = MLDHIP_PREC_F32; c->use_graph = 1;
   c->condition = MLDHIP_COND_TEXT; c->nclasses = 0; c->vae_arch = MLDHIP_VAE_MLD; c->vae_num_layers = 0;
+  c->denoiser_arch = MLDHIP_ARCH_TRANS_ENC; c->scheduler_type = MLDHIP_SCHED_DDIM;
 }
 
 const char* mldhip_last_error(mldhip_handle* h) { return h ? h->err.c_str() : g_last_error.c_str(); }
@@ -897,19 +1084,31 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   auto bad = [&](const char* m) { g_last_error = m; return MLDHIP_EINVAL; };
   if (!cfg || !out) return bad("null argument");
   if (cfg->struct_size != (int32_t)sizeof(mldhip_config)) return bad("mldhip_config.struct_size mismatch (ABI skew)");
-  if (cfg->latent_dim != 256 || cfg->latent_size != 1) return bad("this release supports latent_dim [1, 256] only");
-  if (cfg->num_heads * 64 != cfg->latent_dim) return bad("head_dim must be 64");
-  if (cfg->num_layers < 3 || cfg->num_layers % 2 == 0 || cfg->num_layers > 17) return bad("num_layers must be odd, 3..17 (SkipTransformer)");
+  const bool novae = cfg->vae_arch == MLDHIP_VAE_NONE;
+  if (cfg->vae_arch != MLDHIP_VAE_MLD && cfg->vae_arch != MLDHIP_VAE_ACTOR && !novae) return bad("vae_arch must be mld, actor or none");
+  if (cfg->denoiser_arch != MLDHIP_ARCH_TRANS_ENC && cfg->denoiser_arch != MLDHIP_ARCH_TRANS_DEC) return bad("denoiser_arch must be trans_enc or trans_dec");
+  if (cfg->scheduler_type != MLDHIP_SCHED_DDIM && cfg->scheduler_type != MLDHIP_SCHED_DDPM) return bad("scheduler_type must be ddim or ddpm");
+  if (novae != (cfg->denoiser_arch == MLDHIP_ARCH_TRANS_DEC) || novae != (cfg->scheduler_type == MLDHIP_SCHED_DDPM))
+    return bad("supported combinations: (vae mld|actor, trans_enc, ddim) as in config_mld_*.yaml, or (vae none, trans_dec, ddpm) as in config_novae_humanml3d.yaml");
+  if (novae) {
+    if (cfg->latent_dim != 512 || cfg->latent_size != 1 || cfg->num_heads * 128 != 512) return bad("diffusion-only variant: latent_dim [1, 512], 4 heads of 128");
+    if (cfg->condition != MLDHIP_COND_TEXT) return bad("diffusion-only variant: text condition only");
+    if (cfg->num_layers < 1 || cfg->num_layers > 24) return bad("num_layers must be 1..24");
+  } else {
+    if (cfg->latent_dim != 256 || cfg->latent_size != 1) return bad("latent models: latent_dim [1, 256] only");
+    if (cfg->num_heads * 64 != cfg->latent_dim) return bad("head_dim must be 64");
+    if (cfg->num_layers < 3 || cfg->num_layers % 2 == 0 || cfg->num_layers > 17) return bad("num_layers must be odd, 3..17 (SkipTransformer)");
+  }
   if ((cfg->ff_size != 256 && cfg->ff_size != 512 && cfg->ff_size != 1024) || cfg->text_dim % 32) return bad("ff_size must be 256, 512 or 1024 and text_dim % 32 == 0");
   if (cfg->max_batch < 1 || cfg->max_frames < 1 || cfg->max_frames > 288) return bad("max_batch >= 1, 1 <= max_frames <= 288");
   if (cfg->condition != MLDHIP_COND_TEXT && cfg->condition != MLDHIP_COND_ACTION) return bad("condition must be text or action");
-  if (cfg->vae_arch != MLDHIP_VAE_MLD && cfg->vae_arch != MLDHIP_VAE_ACTOR) return bad("vae_arch must be mld or actor");
   if (cfg->condition == MLDHIP_COND_ACTION && (cfg->nclasses < 1 || cfg->nclasses > 4096)) return bad("action condition needs 1 <= nclasses <= 4096");
   if (cfg->vae_num_layers < 0 || cfg->vae_num_layers > 17) return bad("vae_num_layers must be 0..17");
-  if (cfg->vae_arch == MLDHIP_VAE_MLD && (cfg->nfeats < 67 || cfg->njoints != 22)) return bad("HumanML3D layout expected: nfeats >= 67, njoints 22");
+  if (cfg->vae_arch != MLDHIP_VAE_ACTOR && (cfg->nfeats < 67 || cfg->njoints != 22)) return bad("HumanML3D layout expected: nfeats >= 67, njoints 22");
   if (cfg->nfeats < 1 || cfg->nfeats > 1024) return bad("nfeats must be 1..1024");
   if (cfg->num_inference_steps < 1 || cfg->num_train_timesteps % cfg->num_inference_steps) return bad("num_train_timesteps must be a multiple of num_inference_steps");
-  if ((cfg->num_inference_steps - 1) * (cfg->num_train_timesteps / cfg->num_inference_steps) + cfg->steps_offset >= cfg->num_train_timesteps)
+  if (cfg->scheduler_type == MLDHIP_SCHED_DDIM &&
+      (cfg->num_inference_steps - 1) * (cfg->num_train_timesteps / cfg->num_inference_steps) + cfg->steps_offset >= cfg->num_train_timesteps)
     return bad("steps_offset pushes the first timestep past num_train_timesteps");
   if (cfg->precision != MLDHIP_PREC_F32 && cfg->precision != MLDHIP_PREC_BF16X3_DECODE) return bad("unsupported precision");
 #if !defined(MLDHIP_SIM)
@@ -924,8 +1123,10 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   }
 #endif
   auto* e = new mldhip_engine();
-  if (const char* m = std::getenv("MLDHIP_GEMM")) g_staged_gemm = std::strcmp(m, "direct") != 0;
-  if (const char* m = std::getenv("MLDHIP_SMALL_M")) g_small_m = std::atoi(m);
+  const char* m_gemm = std::getenv("MLDHIP_GEMM");        // process-wide A/B knobs, re-read at every create
+  g_staged_gemm = !(m_gemm && std::strcmp(m_gemm, "direct") == 0);
+  const char* m_small = std::getenv("MLDHIP_SMALL_M");
+  g_small_m = m_small ? std::atoi(m_small) : 256;
   if (const char* m = std::getenv("MLDHIP_TILE16")) e->tile16 = std::atoi(m) != 0;
   e->nchains = 1;   // measured: parallel chains do not shorten the sequential depth
   if (const char* m = std::getenv("MLDHIP_CHAINS")) e->nchains = std::max(1, std::min(8, std::atoi(m)));
@@ -944,6 +1145,21 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   size_t off = 0;
   std::vector<std::pair<float**, size_t>> carve;
   auto want = [&](float** p, size_t nfl) { carve.push_back({p, off}); off += align_up(nfl); };
+  if (is_novae(e)) {
+    // diffusion-only: M = 2*B*T rows of width 512; raw-motion latents [B][T][NF]; eps of the CFG batch [2B][T][NF]
+    const size_t r2 = 2 * Bm * Tm, KPn = novae_kp(e);
+    want(&e->X0, r2 * D); want(&e->Ha, r2 * D); want(&e->Hb, r2 * D); want(&e->H1, r2 * D); want(&e->LNO, 0);
+    for (int i = 0; i < 8; ++i) want(&e->S[i], 0);
+    want(&e->QKV, r2 * 3 * D); want(&e->AO, r2 * D); want(&e->FF, r2 * std::max(F, KPn));
+    want(&e->lat, Bm * Tm * NF); want(&e->zbuf, 0);
+    want(&e->Po, 0); want(&e->Pf, 0); want(&e->Ps, 0); want(&e->TP, 2 * Bm * D);
+    want(&e->T1, n * D); want(&e->temb0, n * TD); want(&e->tmid, n * D);
+    want(&e->text_bias, D); want(&e->time_b2pe, D); want(&e->t1_one, D); want(&e->temb0_one, TD + D);
+    want(&e->cv1, 0); want(&e->cvec, 0);
+    want(&e->WskelP, D * KPn);
+    want(&e->feats_int, 2 * Bm * Tm * NF); want(&e->joints_int, Bm * Tm * cfg->njoints * 3);
+    want(&e->TKV, L * n * 2 * D); want(&e->XKV, L * 2 * Bm * 2 * D); want(&e->TKV_one, L * 2 * D);
+  } else {
   want(&e->X0, rows * D); want(&e->Ha, rows * D); want(&e->Hb, rows * D); want(&e->H1, rows * D); want(&e->LNO, rows * D);
   for (int i = 0; i < 8; ++i) want(&e->S[i], (i < (int)(L - 1) / 2) ? rows * D : 0);
   want(&e->QKV, rows * 3 * D); want(&e->AO, rows * D); want(&e->FF, rows * F);
@@ -954,11 +1170,12 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   want(&e->cv1, Lv * Bm * D); want(&e->cvec, Lv * Bm * D);
   want(&e->WskelP, D * KP);
   want(&e->feats_int, Bm * Tm * NF); want(&e->joints_int, Bm * Tm * cfg->njoints * 3);
+  }
   e->ws_floats = off;
   if (hipMalloc((void**)&e->ws, off * sizeof(float)) != hipSuccess) { e->err = "hipMalloc(workspace) failed"; return fail_create(MLDHIP_EHIP); }
   if (hipMemset(e->ws, 0, off * sizeof(float)) != hipSuccess) { e->err = "hipMemset(workspace) failed"; return fail_create(MLDHIP_EHIP); }
   for (auto& cv : carve) *cv.first = e->ws + cv.second;
-  if (hipMalloc((void**)&e->lens_dev, Bm * sizeof(int32_t)) != hipSuccess || hipMalloc((void**)&e->lens2_dev, Bm * sizeof(int32_t)) != hipSuccess ||
+  if (hipMalloc((void**)&e->lens_dev, 2 * Bm * sizeof(int32_t)) != hipSuccess || hipMalloc((void**)&e->lens2_dev, Bm * sizeof(int32_t)) != hipSuccess ||
       hipMalloc((void**)&e->labels_dev, 2 * Bm * sizeof(int32_t)) != hipSuccess) { e->err = "hipMalloc(lens) failed"; return fail_create(MLDHIP_EHIP); }
 #if !defined(MLDHIP_SIM)
   if (hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return fail_create(MLDHIP_EHIP); }
@@ -972,14 +1189,17 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<18>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  const int big128 = 18 * 16 * 132 * 4;   // attn_seq_kernel<*,128>: one operand (K, then V) of up to 288 keys x 132 floats = 148.5 KiB
+  (void)hipFuncSetAttribute((const void*)attn_seq_kernel<4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, big128);
+  (void)hipFuncSetAttribute((const void*)attn_seq_kernel<7, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, big128);
+  (void)hipFuncSetAttribute((const void*)attn_seq_kernel<13, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, big128);
+  (void)hipFuncSetAttribute((const void*)attn_seq_kernel<18, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, big128);
 #define MLD_T32_ATTR(NS)                                                                                                    \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<32, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<32, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);  \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
   MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4)
-  staged_attrs<2, 2, 2, 4, false, 0>(); staged_attrs<2, 2, 2, 4, false, 1>();
-  staged_attrs<1, 4, 2, 4, true, 0>(); staged_attrs<1, 4, 2, 4, true, 1>();
 #undef MLD_T32_ATTR
   (void)hipGetLastError();
 #endif
@@ -1062,9 +1282,11 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
   const int D = e->cfg.latent_dim, TD = time_width(e), n = e->cfg.num_inference_steps;
   if (e->group_ready[0]) {
     // PE-folded biases: token 1 (time) gets pe[1], token 2 (text) gets pe[2] (mld_denoiser.py:187,196)
-    const float* pe = P(e, "denoiser.query_pos.pe");
-    MLD_LAUNCH(add_rows_kernel, dim3(1), dim3(256), 0, stream, e->time_b2pe, P(e, "denoiser.time_embedding.linear_2.bias"), pe + D, 1, D);
-    if (!is_action(e)) MLD_LAUNCH(add_rows_kernel, dim3(1), dim3(256), 0, stream, e->text_bias, P(e, "denoiser.emb_proj.1.bias"), pe + 2 * D, 1, D);
+    // (trans_dec: the memory tokens [time, text] get mem_pos.pe[0], pe[1] instead, mld_denoiser.py:213)
+    const float* pe_time = is_novae(e) ? P(e, "denoiser.mem_pos.pe") : P(e, "denoiser.query_pos.pe") + D;
+    const float* pe_text = pe_time + D;
+    MLD_LAUNCH(add_rows_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, e->time_b2pe, P(e, "denoiser.time_embedding.linear_2.bias"), pe_time, 1, D);
+    if (!is_action(e)) MLD_LAUNCH(add_rows_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, e->text_bias, P(e, "denoiser.emb_proj.1.bias"), pe_text, 1, D);
     if (check_launch(c, "add_rows")) return c.rc;
     // time-MLP output for every scheduler timestep (sample independent; embeddings.py:245-305)
     std::vector<float> host((size_t)n * TD);
@@ -1072,6 +1294,13 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
     HIP_TRY(e, hipMemcpy(e->temb0, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
     time_mlp(c, e->temb0, e->tmid, e->T1, n);
     if (c.rc) return c.rc;
+    if (is_novae(e)) {
+      // the time token's K|V for every (layer, scheduler step) depend on weights only; pose_embd.weight padded to KP
+      novae_memory_kv(c, e->T1, n, e->TKV, (long long)n * 2 * D);
+      const int NF = e->cfg.nfeats, KP = novae_kp(e);
+      MLD_LAUNCH(pad_cols_kernel, dim3((D * KP + 255) / 256), dim3(256), 0, stream, P(e, "denoiser.pose_embd.weight"), e->WskelP, D, NF, KP);
+      if (check_launch(c, "pad_cols")) return c.rc;
+    }
   }
   if (e->group_ready[3]) {
     const int NF = e->cfg.nfeats, KP = (NF + 31) / 32 * 32;
@@ -1145,6 +1374,7 @@ int mldhip_sample(mldhip_handle* e, const float* text_emb_dev, const float* init
                   int32_t B, float* latents_out_dev, float* feats_out_dev, float* joints_out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
   if (is_action(e)) return e->fail(MLDHIP_ESTATE, "engine was created with the action condition: use mldhip_sample_action");
+  if (is_novae(e)) return e->fail(MLDHIP_ESTATE, "engine was created for the diffusion-only variant: use mldhip_sample_novae");
   if (joints_out_dev && is_actor(e)) return e->fail(MLDHIP_ESTATE, "joints of the ActorVae feature layout need SMPL (out of scope)");
   if (!text_emb_dev) return e->fail(MLDHIP_EINVAL, "null input pointer");
   return sample_impl(e, text_emb_dev, nullptr, init_latents_dev, lengths_host, B, latents_out_dev, feats_out_dev, joints_out_dev, stream_);
@@ -1202,6 +1432,7 @@ int mldhip_denoiser_forward(mldhip_handle* e, const float* sample_dev, int32_t t
                             int32_t R, float* out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
   if (is_action(e)) return e->fail(MLDHIP_ESTATE, "engine was created with the action condition: use mldhip_denoiser_forward_action");
+  if (is_novae(e)) return e->fail(MLDHIP_ESTATE, "engine was created for the diffusion-only variant: use mldhip_denoiser_forward_novae");
   if (!text_emb_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
   return denoiser_forward_impl(e, sample_dev, timestep, text_emb_dev, nullptr, R, out_dev, stream_);
 }
@@ -1212,6 +1443,72 @@ int mldhip_denoiser_forward_action(mldhip_handle* e, const float* sample_dev, in
   if (!is_action(e)) return e->fail(MLDHIP_ESTATE, "engine was created with the text condition: use mldhip_denoiser_forward");
   if (!actions_host) return e->fail(MLDHIP_EINVAL, "null pointer");
   return denoiser_forward_impl(e, sample_dev, timestep, nullptr, actions_host, R, out_dev, stream_);
+}
+
+int mldhip_sample_novae(mldhip_handle* e, const float* text_emb_dev, const float* init_latents_dev, const int32_t* lengths_host,
+                        int32_t B, const float* step_noise_dev, uint64_t seed, float* feats_out_dev, float* joints_out_dev, void* stream_) {
+  if (!e) return MLDHIP_EINVAL;
+  if (!is_novae(e)) return e->fail(MLDHIP_ESTATE, "engine was not created for the diffusion-only variant (vae_arch = MLDHIP_VAE_NONE)");
+  if (!e->finalized || !e->group_ready[0] || (joints_out_dev && !e->group_ready[2]))
+    return e->fail(MLDHIP_ESTATE, "mldhip_sample_novae needs finalize and denoiser.* (and mean/std for joints) loaded");
+  if (!text_emb_dev || !init_latents_dev) return e->fail(MLDHIP_EINVAL, "null input pointer");
+  int T = 0;
+  if (int rc = validate_lengths(e, lengths_host, B, &T)) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  HIP_TRY(e, hipMemcpyAsync(e->lens_dev, lengths_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  HIP_TRY(e, hipMemcpyAsync(e->lens_dev + B, lengths_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));   // lengths * 2 (mld.py:327-328)
+  // ~114 launches of 0.1-2 ms each per step: the GPU, not the host, is the bottleneck -> plain stream launches, no graph
+  return enqueue_sample_novae(e, stream, text_emb_dev, init_latents_dev, B, T, step_noise_dev, seed, feats_out_dev, joints_out_dev);
+}
+
+int mldhip_denoiser_forward_novae(mldhip_handle* e, const float* sample_dev, int32_t timestep, const float* text_emb_dev,
+                                  const int32_t* lengths_host, int32_t R, int32_t T, float* out_dev, void* stream_) {
+  if (!e) return MLDHIP_EINVAL;
+  if (!is_novae(e)) return e->fail(MLDHIP_ESTATE, "engine was not created for the diffusion-only variant (vae_arch = MLDHIP_VAE_NONE)");
+  if (!e->finalized || !e->group_ready[0]) return e->fail(MLDHIP_ESTATE, "denoiser_forward_novae before finalize / denoiser.* not loaded");
+  if (!sample_dev || !text_emb_dev || !lengths_host || !out_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
+  if (R < 1 || R > 2 * e->cfg.max_batch) return e->fail(MLDHIP_EINVAL, "R=%d outside [1, 2*max_batch]", R);
+  if (T < 1 || T > e->cfg.max_frames) return e->fail(MLDHIP_EINVAL, "T=%d outside [1, max_frames=%d]", T, e->cfg.max_frames);
+  if (timestep < 0 || timestep >= e->cfg.num_train_timesteps) return e->fail(MLDHIP_EINVAL, "timestep %d out of range", timestep);
+  for (int i = 0; i < R; ++i)
+    if (lengths_host[i] < 0 || lengths_host[i] > T) return e->fail(MLDHIP_EINVAL, "lengths[%d]=%d outside [0, T=%d]", i, lengths_host[i], T);
+  hipStream_t stream = (hipStream_t)stream_;
+  Ctx c{e, stream};
+  const int D = e->cfg.latent_dim, TD = time_width(e);
+  e->phase = 0;
+  HIP_TRY(e, hipMemcpyAsync(e->lens_dev, lengths_host, (size_t)R * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  std::vector<float> host(TD);
+  timestep_sincos(float(timestep), TD, host.data());
+  HIP_TRY(e, hipMemcpyAsync(e->temb0_one, host.data(), TD * sizeof(float), hipMemcpyHostToDevice, stream));
+  HIP_TRY(e, hipStreamSynchronize(stream));   // `host` is a stack temporary
+  time_mlp(c, e->temb0_one, e->temb0_one + TD, e->t1_one, 1);
+  novae_memory_kv(c, e->t1_one, 1, e->TKV_one, (long long)2 * D);
+  novae_text_memory(c, text_emb_dev, R);
+  novae_pad_input(c, sample_dev, (long long)R * T, 1);
+  novae_denoiser_body(c, R, T, e->TKV_one, (long long)2 * D, out_dev);
+  return c.rc;
+}
+
+int mldhip_ddpm_step(mldhip_handle* e, const float* eps_dev, int32_t timestep, const float* sample_dev, const float* noise_dev,
+                     uint64_t seed, int32_t step_index, float* prev_dev, int64_t n, void* stream_) {
+  if (!e) return MLDHIP_EINVAL;
+  if (!is_ddpm(e)) return e->fail(MLDHIP_ESTATE, "engine was created with the DDIM scheduler: use mldhip_ddim_step");
+  if (!eps_dev || !sample_dev || !prev_dev || n < 1) return e->fail(MLDHIP_EINVAL, "null pointer / n < 1");
+  if (timestep < 0 || timestep >= e->cfg.num_train_timesteps) return e->fail(MLDHIP_EINVAL, "timestep %d out of range", timestep);
+  Ctx c{e, (hipStream_t)stream_};
+  MLD_LAUNCH(cfg_ddpm_step_kernel, dim3((unsigned)std::min<long long>(4096, (n / 4 + 256) / 256)), dim3(256), 0, c.stream, eps_dev,
+             (const float*)nullptr, sample_dev, noise_dev, prev_dev, (long long)n, 1.0f, ddpm_coef(e, timestep), (unsigned long long)seed,
+             (unsigned)step_index);
+  return check_launch(c, "ddpm_step");
+}
+
+int mldhip_philox_normal(mldhip_handle* e, float* out_dev, int64_t n, uint64_t seed, int32_t step_index, void* stream_) {
+  if (!e) return MLDHIP_EINVAL;
+  if (!out_dev || n < 1) return e->fail(MLDHIP_EINVAL, "null pointer / n < 1");
+  Ctx c{e, (hipStream_t)stream_};
+  MLD_LAUNCH(philox_normal_kernel, dim3((unsigned)std::min<long long>(4096, (n / 4 + 256) / 256)), dim3(256), 0, c.stream, out_dev, (long long)n,
+             (unsigned long long)seed, (unsigned)step_index);
+  return check_launch(c, "philox_normal");
 }
 
 int mldhip_vae_decode(mldhip_handle* e, const float* z_dev, const int32_t* lengths_host, int32_t B, float* feats_out_dev,

@@ -33,11 +33,14 @@ class Config(C.Structure):
         ("set_alpha_to_one", C.c_int32), ("beta_start", C.c_float), ("beta_end", C.c_float),
         ("guidance_scale", C.c_float), ("precision", C.c_int32), ("use_graph", C.c_int32),
         ("condition", C.c_int32), ("nclasses", C.c_int32), ("vae_arch", C.c_int32), ("vae_num_layers", C.c_int32),
+        ("denoiser_arch", C.c_int32), ("scheduler_type", C.c_int32),
     ]
 
 
-COND_TEXT, COND_ACTION = 0, 1      # MLDHIP_COND_*
-VAE_MLD, VAE_ACTOR = 0, 1          # MLDHIP_VAE_*
+COND_TEXT, COND_ACTION = 0, 1            # MLDHIP_COND_*
+VAE_MLD, VAE_ACTOR, VAE_NONE = 0, 1, 2   # MLDHIP_VAE_*
+ARCH_TRANS_ENC, ARCH_TRANS_DEC = 0, 1    # MLDHIP_ARCH_*
+SCHED_DDIM, SCHED_DDPM = 0, 1            # MLDHIP_SCHED_*
 
 
 _SYMBOLS = {
@@ -56,6 +59,13 @@ _SYMBOLS = {
                                        C.c_void_p, C.c_void_p]),
     "mldhip_denoiser_forward_action": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_void_p,
                                                  C.c_void_p]),
+    "mldhip_sample_novae": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_uint64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mldhip_denoiser_forward_novae": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.c_int32,
+                                                C.c_int32, C.c_void_p, C.c_void_p]),
+    "mldhip_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
+                                   C.c_int64, C.c_void_p]),
+    "mldhip_philox_normal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int32, C.c_void_p]),
     "mldhip_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p]),
     "mldhip_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -193,6 +203,24 @@ class Engine:
     def denoiser_forward_action(self, sample, timestep: int, actions: Sequence[int], out, stream: int = 0):
         acts = (C.c_int32 * len(actions))(*[int(x) for x in actions])
         self._check(self.lib.mldhip_denoiser_forward_action(self._h, _ptr(sample), int(timestep), acts, len(actions), _ptr(out), stream))
+
+    def sample_novae(self, text_emb, init_latents, lengths: Sequence[int], step_noise=None, seed: int = 0, feats_out=None,
+                     joints_out=None, stream: int = 0):
+        lens = (C.c_int32 * len(lengths))(*[int(x) for x in lengths])
+        self._check(self.lib.mldhip_sample_novae(self._h, _ptr(text_emb), _ptr(init_latents), lens, len(lengths), _ptr(step_noise),
+                                                 int(seed), _ptr(feats_out), _ptr(joints_out), stream))
+
+    def denoiser_forward_novae(self, sample, timestep: int, text_emb, lengths: Sequence[int], T: int, out, stream: int = 0):
+        lens = (C.c_int32 * len(lengths))(*[int(x) for x in lengths])
+        self._check(self.lib.mldhip_denoiser_forward_novae(self._h, _ptr(sample), int(timestep), _ptr(text_emb), lens, len(lengths),
+                                                           int(T), _ptr(out), stream))
+
+    def ddpm_step(self, eps, timestep: int, sample, noise, prev_sample, n: int, seed: int = 0, step_index: int = 0, stream: int = 0):
+        self._check(self.lib.mldhip_ddpm_step(self._h, _ptr(eps), int(timestep), _ptr(sample), _ptr(noise), int(seed), int(step_index),
+                                              _ptr(prev_sample), n, stream))
+
+    def philox_normal(self, out, n: int, seed: int, step_index: int, stream: int = 0):
+        self._check(self.lib.mldhip_philox_normal(self._h, _ptr(out), n, int(seed), int(step_index), stream))
 
     def vae_decode(self, z, lengths: Sequence[int], feats_out, stream: int = 0):
         lens = (C.c_int32 * len(lengths))(*[int(x) for x in lengths])

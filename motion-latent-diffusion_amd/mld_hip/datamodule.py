@@ -18,10 +18,11 @@ class HipDataModule:
 
     def __init__(self, cfg=None, mean: Optional[np.ndarray] = None, std: Optional[np.ndarray] = None,
                  nfeats: int = 263, njoints: int = 22, engine_key: Optional[str] = None, name: str = "humanml3d",
-                 nclasses: int = 12):
+                 nclasses: int = 12, variant: Optional[str] = None):
         """name 'humanml3d' (263-d features, 22 joints) or 'humanact12' (rot6d 25x6 = 150-d features, 12 classes;
         mld/data/HumanAct12.py) -- the latter only carries shapes: its feats2joints needs SMPL."""
         self.name, self.nclasses = name, nclasses
+        self.variant = variant          # engine registry variant; filled in by MLD when left None
         self.nfeats, self.njoints = nfeats, njoints
         if mean is None or std is None:
             root = None
@@ -43,7 +44,7 @@ class HipDataModule:
         self._loaded_on = None
 
     def _engine(self, device):
-        eng = _engine.get_engine(self._engine_key if self._engine_key is not None else device)
+        eng = _engine.get_engine(self._engine_key if self._engine_key is not None else device, self.variant or "text")
         if self._loaded_on is not eng:
             eng.load_tensor("mean", self.mean)
             eng.load_tensor("std", self.std)

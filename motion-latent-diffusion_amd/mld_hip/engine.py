@@ -3,7 +3,7 @@ instantiated separately from YAML (as the reference does, mld.py:56-83) all talk
 handle per (device, model variant), because the fused ``sample()`` needs every weight group in one place.
 
 Variants: "text" = config_mld_humanml3d (MldDenoiser text condition + MldVae), "action" = config_mld_humanact12
-(MldDenoiser action condition + ActorVae).  Modules push their architecture fields with ``configure(variant, ...)``
+(MldDenoiser action condition + ActorVae), "novae" = config_novae_humanml3d (trans_dec MldDenoiser on raw motion, DDPM).  Modules push their architecture fields with ``configure(variant, ...)``
 when constructed and verify them against the live engine before every use (``check_arch``)."""
 from __future__ import annotations
 
@@ -16,6 +16,8 @@ _defaults = {
     "text": dict(max_batch=64, max_frames=196),
     "action": dict(max_batch=64, max_frames=60, condition=_lib.COND_ACTION, vae_arch=_lib.VAE_ACTOR, num_layers=15,
                    vae_num_layers=6, nclasses=12, nfeats=150),
+    "novae": dict(max_batch=64, max_frames=196, latent_dim=512, vae_arch=_lib.VAE_NONE, denoiser_arch=_lib.ARCH_TRANS_DEC,
+                  scheduler_type=_lib.SCHED_DDPM, num_inference_steps=1000, steps_offset=0),
 }
 
 

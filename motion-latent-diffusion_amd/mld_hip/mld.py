@@ -20,7 +20,7 @@ from torch import nn
 from . import engine as _engine
 from .config import instantiate_from_config
 from .denoiser import HipMldDenoiser
-from .scheduler import HipDDIMScheduler
+from .scheduler import HipDDIMScheduler, HipDDPMScheduler
 from .vae import HipActorVae, HipMldVae
 
 
@@ -40,21 +40,27 @@ class MLD(nn.Module):
         self.latent_dim = cfg.model.latent_dim
         self.guidance_scale = cfg.model.guidance_scale
         self.datamodule = datamodule
-        self.vae_type = cfg.model.motion_vae.target.split(".")[-1].lower().replace("hip", "").replace("vae", "")
+        try:                                                                     # mld.py:50-54
+            self.vae_type = cfg.model.vae_type
+        except (KeyError, AttributeError):
+            self.vae_type = cfg.model.motion_vae.target.split(".")[-1].lower().replace("hip", "").replace("vae", "")
         if self.condition not in ("text", "action") or self.stage not in ("diffusion", "vae_diffusion"):
             raise NotImplementedError(f"mld_hip.MLD covers text-/action-to-motion sampling (condition={self.condition!r}, stage={self.stage!r})")
         self._engine_key = engine_key
+        self.variant = "novae" if self.vae_type == "no" else self.condition      # engine registry variant
         if engine_key is None:
-            _engine.configure(self.condition, num_inference_steps=cfg.model.scheduler.num_inference_timesteps,
+            _engine.configure(self.variant, num_inference_steps=cfg.model.scheduler.num_inference_timesteps,
                               guidance_scale=float(self.guidance_scale))
+        if hasattr(datamodule, "variant") and datamodule.variant is None:
+            datamodule.variant = self.variant
         # the reference builds CLIP for every condition (mld.py:60); the action path never calls it, so it is skipped there
         self.text_encoder = text_encoder if (text_encoder is not None or self.condition != "text") \
             else instantiate_from_config(cfg.model.text_encoder)
-        self.vae = instantiate_from_config(cfg.model.motion_vae)
+        self.vae = instantiate_from_config(cfg.model.motion_vae) if self.vae_type != "no" else None      # mld.py:58-59
         self.denoiser = instantiate_from_config(cfg.model.denoiser)
         self.scheduler = instantiate_from_config(cfg.model.scheduler)
         for m in (self.vae, self.denoiser):
-            if engine_key is not None and hasattr(m, "use_engine"):
+            if engine_key is not None and m is not None and hasattr(m, "use_engine"):
                 m.use_engine(engine_key)
         self.sample_mean = False
         self.fact = None
@@ -74,12 +80,16 @@ class MLD(nn.Module):
     # ------------------------------------------------------------------ helpers
     @property
     def fused(self) -> bool:
+        if self.vae_type == "no":
+            return (isinstance(self.denoiser, HipMldDenoiser) and isinstance(self.scheduler, HipDDPMScheduler)
+                    and self.do_classifier_free_guidance)
         return (isinstance(self.denoiser, HipMldDenoiser) and isinstance(self.vae, (HipMldVae, HipActorVae))
                 and isinstance(self.scheduler, HipDDIMScheduler) and self.do_classifier_free_guidance)
 
     def _engine(self):
         eng = self.denoiser.sync_weights()
-        self.vae.sync_weights()
+        if self.vae is not None:
+            self.vae.sync_weights()
         want = self.scheduler.engine_config(self.cfg.model.scheduler.num_inference_timesteps)
         for k in ("num_train_timesteps", "num_inference_steps", "steps_offset", "set_alpha_to_one"):
             if getattr(eng.cfg, k) != want[k]:
@@ -110,6 +120,34 @@ class MLD(nn.Module):
         joints = torch.empty(B, T, self.njoints, 3, device=dev)
         eng.sample(text_emb, init_latents, lengths, lat, feats, joints, _engine.current_stream_handle(text_emb))
         return joints, feats, lat
+
+    @torch.no_grad()
+    def sample_novae(self, text_emb: torch.Tensor, lengths: List[int], init_latents: Optional[torch.Tensor] = None,
+                     step_noise: Optional[torch.Tensor] = None, seed: Optional[int] = None):
+        """Diffusion-only sampling in ONE mldhip_sample_novae call: text_emb [2B, 1, 768] -> (joints [B,T,22,3], feats [B,T,nfeats]).
+        step_noise [steps, B, T, nfeats] injects the scheduler's per-step draws (parity runs); otherwise they come from the
+        engine's Philox stream keyed by `seed` (default: drawn from torch's generator, so torch.manual_seed governs it)."""
+        lengths = [int(x) for x in lengths]
+        B, T = len(lengths), max(lengths)
+        dev = text_emb.device
+        text_emb = text_emb.float().contiguous()
+        if init_latents is None:
+            init_latents = torch.randn((B, T, self.nfeats), device=dev, dtype=torch.float)            # mld.py:296-301
+        init_latents = init_latents.float().contiguous()
+        if step_noise is not None:
+            step_noise = step_noise.float().contiguous()
+            if tuple(step_noise.shape) != (self.cfg.model.scheduler.num_inference_timesteps, B, T, self.nfeats):
+                raise ValueError(f"step_noise must be [steps, B, T, nfeats], got {tuple(step_noise.shape)}")
+        elif seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        eng = self._engine()
+        if hasattr(self.datamodule, "_engine") and self.datamodule._engine(dev) is not eng:
+            raise RuntimeError("datamodule and denoiser are bound to different engines")
+        _engine.finalize_if_dirty(eng, _engine.current_stream_handle(text_emb))
+        feats = torch.empty(B, T, self.nfeats, device=dev)
+        joints = torch.empty(B, T, self.njoints, 3, device=dev)
+        eng.sample_novae(text_emb, init_latents, lengths, step_noise, seed or 0, feats, joints, _engine.current_stream_handle(text_emb))
+        return joints, feats
 
     @torch.no_grad()
     def sample_action(self, actions, lengths: List[int], init_latents: Optional[torch.Tensor] = None, device=None):
@@ -145,11 +183,18 @@ class MLD(nn.Module):
 
     # ------------------------------------------------------------------ reference surface
     @torch.no_grad()
-    def forward(self, batch, init_latents: Optional[torch.Tensor] = None):
+    def forward(self, batch, init_latents: Optional[torch.Tensor] = None, step_noise: Optional[torch.Tensor] = None):
         texts, lengths = list(batch["text"]), list(batch["length"])
         if self.do_classifier_free_guidance:
             texts = [""] * len(texts) + texts                                   # mld.py:224-230: uncond first
         text_emb = self.text_encoder(texts)
+        if self.vae_type == "no":
+            if self.fused:
+                joints, _ = self.sample_novae(text_emb, lengths, init_latents, step_noise)
+            else:
+                z = self._diffusion_reverse(text_emb, lengths, init_latents, step_noise)
+                joints = self.feats2joints(z.permute(1, 0, 2).contiguous())     # mld.py:241-242: "decode" is a permute
+            return remove_padding(joints.detach().cpu(), lengths)
         if self.fused:
             joints, _, _ = self.sample(text_emb, lengths, init_latents)
         else:
@@ -164,18 +209,27 @@ class MLD(nn.Module):
         return remove_padding(self.feats2joints(feats.detach()).cpu(), batch["length"])
 
     @torch.no_grad()
-    def _diffusion_reverse(self, encoder_hidden_states, lengths=None, init_latents: Optional[torch.Tensor] = None):
-        """The reference's Python loop (mld.py:290-360) over the drop-in parts -> [latent_size, B, D]."""
+    def _diffusion_reverse(self, encoder_hidden_states, lengths=None, init_latents: Optional[torch.Tensor] = None,
+                           step_noise: Optional[torch.Tensor] = None):
+        """The reference's Python loop (mld.py:290-360) over the drop-in parts -> [latent_size, B, D]
+        ([T, B, nfeats] for vae_type 'no')."""
         bsz = encoder_hidden_states.shape[0] // (2 if self.do_classifier_free_guidance else 1)
         dev = init_latents.device if init_latents is not None else encoder_hidden_states.device
-        latents = init_latents if init_latents is not None else torch.randn(
-            (bsz, self.latent_dim[0], self.latent_dim[-1]), device=dev, dtype=torch.float)
+        if self.vae_type == "no":
+            assert lengths is not None, "no vae (diffusion only) need lengths for diffusion"          # mld.py:295
+            shape = (bsz, max(lengths), self.nfeats)
+        else:
+            shape = (bsz, self.latent_dim[0], self.latent_dim[-1])
+        latents = init_latents if init_latents is not None else torch.randn(shape, device=dev, dtype=torch.float)
         latents = latents * self.scheduler.init_noise_sigma
         self.scheduler.set_timesteps(self.cfg.model.scheduler.num_inference_timesteps)
         extra = {}
         if "eta" in set(inspect.signature(self.scheduler.step).parameters.keys()):
             extra["eta"] = self.cfg.model.scheduler.eta
-        for t in self.scheduler.timesteps.tolist():
+        takes_noise = "noise" in set(inspect.signature(self.scheduler.step).parameters.keys())
+        for i, t in enumerate(self.scheduler.timesteps.tolist()):
+            if step_noise is not None and takes_noise:
+                extra["noise"] = step_noise[i]
             x = torch.cat([latents] * 2) if self.do_classifier_free_guidance else latents
             noise_pred = self.denoiser(sample=x, timestep=t, encoder_hidden_states=encoder_hidden_states,
                                        lengths=(list(lengths) * 2 if lengths is not None else None))[0]

@@ -74,3 +74,72 @@ class HipDDIMScheduler:
     def add_noise(self, original_samples, noise, timesteps):
         a = self.alphas_cumprod.to(original_samples.device)[timesteps].reshape(-1, *([1] * (original_samples.dim() - 1)))
         return a.sqrt() * original_samples + (1 - a).sqrt() * noise
+
+
+class HipDDPMScheduler:
+    """Drop-in for ``diffusers.DDPMScheduler`` as configs/modules_novae/scheduler.yaml:16-29 uses it (variance_type
+    fixed_small, no clipping, epsilon prediction).  Third-party arithmetic restated from the published algorithm
+    (PARITY UNPINNED).  ``step`` has no ``eta`` parameter -- the reference probes for it
+    (mld.py:318-320) -- and draws its noise from torch's generator unless ``noise=`` is injected."""
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
+                 beta_schedule: str = "linear", variance_type: str = "fixed_small", clip_sample: bool = True,
+                 prediction_type: str = "epsilon", **kwargs):
+        if beta_schedule != "scaled_linear" or variance_type != "fixed_small" or clip_sample or prediction_type != "epsilon":
+            raise NotImplementedError("HipDDPMScheduler: scaled_linear / fixed_small / clip_sample=False / epsilon only "
+                                      "(configs/modules_novae/scheduler.yaml)")
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                      beta_schedule=beta_schedule, variance_type=variance_type, clip_sample=clip_sample,
+                                      prediction_type=prediction_type)
+        f = np.float32      # numpy float32, sequential cumprod: bit-identical to the engine's host tables
+        betas = (np.linspace(f(beta_start) ** f(0.5), f(beta_end) ** f(0.5), num_train_timesteps, dtype=f) ** 2).astype(f)
+        self.betas = torch.from_numpy(betas)
+        self.alphas = torch.from_numpy((f(1.0) - betas).astype(f))
+        self.alphas_cumprod = torch.from_numpy(np.cumprod(self.alphas.numpy(), dtype=f))
+        self.one = torch.tensor(1.0)
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    def engine_config(self, num_inference_steps: int):
+        c = self.config
+        return dict(num_train_timesteps=c.num_train_timesteps, num_inference_steps=num_inference_steps, steps_offset=0,
+                    set_alpha_to_one=0, beta_start=c.beta_start, beta_end=c.beta_end)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.config.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+        self.timesteps = torch.from_numpy(ts).to(device) if device is not None else torch.from_numpy(ts)
+
+    def coeffs(self, t: int):
+        f = np.float32
+        ratio = self.config.num_train_timesteps // (self.num_inference_steps or self.config.num_train_timesteps)
+        acp = self.alphas_cumprod.numpy()
+        ab_t, ab_p = acp[t], (acp[t - ratio] if t - ratio >= 0 else f(1.0))
+        if ratio == 1:      # table values, as the diffusers releases contemporary with the reference read them
+            a_t, b_t = self.alphas.numpy()[t], self.betas.numpy()[t]
+        else:
+            a_t = f(ab_t / ab_p)
+            b_t = f(f(1.0) - a_t)
+        bp_t, bp_p = f(f(1.0) - ab_t), f(f(1.0) - ab_p)
+        var = f(max(float(bp_p / bp_t * b_t), 1e-20))
+        return (float(np.sqrt(ab_t, dtype=f)), float(np.sqrt(bp_t, dtype=f)), float(f(np.sqrt(ab_p, dtype=f) * b_t / bp_t)),
+                float(f(np.sqrt(a_t, dtype=f) * bp_p / bp_t)), float(np.sqrt(var, dtype=f)) if t > 0 else 0.0)
+
+    def step(self, model_output, timestep, sample, generator=None, noise=None, **kwargs):
+        sa, sb, c0, c1, sg = self.coeffs(int(timestep))
+        x0 = (sample - sb * model_output) / sa
+        prev = c0 * x0 + c1 * sample
+        if sg != 0.0:
+            if noise is None:
+                noise = torch.randn(model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
+            prev = prev + sg * noise
+        return SchedulerOutput(prev_sample=prev, pred_original_sample=x0)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        a = self.alphas_cumprod.to(original_samples.device)[timesteps].reshape(-1, *([1] * (original_samples.dim() - 1)))
+        return a.sqrt() * original_samples + (1 - a).sqrt() * noise

@@ -122,6 +122,30 @@ def make_denoiser_state_dict(seed: int = 0, dims: ModelDims = ModelDims(), condi
     return sd
 
 
+def make_novae_denoiser_state_dict(seed: int = 4, dims: ModelDims = ModelDims(latent_dim=512)) -> Dict[str, np.ndarray]:
+    """Synthetic ``MldDenoiser`` weights for the diffusion-only variant (VAE_TYPE 'no', arch trans_dec, text condition;
+    mld_denoiser.py:50-53,57-68,114-131): pose_embd / pose_proj, 9 plain TransformerDecoderLayers + final norm."""
+    sd: Dict[str, np.ndarray] = {}
+    d, ff = dims.latent_dim, dims.ff_size
+    _linear(sd, seed, "pose_embd", d, dims.nfeats)
+    _linear(sd, seed, "pose_proj", dims.nfeats, d)
+    _linear(sd, seed, "time_embedding.linear_1", d, dims.text_dim)
+    _linear(sd, seed, "time_embedding.linear_2", d, d)
+    _linear(sd, seed, "emb_proj.1", d, dims.text_dim)
+    sd["query_pos.pe"] = _rng(seed, "query_pos.pe").uniform(0, 1, (MAX_PE, 1, d)).astype(np.float32)
+    sd["mem_pos.pe"] = _rng(seed, "mem_pos.pe").uniform(0, 1, (MAX_PE, 1, d)).astype(np.float32)
+    for i in range(dims.num_layers):
+        p = f"decoder.layers.{i}"
+        _mha(sd, seed, p + ".self_attn", d)
+        _mha(sd, seed, p + ".multihead_attn", d)
+        _linear(sd, seed, p + ".linear1", ff, d, xavier=True)
+        _linear(sd, seed, p + ".linear2", d, ff, xavier=True)
+        for n in ("norm1", "norm2", "norm3"):
+            _norm(sd, seed, f"{p}.{n}", d)
+    _norm(sd, seed, "decoder.norm", d)
+    return sd
+
+
 def make_vae_state_dict(seed: int = 1, dims: ModelDims = ModelDims()) -> Dict[str, np.ndarray]:
     """Synthetic ``MldVae`` weights (arch encoder_decoder, PE_TYPE mld, MLP_DIST false)."""
     sd: Dict[str, np.ndarray] = {}

@@ -222,7 +222,87 @@ def main_action():
         json.dump(keys, f, indent=0, sort_keys=True)
 
 
+@torch.no_grad()
+def main_novae():
+    """Fixtures for the diffusion-only variant (BASELINE config 4, config_novae_humanml3d.yaml + modules_novae):
+    MldDenoiser(VAE_TYPE 'no', arch trans_dec, latent_dim [1,512]) imported from the reference; the CFG loop of
+    mld.py:290-360 with the restated DDPM (diffusers absent) and injected per-step noise orchestrated below."""
+    import json
+    sys.path.insert(0, REF)
+    from mld.models.architectures.mld_denoiser import MldDenoiser
+    from mld.data.humanml.scripts.motion_process import recover_from_ric
+
+    class Abl:
+        SKIP_CONNECT = True
+        VAE_TYPE = "no"
+        PE_TYPE = "mld"
+        DIFF_PE_TYPE = "mld"
+        MLP_DIST = False
+
+    den = MldDenoiser(ablation=Abl, nfeats=263, condition="text", latent_dim=[1, 512], ff_size=1024, num_layers=9, num_heads=4,
+                      arch="trans_dec", text_encoded_dim=768).eval()
+    sd = syn.make_novae_denoiser_state_dict()
+    den.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    ops = O.NumpyOps(np.float32)
+    bd = O.to_backend(ops, sd)
+    mean, std = syn.make_mean_std()
+
+    # 1. single denoiser calls: ragged small batch at two timesteps
+    g = syn._rng(11, "nv")
+    x = g.standard_normal((4, 24, 263)).astype(np.float32)
+    te = g.standard_normal((4, 1, 768)).astype(np.float32)
+    lens = [24, 17, 24, 9]
+    outs = {}
+    for t in (999, 0):
+        ref = den(sample=torch.from_numpy(x), timestep=torch.tensor(t), encoder_hidden_states=torch.from_numpy(te), lengths=lens)[0].numpy()
+        outs[f"out_t{t}"] = ref
+        outs[f"oracle_diff_t{t}"] = np.abs(ref - O.denoiser_forward_novae(ops, bd, x, t, te, lens)).max()
+    np.savez_compressed(os.path.join(OUT, "novae_denoiser_b4.npz"), sample=x, text_emb=te, lengths=np.array(lens), **outs)
+    print("novae denoiser oracle-vs-reference:", outs["oracle_diff_t999"], outs["oracle_diff_t0"])
+
+    # 2. one call at config 4's full CFG shape (R = 128, T = 196): every 16th sample x every 7th frame kept
+    b64 = syn.make_batch(64)
+    xf = syn._rng(12, "nvfull").standard_normal((64, 196, 263)).astype(np.float32)
+    lens64 = [196 - 4 * (i % 8) for i in range(64)]
+    ref = den(sample=torch.from_numpy(np.concatenate([xf, xf])), timestep=torch.tensor(500),
+              encoder_hidden_states=torch.from_numpy(b64.text_emb), lengths=lens64 * 2)[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "novae_denoiser_full.npz"), lengths=np.array(lens64), out_t500_sub=ref[::16, ::7])
+
+    # 3. short pipeline: B=3 ragged, 10 DDPM steps (ratio 100), CFG 7.5, injected noise -> feats, joints
+    b3 = syn.make_batch(3, [40, 25, 40])
+    g = syn._rng(13, "nvpipe")
+    lat0 = g.standard_normal((3, 40, 263)).astype(np.float32)
+    noise = g.standard_normal((10, 3, 40, 263)).astype(np.float32)
+    sch = O.DDPMSchedule()
+    lat = torch.from_numpy(lat0)
+    enc = torch.from_numpy(b3.text_emb)
+    for i, t in enumerate(sch.set_timesteps(10)):
+        eps = den(sample=torch.cat([lat] * 2), timestep=torch.tensor(int(t)), encoder_hidden_states=enc, lengths=b3.lengths * 2)[0]
+        u, c = eps.chunk(2)
+        lat = torch.from_numpy(np.asarray(sch.step((u + 7.5 * (c - u)).numpy(), int(t), lat.numpy(), noise[i]), np.float32))
+    feats = lat.numpy()
+    joints = recover_from_ric(torch.from_numpy(feats) * torch.from_numpy(std) + torch.from_numpy(mean), 22).numpy()
+    jo, fo = O.sample_novae(ops, bd, b3.text_emb, lat0, b3.lengths, noise, mean, std, steps=10)
+    np.savez_compressed(os.path.join(OUT, "novae_pipeline_b3.npz"), text_emb=b3.text_emb, init_latents=lat0, step_noise=noise,
+                        lengths=np.array(b3.lengths), feats=feats, joints=joints, oracle_diff_feats=np.abs(feats - fo).max(),
+                        oracle_diff_joints=np.abs(joints - jo).max())
+    print("novae_pipeline_b3 oracle-vs-reference:", np.abs(feats - fo).max(), np.abs(joints - jo).max(), np.abs(feats).max())
+    sch.set_timesteps(1000)
+    np.savez_compressed(os.path.join(OUT, "ddpm_table.npz"), coeffs=np.array([sch.coeffs(t) for t in range(1000)], np.float32))
+
+    kp = os.path.join(OUT, "state_dict_keys.json")
+    keys = json.load(open(kp))
+    keys["denoiser_novae"] = {k: list(v.shape) for k, v in den.state_dict().items()}
+    with open(kp, "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
-    if "--action-only" not in sys.argv:
+    if "--action-only" in sys.argv:
+        main_action()
+    elif "--novae-only" in sys.argv:
+        main_novae()
+    else:
         main()
-    main_action()
+        main_action()
+        main_novae()

@@ -19,6 +19,8 @@ names (all citations relative to /root/reference):
   MldVae.decode              mld/models/architectures/mld_vae.py:186-248
   MldVae.encode              mld/models/architectures/mld_vae.py:124-184   (scope row 8f.1)
   action variant (cfg 5)     mld_denoiser.py:69-77,231-279 (EmbedAction); actor_vae.py:176-235 (ActorAgnosticDecoder)
+  no-VAE variant (cfg 4)     mld_denoiser.py:50-53,208-221 (pose_embd/trans_dec/pose_proj); cross_attention.py:195-233;
+                             DDPM scheduler restated (diffusers absent: PARITY UNPINNED)
   lengths_to_mask            mld/utils/temos_utils.py:10-17
   feats2joints               mld/data/HumanML3D.py:41-45
   recover_from_ric           mld/data/humanml/scripts/motion_process.py:362-381,415-432
@@ -364,6 +366,120 @@ def denoiser_forward(ops, sd, sample, timestep, text_emb, nhead=4):
 
 
 # ----------------------------------------------------------------------------- scheduler (third party, restated)
+
+
+def denoiser_forward_novae(ops, sd, sample, timestep, text_emb, lengths: Sequence[int], nhead=4):
+    """MldDenoiser.forward, diffusion-only (VAE_TYPE 'no') + arch trans_dec (mld_denoiser.py:50-53,144-146,208-221):
+    pose_embd -> + query_pos over the T frames; memory = [time, text] tokens + mem_pos; TransformerDecoder
+    (cross_attention.py:195-233: plain layer stack + final norm; self-attention sees ALL T frames, no mask);
+    pose_proj; rows t >= len zeroed.  sample [R,T,nfeats], text_emb [R,1,text_dim] -> [R,T,nfeats]."""
+    r, t = sample.shape[0], sample.shape[1]
+    d = sd["pose_embd.weight"].shape[0]
+    temb0 = timestep_embedding(ops, [float(timestep)], sd["time_embedding.linear_1.weight"].shape[1])
+    temb = linear(ops, silu(ops, linear(ops, temb0, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])),
+                  sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])          # [1, d]
+    cemb = linear(ops, ops.relu(text_emb), sd["emb_proj.1.weight"], sd["emb_proj.1.bias"])          # [R, 1, d]
+    mem = ops.cat([temb[None, :, :] + ops.zeros_like(cemb), cemb], 1)                                # [R, 2, d] time first
+    mem = mem + ops.swap(sd["mem_pos.pe"][:2], 0, 1)
+    x = linear(ops, sample, sd["pose_embd.weight"], sd["pose_embd.bias"]) + ops.swap(sd["query_pos.pe"][:t], 0, 1)
+    i = 0
+    while f"decoder.layers.{i}.linear1.weight" in sd:
+        x = decoder_layer(ops, sd, f"decoder.layers.{i}", x, mem, nhead, None)
+        i += 1
+    x = layer_norm(ops, x, sd["decoder.norm.weight"], sd["decoder.norm.bias"])
+    y = linear(ops, x, sd["pose_proj.weight"], sd["pose_proj.bias"])
+    valid = ops.mask_from_lengths(lengths, t)
+    assert d == x.shape[-1]
+    return ops.where(valid[:, :, None], y, ops.zeros_like(y))
+
+
+class DDPMSchedule:
+    """diffusers.DDPMScheduler as the reference configures it (configs/modules_novae/scheduler.yaml:16-29: 1000 train
+    steps, scaled_linear betas, variance_type fixed_small, clip_sample false, epsilon prediction), restated from the
+    published algorithm.  THIRD PARTY, ABSENT HERE: PARITY UNPINNED.  float32 tables.  At step
+    ratio 1 (the only shipped setting: 1000 inference steps) alpha_t / beta_t are read from the tables, as the diffusers
+    releases contemporary with the reference do; for other ratios (test-size runs) they are recomputed from the cumulative
+    products (alpha_t = ab_t / ab_prev, as newer diffusers do) -- mathematically equal at ratio 1."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
+        f = np.float32
+        self.n_train = num_train_timesteps
+        self.betas = (np.linspace(f(beta_start) ** f(0.5), f(beta_end) ** f(0.5), num_train_timesteps, dtype=f) ** 2).astype(f)
+        self.alphas = (f(1.0) - self.betas).astype(f)
+        self.alphas_cumprod = np.cumprod(self.alphas, dtype=f)
+        self.init_noise_sigma = 1.0
+        self.ratio = 1
+
+    def set_timesteps(self, n):
+        if self.n_train % n:
+            raise ValueError("num_train_timesteps must be a multiple of num_inference_steps")
+        self.ratio = self.n_train // n
+        return (np.arange(0, n) * self.ratio)[::-1].astype(np.int64)
+
+    def coeffs(self, t):
+        """(sqrt(ab_t), sqrt(1-ab_t), c_x0, c_x, sigma) of one step, float32."""
+        f = np.float32
+        prev = t - self.ratio
+        ab_t = self.alphas_cumprod[t]
+        ab_p = self.alphas_cumprod[prev] if prev >= 0 else f(1.0)
+        if self.ratio == 1:                      # the tables, as the diffusers releases of the reference's time read them
+            a_t, b_t = self.alphas[t], self.betas[t]
+        else:                                    # any other ratio: alpha_t = ab_t / ab_prev (newer diffusers)
+            a_t = f(ab_t / ab_p)
+            b_t = f(f(1.0) - a_t)
+        bp_t, bp_p = f(f(1.0) - ab_t), f(f(1.0) - ab_p)
+        c_x0 = f(np.sqrt(ab_p, dtype=f) * b_t / bp_t)
+        c_x = f(np.sqrt(a_t, dtype=f) * bp_p / bp_t)
+        var = f(max(float(bp_p / bp_t * b_t), 1e-20))
+        sigma = f(np.sqrt(var, dtype=f)) if t > 0 else f(0.0)
+        return np.sqrt(ab_t, dtype=f), np.sqrt(bp_t, dtype=f), c_x0, c_x, sigma
+
+    def step(self, eps, t, x, noise=None):
+        sa, sb, c0, c1, sg = (float(v) for v in self.coeffs(int(t)))
+        x0 = (x - sb * eps) / sa
+        y = c0 * x0 + c1 * x
+        if sg != 0.0:
+            y = y + sg * noise
+        return y
+
+
+def sample_novae(ops, sd_den, text_emb, init_latents, lengths, step_noise, mean=None, std=None, guidance_scale=7.5,
+                 steps=1000, nhead=4):
+    """MLD.forward with vae_type 'no' (mld.py:216-265,290-360): latents are raw motion [B,T,nfeats]; DDPM ancestral
+    sampling with the per-step Gaussian draws injected (step_noise [steps,B,T,nfeats]; the reference draws them from
+    torch's global generator inside scheduler.step); "decode" is the identity.  Returns feats (and joints if mean/std)."""
+    sch = DDPMSchedule()
+    lat = init_latents * sch.init_noise_sigma
+    b = lat.shape[0]
+    for i, t in enumerate(sch.set_timesteps(steps)):
+        eps = denoiser_forward_novae(ops, sd_den, ops.cat([lat, lat], 0), t, text_emb, list(lengths) * 2, nhead)
+        u, c = eps[:b], eps[b:]
+        lat = sch.step(u + guidance_scale * (c - u), int(t), lat, step_noise[i])
+    if mean is None:
+        return lat
+    return feats2joints(ops, lat, mean, std), lat
+
+
+PHILOX_M0, PHILOX_M1, PHILOX_W0, PHILOX_W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+
+def philox_normal(n, seed, step):
+    """The engine's counter-based N(0,1) stream (kernels/novae.hpp: Philox4x32-10 + Box-Muller), numpy restatement:
+    element e belongs to counter (e // 4, step), key = seed; uniform = (x >> 8 + 0.5) / 2^24."""
+    nq = (n + 3) // 4
+    c = [np.arange(nq, dtype=np.uint64) & 0xFFFFFFFF, np.arange(nq, dtype=np.uint64) >> 32,
+         np.full(nq, step, np.uint64), np.zeros(nq, np.uint64)]
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = PHILOX_M0 * c[0], PHILOX_M1 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k0, p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ k1, p0 & 0xFFFFFFFF]
+        k0, k1 = (k0 + PHILOX_W0) & 0xFFFFFFFF, (k1 + PHILOX_W1) & 0xFFFFFFFF
+    f = np.float32
+    u = [((x >> 8).astype(f) * f(1.0 / 16777216.0) + f(0.5 / 16777216.0)).astype(f) for x in c]
+    r0, t0 = np.sqrt(f(-2.0) * np.log(u[0])), f(2 * np.pi) * u[1]
+    r1, t1 = np.sqrt(f(-2.0) * np.log(u[2])), f(2 * np.pi) * u[3]
+    z = np.stack([r0 * np.cos(t0), r0 * np.sin(t0), r1 * np.cos(t1), r1 * np.sin(t1)], 1).astype(f)
+    return z.reshape(-1)[:n]
 
 
 class DDIMSchedule:

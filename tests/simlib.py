@@ -65,3 +65,18 @@ def sim_action_engine(**cfg):
     eng = _lib.Engine(lib=sim_library(), use_graph=0, **{**ACTION_CFG, **cfg})
     load_action_weights(eng)
     return eng
+
+
+NOVAE_CFG = dict(latent_dim=512, vae_arch=_lib.VAE_NONE, denoiser_arch=_lib.ARCH_TRANS_DEC, scheduler_type=_lib.SCHED_DDPM,
+                 steps_offset=0)
+
+
+def sim_novae_engine(num_layers=9, **cfg):
+    """Diffusion-only engine (config_novae_humanml3d shape, possibly fewer layers / steps) with synthetic weights."""
+    eng = _lib.Engine(lib=sim_library(), use_graph=0, num_layers=num_layers, **{**NOVAE_CFG, **cfg})
+    eng.load_state_dict(syn.make_novae_denoiser_state_dict(dims=syn.ModelDims(latent_dim=512, num_layers=num_layers)), "denoiser.")
+    mean, std = syn.make_mean_std()
+    eng.load_tensor("mean", mean)
+    eng.load_tensor("std", std)
+    eng.finalize()
+    return eng

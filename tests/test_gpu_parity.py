@@ -387,3 +387,112 @@ def test_action_mld_module_surface_on_gpu(dev):
     fr = O.sample_action(ops, O.to_backend(ops, sdd), O.to_backend(ops, sdv), acts, lat0, lengths)
     assert rs["m_rst"].is_cuda and np.abs(rs["m_rst"].cpu().numpy() - fr).max() < 1e-3
     E.drop_engines()
+
+
+# ------------------------------------------------------------------ diffusion-only variant (BASELINE config 4)
+NOVAE_CFG = dict(latent_dim=512, vae_arch=_lib.VAE_NONE, denoiser_arch=_lib.ARCH_TRANS_DEC, scheduler_type=_lib.SCHED_DDPM,
+                 steps_offset=0)
+
+
+def _novae_engine(steps, max_batch=64, max_frames=196):
+    e = _lib.Engine(device=0, max_batch=max_batch, max_frames=max_frames, num_inference_steps=steps, **NOVAE_CFG)
+    e.load_state_dict(syn.make_novae_denoiser_state_dict(), "denoiser.")
+    mean, std = syn.make_mean_std()
+    e.load_tensor("mean", mean)
+    e.load_tensor("std", std)
+    e.finalize()
+    return e
+
+
+@pytest.fixture(scope="module")
+def neng(dev):
+    e = _novae_engine(10)
+    yield e
+    e.close()
+
+
+def test_novae_denoiser_vs_golden(neng, dev, golden_dir):
+    """trans_dec denoiser on raw motion (d=512, heads of 128, 2-key cross-attention) vs the reference module's outputs:
+    a ragged small batch at the first/last DDPM timestep and one call at config 4's full CFG shape (R=128, T=196)."""
+    g = _gold(golden_dir, "novae_denoiser_b4.npz")
+    lens = g["lengths"].tolist()
+    for t in (999, 0):
+        out = torch.full((4, 24, 263), 7.0, device=dev)
+        neng.denoiser_forward_novae(_cuda(g["sample"], dev), t, _cuda(g["text_emb"], dev), lens, 24, out)
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        assert np.abs(o - g[f"out_t{t}"]).max() < 1e-4
+        assert np.all(o[1, 17:] == 0) and np.all(o[3, 9:] == 0)
+    gf = _gold(golden_dir, "novae_denoiser_full.npz")
+    b64 = syn.make_batch(64)
+    xf = syn._rng(12, "nvfull").standard_normal((64, 196, 263)).astype(np.float32)
+    out = torch.empty(128, 196, 263, device=dev)
+    neng.denoiser_forward_novae(_cuda(np.concatenate([xf, xf]), dev), 500, _cuda(b64.text_emb, dev), gf["lengths"].tolist() * 2, 196, out)
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy()[::16, ::7] - gf["out_t500_sub"]).max() < 1e-4
+
+
+def test_novae_pipeline_vs_golden(neng, dev, golden_dir):
+    """10 DDPM steps with CFG 7.5 and injected per-step noise, B=3 ragged, against the reference-module fixture.
+    Tolerances: |feats| reaches 67 here and the fixture's own oracle-vs-reference floor is 1.6e-4 (feats) / 6.5e-4 (joints)."""
+    g = _gold(golden_dir, "novae_pipeline_b3.npz")
+    lens = g["lengths"].tolist()
+    feats = torch.empty(3, 40, 263, device=dev)
+    joints = torch.empty(3, 40, 22, 3, device=dev)
+    neng.sample_novae(_cuda(g["text_emb"], dev), _cuda(g["init_latents"], dev), lens, _cuda(g["step_noise"], dev), 0, feats, joints)
+    torch.cuda.synchronize()
+    assert np.abs(feats.cpu().numpy() - g["feats"]).max() < 2e-3
+    j = joints.cpu().numpy()
+    for i, n in enumerate(lens):
+        assert np.abs(j[i, :n] - g["joints"][i, :n]).max() < 3e-3
+    assert neng.launch_counts()[0] == 2 + 10 * (1 + 2 + 9 * 11 + 2 + 1)
+
+
+def test_novae_full_size_steps_vs_oracle_and_philox(dev):
+    """Config 4's full shape (B=64, T=196): two DDPM steps against the oracle (torch-CPU backend), and the in-kernel Philox
+    stream == the exposed stream == its numpy restatement."""
+    e = _novae_engine(2)
+    b = syn.make_batch(64)
+    g = syn._rng(31, "nvfull_steps")
+    lat0 = g.standard_normal((64, 196, 263)).astype(np.float32)
+    n = lat0.size
+    z = torch.empty(2, n, device=dev)
+    for s in range(2):
+        e.philox_normal(z[s], n, 1234, s)
+    torch.cuda.synchronize()
+    zr = O.philox_normal(n, 1234, 1)
+    assert np.abs(z[1].cpu().numpy() - zr).max() < 5e-5
+    assert abs(float(z.mean())) < 1e-3 and abs(float(z.std()) - 1.0) < 1e-3
+    f1 = torch.empty(64, 196, 263, device=dev)
+    f2 = torch.empty_like(f1)
+    text, x0 = _cuda(b.text_emb, dev), _cuda(lat0, dev)
+    e.sample_novae(text, x0, b.lengths, None, 1234, f1, None)                        # in-kernel Philox
+    e.sample_novae(text, x0, b.lengths, z.view(2, 64, 196, 263), 0, f2, None)        # the same draws, injected
+    torch.cuda.synchronize()
+    assert torch.equal(f1, f2)
+    ops = O.TorchOps()
+    fr = O.sample_novae(ops, O.to_backend(ops, syn.make_novae_denoiser_state_dict()), ops.asarray(b.text_emb), ops.asarray(lat0),
+                        b.lengths, ops.asarray(z.view(2, 64, 196, 263).cpu().numpy()), steps=2)
+    assert np.abs(f1.cpu().numpy() - ops.to_numpy(fr)).max() < 1e-3
+    e.close()
+
+
+def test_novae_mld_module_surface_on_gpu(dev, golden_dir):
+    from mld_hip import config as C
+    from mld_hip import engine as E
+    from mld_hip.datamodule import HipDataModule
+    from mld_hip.mld import MLD
+    from mld_hip.text_encoder import SyntheticTextEncoder
+
+    cfg = C.load_config(os.path.join(C.CONFIG_DIR, "config_novae_humanml3d.yaml"), overrides={"model.scheduler.num_inference_timesteps": 10})
+    E.configure("novae", max_batch=4, max_frames=64)
+    model = MLD(cfg, HipDataModule(cfg), text_encoder=SyntheticTextEncoder()).to(dev).eval()
+    model.denoiser.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_novae_denoiser_state_dict().items()}, strict=True)
+    assert model.fused and model.vae is None
+    g = _gold(golden_dir, "novae_pipeline_b3.npz")
+    lens = g["lengths"].tolist()
+    joints, feats = model.sample_novae(_cuda(g["text_emb"], dev), lens, _cuda(g["init_latents"], dev), _cuda(g["step_noise"], dev))
+    assert np.abs(feats.cpu().numpy() - g["feats"]).max() < 2e-3
+    z = model._diffusion_reverse(_cuda(g["text_emb"], dev), lens, _cuda(g["init_latents"], dev), _cuda(g["step_noise"], dev))
+    assert np.abs(z.permute(1, 0, 2).cpu().numpy() - g["feats"]).max() < 2e-3
+    E.drop_engines()

@@ -14,7 +14,7 @@ from mld_hip import synthetic as syn
 from mld_hip.datamodule import HipDataModule
 from mld_hip.denoiser import HipMldDenoiser
 from mld_hip.mld import MLD
-from mld_hip.scheduler import HipDDIMScheduler
+from mld_hip.scheduler import HipDDIMScheduler, HipDDPMScheduler
 from mld_hip.text_encoder import SyntheticTextEncoder
 from mld_hip.vae import HipActorVae, HipMldVae
 from oracle import mld_oracle as O
@@ -104,7 +104,7 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(NotImplementedError):
         HipMldDenoiser(ablation=abl, condition="text_uncond", num_layers=9)
     with pytest.raises(NotImplementedError):
-        HipMldDenoiser(ablation={**abl, "VAE_TYPE": "no"}, num_layers=9)
+        HipMldDenoiser(ablation={**abl, "VAE_TYPE": "no"}, num_layers=9)          # raw motion needs arch trans_dec + d=512
     with pytest.raises(NotImplementedError):
         HipMldVae(ablation=abl, nfeats=263, arch="all_encoder")
     d = HipMldDenoiser(ablation=abl, num_layers=9)
@@ -255,6 +255,84 @@ def test_action_mld_fused_and_modular_agree_with_oracle():
         with pytest.raises(RuntimeError):
             C.instantiate_from_config(C.load_config().model.denoiser).use_engine(key)(
                 torch.zeros(2, 1, 256), 5, torch.zeros(2, 1, 768))
+    finally:
+        E._engines.pop(key, None)
+        eng.close()
+
+
+# ------------------------------------------------------------------------------------------ diffusion-only variant (config 4)
+NOVAE_CFG = os.path.join(C.CONFIG_DIR, "config_novae_humanml3d.yaml")
+
+
+def test_novae_config_and_reference_yaml_parity(golden_dir):
+    cfg = C.load_config(NOVAE_CFG)
+    assert cfg.model.vae_type == "no" and cfg.model.denoiser.params.arch == "trans_dec"
+    assert cfg.model.denoiser.params.ablation.VAE_TYPE == "no" and cfg.model.latent_dim == [1, 512]
+    assert cfg.model.scheduler.target == "mld_hip.scheduler.HipDDPMScheduler" and cfg.model.scheduler.num_inference_timesteps == 1000
+    den = C.instantiate_from_config(cfg.model.denoiser)
+    keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
+    assert {k: list(v.shape) for k, v in den.state_dict().items()} == keys["denoiser_novae"]
+    if not os.path.isdir(REF):
+        pytest.skip("reference tree not present")
+    import yaml
+    for part, fn in (("denoiser", "denoiser.yaml"), ("scheduler", "scheduler.yaml")):
+        ref = yaml.safe_load(open(os.path.join(REF, "configs", "modules_novae", fn)))[part]
+        got = yaml.safe_load(open(os.path.join(C.CONFIG_DIR, "modules_hip_novae", fn)))[part]
+        assert ref["params"] == got["params"], part
+        if part == "scheduler":
+            assert ref["num_inference_timesteps"] == got["num_inference_timesteps"]
+    ref_exp = yaml.safe_load(open(os.path.join(REF, "configs", "config_novae_humanml3d.yaml")))
+    for k in ("latent_dim", "ff_size", "num_layers", "num_head", "guidance_scale", "guidance_uncondp", "condition", "vae", "vae_type"):
+        assert ref_exp["model"][k] == cfg.model[k], k
+
+
+def test_ddpm_scheduler_matches_oracle_tables(golden_dir):
+    s = HipDDPMScheduler(**C.load_config(NOVAE_CFG).model.scheduler.params)
+    o = O.DDPMSchedule()
+    s.set_timesteps(1000)
+    np.testing.assert_array_equal(s.timesteps.numpy(), o.set_timesteps(1000))
+    tab = np.load(os.path.join(golden_dir, "ddpm_table.npz"))["coeffs"]
+    for t in (999, 500, 1, 0):
+        np.testing.assert_allclose(np.array(s.coeffs(t), np.float32), tab[t], rtol=1e-6)
+        np.testing.assert_allclose(np.array(o.coeffs(t), np.float32), tab[t], rtol=0)
+    x, e, nz = torch.randn(2, 5, 263), torch.randn(2, 5, 263), torch.randn(2, 5, 263)
+    np.testing.assert_allclose(s.step(e, 500, x, noise=nz).prev_sample.numpy(), o.step(e.numpy(), 500, x.numpy(), nz.numpy()), atol=2e-6)
+    np.testing.assert_allclose(s.step(e, 0, x).prev_sample.numpy(), o.step(e.numpy(), 0, x.numpy()), atol=2e-6)   # no noise at t = 0
+    import inspect
+    assert "eta" not in inspect.signature(s.step).parameters          # the reference probes for it (mld.py:318-320)
+
+
+def test_novae_mld_fused_and_modular_agree_with_oracle():
+    eng = simlib.sim_novae_engine(num_layers=2, max_batch=2, max_frames=24, num_inference_steps=4)
+    key = E.inject_engine(eng, "inject:hostmirror_novae")
+    try:
+        cfg = C.load_config(NOVAE_CFG, overrides={"model.scheduler.num_inference_timesteps": 4, "model.denoiser.params.num_layers": 2})
+        dm = HipDataModule(cfg, engine_key=key)
+        enc = SyntheticTextEncoder()
+        model = MLD(cfg, dm, text_encoder=enc, engine_key=key).eval()
+        assert model.vae is None and model.vae_type == "no" and model.fused
+        texts, lengths = ["a man kicks with his left leg.", "a person walks backward slowly."], [20, 11]
+        g = syn._rng(21, "hm_novae")
+        lat0 = torch.from_numpy(g.standard_normal((2, 20, 263)).astype(np.float32))
+        noise = torch.from_numpy(g.standard_normal((4, 2, 20, 263)).astype(np.float32))
+        joints = model({"text": texts, "length": lengths}, init_latents=lat0, step_noise=noise)
+        assert [tuple(j.shape) for j in joints] == [(20, 22, 3), (11, 22, 3)]
+        ops = O.NumpyOps(np.float32)
+        sd = syn.make_novae_denoiser_state_dict(dims=syn.ModelDims(latent_dim=512, num_layers=2))
+        emb = enc([""] * 2 + texts).numpy()
+        mean, std = syn.make_mean_std()
+        jr, fr = O.sample_novae(ops, O.to_backend(ops, sd), emb, lat0.numpy(), lengths, noise.numpy(), mean, std, steps=4)
+        for i, n in enumerate(lengths):
+            assert np.abs(joints[i].numpy() - jr[i, :n]).max() < 2e-4
+        # the reference-style loop over the per-op drop-ins (denoiser + HipDDPMScheduler.step with the same noise)
+        z = model._diffusion_reverse(torch.from_numpy(emb), lengths, init_latents=lat0, step_noise=noise)
+        assert z.shape == (20, 2, 263)
+        assert np.abs(z.permute(1, 0, 2).numpy() - fr).max() < 2e-4
+        # without injected noise the engine's Philox stream is used: reproducible per seed, different across seeds
+        j1, f1 = model.sample_novae(torch.from_numpy(emb), lengths, lat0, seed=5)
+        j2, f2 = model.sample_novae(torch.from_numpy(emb), lengths, lat0, seed=5)
+        j3, f3 = model.sample_novae(torch.from_numpy(emb), lengths, lat0, seed=6)
+        assert torch.equal(f1, f2) and (f1 - f3).abs().max() > 1e-3
     finally:
         E._engines.pop(key, None)
         eng.close()

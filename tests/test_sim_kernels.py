@@ -230,3 +230,99 @@ def test_action_full_sample_sim(aeng, aow):
     den, dec, _ = aeng.launch_counts()
     # label gather + init + steps * (15 layers * 4 + 7 skip + 1 final); decode: 2 cross-attn + queries + 6 * 5 + final
     assert den == 1 + 1 + 2 * (15 * 4 + 7 + 1) and dec == 2 + 1 + 6 * 5 + 1
+
+
+# ------------------------------------------------------------------ diffusion-only variant (BASELINE config 4)
+@pytest.fixture(scope="module")
+def neng():
+    e = simlib.sim_novae_engine(num_layers=2, max_batch=2, max_frames=40, num_inference_steps=4)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def now():
+    ops = O.NumpyOps(np.float32)
+    return ops, O.to_backend(ops, syn.make_novae_denoiser_state_dict(dims=syn.ModelDims(latent_dim=512, num_layers=2)))
+
+
+def test_novae_schedule_and_keys_sim(neng):
+    sch = O.DDPMSchedule()
+    np.testing.assert_array_equal(neng.timesteps(), sch.set_timesteps(4))          # [750, 500, 250, 0]
+    e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=2, max_frames=16, **simlib.NOVAE_CFG)
+    # pose_embd/pose_proj 4, time MLP 4, emb_proj 2, two PEs, 9 decoder layers x 18, final norm 2, mean/std
+    assert len(e.missing_keys()) == 4 + 4 + 2 + 2 + 9 * 18 + 2 + 2
+    e.close()
+    with pytest.raises(_lib.MldHipError):                      # unsupported combination fails at create
+        _lib.Engine(lib=simlib.sim_library(), latent_dim=512, vae_arch=_lib.VAE_NONE)
+    with pytest.raises(_lib.MldHipError):                      # text-latent entry point on a diffusion-only engine
+        neng.sample(np.zeros((4, 1, 768), np.float32), np.zeros((2, 1, 256), np.float32), [8, 8], None, None, None)
+
+
+def test_novae_denoiser_forward_sim(neng, now):
+    ops, bd = now
+    g = syn._rng(11, "nv")
+    R, T = 3, 21                                               # ragged tiles: 63 rows, T not a multiple of 16
+    x = g.standard_normal((R, T, 263)).astype(np.float32)
+    te = g.standard_normal((R, 1, 768)).astype(np.float32)
+    lens = [21, 13, 0]
+    out = np.full((R, T, 263), 7.0, np.float32)
+    neng.denoiser_forward_novae(x, 999, te, lens, T, out)
+    ref = O.denoiser_forward_novae(ops, bd, x, 999, te, lens)
+    assert np.abs(out - ref).max() < 5e-5
+    assert np.all(out[1, 13:] == 0) and np.all(out[2] == 0)
+
+
+def test_ddpm_step_and_philox_sim(neng):
+    sch = O.DDPMSchedule()
+    sch.set_timesteps(4)
+    g = syn._rng(12, "dd")
+    x, eps, nz = (g.standard_normal(1001).astype(np.float32) for _ in range(3))
+    for t in (750, 250, 0):
+        o = np.zeros_like(x)
+        neng.ddpm_step(eps, t, x, nz, o, x.size)
+        assert np.abs(o - sch.step(eps, t, x, nz)).max() < 2e-6
+    z = np.zeros(1001, np.float32)
+    neng.philox_normal(z, z.size, 0x1234567890ABCDEF, 7)
+    zr = O.philox_normal(z.size, 0x1234567890ABCDEF, 7)
+    assert np.abs(z - zr).max() < 2e-5                          # same Philox bits; libm log/cos/sin differ in the last ulps
+    o1, o2 = np.zeros_like(x), np.zeros_like(x)
+    neng.ddpm_step(eps, 500, x, None, o1, x.size, seed=0x1234567890ABCDEF, step_index=7)   # in-kernel noise == the exposed stream
+    neng.ddpm_step(eps, 500, x, z, o2, x.size)
+    assert np.abs(o1 - o2).max() < 1e-6
+
+
+def test_novae_full_sample_sim(neng, now):
+    ops, bd = now
+    B, T = 2, 20
+    b = syn.make_batch(B, [20, 11])
+    g = syn._rng(13, "nvs")
+    lat0 = g.standard_normal((B, T, 263)).astype(np.float32)
+    noise = g.standard_normal((4, B, T, 263)).astype(np.float32)
+    mean, std = syn.make_mean_std()
+    feats = np.zeros((B, T, 263), np.float32)
+    joints = np.zeros((B, T, 22, 3), np.float32)
+    neng.sample_novae(b.text_emb, lat0, b.lengths, noise, 0, feats, joints)
+    jr, fr = O.sample_novae(ops, bd, b.text_emb, lat0, b.lengths, noise, mean, std, steps=4)
+    assert np.abs(feats - fr).max() < 2e-4
+    assert np.abs(joints - jr).max() < 2e-4
+    den, dec, jn = neng.launch_counts()
+    # text memory 2 + steps * (pad + embed 2 + 2 layers * 11 + final norm/proj 2 + step)
+    assert den == 2 + 4 * (1 + 2 + 2 * 11 + 2 + 1) and dec == 0 and jn == 1
+
+
+def test_novae_denoiser_forward_staged_gemms_sim(monkeypatch, now):
+    """Same check with the LDS-staged GEMM pipeline forced (production shape: K = 384 / 512 / 1024 chunk pipelines)."""
+    ops, bd = now
+    monkeypatch.setenv("MLDHIP_SMALL_M", "0")
+    e = simlib.sim_novae_engine(num_layers=2, max_batch=2, max_frames=40, num_inference_steps=4)
+    g = syn._rng(11, "nv")
+    R, T = 3, 21
+    x = g.standard_normal((R, T, 263)).astype(np.float32)
+    te = g.standard_normal((R, 1, 768)).astype(np.float32)
+    lens = [21, 13, 5]
+    out = np.zeros((R, T, 263), np.float32)
+    e.denoiser_forward_novae(x, 999, te, lens, T, out)
+    ref = O.denoiser_forward_novae(ops, bd, x, 999, te, lens)
+    assert np.abs(out - ref).max() < 5e-5
+    e.close()
