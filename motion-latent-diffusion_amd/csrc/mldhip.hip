@@ -55,13 +55,13 @@ struct DecLayerP {   // TransformerDecoderLayer (cross_attention.py:297-345)
   const float *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b, *n3_w, *n3_b;
 };
 
+// A captured sample() is independent of the caller's buffers: inputs are copied into engine-owned staging before
+// the replay and outputs copied out after it (<= 17 MB of D2D copies, ~0.1 % of a batch), so a caller that allocates
+// fresh output tensors on every call (as MLD.forward does) replays instead of re-capturing ~2 000 nodes.
 struct GraphKey {
   int B, T;
-  const void *text, *lat_in, *lat_out, *feats, *joints;
-  bool operator<(const GraphKey& o) const {
-    return std::tie(B, T, text, lat_in, lat_out, feats, joints) <
-           std::tie(o.B, o.T, o.text, o.lat_in, o.lat_out, o.feats, o.joints);
-  }
+  bool feats, joints;
+  bool operator<(const GraphKey& o) const { return std::tie(B, T, feats, joints) < std::tie(o.B, o.T, o.feats, o.joints); }
 };
 
 }  // namespace
@@ -106,6 +106,7 @@ struct mldhip_engine {
   int32_t* labels_dev = nullptr; // action labels of the CFG batch [2*max_batch] (uncond half first, ignored there)
   int32_t* lens2_dev = nullptr;  // lengths + 2 (encoder key-padding mask incl. the two distribution tokens)
   std::vector<int32_t> lens2_host;
+  float *text_in = nullptr, *lat_in = nullptr;   // graph staging of the caller's inputs
   float* TP;             // text projection rows [2*max_batch][256] (+pe[2]), gathered per chain
   bool tile16 = true;    // MLDHIP_TILE16=0 disables the 16-row K-split tiles (A/B runs)
   int nchains = 1;       // independent sub-batch chains of the reverse loop (parallel graph branches)
@@ -1170,6 +1171,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   want(&e->cv1, Lv * Bm * D); want(&e->cvec, Lv * Bm * D);
   want(&e->WskelP, D * KP);
   want(&e->feats_int, Bm * Tm * NF); want(&e->joints_int, Bm * Tm * cfg->njoints * 3);
+  want(&e->text_in, 2 * Bm * TD); want(&e->lat_in, Bm * D);
   }
   e->ws_floats = off;
   if (hipMalloc((void**)&e->ws, off * sizeof(float)) != hipSuccess) { e->err = "hipMalloc(workspace) failed"; return fail_create(MLDHIP_EHIP); }
@@ -1341,7 +1343,12 @@ int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* acti
   }
 #if !defined(MLDHIP_SIM)
   if (e->cfg.use_graph) {
-    GraphKey key{B, T, text_emb_dev, init_latents_dev, latents_out_dev, feats_out_dev, joints_out_dev};
+    const size_t D = e->cfg.latent_dim, NF = e->cfg.nfeats;
+    const bool want_j = joints_out_dev != nullptr, want_f = feats_out_dev != nullptr || want_j;
+    if (text_emb_dev)
+      HIP_TRY(e, hipMemcpyAsync(e->text_in, text_emb_dev, (size_t)2 * B * e->cfg.text_dim * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(e, hipMemcpyAsync(e->lat_in, init_latents_dev, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    GraphKey key{B, T, want_f, want_j};
     auto it = e->graphs.find(key);
     if (it == e->graphs.end()) {
       if (e->graphs.size() >= 16) {
@@ -1350,7 +1357,8 @@ int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* acti
       }
       hipGraph_t graph = nullptr;
       HIP_TRY(e, hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
-      int rc = enqueue_sample(e, e->cap_stream, text_emb_dev, init_latents_dev, B, T, latents_out_dev, feats_out_dev, joints_out_dev);
+      int rc = enqueue_sample(e, e->cap_stream, text_emb_dev ? e->text_in : nullptr, e->lat_in, B, T, nullptr,
+                              want_f ? e->feats_int : nullptr, want_j ? e->joints_int : nullptr);
       hipError_t s = hipStreamEndCapture(e->cap_stream, &graph);
       if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
       if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(s));
@@ -1361,6 +1369,10 @@ int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* acti
       it = e->graphs.emplace(key, exec).first;
     }
     HIP_TRY(e, hipGraphLaunch(it->second, stream));
+    if (latents_out_dev) HIP_TRY(e, hipMemcpyAsync(latents_out_dev, e->lat, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (feats_out_dev) HIP_TRY(e, hipMemcpyAsync(feats_out_dev, e->feats_int, (size_t)B * T * NF * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (joints_out_dev)
+      HIP_TRY(e, hipMemcpyAsync(joints_out_dev, e->joints_int, (size_t)B * T * e->cfg.njoints * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return MLDHIP_OK;
   }
 #endif
