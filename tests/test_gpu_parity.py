@@ -496,3 +496,21 @@ def test_novae_mld_module_surface_on_gpu(dev, golden_dir):
     z = model._diffusion_reverse(_cuda(g["text_emb"], dev), lens, _cuda(g["init_latents"], dev), _cuda(g["step_noise"], dev))
     assert np.abs(z.permute(1, 0, 2).cpu().numpy() - g["feats"]).max() < 2e-3
     E.drop_engines()
+
+
+def test_graph_replay_is_independent_of_caller_buffers(eng, dev):
+    """Fresh input/output tensors on every call (what MLD.forward does) must replay the same captured graph correctly."""
+    b = syn.make_batch(5, [60, 33, 60, 41, 8])
+    outs = []
+    for rep in range(3):
+        text, x0 = _cuda(b.text_emb, dev).clone(), _cuda(b.init_latents, dev).clone()
+        pad = torch.empty(1000 * (rep + 1), device=dev)             # shift the allocator so the addresses differ
+        joints = torch.full((5, 60, 22, 3), float("nan"), device=dev)
+        lat = torch.full((5, 1, 256), float("nan"), device=dev)
+        eng.sample(text, x0, b.lengths, lat, None, joints)
+        torch.cuda.synchronize()
+        outs.append((joints.cpu().numpy(), lat.cpu().numpy(), joints.data_ptr()))
+        del pad
+    assert np.isfinite(outs[0][0]).all() and np.isfinite(outs[0][1]).all()
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
