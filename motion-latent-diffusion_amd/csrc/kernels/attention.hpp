@@ -26,8 +26,10 @@ namespace mld {
 //   transpose, no LDS round trip for P (cdna_hip_programming.md T12 idea, fp32 form).
 // Single pass (all scores of a 16-query tile live in registers: NKT tiles x 4 VGPRs), no online
 // rescale needed at T <= 16*NKT.
-template <int NKT>   // max key tiles (NKT*16 >= T)
-__global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+// NW waves per workgroup: 8 puts two waves on every SIMD, so one wave's softmax (VALU) and LDS reads overlap the
+// other's MFMAs -- with one wave per SIMD they serialise and the kernel runs at ~2.4x its MFMA time.
+template <int NKT, int NW = 8>   // max key tiles (NKT*16 >= T); waves per workgroup
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                           const int* __restrict__ lens, int T, int H) {
   constexpr int HD = 64, LDS_STRIDE = 68;
 #if defined(MLDHIP_SIM)
@@ -45,21 +47,35 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   float* Ks = smem;
   float* Vs = smem + (size_t)NKT * 16 * LDS_STRIDE;
 
-  // ---- stage K and V (rows >= len are zero: P is 0 there and 0*garbage must not be NaN)
-  for (int idx = tid; idx < nkt * 16 * 16; idx += 256) {
-    const int key = idx >> 4, c4 = idx & 15;
-    F4 kv = F4{0.f, 0.f, 0.f, 0.f}, vv = kv;
-    if (key < len) {
-      const float* base = qkv + (long long)(b * T + key) * 3 * D + h * HD + c4 * 4;
-      kv = ld4(base + D);
-      vv = ld4(base + 2 * D);
+  // ---- stage K and V.  All of a thread's global loads of one operand are issued before its first LDS store (a
+  // load-store-per-iteration loop pays the memory latency once per iteration); addresses are clamped and rows >= len
+  // zeroed by a multiply (P is 0 there and 0*garbage must not be NaN), so no load sits behind a branch.
+  {
+    constexpr int KPI = NW * 4, NIT = (NKT * 16 + KPI - 1) / KPI;   // keys per pass (16 float4 per 64-wide row); passes
+    const int c4 = tid & 15, k0 = tid >> 4;
+    const float* base = qkv + (long long)b * T * 3 * D + h * HD + c4 * 4;
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+      float* dst = op == 0 ? Ks : Vs;
+      const float* src = base + (op + 1) * D;
+      F4 v[NIT];
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const int key = j * KPI + k0;
+        const int kc = key < len ? key : len - 1;
+        v[j] = ld4(src + (long long)kc * 3 * D);
+      }
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const int key = j * KPI + k0;
+        const float m = key < len ? 1.f : 0.f;
+        if (key < nkt * 16) st4(dst + key * LDS_STRIDE + c4 * 4, F4{v[j].x * m, v[j].y * m, v[j].z * m, v[j].w * m});
+      }
     }
-    st4(Ks + key * LDS_STRIDE + c4 * 4, kv);
-    st4(Vs + key * LDS_STRIDE + c4 * 4, vv);
   }
   __syncthreads();
 
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += NW) {
     // Q fragment: query q0+r, head dims g*16 .. g*16+15, pre-scaled by 1/sqrt(64)
     int qrow = qt * 16 + r;
     qrow = qrow < T ? qrow : T - 1;

@@ -85,11 +85,12 @@ __global__ __launch_bounds__(256) void add_layernorm_rows_kernel(const float* __
 // Self-attention over the T frames of one (sample, head) for head dims that do not leave room for K AND V in LDS
 // (HD = 128: 208 keys x 132 floats = 107 KiB per operand).  Same MFMA mapping as attn_decode_kernel (swapped QK^T,
 // P registers as the A operand of P.V) but K and V pass through ONE LDS buffer in turn, and a workgroup owns only
-// 4 query tiles (one per wave) so the scores of its queries stay in registers across the K -> V switch.
-//   grid = (samples * H, ceil(ceil(T/16) / 4)), block = 256, dynamic LDS = NKT*16*(HD+4)*4 bytes.
+// NW query tiles (one per wave) so the scores of its queries stay in registers across the K -> V switch.
+//   grid = (samples * H, ceil(ceil(T/16) / NW)), block = 64*NW, dynamic LDS = NKT*16*(HD+4)*4 bytes.
+// NW = 8: two waves per SIMD (one wave's softmax / LDS reads overlap the other's MFMAs) and K/V staged half as often.
 // lens == nullptr: no key-padding mask (the trans_dec denoiser attends to all T frames, mld_denoiser.py:215).
-template <int NKT, int HD>
-__global__ __launch_bounds__(256) void attn_seq_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+template <int NKT, int HD, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void attn_seq_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                        const int* __restrict__ lens, int T, int H) {
   constexpr int ST = HD + 4, C4 = HD / 4, KPL = HD / 4;   // LDS row stride; float4 chunks per row; q/k dims per lane
 #if defined(MLDHIP_SIM)
@@ -105,16 +106,34 @@ __global__ __launch_bounds__(256) void attn_seq_kernel(const float* __restrict__
   int len = T;
   if (lens) len = lens[b] < T ? lens[b] : T;
   const int nkt = (len + 15) >> 4, nqt = (T + 15) >> 4;
-  const int qt = blockIdx.y * 4 + wave;
+  const int qt = blockIdx.y * NW + wave;
   const bool active = qt < nqt;                       // idle waves still take part in the barriers
   const float scale = rsqrtf((float)HD);
 
-  auto stage = [&](int col0) {                        // K (col0 = D) or V (col0 = 2D) rows of this (sample, head)
-    for (int idx = tid; idx < nkt * 16 * C4; idx += 256) {
-      const int key = idx / C4, c4 = idx - key * C4;
-      F4 v = F4{0.f, 0.f, 0.f, 0.f};                  // rows >= len are zero: P is 0 there and 0*garbage must not be NaN
-      if (key < len) v = ld4(qkv + (long long)(b * T + key) * 3 * D + col0 + h * HD + c4 * 4);
-      st4(KV + key * ST + c4 * 4, v);
+  // K (col0 = D) or V (col0 = 2D) rows of this (sample, head) -> LDS.  Every thread issues ALL its global loads of a
+  // half-pass before the first LDS store (a load-store-per-iteration loop pays the full memory latency per iteration:
+  // 26 x ~1 us per operand, 3x the MFMA time of the whole workgroup -- profiles/r01_v12_novae_kernel_stats.csv).
+  // Addresses are clamped and rows >= len zeroed by a multiply (P is 0 there and 0*garbage must not be NaN), so no
+  // load sits behind a branch.
+  auto stage = [&](int col0) {
+    constexpr int KPI = NW * 64 / C4, NIT = (NKT * 16 + KPI - 1) / KPI, UB = (NIT + 1) / 2;
+    const int c4 = tid % C4, k0 = tid / C4;
+    const float* base = qkv + (long long)b * T * 3 * D + col0 + h * HD + c4 * 4;
+#pragma unroll
+    for (int j0 = 0; j0 < NIT; j0 += UB) {
+      F4 v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int key = (j0 + u) * KPI + k0;
+        const int kc = key < len ? key : len - 1;
+        v[u] = ld4(base + (long long)kc * 3 * D);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int key = (j0 + u) * KPI + k0;
+        const float m = key < len ? 1.f : 0.f;
+        if (j0 + u < NIT && key < nkt * 16) st4(KV + key * ST + c4 * 4, F4{v[u].x * m, v[u].y * m, v[u].z * m, v[u].w * m});
+      }
     }
   };
 

@@ -688,7 +688,7 @@ void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr) {
   const int H = e->cfg.num_heads;
   const int nkt = pick_nkt(T);
   const size_t shmem = (size_t)2 * nkt * 16 * 68 * sizeof(float);
-  dim3 grid(B * H), block(256);
+  dim3 grid(B * H), block(512);
   switch (nkt) {
     case 4: MLD_LAUNCH((attn_decode_kernel<4>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
     case 7: MLD_LAUNCH((attn_decode_kernel<7>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
@@ -863,7 +863,7 @@ void novae_self_attention(Ctx& c, int R, int T) {
   E* e = c.e;
   const int H = e->cfg.num_heads, nkt = pick_nkt(T), nqt = (T + 15) / 16;
   const size_t shmem = (size_t)nkt * 16 * 132 * sizeof(float);
-  dim3 grid(R * H, (nqt + 3) / 4), block(256);
+  dim3 grid(R * H, (nqt + 7) / 8), block(512);
   const int* nolens = nullptr;    // the reference passes no key-padding mask to the trans_dec denoiser (mld_denoiser.py:215)
   switch (nkt) {
     case 4: MLD_LAUNCH((attn_seq_kernel<4, 128>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
