@@ -225,8 +225,9 @@ def main():
         # ---- roofline: per-kernel durations with HIP events on the launch stream, weighted by launch counts
         gf_total, gf_den, gf_dec = algorithmic_gflop(BATCH, FRAMES)
         nb = 4
-        per_sample = {"den_qkv": 9 * STEPS_DDIM, "den_outproj": 9 * STEPS_DDIM, "den_ffn1": 9 * STEPS_DDIM,
-                      "den_ffn2": 9 * STEPS_DDIM, "den_final": STEPS_DDIM,
+        fused_ffn = os.environ.get("MLDHIP_FUSED_FFN", "0") != "0"
+        ffn = {"den_ffn": 9 * STEPS_DDIM} if fused_ffn else {"den_ffn1": 9 * STEPS_DDIM, "den_ffn2": 9 * STEPS_DDIM}
+        per_sample = {"den_qkv": 9 * STEPS_DDIM, "den_outproj": 9 * STEPS_DDIM, **ffn, "den_final": STEPS_DDIM,
                       "dec_qkv": 9, "dec_attn": 9, "dec_outproj_ln": 9, "dec_ffn1": 9, "dec_ffn2_ln": 9}
         kern = {}
         for name, cnt in per_sample.items():

@@ -210,7 +210,7 @@ int mldhip_get_alphas_cumprod(mldhip_handle* h, float* out_host, int32_t n);
 
 /* Measurement hook (no reference counterpart): enqueue ONE named kernel of the path `iters` times on
  * `stream` at its production shape for batch B / Tmax T; writes its algorithmic FLOPs per launch.
- * names: den_{qkv,outproj,ffn1,ffn2,final}, dec_{qkv,attn,outproj_ln,ffn1,ffn2_ln}.  The caller times it with events on `stream`. */
+ * names: den_{qkv,outproj,ffn,ffn1,ffn2,final}, dec_{qkv,attn,outproj_ln,ffn1,ffn2_ln}.  The caller times it with events on `stream`. */
 int mldhip_profile_kernel(mldhip_handle* h, const char* name, int32_t B, int32_t T, int32_t iters,
                           double* flops_per_launch, void* stream);
 

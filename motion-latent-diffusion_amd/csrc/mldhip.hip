@@ -30,6 +30,7 @@
 #include "kernels/novae.hpp"
 #include "kernels/rt.hpp"
 #include "kernels/tile32.hpp"
+#include "kernels/fused_layer.hpp"
 
 using namespace mld;
 
@@ -108,6 +109,7 @@ struct mldhip_engine {
   std::vector<int32_t> lens2_host;
   float *text_in = nullptr, *lat_in = nullptr;   // graph staging of the caller's inputs
   float* TP;             // text projection rows [2*max_batch][256] (+pe[2]), gathered per chain
+  bool fused_ffn = false; // MLDHIP_FUSED_FFN=1: linear1+GELU+linear2 in one launch (measured slower: DESIGN.md §3 point 9)
   bool tile16 = true;    // MLDHIP_TILE16=0 disables the 16-row K-split tiles (A/B runs)
   int nchains = 1;       // independent sub-batch chains of the reverse loop (parallel graph branches)
 
@@ -540,6 +542,7 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
     case 1: MLD_T32(MT, 1); break;                                                                               \
     case 2: MLD_T32(MT, 2); break;                                                                               \
     case 4: MLD_T32(MT, 4); break;                                                                               \
+    case 8: MLD_T32(MT, 8); break;                                                                               \
     default: c.rc = c.e->fail(MLDHIP_EINVAL, "tile32: unsupported slab count %d", ns); return;                   \
   }
   if (mt16) { MLD_T32_NS(16) } else { MLD_T32_NS(32) }
@@ -609,8 +612,20 @@ void den_ffn2(Ctx& c, const DenView& v, const EncLayerP& L) {
   a.nz0 = F / 256; a.W = L.l2_w; a.ldw = F; a.P = v.Pf; a.pstride = den_slab(c.e); a.M = 3 * v.R; a.N = 256;
   tile32(c, a, F / 256);
 }
+int den_ffn_slabs(const E* e) { return e->fused_ffn ? e->cfg.ff_size / kFfnHS : e->cfg.ff_size / 256; }
 ASrc den_layer_output(E* e, const DenView& v, const EncLayerP& L, float* write_back) {   // LN2(sum Pf + b2 + h1)
-  return combine_src(v.Pf, e->cfg.ff_size / 256, den_slab(e), L.l2_b, v.H1, L.n2_w, L.n2_b, write_back);
+  return combine_src(v.Pf, den_ffn_slabs(e), den_slab(e), L.l2_b, v.H1, L.n2_w, L.n2_b, write_back);
+}
+// linear1 + GELU + linear2 in one launch (kernels/fused_layer.hpp): h1 = LN1(x + out_proj) assembled on load (written
+// to H1), raw FFN2 partial slabs -> Pf[ff_size/128]
+void den_ffn_fused(Ctx& c, const DenView& v, const EncLayerP& L, const float* xn) {
+  FfnFusedArgs a;
+  a.src = combine_src(v.Po, 1, 0, L.out_b, xn, L.n1_w, L.n1_b, v.H1);
+  a.W1 = L.l1_w; a.b1 = L.l1_b; a.W2 = L.l2_w; a.P = v.Pf; a.pstride = den_slab(c.e); a.M = 3 * v.R; a.F = c.e->cfg.ff_size;
+  dim3 grid((a.M + 15) / 16, a.F / kFfnHS);
+  MLD_LAUNCH((den_ffn_fused_kernel<1>), grid, dim3(512), kFfnLdsBytes, c.stream, a);
+  count(c);
+  check_launch(c, "den_ffn_fused");
 }
 
 // SkipTransformerEncoder over the 3-token sequences (cross_attention.py:41-64).  Leaves the last layer's
@@ -624,8 +639,12 @@ void denoiser_body(Ctx& c, const DenView& v) {
     const EncLayerP& P_ = e->den[l];
     den_qkv(c, v, P_, x);
     den_outproj(c, v, P_);
-    den_ffn1(c, v, P_, xn);
-    den_ffn2(c, v, P_);
+    if (e->fused_ffn) {
+      den_ffn_fused(c, v, P_, xn);
+    } else {
+      den_ffn1(c, v, P_, xn);
+      den_ffn2(c, v, P_);
+    }
     if (l + 1 == L) break;
     if (l < nb) {
       // next layer input = LN2(...), kept in S[l] for the skip connection (written by the next QKV prologue)
@@ -652,7 +671,7 @@ void denoiser_body(Ctx& c, const DenView& v) {
 FinalArgs den_final_args(E* e, const DenView& v) {
   const EncLayerP& L = e->den.back();
   FinalArgs f;
-  f.P = v.Pf; f.nsplit = e->cfg.ff_size / 256; f.pstride = den_slab(e);
+  f.P = v.Pf; f.nsplit = den_ffn_slabs(e); f.pstride = den_slab(e);
   f.b2 = L.l2_b; f.H1 = v.H1; f.g2 = L.n2_w; f.be2 = L.n2_b;
   f.gf = P(e, "denoiser.encoder.norm.weight"); f.bef = P(e, "denoiser.encoder.norm.bias");
   return f;
@@ -1129,6 +1148,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   const char* m_small = std::getenv("MLDHIP_SMALL_M");
   g_small_m = m_small ? std::atoi(m_small) : 256;
   if (const char* m = std::getenv("MLDHIP_TILE16")) e->tile16 = std::atoi(m) != 0;
+  if (const char* m = std::getenv("MLDHIP_FUSED_FFN")) e->fused_ffn = std::atoi(m) != 0;
   e->nchains = 1;   // measured: parallel chains do not shorten the sequential depth
   if (const char* m = std::getenv("MLDHIP_CHAINS")) e->nchains = std::max(1, std::min(8, std::atoi(m)));
   e->cfg = *cfg;
@@ -1165,7 +1185,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   for (int i = 0; i < 8; ++i) want(&e->S[i], (i < (int)(L - 1) / 2) ? rows * D : 0);
   want(&e->QKV, rows * 3 * D); want(&e->AO, rows * D); want(&e->FF, rows * F);
   want(&e->lat, Bm * D); want(&e->zbuf, Bm * D);
-  want(&e->Po, 6 * Bm * D); want(&e->Pf, 4 * 6 * Bm * D); want(&e->Ps, 2 * 6 * Bm * D); want(&e->TP, 2 * Bm * D);
+  want(&e->Po, 6 * Bm * D); want(&e->Pf, 8 * 6 * Bm * D); want(&e->Ps, 2 * 6 * Bm * D); want(&e->TP, 2 * Bm * D);
   want(&e->T1, n * D); want(&e->temb0, n * TD); want(&e->tmid, n * D);
   want(&e->text_bias, D); want(&e->time_b2pe, D); want(&e->t1_one, D); want(&e->temb0_one, TD + D);
   want(&e->cv1, Lv * Bm * D); want(&e->cvec, Lv * Bm * D);
@@ -1201,7 +1221,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<32, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);  \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
-  MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4)
+  MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4) MLD_T32_ATTR(8)
+  (void)hipFuncSetAttribute((const void*)den_ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLdsBytes);
 #undef MLD_T32_ATTR
   (void)hipGetLastError();
 #endif
@@ -1615,6 +1636,9 @@ int mldhip_profile_kernel(mldhip_handle* e, const char* name, int32_t B, int32_t
     } else if (n == "den_outproj") {
       den_outproj(c, v, DL);
       *flops_per_launch = 2.0 * M * D * D + 4.0 * M * 3 * D;
+    } else if (n == "den_ffn") {      // linear1 + GELU + linear2 fused (kernels/fused_layer.hpp)
+      den_ffn_fused(c, v, DL, v.S[mid - 1]);
+      *flops_per_launch = 4.0 * M * D * F;
     } else if (n == "den_ffn1") {
       den_ffn1(c, v, DL, v.S[mid - 1]);
       *flops_per_launch = 2.0 * M * D * F;

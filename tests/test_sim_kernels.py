@@ -326,3 +326,18 @@ def test_novae_denoiser_forward_staged_gemms_sim(monkeypatch, now):
     ref = O.denoiser_forward_novae(ops, bd, x, 999, te, lens)
     assert np.abs(out - ref).max() < 5e-5
     e.close()
+
+
+def test_fused_ffn_knob_is_exact_sim(monkeypatch, ow):
+    """MLDHIP_FUSED_FFN=1 (linear1 + GELU + linear2 in one launch, 8 partial slabs; an A/B knob, default off)."""
+    ops, bd, bv = ow
+    monkeypatch.setenv("MLDHIP_FUSED_FFN", "1")
+    e = simlib.sim_engine(max_batch=4, max_frames=24, num_inference_steps=2)
+    b = syn.make_batch(3, [20, 13, 7])
+    mean, std = syn.make_mean_std()
+    joints = np.zeros((3, 20, 22, 3), np.float32)
+    e.sample(b.text_emb, b.init_latents, b.lengths, None, None, joints)
+    jr = O.sample(ops, bd, bv, b.text_emb, b.init_latents, b.lengths, mean, std, steps=2)
+    assert np.abs(joints - jr).max() < 1e-4
+    assert e.launch_counts()[0] == 1 + 1 + 2 * (9 * 3 + 4 + 1)
+    e.close()
