@@ -82,6 +82,10 @@ typedef struct mldhip_config {
    * vae_arch NONE, denoiser_arch TRANS_DEC, scheduler_type DDPM with num_inference_steps 1000, steps_offset 0 */
   int32_t denoiser_arch;        /* MLDHIP_ARCH_TRANS_ENC (skip encoder, mld_denoiser.py:98-119) | MLDHIP_ARCH_TRANS_DEC (:120-133) */
   int32_t scheduler_type;       /* MLDHIP_SCHED_DDIM | MLDHIP_SCHED_DDPM (variance_type fixed_small) */
+  /* ---- serving */
+  int32_t max_in_flight;        /* 1..8 activation workspaces sharing the weights.  Consecutive calls rotate through them, so
+                                 * calls issued on DIFFERENT streams overlap on the GPU (a workspace is reused only after the
+                                 * new call's stream has waited for its previous user).  1 = calls serialise as before. */
 } mldhip_config;
 
 enum { MLDHIP_COND_TEXT = 0, MLDHIP_COND_ACTION = 1 };

@@ -67,6 +67,20 @@ struct GraphKey {
 
 }  // namespace
 
+// One activation workspace.  cfg.max_in_flight of them share the weight arena: consecutive calls rotate through them,
+// so calls issued on different streams overlap on the GPU (the reverse loop of one batch leaves most CUs idle most of
+// the time: 1.6-1.8x throughput with 2-3 batches in flight, DESIGN.md §3 point 11).  A context is reused only after
+// the stream of its new call has waited on the event recorded at the end of its previous call.
+struct WsContext {
+  float* ws = nullptr;
+  int32_t *lens = nullptr, *lens2 = nullptr, *labels = nullptr;
+  bool used = false;
+#if !defined(MLDHIP_SIM)
+  hipEvent_t done = nullptr;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+#endif
+};
+
 struct mldhip_engine {
   mldhip_config cfg;
   int device = 0;
@@ -92,8 +106,11 @@ struct mldhip_engine {
   std::vector<float> alphas_cumprod, betas;
   float final_alpha_cumprod = 1.f;
 
-  // ---- workspace
-  float* ws = nullptr;
+  // ---- workspace (the pointers below are those of the currently bound context)
+  std::vector<WsContext> ctxs;
+  std::vector<std::pair<float**, size_t>> carve;   // (member pointer, offset in floats) of every workspace buffer
+  int cur_ctx = 0;
+  unsigned next_ctx = 0;
   size_t ws_floats = 0;
   int32_t* lens_dev = nullptr;
   // denoiser
@@ -120,7 +137,6 @@ struct mldhip_engine {
   hipStream_t cap_stream = nullptr;
   hipStream_t side[7] = {};
   hipEvent_t ev_fork = nullptr, ev_join[7] = {};
-  std::map<GraphKey, hipGraphExec_t> graphs;
 #endif
 
   int fail(int code, const char* fmt, ...) {
@@ -143,6 +159,39 @@ using E = mldhip_engine;
     hipError_t _s = (call);                                                                    \
     if (_s != hipSuccess) return (e)->fail(MLDHIP_EHIP, "%s failed: %s", #call, hipGetErrorString(_s)); \
   } while (0)
+
+void bind_context(E* e, int k) {
+  WsContext& x = e->ctxs[k];
+  for (auto& cv : e->carve) *cv.first = x.ws + cv.second;
+  e->lens_dev = x.lens; e->lens2_dev = x.lens2; e->labels_dev = x.labels;
+  e->cur_ctx = k;
+}
+
+// Scope of one workspace-using call on `stream`: picks the next context round-robin, orders the stream behind the
+// context's previous user, binds its buffers; on exit records the context's "done" event on the stream.
+struct CtxUse {
+  E* e;
+  hipStream_t stream;
+  int rc = 0;
+  CtxUse(E* e_, hipStream_t s) : e(e_), stream(s) {
+    const int k = int(e->next_ctx++ % e->ctxs.size());
+#if !defined(MLDHIP_SIM)
+    WsContext& x = e->ctxs[k];
+    if (x.used && e->ctxs.size() > 1) {
+      hipError_t st = hipStreamWaitEvent(stream, x.done, 0);
+      if (st != hipSuccess) rc = e->fail(MLDHIP_EHIP, "hipStreamWaitEvent(context): %s", hipGetErrorString(st));
+    }
+#endif
+    bind_context(e, k);
+  }
+  ~CtxUse() {
+#if !defined(MLDHIP_SIM)
+    WsContext& x = e->ctxs[e->cur_ctx];
+    if (e->ctxs.size() > 1) (void)hipEventRecord(x.done, stream);
+    x.used = true;
+#endif
+  }
+};
 
 bool is_action(const E* e) { return e->cfg.condition == MLDHIP_COND_ACTION; }
 bool is_actor(const E* e) { return e->cfg.vae_arch == MLDHIP_VAE_ACTOR; }
@@ -1096,6 +1145,7 @@ void mldhip_default_config(mldhip_config* c) {
   c->precision = MLDHIP_PREC_F32; c->use_graph = 1;
   c->condition = MLDHIP_COND_TEXT; c->nclasses = 0; c->vae_arch = MLDHIP_VAE_MLD; c->vae_num_layers = 0;
   c->denoiser_arch = MLDHIP_ARCH_TRANS_ENC; c->scheduler_type = MLDHIP_SCHED_DDIM;
+  c->max_in_flight = 1;
 }
 
 const char* mldhip_last_error(mldhip_handle* h) { return h ? h->err.c_str() : g_last_error.c_str(); }
@@ -1131,6 +1181,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
       (cfg->num_inference_steps - 1) * (cfg->num_train_timesteps / cfg->num_inference_steps) + cfg->steps_offset >= cfg->num_train_timesteps)
     return bad("steps_offset pushes the first timestep past num_train_timesteps");
   if (cfg->precision != MLDHIP_PREC_F32 && cfg->precision != MLDHIP_PREC_BF16X3_DECODE) return bad("unsupported precision");
+  if (cfg->max_in_flight < 1 || cfg->max_in_flight > 8) return bad("max_in_flight must be 1..8");
 #if !defined(MLDHIP_SIM)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_last_error = "no HIP device visible (libmldhip has no CPU path)"; return MLDHIP_ENODEV; }
@@ -1164,7 +1215,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   const size_t rows = std::max(Bm * (Tm + 2), 6 * Bm);   // decoder: B*T frame rows; encoder: B*(T+2) token rows
   const size_t KP = (NF + 31) / 32 * 32;                 // feature width padded to the MFMA K chunk
   size_t off = 0;
-  std::vector<std::pair<float**, size_t>> carve;
+  auto& carve = e->carve;
   auto want = [&](float** p, size_t nfl) { carve.push_back({p, off}); off += align_up(nfl); };
   if (is_novae(e)) {
     // diffusion-only: M = 2*B*T rows of width 512; raw-motion latents [B][T][NF]; eps of the CFG batch [2B][T][NF]
@@ -1194,11 +1245,17 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   want(&e->text_in, 2 * Bm * TD); want(&e->lat_in, Bm * D);
   }
   e->ws_floats = off;
-  if (hipMalloc((void**)&e->ws, off * sizeof(float)) != hipSuccess) { e->err = "hipMalloc(workspace) failed"; return fail_create(MLDHIP_EHIP); }
-  if (hipMemset(e->ws, 0, off * sizeof(float)) != hipSuccess) { e->err = "hipMemset(workspace) failed"; return fail_create(MLDHIP_EHIP); }
-  for (auto& cv : carve) *cv.first = e->ws + cv.second;
-  if (hipMalloc((void**)&e->lens_dev, 2 * Bm * sizeof(int32_t)) != hipSuccess || hipMalloc((void**)&e->lens2_dev, Bm * sizeof(int32_t)) != hipSuccess ||
-      hipMalloc((void**)&e->labels_dev, 2 * Bm * sizeof(int32_t)) != hipSuccess) { e->err = "hipMalloc(lens) failed"; return fail_create(MLDHIP_EHIP); }
+  e->ctxs.resize(cfg->max_in_flight);
+  for (auto& x : e->ctxs) {
+    if (hipMalloc((void**)&x.ws, off * sizeof(float)) != hipSuccess) { e->err = "hipMalloc(workspace) failed"; return fail_create(MLDHIP_EHIP); }
+    if (hipMemset(x.ws, 0, off * sizeof(float)) != hipSuccess) { e->err = "hipMemset(workspace) failed"; return fail_create(MLDHIP_EHIP); }
+    if (hipMalloc((void**)&x.lens, 2 * Bm * sizeof(int32_t)) != hipSuccess || hipMalloc((void**)&x.lens2, Bm * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&x.labels, 2 * Bm * sizeof(int32_t)) != hipSuccess) { e->err = "hipMalloc(lens) failed"; return fail_create(MLDHIP_EHIP); }
+#if !defined(MLDHIP_SIM)
+    if (hipEventCreateWithFlags(&x.done, hipEventDisableTiming) != hipSuccess) { e->err = "event create failed"; return fail_create(MLDHIP_EHIP); }
+#endif
+  }
+  bind_context(e, 0);
 #if !defined(MLDHIP_SIM)
   if (hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return fail_create(MLDHIP_EHIP); }
   for (int i = 0; i < 7; ++i) {
@@ -1233,16 +1290,21 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
 void mldhip_destroy(mldhip_handle* e) {
   if (!e) return;
 #if !defined(MLDHIP_SIM)
-  for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+  for (auto& x : e->ctxs) {
+    for (auto& kv : x.graphs) (void)hipGraphExecDestroy(kv.second);
+    if (x.done) (void)hipEventDestroy(x.done);
+  }
   if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
   for (int i = 0; i < 7; ++i) { if (e->side[i]) (void)hipStreamDestroy(e->side[i]); if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]); }
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
 #endif
   if (e->arena) (void)hipFree(e->arena);
-  if (e->ws) (void)hipFree(e->ws);
-  if (e->lens_dev) (void)hipFree(e->lens_dev);
-  if (e->lens2_dev) (void)hipFree(e->lens2_dev);
-  if (e->labels_dev) (void)hipFree(e->labels_dev);
+  for (auto& x : e->ctxs) {
+    if (x.ws) (void)hipFree(x.ws);
+    if (x.lens) (void)hipFree(x.lens);
+    if (x.lens2) (void)hipFree(x.lens2);
+    if (x.labels) (void)hipFree(x.labels);
+  }
   if (e->trace_buf) (void)hipFree(e->trace_buf);
   delete e;
 }
@@ -1303,6 +1365,9 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
   bind_layers(e);
   Ctx c{e, stream};
   const int D = e->cfg.latent_dim, TD = time_width(e), n = e->cfg.num_inference_steps;
+  HIP_TRY(e, hipDeviceSynchronize());                   // no call may be in flight on any context while tables are rebuilt
+  for (int k = 0; k < (int)e->ctxs.size(); ++k) {       // the derived tables live in each context's workspace
+  bind_context(e, k);
   if (e->group_ready[0]) {
     // PE-folded biases: token 1 (time) gets pe[1], token 2 (text) gets pe[2] (mld_denoiser.py:187,196)
     // (trans_dec: the memory tokens [time, text] get mem_pos.pe[0], pe[1] instead, mld_denoiser.py:213)
@@ -1330,11 +1395,17 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
     MLD_LAUNCH(pad_cols_kernel, dim3((D * KP + 255) / 256), dim3(256), 0, stream, P(e, "vae.skel_embedding.weight"), e->WskelP, D, NF, KP);
     if (check_launch(c, "pad_cols")) return c.rc;
   }
+  }
   HIP_TRY(e, hipStreamSynchronize(stream));
 #if !defined(MLDHIP_SIM)
-  for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
-  e->graphs.clear();
+  for (auto& x : e->ctxs) {
+    for (auto& kv : x.graphs) (void)hipGraphExecDestroy(kv.second);
+    x.graphs.clear();
+    x.used = false;
+  }
 #endif
+  bind_context(e, 0);
+  e->next_ctx = 0;
   e->finalized = true;
   return MLDHIP_OK;
 }
@@ -1353,6 +1424,8 @@ int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* acti
   int T = 0;
   if (int rc = validate_lengths(e, lengths_host, B, &T)) return rc;
   hipStream_t stream = (hipStream_t)stream_;
+  CtxUse use(e, stream);                                  // picks + binds a workspace context (see WsContext)
+  if (use.rc) return use.rc;
   HIP_TRY(e, hipMemcpyAsync(e->lens_dev, lengths_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   if (actions_host) {
     for (int i = 0; i < B; ++i)
@@ -1370,11 +1443,12 @@ int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* acti
       HIP_TRY(e, hipMemcpyAsync(e->text_in, text_emb_dev, (size_t)2 * B * e->cfg.text_dim * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(e, hipMemcpyAsync(e->lat_in, init_latents_dev, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
     GraphKey key{B, T, want_f, want_j};
-    auto it = e->graphs.find(key);
-    if (it == e->graphs.end()) {
-      if (e->graphs.size() >= 16) {
-        for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
-        e->graphs.clear();
+    auto& graphs = e->ctxs[e->cur_ctx].graphs;
+    auto it = graphs.find(key);
+    if (it == graphs.end()) {
+      if (graphs.size() >= 16) {
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear();
       }
       hipGraph_t graph = nullptr;
       HIP_TRY(e, hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
@@ -1387,7 +1461,7 @@ int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* acti
       s = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(s));
-      it = e->graphs.emplace(key, exec).first;
+      it = graphs.emplace(key, exec).first;
     }
     HIP_TRY(e, hipGraphLaunch(it->second, stream));
     if (latents_out_dev) HIP_TRY(e, hipMemcpyAsync(latents_out_dev, e->lat, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -1431,6 +1505,8 @@ int denoiser_forward_impl(mldhip_handle* e, const float* sample_dev, int32_t tim
   if (R < 1 || R > 2 * e->cfg.max_batch) return e->fail(MLDHIP_EINVAL, "R=%d outside [1, 2*max_batch]", R);
   if (timestep < 0 || timestep >= e->cfg.num_train_timesteps) return e->fail(MLDHIP_EINVAL, "timestep %d out of range", timestep);
   hipStream_t stream = (hipStream_t)stream_;
+  CtxUse use(e, stream);                                  // picks + binds a workspace context (see WsContext)
+  if (use.rc) return use.rc;
   Ctx c{e, stream};
   const int D = e->cfg.latent_dim, TD = time_width(e);
   e->phase = 0;
@@ -1488,6 +1564,8 @@ int mldhip_sample_novae(mldhip_handle* e, const float* text_emb_dev, const float
   int T = 0;
   if (int rc = validate_lengths(e, lengths_host, B, &T)) return rc;
   hipStream_t stream = (hipStream_t)stream_;
+  CtxUse use(e, stream);                                  // picks + binds a workspace context (see WsContext)
+  if (use.rc) return use.rc;
   HIP_TRY(e, hipMemcpyAsync(e->lens_dev, lengths_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   HIP_TRY(e, hipMemcpyAsync(e->lens_dev + B, lengths_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));   // lengths * 2 (mld.py:327-328)
   // ~114 launches of 0.1-2 ms each per step: the GPU, not the host, is the bottleneck -> plain stream launches, no graph
@@ -1506,6 +1584,8 @@ int mldhip_denoiser_forward_novae(mldhip_handle* e, const float* sample_dev, int
   for (int i = 0; i < R; ++i)
     if (lengths_host[i] < 0 || lengths_host[i] > T) return e->fail(MLDHIP_EINVAL, "lengths[%d]=%d outside [0, T=%d]", i, lengths_host[i], T);
   hipStream_t stream = (hipStream_t)stream_;
+  CtxUse use(e, stream);                                  // picks + binds a workspace context (see WsContext)
+  if (use.rc) return use.rc;
   Ctx c{e, stream};
   const int D = e->cfg.latent_dim, TD = time_width(e);
   e->phase = 0;
@@ -1552,6 +1632,8 @@ int mldhip_vae_decode(mldhip_handle* e, const float* z_dev, const int32_t* lengt
   int T = 0;
   if (int rc = validate_lengths(e, lengths_host, B, &T)) return rc;
   hipStream_t stream = (hipStream_t)stream_;
+  CtxUse use(e, stream);                                  // picks + binds a workspace context (see WsContext)
+  if (use.rc) return use.rc;
   HIP_TRY(e, hipMemcpyAsync(e->lens_dev, lengths_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   Ctx c{e, stream};
   e->phase = 1;
@@ -1569,6 +1651,8 @@ int mldhip_vae_encode(mldhip_handle* e, const float* feats_dev, const int32_t* l
   if (int rc = validate_lengths(e, lengths_host, B, &Tm)) return rc;
   if (T < Tm || T > e->cfg.max_frames || T + 2 > 288) return e->fail(MLDHIP_EINVAL, "T=%d must satisfy max(lengths) <= T <= min(max_frames, 286)", T);
   hipStream_t stream = (hipStream_t)stream_;
+  CtxUse use(e, stream);                                  // picks + binds a workspace context (see WsContext)
+  if (use.rc) return use.rc;
   e->lens2_host.assign(lengths_host, lengths_host + B);
   for (auto& v : e->lens2_host) v += 2;                       // the two distribution tokens are always attended to
   HIP_TRY(e, hipMemcpyAsync(e->lens2_dev, e->lens2_host.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
@@ -1618,6 +1702,8 @@ int mldhip_profile_kernel(mldhip_handle* e, const char* name, int32_t B, int32_t
   if (!e || !name || !flops_per_launch) return MLDHIP_EINVAL;
   if (!e->finalized || !e->group_ready[0] || !e->group_ready[1]) return e->fail(MLDHIP_ESTATE, "profile before finalize");
   if (B < 1 || B > e->cfg.max_batch || T < 1 || T > e->cfg.max_frames || iters < 1) return e->fail(MLDHIP_EINVAL, "bad B/T/iters");
+  CtxUse use(e, (hipStream_t)stream_);
+  if (use.rc) return use.rc;
   Ctx c{e, (hipStream_t)stream_};
   const int D = e->cfg.latent_dim, F = e->cfg.ff_size, H = e->cfg.num_heads;
   const std::string n = name;

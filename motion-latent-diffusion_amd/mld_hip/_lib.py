@@ -33,7 +33,7 @@ class Config(C.Structure):
         ("set_alpha_to_one", C.c_int32), ("beta_start", C.c_float), ("beta_end", C.c_float),
         ("guidance_scale", C.c_float), ("precision", C.c_int32), ("use_graph", C.c_int32),
         ("condition", C.c_int32), ("nclasses", C.c_int32), ("vae_arch", C.c_int32), ("vae_num_layers", C.c_int32),
-        ("denoiser_arch", C.c_int32), ("scheduler_type", C.c_int32),
+        ("denoiser_arch", C.c_int32), ("scheduler_type", C.c_int32), ("max_in_flight", C.c_int32),
     ]
 
 

@@ -341,3 +341,19 @@ def test_fused_ffn_knob_is_exact_sim(monkeypatch, ow):
     assert np.abs(joints - jr).max() < 1e-4
     assert e.launch_counts()[0] == 1 + 1 + 2 * (9 * 3 + 4 + 1)
     e.close()
+
+
+def test_contexts_rotate_and_stay_exact_sim(ow):
+    """max_in_flight = 2: consecutive calls alternate between two workspaces (shared weights); results must not depend on it."""
+    ops, bd, bv = ow
+    e = simlib.sim_engine(max_batch=4, max_frames=24, num_inference_steps=2, max_in_flight=2)
+    mean, std = syn.make_mean_std()
+    for seed, lens in ((1, [20, 13]), (2, [9, 24, 17]), (3, [5])):
+        b = syn.make_batch(len(lens), lens, seed=seed)
+        joints = np.zeros((len(lens), max(lens), 22, 3), np.float32)
+        e.sample(b.text_emb, b.init_latents, b.lengths, None, None, joints)
+        jr = O.sample(ops, bd, bv, b.text_emb, b.init_latents, b.lengths, mean, std, steps=2)
+        assert np.abs(joints - jr).max() < 1e-4
+    with pytest.raises(_lib.MldHipError):
+        _lib.Engine(lib=simlib.sim_library(), max_in_flight=9)
+    e.close()
