@@ -514,3 +514,27 @@ def test_graph_replay_is_independent_of_caller_buffers(eng, dev):
     assert np.isfinite(outs[0][0]).all() and np.isfinite(outs[0][1]).all()
     for o in outs[1:]:
         assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+
+
+def test_batches_in_flight_on_three_streams_are_exact(eng, dev):
+    """max_in_flight = 3: six different batches issued round-robin on three HIP streams (overlapping on the GPU) must give
+    bit-identical motions to the same batches sampled one at a time on the single-workspace engine."""
+    e3 = _lib.Engine(device=0, max_batch=64, max_frames=196, max_in_flight=3)
+    _load(e3)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    jobs = []
+    for i in range(6):
+        b = syn.make_batch(64 if i % 2 == 0 else 17, None, seed=100 + i, max_len=196 if i < 4 else 120)
+        jobs.append((b, _cuda(b.text_emb, dev), _cuda(b.init_latents, dev),
+                     torch.empty(len(b.lengths), max(b.lengths), 22, 3, device=dev)))
+    torch.cuda.synchronize()
+    for rep in range(2):                                   # second round replays the captured graphs
+        for i, (b, text, x0, joints) in enumerate(jobs):
+            e3.sample(text, x0, b.lengths, None, None, joints, streams[i % 3].cuda_stream)
+    torch.cuda.synchronize()
+    for b, text, x0, joints in jobs:
+        ref = torch.empty_like(joints)
+        eng.sample(text, x0, b.lengths, None, None, ref)
+        torch.cuda.synchronize()
+        assert torch.equal(joints, ref)
+    e3.close()

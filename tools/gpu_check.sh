@@ -12,10 +12,16 @@ TAG=${1:-r01}
   tail -5 gpurun_out/bench_${TAG}.err
 } 2>&1 | tee gpurun_out/check_${TAG}.log
 echo "== rocprofv3" | tee -a gpurun_out/check_${TAG}.log
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG} -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}.log 2>&1
-cd $GRAFT_REPO_ROOT
-find gpurun_out/prof_${TAG} -name "*stats*" | head; 
-f=$(find gpurun_out/prof_${TAG} -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && head -30 "$f" | tee -a gpurun_out/check_${TAG}.log
-# keep the merged-back payload small: drop the raw per-dispatch trace
-find gpurun_out/prof_${TAG} -name "*kernel_trace*.csv" -size +20M -delete
-tail -3 gpurun_out/prof_${TAG}.log
+# Kernel stats of the HEADLINE workload only, one step in flight: the per-kernel averages then correspond to the isolated
+# per-kernel timings bench.py reports in `kernels` / `roofline` (with 3 steps in flight kernels of different batches
+# overlap and each one's wall duration is longer; the secondary workloads reuse the same kernels at other shapes).
+prof() {  # $1 = suffix, rest = bench flags
+  local sfx=$1; shift
+  cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${sfx} -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-a2m --no-novae "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${sfx}.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  find gpurun_out/prof_${TAG}_${sfx} -name "*kernel_trace*.csv" -size +20M -delete
+}
+prof inflight1 --in-flight 1
+prof inflight3 --in-flight 3
+f=$(find gpurun_out/prof_${TAG}_inflight1 -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && head -24 "$f" | tee -a gpurun_out/check_${TAG}.log
+tail -3 gpurun_out/prof_${TAG}_inflight1.log
