@@ -505,6 +505,7 @@ int check_launch(Ctx& c, const char* what) {
 // Tile configurations.  "small" targets the latency-bound denoiser (M = 6B rows): one 16x16 tile per
 // wave so a GEMM spreads over as many SIMDs as possible; "large" targets the MFMA-bound decoder.
 int g_small_m = 256;         // MLDHIP_SMALL_M: row count up to which the 16x64 one-tile-per-wave shape is used (tiny one-off GEMMs)
+bool g_gemm8 = true;         // MLDHIP_GEMM8=0: the 4-wave variants of the staged fp32 GEMM tiles (A/B runs)
 bool g_staged_gemm = true;   // MLDHIP_GEMM=direct selects the first-version register-direct main loop (A/B runs)
 
 // staged (LDS, prefetch ring) launch of one tile shape; K / 32 is a template parameter
@@ -543,6 +544,7 @@ void gemm(Ctx& c, const GemmArgs& a, int nz = 1) {
   } else {
     dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);
     if (x3) launch_staged<2, 2, 2, 4, false, 1>(c, a, grid);
+    else if (g_gemm8) launch_staged<2, 4, 2, 2, false, 0>(c, a, grid);   // same 64x128 tile on 8 waves (2 per SIMD)
     else launch_staged<2, 2, 2, 4, false, 0>(c, a, grid);
   }
   count(c);
@@ -556,6 +558,8 @@ void gemm_ln(Ctx& c, const GemmArgs& a) {   // N == 256; full rows per workgroup
     MLD_LAUNCH((gemm_kernel<1, 4, 2, 4, true>), grid, dim3(256), 0, c.stream, a);
   } else if (x3) {
     launch_staged<1, 4, 2, 4, true, 1>(c, a, grid);
+  } else if (g_gemm8) {
+    launch_staged<2, 4, 2, 4, true, 0>(c, a, dim3((a.M + 63) / 64, 1, 1));   // 64 x 256 tile on 8 waves
   } else {
     launch_staged<1, 4, 2, 4, true, 0>(c, a, grid);
   }
@@ -1196,6 +1200,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   auto* e = new mldhip_engine();
   const char* m_gemm = std::getenv("MLDHIP_GEMM");        // process-wide A/B knobs, re-read at every create
   g_staged_gemm = !(m_gemm && std::strcmp(m_gemm, "direct") == 0);
+  const char* m_g8 = std::getenv("MLDHIP_GEMM8");
+  g_gemm8 = !(m_g8 && std::atoi(m_g8) == 0);
   const char* m_small = std::getenv("MLDHIP_SMALL_M");
   g_small_m = m_small ? std::atoi(m_small) : 256;
   if (const char* m = std::getenv("MLDHIP_TILE16")) e->tile16 = std::atoi(m) != 0;

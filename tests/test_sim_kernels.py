@@ -357,3 +357,19 @@ def test_contexts_rotate_and_stay_exact_sim(ow):
     with pytest.raises(_lib.MldHipError):
         _lib.Engine(lib=simlib.sim_library(), max_in_flight=9)
     e.close()
+
+
+@pytest.mark.parametrize("g8", ["1", "0"])
+def test_staged_gemm_tiles_are_exact_sim(monkeypatch, ow, g8):
+    """The staged fp32 GEMM tiles on 8 waves (default: 64x128 plain, 64x256 with the LayerNorm epilogue) and on 4 waves
+    (MLDHIP_GEMM8=0: 64x128 / 32x256), forced at simulator-sized M."""
+    ops, _, bv = ow
+    monkeypatch.setenv("MLDHIP_GEMM8", g8)
+    monkeypatch.setenv("MLDHIP_SMALL_M", "0")          # force the staged kernels at simulator-sized M
+    e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2)
+    z = syn._rng(7, "g8").standard_normal((3, 1, 256)).astype(np.float32)
+    lens = [40, 23, 7]
+    feats = np.zeros((3, 40, 263), np.float32)
+    e.vae_decode(z, lens, feats)
+    assert np.abs(feats - O.vae_decode(ops, bv, z, lens)).max() < 5e-5
+    e.close()
