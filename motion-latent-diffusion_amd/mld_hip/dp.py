@@ -54,20 +54,46 @@ def gather_lengths_order(n: int, world: int) -> List[Tuple[int, int]]:
 
 
 class DataParallelSampler:
-    """Shard a list of prompts over the ranks of the default process group; each rank runs `model.forward`
-    on its block in chunks of `batch_size` and returns (global_indices, joints_list) for its block."""
+    """Shard a list of prompts over the ranks of the default process group; each rank runs the model on its block in
+    chunks of `batch_size` and returns (global_indices, joints_list) for its block.
 
-    def __init__(self, model, batch_size: int = 64):
+    in_flight > 1 (text-to-motion models on the fused engine path): consecutive chunks are issued on `in_flight` rotating
+    HIP streams, so several batches overlap on the GPU (the engine must have been configured with
+    ``mld_hip.engine.configure("text", max_in_flight=in_flight)`` before its first use; with fewer workspaces the calls
+    simply serialise).  Results are identical either way."""
+
+    def __init__(self, model, batch_size: int = 64, in_flight: int = 1):
         self.model = model
         self.batch_size = batch_size
+        self.in_flight = max(1, int(in_flight))
 
     def __call__(self, texts: Sequence[str], lengths: Sequence[int]):
         import torch.distributed as dist
         rank = dist.get_rank() if dist.is_initialized() else 0
         world = dist.get_world_size() if dist.is_initialized() else 1
         lo, hi = shard_range(len(texts), rank, world)
+        chunks = [(s, min(hi, s + self.batch_size)) for s in range(lo, hi, self.batch_size)]
+        m = self.model
+        overlap = (self.in_flight > 1 and torch.cuda.is_available() and getattr(m, "fused", False)
+                   and getattr(m, "condition", None) == "text" and getattr(m, "vae_type", "") != "no")
         out = []
-        for s in range(lo, hi, self.batch_size):
-            e = min(hi, s + self.batch_size)
-            out.extend(self.model({"text": list(texts[s:e]), "length": list(lengths[s:e])}))
+        if not overlap:
+            for s, e in chunks:
+                out.extend(m({"text": list(texts[s:e]), "length": list(lengths[s:e])}))
+            return list(range(lo, hi)), out
+        streams = [torch.cuda.Stream() for _ in range(self.in_flight)]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+        pending = []
+        for i, (s, e) in enumerate(chunks):
+            with torch.cuda.stream(streams[i % self.in_flight]):
+                tx, ln = list(texts[s:e]), [int(x) for x in lengths[s:e]]
+                emb = m.text_encoder([""] * len(tx) + tx)                      # mld.py:224-231: unconditional half first
+                joints, _, _ = m.sample(emb, ln)
+                pending.append((joints, ln))
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+        for joints, ln in pending:
+            j = joints.cpu()
+            out.extend(j[k, :n] for k, n in enumerate(ln))
         return list(range(lo, hi)), out

@@ -538,3 +538,35 @@ def test_batches_in_flight_on_three_streams_are_exact(eng, dev):
         torch.cuda.synchronize()
         assert torch.equal(joints, ref)
     e3.close()
+
+
+def test_data_parallel_sampler_with_batches_in_flight(dev):
+    """DataParallelSampler(in_flight=3) on one rank: chunks on rotating streams give the same motions as the serial loop
+    (noise comes from torch.randn inside MLD.sample, so both runs are seeded identically per chunk order)."""
+    from mld_hip import config as C
+    from mld_hip import engine as E
+    from mld_hip.datamodule import HipDataModule
+    from mld_hip.dp import DataParallelSampler
+    from mld_hip.mld import MLD
+    from mld_hip.text_encoder import SyntheticTextEncoder
+
+    E.drop_engines()
+    cfg = C.load_config()
+    E.configure("text", max_batch=8, max_frames=196, max_in_flight=3)
+    model = MLD(cfg, HipDataModule(cfg), text_encoder=SyntheticTextEncoder()).to(dev).eval()
+    texts = [f"prompt number {i}" for i in range(20)]
+    lengths = [40 + 7 * (i % 9) for i in range(20)]
+
+    orig = model.sample          # wrap it: the same start noise whichever stream / order a chunk runs in
+
+    def seeded(text_emb, lens, init_latents=None):
+        g = torch.Generator(device=dev).manual_seed(sum(lens))
+        return orig(text_emb, lens, torch.randn((len(lens), 1, 256), device=dev, generator=g))
+    model.sample = seeded
+    idx1, serial = DataParallelSampler(model, batch_size=8, in_flight=1)(texts, lengths)
+    idx3, flight = DataParallelSampler(model, batch_size=8, in_flight=3)(texts, lengths)
+    assert idx1 == idx3 == list(range(20))
+    for a, b, n in zip(serial, flight, lengths):
+        assert a.shape == (n, 22, 3) and torch.equal(a, b)
+    E.configure("text", max_in_flight=1)
+    E.drop_engines()
