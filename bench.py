@@ -80,33 +80,41 @@ def cpu_baseline(seed, threads, timeout=420):
         return {"error": repr(ex)[:200]}, None
 
 
-def bench_a2m(local, dev, stream, warmup, steps, B=256, T=60):
+def bench_a2m(local, dev, stream, warmup, steps, B=256, T=60, nfl=2):
     """BASELINE config 5 shape (config_mld_humanact12.yaml: action condition, 15-layer denoiser, ActorVae decoder,
-    bs=256, T=60), same timing rule; a secondary line, never the headline `value`.  fp32 like the headline (the fp8
-    denoiser GEMMs BASELINE.json muses about cannot meet the parity tolerance: DESIGN.md §3 point 9, §7)."""
+    bs=256, T=60), same timing rule, `nfl` steps in flight; a secondary line, never the headline `value`.  fp32 like the
+    headline (the fp8 denoiser GEMMs BASELINE.json muses about cannot meet the parity tolerance: DESIGN.md §3 point 9, §7)."""
     eng = _lib.Engine(device=local, max_batch=B, max_frames=T, condition=_lib.COND_ACTION, nclasses=12,
-                      vae_arch=_lib.VAE_ACTOR, vae_num_layers=6, num_layers=15, nfeats=150)
+                      vae_arch=_lib.VAE_ACTOR, vae_num_layers=6, num_layers=15, nfeats=150, max_in_flight=nfl)
     dims = syn.ModelDims(num_layers=15, nfeats=150)
     eng.load_state_dict(syn.make_denoiser_state_dict(seed=3, dims=dims, condition="action", nclasses=12), "denoiser.")
     eng.load_state_dict(syn.make_actor_vae_state_dict(), "vae.")
     eng.finalize()
-    acts, lat0, lens = syn.make_action_batch(B, nframes=T)
-    x0 = torch.from_numpy(lat0).to(dev)
-    feats = torch.empty(B, T, 150, device=dev)
-    for _ in range(warmup):
-        eng.sample_action(acts, x0, lens, None, feats, stream.cuda_stream)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        eng.sample_action(acts, x0, lens, None, feats, stream.cuda_stream)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    slots = []
+    for sl in range(nfl):
+        acts, lat0, lens = syn.make_action_batch(B, nframes=T, seed=1234 + sl)
+        slots.append((acts, torch.from_numpy(lat0).to(dev), lens, torch.empty(B, T, 150, device=dev),
+                      stream if sl == 0 else torch.cuda.Stream(device=dev)))
+
+    def run(n, single):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            acts, x0, lens, feats, st = slots[i % nfl]
+            eng.sample_action(acts, x0, lens, None, feats, (stream if single else st).cuda_stream)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(max(warmup, nfl), False)
+    dt = run(steps, False)
+    dt1 = run(steps, True) if nfl > 1 else dt
     _, den15, _ = algorithmic_gflop(B, T, L=15, NF=150)     # 15-layer skip denoiser, per step
     _, _, dec6 = algorithmic_gflop(B, T, L=6, NF=150)       # 6 decoder layers ...
     gflop = den15 * STEPS_DDIM + dec6 - (6 - 1) / 2 * 2.0 * B * T * 512 * 256 / 1e9   # ... minus the skip linears ActorVae lacks
-    out = {"workload": "config_mld_humanact12.yaml (action-to-motion), bs=256, T=60, 50-step DDIM, CFG 7.5, ActorVae decode -> feats",
+    out = {"workload": "config_mld_humanact12.yaml (action-to-motion), bs=256, T=60, 50-step DDIM, CFG 7.5, ActorVae decode -> feats; "
+                       "%d steps in flight" % nfl,
            "value": round(B * steps / dt, 2), "unit": "motions/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
-           "dtype": "f32", "algorithmic_gflop_per_batch": round(gflop, 1),
+           "single_stream_value": round(B * steps / dt1, 2), "dtype": "f32", "algorithmic_gflop_per_batch": round(gflop, 1),
            "achieved_tflops": round(gflop / 1e3 / (dt / steps), 2), "launches_per_step": eng.launch_counts()}
     eng.close()
     return out

@@ -543,7 +543,8 @@ void gemm(Ctx& c, const GemmArgs& a, int nz = 1) {
     MLD_LAUNCH((gemm_kernel<2, 2, 2, 4, false>), grid, dim3(256), 0, c.stream, a);
   } else {
     dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);
-    if (x3) launch_staged<2, 2, 2, 4, false, 1>(c, a, grid);
+    if (x3 && g_gemm8) launch_staged<2, 4, 2, 2, false, 1>(c, a, grid);
+    else if (x3) launch_staged<2, 2, 2, 4, false, 1>(c, a, grid);
     else if (g_gemm8) launch_staged<2, 4, 2, 2, false, 0>(c, a, grid);   // same 64x128 tile on 8 waves (2 per SIMD)
     else launch_staged<2, 2, 2, 4, false, 0>(c, a, grid);
   }
@@ -556,6 +557,8 @@ void gemm_ln(Ctx& c, const GemmArgs& a) {   // N == 256; full rows per workgroup
   const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_DECODE && c.e->phase == 1;
   if (!g_staged_gemm) {
     MLD_LAUNCH((gemm_kernel<1, 4, 2, 4, true>), grid, dim3(256), 0, c.stream, a);
+  } else if (x3 && g_gemm8) {
+    launch_staged<2, 4, 2, 4, true, 1>(c, a, dim3((a.M + 63) / 64, 1, 1));
   } else if (x3) {
     launch_staged<1, 4, 2, 4, true, 1>(c, a, grid);
   } else if (g_gemm8) {

@@ -570,3 +570,28 @@ def test_data_parallel_sampler_with_batches_in_flight(dev):
         assert a.shape == (n, 22, 3) and torch.equal(a, b)
     E.configure("text", max_in_flight=1)
     E.drop_engines()
+
+
+def test_extreme_shapes_vs_oracle(dev, oracle_weights):
+    """Edges of the capacity envelope: the longest supported motion (288 frames: 18 key tiles in the attention kernel)
+    next to a 1-frame motion, and a batch of one 1-frame motion."""
+    ops, bd, bv = oracle_weights
+    mean, std = syn.make_mean_std()
+    e = _lib.Engine(device=0, max_batch=2, max_frames=288, num_inference_steps=4)
+    _load(e)
+    for lens in ([288, 1], [1]):
+        b = syn.make_batch(len(lens), lens, seed=55)
+        B, T = len(lens), max(lens)
+        joints = torch.empty(B, T, 22, 3, device=dev)
+        feats = torch.empty(B, T, 263, device=dev)
+        e.sample(_cuda(b.text_emb, dev), _cuda(b.init_latents, dev), lens, None, feats, joints)
+        torch.cuda.synchronize()
+        jr, fr, _ = O.sample(ops, bd, bv, b.text_emb, b.init_latents, lens, mean, std, steps=4, return_intermediates=True)
+        assert np.abs(feats.cpu().numpy() - fr).max() < 1e-4
+        j = joints.cpu().numpy()
+        for i, n in enumerate(lens):
+            assert np.abs(j[i, :n] - jr[i, :n]).max() < 1e-3
+        assert np.all(feats.cpu().numpy()[-1, lens[-1]:] == 0)
+    with pytest.raises(_lib.MldHipError):
+        _lib.Engine(device=0, max_frames=289)
+    e.close()
