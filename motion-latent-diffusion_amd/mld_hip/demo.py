@@ -53,7 +53,8 @@ def main(argv=None):
         note = "SYNTHETIC text encoder (no CLIP weights on disk)"
     ckpt = cfg.TEST.CHECKPOINTS
     if os.path.exists(ckpt):
-        model.load_state_dict(torch.load(ckpt, map_location="cpu")["state_dict"], strict=True)
+        from .checkpoint import load_lightning_state_dict       # works without pytorch_lightning / omegaconf installed
+        model.load_state_dict(load_lightning_state_dict(ckpt), strict=True)
     else:
         note += "; SYNTHETIC weights (checkpoint %s not found)" % ckpt
     model.to(dev).eval()

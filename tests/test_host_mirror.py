@@ -344,3 +344,39 @@ def test_demo_example_parser(tmp_path):
     p.write_text("50 a man kicks with something or someone with his left leg.\n100 A person is skipping rope.\n")
     texts, lens = load_example_input(str(p))
     assert lens == [50, 100] and texts[1] == "A person is skipping rope."
+
+
+def test_lightning_checkpoint_is_readable_without_lightning(tmp_path):
+    """A checkpoint whose pickle references classes of packages that are not installed (as the released Lightning files do
+    with omegaconf / pytorch_lightning) still yields its state_dict; plain torch.load cannot read it."""
+    import sys
+    import types
+    from mld_hip.checkpoint import load_lightning_state_dict
+
+    mod = types.ModuleType("fake_lightning_pkg")
+
+    class DictConfig(dict):
+        pass
+
+    class ModelCheckpoint:
+        def __init__(self):
+            self.best = 0.41
+    DictConfig.__module__ = ModelCheckpoint.__module__ = "fake_lightning_pkg"
+    DictConfig.__qualname__, ModelCheckpoint.__qualname__ = "DictConfig", "ModelCheckpoint"
+    mod.DictConfig, mod.ModelCheckpoint = DictConfig, ModelCheckpoint
+    sys.modules["fake_lightning_pkg"] = mod
+    sd = {"denoiser.encoder.norm.weight": torch.arange(4.0), "vae.final_layer.bias": torch.ones(3), "t2m_moveencoder.w": torch.zeros(2)}
+    path = str(tmp_path / "fake.ckpt")
+    try:
+        torch.save({"state_dict": sd, "hyper_parameters": DictConfig(a=1), "callbacks": {"ckpt": ModelCheckpoint()},
+                    "pytorch-lightning_version": "1.7.7", "epoch": 5}, path)
+    finally:
+        del sys.modules["fake_lightning_pkg"]
+    with pytest.raises(Exception):
+        torch.load(path, map_location="cpu", weights_only=False)            # ModuleNotFoundError: fake_lightning_pkg
+    got, missing = load_lightning_state_dict(path, report_missing=True)
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    assert missing == ["fake_lightning_pkg.DictConfig", "fake_lightning_pkg.ModelCheckpoint"]
+    flat = str(tmp_path / "flat.pt")
+    torch.save(sd, flat)
+    assert set(load_lightning_state_dict(flat)) == set(sd)                   # a bare state dict is accepted too
