@@ -13,7 +13,7 @@ TAG=${1:-r01}
 } 2>&1 | tee gpurun_out/check_${TAG}.log
 echo "== rocprofv3" | tee -a gpurun_out/check_${TAG}.log
 # Kernel stats of the HEADLINE workload only, one step in flight: the per-kernel averages then correspond to the isolated
-# per-kernel timings bench.py reports in `kernels` / `roofline` (with 3 steps in flight kernels of different batches
+# per-kernel timings bench.py reports in `kernels` / `roofline` (with 4 steps in flight kernels of different batches
 # overlap and each one's wall duration is longer; the secondary workloads reuse the same kernels at other shapes).
 prof() {  # $1 = suffix, rest = bench flags
   local sfx=$1; shift
@@ -22,6 +22,6 @@ prof() {  # $1 = suffix, rest = bench flags
   find gpurun_out/prof_${TAG}_${sfx} -name "*kernel_trace*.csv" -size +20M -delete
 }
 prof inflight1 --in-flight 1
-prof inflight3 --in-flight 3
+prof inflight4 --in-flight 4
 f=$(find gpurun_out/prof_${TAG}_inflight1 -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && head -24 "$f" | tee -a gpurun_out/check_${TAG}.log
 tail -3 gpurun_out/prof_${TAG}_inflight1.log
