@@ -76,19 +76,30 @@ __device__ __forceinline__ F4 f4add(F4 a, F4 b) { return F4{a.x + b.x, a.y + b.y
 // NS0 = compile-time slab count of src[0] when it is a combine source (0: src[0] is plain / attention):
 // keeps every load unconditional and straight-line (a per-load `cond ? load : 0` makes hipcc branch and
 // wait per element -- cdna_hip_programming.md, "three .s-level traps" (c)).
-template <int MT, int NS0, bool TRACE>
-__global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
+// KH = number of K pieces that pass through LDS one after the other (1: the whole 256-wide slice is resident, 99.8 KB
+// for MT = 32; 2: 128 columns at a time, 50.7 KB, and the register budget is capped at 128 so that TWO workgroups fit a
+// CU -- with several batches in flight (DESIGN.md §3 point 11) another chain's kernel can then run its MFMAs while this
+// one waits for its loads).  The global loads are identical (all issued up front, full K in registers).
+template <int MT, int NS0, bool TRACE, int KH = 1>
+__global__ __launch_bounds__(512, KH == 2 ? 4 : 2) void gemm_tile32_kernel(Tile32Args p) {
   static_assert(MT == 16 || MT == 32, "row tile");
+  static_assert(KH == 1 || KH == 2, "K pieces");
   constexpr int RPW = MT / 8;                 // A rows assembled per wave
+  constexpr int KW = 256 / KH, ST = KW + 4;   // K columns resident in LDS, LDS row stride (floats)
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
 #else
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #endif
-  float* As = smem;                          // [MT][260]
-  float* Ws = smem + MT * kT32Stride;        // [64][260]
+  float* As = smem;                          // [MT][ST]
+  float* Ws = smem + MT * ST;                // [64][ST]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * MT, n0 = blockIdx.y * 64, z = blockIdx.z;
+  // (An XCD-aware tile order -- block b runs on XCD b % 8; give each XCD a contiguous range of column tiles so that it
+  // pulls 1/8 of the weight panel instead of all of it -- was measured SLOWER: 6 825 vs 7 260 motions/s at 4 batches in
+  // flight, 3 397 vs 3 728 single-stream.  All workgroups of an XCD then hammer the same few L2 channels at the same
+  // instant; in dispatch order the reads spread over every channel of every XCD.  profiles/r01_v17_xcd_kh_ab.txt.)
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int m0 = bx * MT, n0 = by * 64, z = bz;
   const bool second = z >= p.nz0;
   const ASrc& src = second ? p.src[1] : p.src[0];
   const int acol = (second ? z - p.nz0 : z) * 256;
@@ -205,42 +216,47 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
                      areg[i].w * rstd * gm.w + bt.w};
       }
     }
-    if (src.out && blockIdx.y == 0) {
+    if (src.out && by == 0) {
 #pragma unroll
       for (int i = 0; i < RPW; ++i)
         if (live[i]) st4(src.out + (long long)rows[i] * src.ldout + lane * 4, areg[i]);
     }
   }
   if constexpr (tracing) ts[1] = clock_pinned();      // every load landed, prologue math done
-#pragma unroll
-  for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * kT32Stride + lane * 4, wreg[i]);
-#pragma unroll
-  for (int i = 0; i < RPW; ++i) st4(As + (wave + i * 8) * kT32Stride + lane * 4, areg[i]);
-  if constexpr (tracing) ts[2] = clock_pinned();      // tile parked in LDS (this wave)
-  __syncthreads();
-  if constexpr (tracing) ts[3] = clock_pinned();      // barrier passed
-
   // ---- one 16x16 tile per wave; two accumulators hide the MFMA dependent latency
   const int r = lane & 15, g = lane >> 4;
   const int ct = wave & 3;
   const int rt = MT == 32 ? (wave >> 2) : 0;          // row tile (MT = 32)
-  const int kh = MT == 16 ? (wave >> 2) : 0;          // K half   (MT = 16)
-  constexpr int KCH = MT == 32 ? 8 : 4;               // 32-wide K chunks per wave
-  const float* ap = As + (rt * 16 + r) * kT32Stride + g * 8 + kh * 128;
-  const float* wp = Ws + (ct * 16 + r) * kT32Stride + g * 8 + kh * 128;
+  const int kh = MT == 16 ? (wave >> 2) : 0;          // K half of the resident piece (MT = 16)
+  constexpr int KCH = (MT == 32 ? 8 : 4) / KH;        // 32-wide K chunks per wave and resident piece
+  const float* ap = As + (rt * 16 + r) * ST + g * 8 + kh * (KW / 2);
+  const float* wp = Ws + (ct * 16 + r) * ST + g * 8 + kh * (KW / 2);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kc = 0; kc < KCH; ++kc) {
-    const F4 a0 = ld4(ap + kc * 32), a1 = ld4(ap + kc * 32 + 4);
-    const F4 b0 = ld4(wp + kc * 32), b1 = ld4(wp + kc * 32 + 4);
-    acc0 = mfma_f32_16x16x4(a0.x, b0.x, acc0);
-    acc1 = mfma_f32_16x16x4(a0.y, b0.y, acc1);
-    acc0 = mfma_f32_16x16x4(a0.z, b0.z, acc0);
-    acc1 = mfma_f32_16x16x4(a0.w, b0.w, acc1);
-    acc0 = mfma_f32_16x16x4(a1.x, b1.x, acc0);
-    acc1 = mfma_f32_16x16x4(a1.y, b1.y, acc1);
-    acc0 = mfma_f32_16x16x4(a1.z, b1.z, acc0);
-    acc1 = mfma_f32_16x16x4(a1.w, b1.w, acc1);
+  for (int h = 0; h < KH; ++h) {
+    if (h > 0) __syncthreads();                       // the previous piece's MFMAs have read their fragments
+    if (KH == 1 || (lane * 4) / KW == h) {            // lane l owns columns 4l..4l+3 of its rows: piece (4l / KW)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * ST + lane * 4 - h * KW, wreg[i]);
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) st4(As + (wave + i * 8) * ST + lane * 4 - h * KW, areg[i]);
+    }
+    if constexpr (tracing) { if (h == 0) ts[2] = clock_pinned(); }      // tile parked in LDS (this wave)
+    __syncthreads();
+    if constexpr (tracing) { if (h == 0) ts[3] = clock_pinned(); }      // barrier passed
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      const F4 a0 = ld4(ap + kc * 32), a1 = ld4(ap + kc * 32 + 4);
+      const F4 b0 = ld4(wp + kc * 32), b1 = ld4(wp + kc * 32 + 4);
+      acc0 = mfma_f32_16x16x4(a0.x, b0.x, acc0);
+      acc1 = mfma_f32_16x16x4(a0.y, b0.y, acc1);
+      acc0 = mfma_f32_16x16x4(a0.z, b0.z, acc0);
+      acc1 = mfma_f32_16x16x4(a0.w, b0.w, acc1);
+      acc0 = mfma_f32_16x16x4(a1.x, b1.x, acc0);
+      acc1 = mfma_f32_16x16x4(a1.y, b1.y, acc1);
+      acc0 = mfma_f32_16x16x4(a1.z, b1.z, acc0);
+      acc1 = mfma_f32_16x16x4(a1.w, b1.w, acc1);
+    }
   }
   f32x4 acc = acc0 + acc1;
   if constexpr (MT == 16) {
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(512) void gemm_tile32_kernel(Tile32Args p) {
   if constexpr (tracing) {
     ts[5] = clock_pinned();                 // epilogue stores issued and drained
     if (lane == 0) {
-      const long long wg = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+      const long long wg = bx + (long long)gridDim.x * (by + (long long)gridDim.y * bz);
       unsigned long long* o = p.trace + (wg * 8 + wave) * 8;
       for (int i = 0; i < 6; ++i) o[i] = ts[i];
       o[6] = rt0;

@@ -127,6 +127,7 @@ struct mldhip_engine {
   float *text_in = nullptr, *lat_in = nullptr;   // graph staging of the caller's inputs
   float* TP;             // text projection rows [2*max_batch][256] (+pe[2]), gathered per chain
   bool fused_ffn = false; // MLDHIP_FUSED_FFN=1: linear1+GELU+linear2 in one launch (measured slower: DESIGN.md §3 point 9)
+  int t32_kh = 1;        // MLDHIP_T32_KH=2: tile32 kernels pass K through LDS in two pieces (two workgroups per CU)
   bool tile16 = true;    // MLDHIP_TILE16=0 disables the 16-row K-split tiles (A/B runs)
   int nchains = 1;       // independent sub-batch chains of the reverse loop (parallel graph branches)
 
@@ -577,7 +578,7 @@ GemmArgs lin_args(const float* A, int lda, int K, const float* W, const float* b
 }
 
 // ---- denoiser layer pipeline on the tile32 kernels (4 launches per encoder layer) ----------------
-constexpr int t32_lds_bytes(int mt) { return (mt + 64) * kT32Stride * 4; }
+constexpr int t32_lds_bytes(int mt, int kh = 1) { return (mt + 64) * (256 / kh + 4) * 4; }
 
 void tile32(Ctx& c, const Tile32Args& a_, int nz) {
   Tile32Args a = a_;
@@ -590,6 +591,7 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
 #define MLD_T32(MT, NS)                                                                                          \
   do {                                                                                                           \
     if (a.trace) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, true>), grid, dim3(512), t32_lds_bytes(MT), c.stream, a); }  \
+    else if (c.e->t32_kh == 2) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, 2>), grid, dim3(512), t32_lds_bytes(MT, 2), c.stream, a); } \
     else { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false>), grid, dim3(512), t32_lds_bytes(MT), c.stream, a); }         \
   } while (0)
 #define MLD_T32_NS(MT)                                                                                           \
@@ -1209,6 +1211,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   g_small_m = m_small ? std::atoi(m_small) : 256;
   if (const char* m = std::getenv("MLDHIP_TILE16")) e->tile16 = std::atoi(m) != 0;
   if (const char* m = std::getenv("MLDHIP_FUSED_FFN")) e->fused_ffn = std::atoi(m) != 0;
+  if (const char* m = std::getenv("MLDHIP_T32_KH")) e->t32_kh = std::atoi(m) == 2 ? 2 : 1;
   e->nchains = 1;   // measured: parallel chains do not shorten the sequential depth
   if (const char* m = std::getenv("MLDHIP_CHAINS")) e->nchains = std::max(1, std::min(8, std::atoi(m)));
   e->cfg = *cfg;

@@ -373,3 +373,18 @@ def test_staged_gemm_tiles_are_exact_sim(monkeypatch, ow, g8):
     e.vae_decode(z, lens, feats)
     assert np.abs(feats - O.vae_decode(ops, bv, z, lens)).max() < 5e-5
     e.close()
+
+
+def test_tile32_two_k_pieces_knob_is_exact_sim(monkeypatch, ow):
+    """MLDHIP_T32_KH=2: the loop GEMMs pass K through LDS in two 128-wide pieces (half the LDS, two workgroups per CU)."""
+    ops, bd, bv = ow
+    monkeypatch.setenv("MLDHIP_T32_KH", "2")
+    e = simlib.sim_engine(max_batch=4, max_frames=24, num_inference_steps=2)
+    b = syn.make_batch(3, [20, 13, 7])
+    mean, std = syn.make_mean_std()
+    joints = np.zeros((3, 20, 22, 3), np.float32)
+    lat = np.zeros((3, 1, 256), np.float32)
+    e.sample(b.text_emb, b.init_latents, b.lengths, lat, None, joints)
+    jr, _, lr = O.sample(ops, bd, bv, b.text_emb, b.init_latents, b.lengths, mean, std, steps=2, return_intermediates=True)
+    assert np.abs(lat - lr).max() < 5e-4 and np.abs(joints - jr).max() < 1e-4
+    e.close()
