@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void enc_finish_kernel(const float* __restrict
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const float x = H[((long long)b * S + s) * 256 + d];
+    if (!gamma) { out[s] = x; continue; }     // ActorAgnosticEncoder has no final norm (actor_vae.py:166-170); uniform branch
     const float mean = block_sum_256(x, sh, d) * (1.0f / 256.0f);
     const float xc = x - mean;
     const float var = block_sum_256(xc * xc, sh, d) * (1.0f / 256.0f);

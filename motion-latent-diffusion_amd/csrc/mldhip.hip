@@ -316,6 +316,20 @@ void declare_params(E* e) {
     }
     e->dec_layer_stride = second - first;
     lin("vae.decoder.final_layer", NF, D);
+    // ActorVae encoder (actor_vae.py:84-175) -- optional weight group, like MldVae's: [mu_token | logvar_token] are
+    // declared back to back so that together they form the [2][D] token block the token-assembly kernel expects
+    add_param(e, "vae.encoder.mu_token", {D});
+    add_param(e, "vae.encoder.logvar_token", {D});
+    add_param(e, "vae.encoder.sequence_pos_encoding.pe", {5000, 1, D});
+    lin("vae.encoder.skel_embedding", D, NF);
+    for (int i = 0; i < vae_layers(e); ++i) {
+      std::string p = "vae.encoder.seqTransEncoder.layers." + std::to_string(i);
+      mha(p + ".self_attn");
+      lin(p + ".linear1", F, D);
+      lin(p + ".linear2", D, F);
+      norm(p + ".norm1");
+      norm(p + ".norm2");
+    }
     add_param(e, "mean", {NF});
     add_param(e, "std", {NF});
     return;
@@ -395,8 +409,10 @@ void bind_layers(E* e) {
     e->den.push_back(L);
   }
   e->venc.clear();
-  for (auto& b : block_names(is_actor(e) ? -1 : nb)) {
-    std::string p = "vae.encoder." + b;
+  std::vector<std::string> venc_names;
+  if (is_actor(e)) for (int i = 0; i < vae_layers(e); ++i) venc_names.push_back("vae.encoder.seqTransEncoder.layers." + std::to_string(i));
+  else for (auto& b : block_names(nb)) venc_names.push_back("vae.encoder." + b);
+  for (auto& p : venc_names) {
     EncLayerP L;
     L.in_w = P(e, p + ".self_attn.in_proj_weight"); L.in_b = P(e, p + ".self_attn.in_proj_bias");
     L.out_w = P(e, p + ".self_attn.out_proj.weight"); L.out_b = P(e, p + ".self_attn.out_proj.bias");
@@ -890,14 +906,33 @@ void encode_body(Ctx& c, const float* feats, int B, int T, const float* eps, flo
   MLD_LAUNCH(pad_cols_kernel, dim3(std::min(4096, (B * T * KP + 255) / 256)), dim3(256), 0, c.stream, feats, e->FF, B * T, NF, KP);
   count(c);
   check_launch(c, "pad_cols");
+  const bool actor = is_actor(e);
   {
-    GemmArgs g = lin_args(e->FF, KP, KP, e->WskelP, P(e, "vae.skel_embedding.bias"), e->LNO, D, B * T, D);
+    GemmArgs g = lin_args(e->FF, KP, KP, e->WskelP, P(e, actor ? "vae.encoder.skel_embedding.bias" : "vae.skel_embedding.bias"), e->LNO, D,
+                          B * T, D);
     gemm(c, g);
   }
+  // [token 0, token 1, frames] + positional rows (MldVae: global_motion_token + learned PE, mld_vae.py:150-163;
+  // ActorVae: [mu_token, logvar_token] + sinusoidal PE, actor_vae.py:141-163)
   MLD_LAUNCH(enc_tokens_kernel, dim3(std::min(4096, (M * D / 4 + 255) / 256)), dim3(256), 0, c.stream, (const float*)e->LNO,
-             P(e, "vae.global_motion_token"), P(e, "vae.query_pos_encoder.pe"), e->X0, B, T, D);
+             P(e, actor ? "vae.encoder.mu_token" : "vae.global_motion_token"),
+             P(e, actor ? "vae.encoder.sequence_pos_encoding.pe" : "vae.query_pos_encoder.pe"), e->X0, B, T, D);
   count(c);
   check_launch(c, "enc_tokens");
+  if (actor) {
+    // ActorAgnosticEncoder (actor_vae.py:164-170): stock nn.TransformerEncoder, no skip links, NO final norm
+    const float* xin = e->X0;
+    for (int l = 0; l < (int)e->venc.size(); ++l) {
+      float* xout = (l & 1) ? e->Hb : e->Ha;
+      venc_layer(c, e->venc[l], xin, xout, B, S);
+      xin = xout;
+    }
+    MLD_LAUNCH(enc_finish_kernel, dim3(B), dim3(256), 0, c.stream, xin, (const float*)nullptr, (const float*)nullptr, eps, latent, mu,
+               logvar, S);
+    count(c);
+    check_launch(c, "enc_finish");
+    return;
+  }
   const float* x = e->X0;
   for (int l = 0; l < nb; ++l) {
     venc_layer(c, e->venc[l], x, e->S[l], B, S);
@@ -1331,7 +1366,6 @@ int mldhip_load_tensor(mldhip_handle* e, const char* key, const void* data, cons
                                       "denoiser.mem_pos.", "text_encoder.", "t2m_", "vae.dist_layer."};
     for (auto p : ignorable)
       if (std::strncmp(key, p, std::strlen(p)) == 0) return 1;
-    if (is_actor(e) && std::strncmp(key, "vae.encoder.", 12) == 0) return 1;   // ActorVae encoder: not on the sampling path
     return e->fail(MLDHIP_EINVAL, "unexpected key %s", key);
   }
   Param& p = e->params[it->second];
@@ -1404,7 +1438,8 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
   }
   if (e->group_ready[3]) {
     const int NF = e->cfg.nfeats, KP = (NF + 31) / 32 * 32;
-    MLD_LAUNCH(pad_cols_kernel, dim3((D * KP + 255) / 256), dim3(256), 0, stream, P(e, "vae.skel_embedding.weight"), e->WskelP, D, NF, KP);
+    MLD_LAUNCH(pad_cols_kernel, dim3((D * KP + 255) / 256), dim3(256), 0, stream,
+               P(e, is_actor(e) ? "vae.encoder.skel_embedding.weight" : "vae.skel_embedding.weight"), e->WskelP, D, NF, KP);
     if (check_launch(c, "pad_cols")) return c.rc;
   }
   }

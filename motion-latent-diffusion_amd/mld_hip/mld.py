@@ -209,6 +209,16 @@ class MLD(nn.Module):
         return remove_padding(self.feats2joints(feats.detach()).cpu(), batch["length"])
 
     @torch.no_grad()
+    def recon_from_motion(self, batch):
+        """mld.py:277-288: encode -> decode -> joints for the reconstruction and the reference motion."""
+        feats_ref, length = batch["motion"], list(batch["length"])
+        z, _ = self.vae.encode(feats_ref, length)
+        feats_rst = self.vae.decode(z.contiguous(), length)
+        joints = self.feats2joints(feats_rst.detach())
+        joints_ref = self.feats2joints(feats_ref.detach().contiguous())
+        return remove_padding(joints.cpu(), length), remove_padding(joints_ref.cpu(), length)
+
+    @torch.no_grad()
     def _diffusion_reverse(self, encoder_hidden_states, lengths=None, init_latents: Optional[torch.Tensor] = None,
                            step_noise: Optional[torch.Tensor] = None):
         """The reference's Python loop (mld.py:290-360) over the drop-in parts -> [latent_size, B, D]

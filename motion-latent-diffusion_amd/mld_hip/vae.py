@@ -81,8 +81,8 @@ class HipMldVae(HipModule):
 
 class HipActorVae(HipModule):
     """Drop-in for ``mld.models.architectures.actor_vae.ActorVae`` on the sampling path: ``decode(z, lengths)``
-    (actor_vae.py:72-74 -> ActorAgnosticDecoder.forward, :209-235).  The state_dict carries the encoder tensors too
-    (so reference checkpoints load strictly) but ``encode`` -- reconstruction / VAE-stage training only -- is not built."""
+    (actor_vae.py:72-74 -> ActorAgnosticDecoder.forward, :209-235) and ``encode(features, lengths)`` (:64-76 ->
+    ActorAgnosticEncoder.forward, :121-175), both on the HIP engine."""
     _prefix = "vae."
 
     def __init__(self, ablation, nfeats: int, latent_dim: list = [1, 256], ff_size: int = 1024, num_layers: int = 7,
@@ -108,8 +108,26 @@ class HipActorVae(HipModule):
         eng.vae_decode(z, lengths, feats, self._stream())
         return feats
 
-    def encode(self, features, lengths=None):
-        raise NotImplementedError("ActorVae.encode is used by the VAE training stage / reconstruction only (out of scope, DESIGN.md §9)")
+    def encode(self, features: torch.Tensor, lengths: Optional[List[int]] = None, eps: Optional[torch.Tensor] = None):
+        """features [B, T, nfeats] (zero padded) -> (latent [1, B, D], torch.distributions.Normal(mu [B, D], std [B, D]))
+        like ActorVae.encode (actor_vae.py:64-76; sample_from_distribution = dist.rsample().unsqueeze(0))."""
+        features = self._check(features, "features")
+        if features.dim() != 3 or features.shape[2] != self.nfeats:
+            raise ValueError(f"features must be [B, T, {self.nfeats}], got {tuple(features.shape)}")
+        B, T = features.shape[0], features.shape[1]
+        lengths = [T] * B if lengths is None else [int(x) for x in lengths]
+        if len(lengths) != B or max(lengths) > T:
+            raise ValueError("lengths must have one entry per sample and not exceed the padded length")
+        eng = self.sync_weights()
+        dev = features.device
+        if eps is None:
+            eps = torch.randn(B, self.latent_dim, device=dev, dtype=torch.float32)
+        eps = self._check(eps.reshape(B, self.latent_dim), "eps")
+        lat = torch.empty(B, self.latent_dim, device=dev)
+        mu = torch.empty_like(lat)
+        logvar = torch.empty_like(lat)
+        eng.vae_encode(features, lengths, T, eps, lat, mu, logvar, self._stream())
+        return lat.unsqueeze(0), torch.distributions.Normal(mu, logvar.exp().pow(0.5))
 
     def forward(self, features, lengths=None):
         raise NotImplementedError("ActorVae.forward is a stub in the reference too (actor_vae.py:57-65); use decode().")

@@ -196,6 +196,17 @@ def main_action():
                         lengths=np.array(lens2), feats=fr, oracle_diff_den=np.abs(ref - mine).max(),
                         oracle_diff_feats=np.abs(fr - fm).max())
     print("action ops oracle-vs-reference:", np.abs(ref - mine).max(), np.abs(fr - fm).max())
+    # ActorVae.encode: Normal(mu, std) of a ragged batch
+    fe = syn._rng(9, "actor_feats").standard_normal((3, 60, 150)).astype(np.float32)
+    lens3 = [60, 33, 7]
+    for i, n in enumerate(lens3):
+        fe[i, n:] = 0
+    _, dist = vae.encode(torch.from_numpy(fe), lens3)
+    mu_r, std_r = dist.loc.numpy(), dist.scale.numpy()                     # [B, D]
+    _, mu_o, lv_o = O.actor_encode(ops, bv, fe, lens3)
+    np.savez_compressed(os.path.join(OUT, "actor_encode_b3.npz"), feats=fe, lengths=np.array(lens3), mu=mu_r, std=std_r,
+                        oracle_diff_mu=np.abs(mu_r - mu_o[:, 0]).max(), oracle_diff_std=np.abs(std_r - np.sqrt(np.exp(lv_o[:, 0]))).max())
+    print("actor_encode_b3 oracle-vs-reference:", np.abs(mu_r - mu_o[:, 0]).max(), np.abs(std_r - np.sqrt(np.exp(lv_o[:, 0]))).max())
 
     # full pipeline at config 5's shape: B=256, T=60, 50 steps (every 8th sample of feats kept)
     acts, lat0, lens = syn.make_action_batch(256, nframes=60)

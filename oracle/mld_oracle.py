@@ -578,6 +578,25 @@ def actor_decode(ops, sd, z, lengths: Sequence[int], nhead=4):
     return ops.where(valid[:, :, None], feats, ops.zeros_like(feats))
 
 
+def actor_encode(ops, sd, feats, lengths: Sequence[int], eps=None, nhead=4):
+    """ActorVae.encode -> ActorAgnosticEncoder.forward (actor_vae.py:64-76,121-175): skel_embedding, [mu_token,
+    logvar_token, frames] + sinusoidal PE, stock post-norm nn.TransformerEncoderLayer stack with the key-padding mask
+    (tokens always visible), NO final norm; mu = out[0], logvar = out[1].  feats [B,T,nfeats] ->
+    (latent [B,1,D] or None, mu [B,1,D], logvar [B,1,D])."""
+    b, t = feats.shape[0], feats.shape[1]
+    x = linear(ops, feats, sd["encoder.skel_embedding.weight"], sd["encoder.skel_embedding.bias"])
+    tok = ops.stack([sd["encoder.mu_token"], sd["encoder.logvar_token"]], 0)[None, :, :] + ops.zeros_like(x[:, :2, :])
+    xseq = ops.cat([tok, x], 1) + ops.swap(sd["encoder.sequence_pos_encoding.pe"][: t + 2], 0, 1)
+    valid = ops.mask_from_lengths([n + 2 for n in lengths], t + 2)
+    i = 0
+    while f"encoder.seqTransEncoder.layers.{i}.linear1.weight" in sd:
+        xseq = encoder_layer(ops, sd, f"encoder.seqTransEncoder.layers.{i}", xseq, nhead, valid)
+        i += 1
+    mu, logvar = xseq[:, 0:1, :], xseq[:, 1:2, :]
+    latent = None if eps is None else mu + ops.sqrt(ops.exp(logvar)) * eps
+    return latent, mu, logvar
+
+
 def sample_action(ops, sd_den, sd_vae, actions, init_latents, lengths, guidance_scale=7.5, steps=50, nhead=4,
                   return_intermediates=False):
     """MLD.a2m_eval's sampling core (mld.py:710-735): cond = cat(zeros_like(actions), actions), reverse diffusion,

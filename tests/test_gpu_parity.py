@@ -595,3 +595,15 @@ def test_extreme_shapes_vs_oracle(dev, oracle_weights):
     with pytest.raises(_lib.MldHipError):
         _lib.Engine(device=0, max_frames=289)
     e.close()
+
+
+def test_actor_encode_vs_golden(aeng, dev, golden_dir):
+    """ActorVae.encode (actor_vae.py:64-76,121-175) vs the reference module's Normal(mu, std) on a ragged batch."""
+    g = _gold(golden_dir, "actor_encode_b3.npz")
+    lens = g["lengths"].tolist()
+    mu = torch.empty(3, 256, device=dev)
+    lv = torch.empty_like(mu)
+    aeng.vae_encode(_cuda(g["feats"], dev), lens, 60, None, None, mu, lv)
+    torch.cuda.synchronize()
+    assert np.abs(mu.cpu().numpy() - g["mu"]).max() < 1e-4
+    assert np.abs(np.sqrt(np.exp(lv.cpu().numpy())) - g["std"]).max() < 1e-4

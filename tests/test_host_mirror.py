@@ -183,6 +183,13 @@ def test_mld_forward_fused_and_modular_agree_with_oracle(sim_key):
     feats = model.vae.decode(z.contiguous(), lengths)
     j2 = model.feats2joints(feats)
     assert np.abs(j2.numpy() - jr).max() < 1e-4
+    # recon_from_motion (mld.py:277-288): encode -> decode -> joints, plus the joints of the reference motion
+    fr = torch.randn(2, 24, 263) * 0.3
+    fr[1, 17:] = 0
+    torch.manual_seed(3)
+    jr_rec, jr_ref = model.recon_from_motion({"motion": fr, "length": lengths})
+    assert [tuple(j.shape) for j in jr_rec] == [(24, 22, 3), (17, 22, 3)] and [tuple(j.shape) for j in jr_ref] == [(24, 22, 3), (17, 22, 3)]
+    assert np.abs(jr_ref[1].numpy() - O.feats2joints(ops, fr.numpy(), mean, std)[1, :17]).max() < 1e-4
     # checkpoint contract: denoiser.* / vae.* keys, text_encoder.* re-injected, t2m_* ignored (base.py:117-127)
     sd = {k: v for k, v in model.state_dict().items() if not k.startswith("text_encoder.")}
     sd["t2m_textencoder.fake"] = torch.zeros(1)
@@ -221,8 +228,6 @@ def test_action_state_dict_keys_match_the_reference_modules(golden_dir):
     assert isinstance(vae, HipActorVae)
     assert {k: list(v.shape) for k, v in den.state_dict().items()} == keys["denoiser_action"]
     assert {k: list(v.shape) for k, v in vae.state_dict().items()} == keys["actor_vae"]
-    with pytest.raises(NotImplementedError):
-        vae.encode(torch.zeros(1, 8, 150), [8])
 
 
 def test_action_mld_fused_and_modular_agree_with_oracle():
@@ -251,6 +256,16 @@ def test_action_mld_fused_and_modular_agree_with_oracle():
         assert np.abs(f2.numpy() - fr).max() < 1e-4
         with pytest.raises(NotImplementedError):
             model.feats2joints(f2)                                  # SMPL layout: out of scope, fails loudly
+        # ActorVae.encode through the drop-in: (latent [1,B,D], Normal(mu, std)) like the reference
+        fe = torch.randn(2, 16, 150)
+        fe[1, 9:] = 0
+        eps = torch.randn(2, 256)
+        latent, dist = model.vae.encode(fe, [16, 9], eps=eps)
+        lr, mr, lvr = O.actor_encode(ops, O.to_backend(ops, sdv), fe.numpy(), [16, 9], eps.numpy()[:, None, :])
+        assert latent.shape == (1, 2, 256) and isinstance(dist, torch.distributions.Normal) and dist.loc.shape == (2, 256)
+        assert np.abs(dist.loc.numpy() - mr[:, 0]).max() < 5e-5
+        assert np.abs(dist.scale.numpy() - np.sqrt(np.exp(lvr[:, 0]))).max() < 5e-5
+        assert np.abs(latent[0].numpy() - lr[:, 0]).max() < 1e-4
         # a text-variant module must refuse an action engine instead of mis-loading
         with pytest.raises(RuntimeError):
             C.instantiate_from_config(C.load_config().model.denoiser).use_engine(key)(

@@ -178,11 +178,12 @@ def aow():
 
 def test_action_required_keys_sim():
     e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=2, max_frames=16, **simlib.ACTION_CFG)
-    # denoiser: time MLP 4 + table 1 + pe 1 + 15 layers * 12 + 7 skip linears * 2 + norm 2; ActorVae decoder: pe + 6 * 18 + final 2; mean/std
-    assert len(e.missing_keys()) == (4 + 1 + 1 + 15 * 12 + 14 + 2) + (1 + 6 * 18 + 2) + 2
+    # denoiser: time MLP 4 + table 1 + pe 1 + 15 layers * 12 + 7 skip linears * 2 + norm 2; ActorVae decoder: pe + 6 * 18 + final 2;
+    # ActorVae encoder: 2 tokens + pe + skel_embedding 2 + 6 * 12; mean/std
+    assert len(e.missing_keys()) == (4 + 1 + 1 + 15 * 12 + 14 + 2) + (1 + 6 * 18 + 2) + (2 + 1 + 2 + 6 * 12) + 2
     ignored = simlib.load_action_weights(e, finalize=False)
     assert e.missing_keys() == ["mean", "std"]                 # optional group (no joints on this layout)
-    assert "denoiser.mem_pos.pe" in ignored and all(k == "denoiser.mem_pos.pe" or k.startswith("vae.encoder.") for k in ignored)
+    assert ignored == ["denoiser.mem_pos.pe"]
     e.finalize()
     with pytest.raises(_lib.MldHipError):                      # text entry point on an action engine
         e.sample(np.zeros((4, 1, 768), np.float32), np.zeros((2, 1, 256), np.float32), [8, 8], None, None, None)
@@ -388,3 +389,18 @@ def test_tile32_two_k_pieces_knob_is_exact_sim(monkeypatch, ow):
     jr, _, lr = O.sample(ops, bd, bv, b.text_emb, b.init_latents, b.lengths, mean, std, steps=2, return_intermediates=True)
     assert np.abs(lat - lr).max() < 5e-4 and np.abs(joints - jr).max() < 1e-4
     e.close()
+
+
+def test_actor_encode_sim(aeng, aow):
+    ops, _, bv = aow
+    g = syn._rng(9, "actor_feats_sim")
+    fe = g.standard_normal((3, 20, 150)).astype(np.float32)
+    lens = [20, 11, 3]
+    for i, n in enumerate(lens):
+        fe[i, n:] = 0
+    eps = g.standard_normal((3, 256)).astype(np.float32)
+    lat, mu, lv = (np.zeros((3, 256), np.float32) for _ in range(3))
+    aeng.vae_encode(fe, lens, 20, eps, lat, mu, lv)
+    lr, mr, lvr = O.actor_encode(ops, bv, fe, lens, eps[:, None, :])
+    assert np.abs(mu - mr[:, 0]).max() < 5e-5 and np.abs(lv - lvr[:, 0]).max() < 5e-5
+    assert np.abs(lat - lr[:, 0]).max() < 1e-4
