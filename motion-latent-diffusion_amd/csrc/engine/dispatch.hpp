@@ -1,0 +1,101 @@
+// Launch helpers: which GEMM tile / kernel instance a call maps to.
+// Part of libmldhip's single translation unit (included by ../mldhip.hip, in this order: state, params, dispatch,
+// path_latent, path_novae).  Internal linkage throughout (anonymous namespace) except the handle type itself.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------ launches
+
+struct Ctx {
+  E* e;
+  hipStream_t stream;
+  int rc = 0;
+};
+
+void count(Ctx& c) { c.e->launches[c.e->phase]++; }
+
+int check_launch(Ctx& c, const char* what) {
+#if !defined(MLDHIP_SIM)
+  hipError_t s = hipGetLastError();
+  if (s != hipSuccess && c.rc == 0) c.rc = c.e->fail(MLDHIP_EHIP, "launch %s: %s", what, hipGetErrorString(s));
+#endif
+  (void)what;
+  return c.rc;
+}
+
+// Tile configurations.  "small" targets the latency-bound denoiser (M = 6B rows): one 16x16 tile per
+// wave so a GEMM spreads over as many SIMDs as possible; "large" targets the MFMA-bound decoder.
+int g_small_m = 256;         // MLDHIP_SMALL_M: row count up to which the 16x64 one-tile-per-wave shape is used (tiny one-off GEMMs)
+bool g_gemm8 = true;         // MLDHIP_GEMM8=0: the 4-wave variants of the staged fp32 GEMM tiles (A/B runs)
+bool g_staged_gemm = true;   // MLDHIP_GEMM=direct selects the first-version register-direct main loop (A/B runs)
+
+// staged (LDS, prefetch ring) launch of one tile shape; K / 32 is a template parameter
+template <int WM, int WN, int MREP, int NREP, bool LN, int PREC>
+void launch_staged(Ctx& c, const GemmArgs& a, dim3 grid) {
+  const int kcs = (a.K1 + a.K2) / 32;
+  constexpr int lds = gemm_lds_bytes<WM, WN, MREP, NREP>();
+  if (c.e->trace_on) {   // measurement build of the same kernel (K = 256 shapes only)
+    GemmArgs t = a;
+    t.trace = c.e->trace_on;
+    if (kcs == 8) { MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 8, true>), grid, dim3(WM * WN * 64), lds, c.stream, t); }
+    else if (kcs == 32) { MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 32, true>), grid, dim3(WM * WN * 64), lds, c.stream, t); }
+    return;
+  }
+  switch (kcs) {
+    case 8: MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 8>), grid, dim3(WM * WN * 64), lds, c.stream, a); break;
+    case 12:   // K = 384: the 263-wide motion features padded to the chunk pipeline (pose_embd of the no-VAE denoiser)
+      if constexpr (!LN && PREC == 0) { MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 12>), grid, dim3(WM * WN * 64), lds, c.stream, a); }
+      else c.rc = c.e->fail(MLDHIP_EINVAL, "staged GEMM: K=384 is built for the plain fp32 tile only");
+      break;
+    case 16: MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 16>), grid, dim3(WM * WN * 64), lds, c.stream, a); break;
+    case 32: MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 32>), grid, dim3(WM * WN * 64), lds, c.stream, a); break;
+    default: c.rc = c.e->fail(MLDHIP_EINVAL, "staged GEMM: K=%d not in {256,384,512,1024}", a.K1 + a.K2);
+  }
+}
+void gemm(Ctx& c, const GemmArgs& a, int nz = 1) {
+  const int K = a.K1 + a.K2;
+  const bool small = a.M <= g_small_m || (K != 256 && K != 384 && K != 512 && K != 1024);
+  const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_DECODE && c.e->phase == 1 && K != 384;   // decoder GEMMs only
+  if (small) {
+    dim3 grid((a.M + 15) / 16, (a.N + 63) / 64, nz);
+    MLD_LAUNCH((gemm_kernel<1, 4, 1, 1, false>), grid, dim3(256), 0, c.stream, a);
+  } else if (!g_staged_gemm) {
+    dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);
+    MLD_LAUNCH((gemm_kernel<2, 2, 2, 4, false>), grid, dim3(256), 0, c.stream, a);
+  } else {
+    dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);
+    if (x3 && g_gemm8) launch_staged<2, 4, 2, 2, false, 1>(c, a, grid);
+    else if (x3) launch_staged<2, 2, 2, 4, false, 1>(c, a, grid);
+    else if (g_gemm8) launch_staged<2, 4, 2, 2, false, 0>(c, a, grid);   // same 64x128 tile on 8 waves (2 per SIMD)
+    else launch_staged<2, 2, 2, 4, false, 0>(c, a, grid);
+  }
+  count(c);
+  check_launch(c, "gemm");
+}
+
+void gemm_ln(Ctx& c, const GemmArgs& a) {   // N == 256; full rows per workgroup (32 x 256 tile)
+  dim3 grid((a.M + 31) / 32, 1, 1);
+  const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_DECODE && c.e->phase == 1;
+  if (!g_staged_gemm) {
+    MLD_LAUNCH((gemm_kernel<1, 4, 2, 4, true>), grid, dim3(256), 0, c.stream, a);
+  } else if (x3 && g_gemm8) {
+    launch_staged<2, 4, 2, 4, true, 1>(c, a, dim3((a.M + 63) / 64, 1, 1));
+  } else if (x3) {
+    launch_staged<1, 4, 2, 4, true, 1>(c, a, grid);
+  } else if (g_gemm8) {
+    launch_staged<2, 4, 2, 4, true, 0>(c, a, dim3((a.M + 63) / 64, 1, 1));   // 64 x 256 tile on 8 waves
+  } else {
+    launch_staged<1, 4, 2, 4, true, 0>(c, a, grid);
+  }
+  count(c);
+  check_launch(c, "gemm_ln");
+}
+
+GemmArgs lin_args(const float* A, int lda, int K, const float* W, const float* b, float* Y, int ldy, int M, int N) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.K1 = K; g.W = W; g.ldw = K; g.bias = b; g.Y = Y; g.ldy = ldy; g.M = M; g.N = N;
+  return g;
+}
+
+}  // namespace

@@ -1,0 +1,471 @@
+// Latent-diffusion paths (configs 1-3, 5): denoiser loop, VAE decode / encode, feats2joints, sample() enqueue.
+// Part of libmldhip's single translation unit (included by ../mldhip.hip, in this order: state, params, dispatch,
+// path_latent, path_novae).  Internal linkage throughout (anonymous namespace) except the handle type itself.
+#pragma once
+
+namespace {
+
+// ---- denoiser layer pipeline on the tile32 kernels (4 launches per encoder layer) ----------------
+constexpr int t32_lds_bytes(int mt, int kh = 1) { return (mt + 64) * (256 / kh + 4) * 4; }
+
+void tile32(Ctx& c, const Tile32Args& a_, int nz) {
+  Tile32Args a = a_;
+  a.trace = c.e->trace_on;
+  // 16-row K-split tiles for the narrow (N = 256) GEMMs: more workgroups, fewer bytes and MFMAs per CU
+  const bool mt16 = a.N <= 256 && ((a.M + 15) / 16) * ((a.N + 63) / 64) * nz <= 256 && c.e->tile16;
+  const int mt = mt16 ? 16 : 32;
+  dim3 grid((a.M + mt - 1) / mt, (a.N + 63) / 64, nz);
+  const int ns = a.src[0].attn_R > 0 ? 0 : a.src[0].nsplit;
+#define MLD_T32(MT, NS)                                                                                          \
+  do {                                                                                                           \
+    if (a.trace) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, true>), grid, dim3(512), t32_lds_bytes(MT), c.stream, a); }  \
+    else if (c.e->t32_kh == 2) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, 2>), grid, dim3(512), t32_lds_bytes(MT, 2), c.stream, a); } \
+    else { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false>), grid, dim3(512), t32_lds_bytes(MT), c.stream, a); }         \
+  } while (0)
+#define MLD_T32_NS(MT)                                                                                           \
+  switch (ns) {                                                                                                  \
+    case 0: MLD_T32(MT, 0); break;                                                                               \
+    case 1: MLD_T32(MT, 1); break;                                                                               \
+    case 2: MLD_T32(MT, 2); break;                                                                               \
+    case 4: MLD_T32(MT, 4); break;                                                                               \
+    case 8: MLD_T32(MT, 8); break;                                                                               \
+    default: c.rc = c.e->fail(MLDHIP_EINVAL, "tile32: unsupported slab count %d", ns); return;                   \
+  }
+  if (mt16) { MLD_T32_NS(16) } else { MLD_T32_NS(32) }
+#undef MLD_T32_NS
+#undef MLD_T32
+  count(c);
+  check_launch(c, "gemm_tile32");
+}
+
+ASrc plain_src(const float* base, int ld) {
+  ASrc s;
+  s.base = base; s.ld = ld;
+  return s;
+}
+ASrc combine_src(const float* slabs, int nsplit, long long pstride, const float* bias, const float* res,
+                 const float* gamma, const float* beta, float* out) {
+  ASrc s;
+  s.base = slabs; s.ld = 256; s.nsplit = nsplit; s.pstride = pstride; s.bias = bias; s.res = res; s.ldres = 256;
+  s.gamma = gamma; s.beta = beta; s.out = out; s.ldout = 256;
+  return s;
+}
+
+// One chain's slice of the denoiser workspace: rows [row0, row0 + 3R) of every row-indexed buffer.
+struct DenView {
+  float *X0, *QKV, *FF, *H1, *Ha, *Po, *Pf, *Ps, *S[8], *lat;
+  int R;            // samples in this chain's CFG batch (uncond half first)
+};
+
+DenView den_view(E* e, int row0, int b0, int R) {
+  DenView v;
+  const size_t D = e->cfg.latent_dim, F = e->cfg.ff_size, r0 = (size_t)row0;
+  v.X0 = e->X0 + r0 * D; v.QKV = e->QKV + r0 * 3 * D; v.FF = e->FF + r0 * F; v.H1 = e->H1 + r0 * D; v.Ha = e->Ha + r0 * D;
+  v.Po = e->Po + r0 * D; v.Pf = e->Pf + r0 * D; v.Ps = e->Ps + r0 * D;
+  for (int i = 0; i < 8; ++i) v.S[i] = e->S[i] ? e->S[i] + r0 * D : nullptr;
+  v.lat = e->lat + (size_t)b0 * D;
+  v.R = R;
+  return v;
+}
+long long den_slab(const E* e) { return (long long)6 * e->cfg.max_batch * 256; }
+
+// QKV projection; `x` describes how the layer input rows are obtained (and where they are written back).
+void den_qkv(Ctx& c, const DenView& v, const EncLayerP& L, const ASrc& x) {
+  Tile32Args a;
+  a.src[0] = x; a.nz0 = 1; a.W = L.in_w; a.ldw = 256; a.bias = L.in_b; a.Y = v.QKV; a.ldy = 768; a.M = 3 * v.R; a.N = 768;
+  tile32(c, a, 1);
+}
+// out-projection of the 3-token self-attention (computed while the A tile is assembled) -> raw slab Po
+void den_outproj(Ctx& c, const DenView& v, const EncLayerP& L) {
+  Tile32Args a;
+  a.src[0].base = v.QKV; a.src[0].attn_R = v.R;
+  a.nz0 = 1; a.W = L.out_w; a.ldw = 256; a.P = v.Po; a.pstride = 0; a.M = 3 * v.R; a.N = 256;
+  tile32(c, a, 1);
+}
+// h1 = LN1(x + out_proj) assembled on load (written to H1), FF = gelu(h1 W1^T + b1)
+void den_ffn1(Ctx& c, const DenView& v, const EncLayerP& L, const float* xn) {
+  const int F = c.e->cfg.ff_size;
+  Tile32Args a;
+  a.src[0] = combine_src(v.Po, 1, 0, L.out_b, xn, L.n1_w, L.n1_b, v.H1);
+  a.nz0 = 1; a.W = L.l1_w; a.ldw = 256; a.bias = L.l1_b; a.act = 1; a.Y = v.FF; a.ldy = F; a.M = 3 * v.R; a.N = F;
+  tile32(c, a, 1);
+}
+// FFN2 as ff_size/256 K-slices -> raw slabs Pf; bias, residual and norm2 are applied by whoever reads them
+void den_ffn2(Ctx& c, const DenView& v, const EncLayerP& L) {
+  const int F = c.e->cfg.ff_size;
+  Tile32Args a;
+  a.src[0] = plain_src(v.FF, F);
+  a.nz0 = F / 256; a.W = L.l2_w; a.ldw = F; a.P = v.Pf; a.pstride = den_slab(c.e); a.M = 3 * v.R; a.N = 256;
+  tile32(c, a, F / 256);
+}
+int den_ffn_slabs(const E* e) { return e->fused_ffn ? e->cfg.ff_size / kFfnHS : e->cfg.ff_size / 256; }
+ASrc den_layer_output(E* e, const DenView& v, const EncLayerP& L, float* write_back) {   // LN2(sum Pf + b2 + h1)
+  return combine_src(v.Pf, den_ffn_slabs(e), den_slab(e), L.l2_b, v.H1, L.n2_w, L.n2_b, write_back);
+}
+// linear1 + GELU + linear2 in one launch (kernels/fused_layer.hpp): h1 = LN1(x + out_proj) assembled on load (written
+// to H1), raw FFN2 partial slabs -> Pf[ff_size/128]
+void den_ffn_fused(Ctx& c, const DenView& v, const EncLayerP& L, const float* xn) {
+  FfnFusedArgs a;
+  a.src = combine_src(v.Po, 1, 0, L.out_b, xn, L.n1_w, L.n1_b, v.H1);
+  a.W1 = L.l1_w; a.b1 = L.l1_b; a.W2 = L.l2_w; a.P = v.Pf; a.pstride = den_slab(c.e); a.M = 3 * v.R; a.F = c.e->cfg.ff_size;
+  dim3 grid((a.M + 15) / 16, a.F / kFfnHS);
+  MLD_LAUNCH((den_ffn_fused_kernel<1>), grid, dim3(512), kFfnLdsBytes, c.stream, a);
+  count(c);
+  check_launch(c, "den_ffn_fused");
+}
+
+// SkipTransformerEncoder over the 3-token sequences (cross_attention.py:41-64).  Leaves the last layer's
+// FFN2 slabs in Pf and its norm1 output in H1; the caller applies norm2 + encoder.norm (FinalArgs).
+void denoiser_body(Ctx& c, const DenView& v) {
+  E* e = c.e;
+  const int nb = (e->cfg.num_layers - 1) / 2, L = e->cfg.num_layers;
+  ASrc x = plain_src(v.X0, 256);
+  const float* xn = v.X0;                  // where the (normalised) layer input lives, for the norm1 residual
+  for (int l = 0; l < L; ++l) {
+    const EncLayerP& P_ = e->den[l];
+    den_qkv(c, v, P_, x);
+    den_outproj(c, v, P_);
+    if (e->fused_ffn) {
+      den_ffn_fused(c, v, P_, xn);
+    } else {
+      den_ffn1(c, v, P_, xn);
+      den_ffn2(c, v, P_);
+    }
+    if (l + 1 == L) break;
+    if (l < nb) {
+      // next layer input = LN2(...), kept in S[l] for the skip connection (written by the next QKV prologue)
+      x = den_layer_output(e, v, P_, v.S[l]);
+      xn = v.S[l];
+    } else {
+      // Linear(cat[x, skip]) as two K slices (cross_attention.py:56-58): slice 0 assembles x = LN2(...) on load,
+      // slice 1 reads the stored skip activation; the sum + bias is assembled by the next QKV prologue.
+      const int i = l - nb;
+      Tile32Args a;
+      a.src[0] = den_layer_output(e, v, P_, nullptr);
+      a.src[1] = plain_src(v.S[nb - 1 - i], 256);
+      a.nz0 = 1;
+      a.W = P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".weight"); a.ldw = 512;
+      a.P = v.Ps; a.pstride = den_slab(e); a.M = 3 * v.R; a.N = 256;
+      tile32(c, a, 2);
+      x = combine_src(v.Ps, 2, den_slab(e), P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".bias"), nullptr, nullptr,
+                      nullptr, v.Ha);
+      xn = v.Ha;
+    }
+  }
+}
+
+FinalArgs den_final_args(E* e, const DenView& v) {
+  const EncLayerP& L = e->den.back();
+  FinalArgs f;
+  f.P = v.Pf; f.nsplit = den_ffn_slabs(e); f.pstride = den_slab(e);
+  f.b2 = L.l2_b; f.H1 = v.H1; f.g2 = L.n2_w; f.be2 = L.n2_b;
+  f.gf = P(e, "denoiser.encoder.norm.weight"); f.bef = P(e, "denoiser.encoder.norm.bias");
+  return f;
+}
+
+// emb_proj = Sequential(ReLU, Linear) (mld_denoiser.py:65-68) for `rows` text rows -> dst[rows][D]; the
+// bias already holds + pe[2] (token 2 of the sequence).
+void text_projection(Ctx& c, const float* text_emb, int rows, float* dst) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim, TD = e->cfg.text_dim;
+  GemmArgs g = lin_args(text_emb, TD, TD, P(e, "denoiser.emb_proj.1.weight"), e->text_bias, dst, D, rows, D);
+  g.relu_in = 1;
+  gemm(c, g);
+}
+
+// time-MLP rows for `n` timestep embeddings already in `temb0` -> out[n, D] (+pe[1] folded in the bias)
+void time_mlp(Ctx& c, const float* temb0, float* mid, float* out, int n) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim, TD = time_width(e);
+  GemmArgs a = lin_args(temb0, TD, TD, P(e, "denoiser.time_embedding.linear_1.weight"),
+                        P(e, "denoiser.time_embedding.linear_1.bias"), mid, D, n, D);
+  a.act = ACT_SILU;
+  gemm(c, a);
+  gemm(c, lin_args(mid, D, D, P(e, "denoiser.time_embedding.linear_2.weight"), e->time_b2pe, out, D, n, D));
+}
+
+// One decoder layer over M = B*T frame rows with memory = the sample's latent (cross_attention.py:323-345).
+int pick_nkt(int T) { return T <= 64 ? 4 : T <= 112 ? 7 : T <= 208 ? 13 : 18; }
+
+void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr) {
+  if (!lens) lens = c.e->lens_dev;
+  E* e = c.e;
+  const int H = e->cfg.num_heads;
+  const int nkt = pick_nkt(T);
+  const size_t shmem = (size_t)2 * nkt * 16 * 68 * sizeof(float);
+  dim3 grid(B * H), block(512);
+  switch (nkt) {
+    case 4: MLD_LAUNCH((attn_decode_kernel<4>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
+    case 7: MLD_LAUNCH((attn_decode_kernel<7>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
+    case 13: MLD_LAUNCH((attn_decode_kernel<13>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
+    default: MLD_LAUNCH((attn_decode_kernel<18>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
+  }
+  count(c);
+  check_launch(c, "attn_decode");
+}
+
+void dec_layer(Ctx& c, int l, const float* xin, float* xout, int B, int T) {
+  E* e = c.e;
+  const DecLayerP& L = e->dec[l];
+  const int D = e->cfg.latent_dim, F = e->cfg.ff_size, M = B * T;
+  gemm(c, lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
+  dec_attention(c, B, T);
+  // out-proj + residual + norm1, then the 1-key cross-attention (a per-sample vector) + norm2
+  GemmArgs o = lin_args(e->AO, D, D, L.out_w, L.out_b, e->H1, D, M, D);
+  o.res = xin; o.ldres = D; o.g1 = L.n1_w; o.b1 = L.n1_b;
+  o.cvec = e->cvec + (size_t)l * e->cfg.max_batch * D; o.ldcvec = D; o.rows_per_group = T;
+  o.g2 = L.n2_w; o.b2 = L.n2_b;
+  gemm_ln(c, o);
+  GemmArgs f1 = lin_args(e->H1, D, D, L.l1_w, L.l1_b, e->FF, F, M, F);
+  f1.act = ACT_GELU;
+  gemm(c, f1);
+  GemmArgs f2 = lin_args(e->FF, F, F, L.l2_w, L.l2_b, xout, D, M, D);
+  f2.res = e->H1; f2.ldres = D; f2.g1 = L.n3_w; f2.b1 = L.n3_b;
+  gemm_ln(c, f2);
+}
+
+void skip_linear(Ctx& c, const std::string& prefix, int i, const float* x, const float* skip, float* y, int M) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim;
+  GemmArgs g;
+  g.A = x; g.lda = D; g.K1 = D; g.A2 = skip; g.lda2 = D; g.K2 = D;
+  g.W = P(e, prefix + ".linear_blocks." + std::to_string(i) + ".weight"); g.ldw = 2 * D;
+  g.bias = P(e, prefix + ".linear_blocks." + std::to_string(i) + ".bias");
+  g.Y = y; g.ldy = D; g.M = M; g.N = D;
+  gemm(c, g);
+}
+
+// MldVae.decode (mld_vae.py:186-248).  z [B, D]; lens_dev already holds the lengths.
+void decode_body(Ctx& c, const float* z, int B, int T, float* feats_out) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim, NF = e->cfg.nfeats, nb = (e->cfg.num_layers - 1) / 2, M = B * T;
+  const int L = vae_layers(e);
+  // cross-attention with ONE memory token: softmax == 1, so the sub-layer adds
+  // out_proj(v_proj(z_b)) to every frame of sample b (exact).  All layers at once.
+  {
+    GemmArgs v = lin_args(z, D, D, e->dec[0].cin_w + (size_t)2 * D * D, e->dec[0].cin_b + 2 * D, e->cv1, D, B, D);
+    v.sW = (long long)e->dec_layer_stride; v.sBias = (long long)e->dec_layer_stride; v.sY = (long long)e->cfg.max_batch * D;
+    gemm(c, v, L);
+    GemmArgs o = lin_args(e->cv1, D, D, e->dec[0].cout_w, e->dec[0].cout_b, e->cvec, D, B, D);
+    o.sA = (long long)e->cfg.max_batch * D; o.sW = (long long)e->dec_layer_stride; o.sBias = (long long)e->dec_layer_stride;
+    o.sY = (long long)e->cfg.max_batch * D;
+    gemm(c, o, L);
+  }
+  {
+    // time queries = zeros + PE rows (learned: mld_vae.py:216-222; sinusoidal: actor_vae.py:221-222)
+    MLD_LAUNCH(init_queries_kernel, dim3(std::min(2048, (M * D / 4 + 255) / 256)), dim3(256), 0, c.stream, e->X0,
+               P(e, is_actor(e) ? "vae.decoder.sequence_pos_encoding.pe" : "vae.query_pos_decoder.pe"), B, T, D);
+    count(c);
+    check_launch(c, "init_queries");
+  }
+  if (is_actor(e)) {
+    // ActorAgnosticDecoder (actor_vae.py:224-235): plain stack, no skip links, no final LayerNorm
+    const float* xin = e->X0;
+    for (int l = 0; l < L; ++l) {
+      float* xout = (l & 1) ? e->Hb : e->Ha;
+      dec_layer(c, l, xin, xout, B, T);
+      xin = xout;
+    }
+    GemmArgs f = lin_args(xin, D, D, P(e, "vae.decoder.final_layer.weight"), P(e, "vae.decoder.final_layer.bias"), feats_out, NF, M, NF);
+    f.lens = e->lens_dev; f.rows_per_group = T;   // output[~mask.T] = 0 (actor_vae.py:231)
+    gemm(c, f);
+    return;
+  }
+  const float* x = e->X0;
+  for (int l = 0; l < nb; ++l) {
+    dec_layer(c, l, x, e->S[l], B, T);
+    x = e->S[l];
+  }
+  dec_layer(c, nb, x, e->Ha, B, T);
+  for (int i = 0; i < nb; ++i) {
+    skip_linear(c, "vae.decoder", i, e->Ha, e->S[nb - 1 - i], e->Hb, M);
+    dec_layer(c, nb + 1 + i, e->Hb, e->Ha, B, T);
+  }
+  MLD_LAUNCH(layernorm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, c.stream, (const float*)e->Ha, e->LNO,
+             P(e, "vae.decoder.norm.weight"), P(e, "vae.decoder.norm.bias"), M);
+  count(c);
+  check_launch(c, "layernorm_rows");
+  GemmArgs f = lin_args(e->LNO, D, D, P(e, "vae.final_layer.weight"), P(e, "vae.final_layer.bias"), feats_out, NF, M, NF);
+  f.lens = e->lens_dev; f.rows_per_group = T;   // output[~mask.T] = 0 (mld_vae.py:245)
+  gemm(c, f);
+}
+
+
+// One post-norm encoder layer over M = B*S token rows with a key-padding mask (cross_attention.py:259-272),
+// on the decoder's kernels: packed in-proj GEMM, masked MFMA attention, out-proj + res + norm1, FFN.
+void venc_layer(Ctx& c, const EncLayerP& L, const float* xin, float* xout, int B, int S) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim, F = e->cfg.ff_size, M = B * S;
+  gemm(c, lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
+  dec_attention(c, B, S, e->lens2_dev);
+  GemmArgs o = lin_args(e->AO, D, D, L.out_w, L.out_b, e->H1, D, M, D);
+  o.res = xin; o.ldres = D; o.g1 = L.n1_w; o.b1 = L.n1_b;
+  gemm_ln(c, o);
+  GemmArgs f1 = lin_args(e->H1, D, D, L.l1_w, L.l1_b, e->FF, F, M, F);
+  f1.act = ACT_GELU;
+  gemm(c, f1);
+  GemmArgs f2 = lin_args(e->FF, F, F, L.l2_w, L.l2_b, xout, D, M, D);
+  f2.res = e->H1; f2.ldres = D; f2.g1 = L.n2_w; f2.b1 = L.n2_b;
+  gemm_ln(c, f2);
+}
+
+// MldVae.encode (mld_vae.py:124-184): feats [B,T,nfeats] -> mu, logvar (and latent = mu + exp(logvar)^0.5 * eps).
+void encode_body(Ctx& c, const float* feats, int B, int T, const float* eps, float* latent, float* mu, float* logvar) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim, NF = e->cfg.nfeats, KP = (NF + 31) / 32 * 32, nb = (e->cfg.num_layers - 1) / 2;
+  const int S = T + 2, M = B * S;
+  // skel_embedding: K = 263 is padded to 288 so the MFMA K chunks stay full (zeros contribute nothing)
+  MLD_LAUNCH(pad_cols_kernel, dim3(std::min(4096, (B * T * KP + 255) / 256)), dim3(256), 0, c.stream, feats, e->FF, B * T, NF, KP);
+  count(c);
+  check_launch(c, "pad_cols");
+  const bool actor = is_actor(e);
+  {
+    GemmArgs g = lin_args(e->FF, KP, KP, e->WskelP, P(e, actor ? "vae.encoder.skel_embedding.bias" : "vae.skel_embedding.bias"), e->LNO, D,
+                          B * T, D);
+    gemm(c, g);
+  }
+  // [token 0, token 1, frames] + positional rows (MldVae: global_motion_token + learned PE, mld_vae.py:150-163;
+  // ActorVae: [mu_token, logvar_token] + sinusoidal PE, actor_vae.py:141-163)
+  MLD_LAUNCH(enc_tokens_kernel, dim3(std::min(4096, (M * D / 4 + 255) / 256)), dim3(256), 0, c.stream, (const float*)e->LNO,
+             P(e, actor ? "vae.encoder.mu_token" : "vae.global_motion_token"),
+             P(e, actor ? "vae.encoder.sequence_pos_encoding.pe" : "vae.query_pos_encoder.pe"), e->X0, B, T, D);
+  count(c);
+  check_launch(c, "enc_tokens");
+  if (actor) {
+    // ActorAgnosticEncoder (actor_vae.py:164-170): stock nn.TransformerEncoder, no skip links, NO final norm
+    const float* xin = e->X0;
+    for (int l = 0; l < (int)e->venc.size(); ++l) {
+      float* xout = (l & 1) ? e->Hb : e->Ha;
+      venc_layer(c, e->venc[l], xin, xout, B, S);
+      xin = xout;
+    }
+    MLD_LAUNCH(enc_finish_kernel, dim3(B), dim3(256), 0, c.stream, xin, (const float*)nullptr, (const float*)nullptr, eps, latent, mu,
+               logvar, S);
+    count(c);
+    check_launch(c, "enc_finish");
+    return;
+  }
+  const float* x = e->X0;
+  for (int l = 0; l < nb; ++l) {
+    venc_layer(c, e->venc[l], x, e->S[l], B, S);
+    x = e->S[l];
+  }
+  venc_layer(c, e->venc[nb], x, e->Ha, B, S);
+  for (int i = 0; i < nb; ++i) {
+    skip_linear(c, "vae.encoder", i, e->Ha, e->S[nb - 1 - i], e->Hb, M);
+    venc_layer(c, e->venc[nb + 1 + i], e->Hb, e->Ha, B, S);
+  }
+  MLD_LAUNCH(enc_finish_kernel, dim3(B), dim3(256), 0, c.stream, (const float*)e->Ha, P(e, "vae.encoder.norm.weight"),
+             P(e, "vae.encoder.norm.bias"), eps, latent, mu, logvar, S);
+  count(c);
+  check_launch(c, "enc_finish");
+}
+
+void joints_body(Ctx& c, const float* feats, int B, int T, float* joints) {
+  E* e = c.e;
+  if (T <= 256) {
+    MLD_LAUNCH((feats2joints_kernel<256>), dim3(B), dim3(256), 0, c.stream, feats, joints, P(e, "mean"), P(e, "std"), T,
+               e->cfg.nfeats, e->cfg.njoints);
+  } else {
+    MLD_LAUNCH((feats2joints_kernel<512>), dim3(B), dim3(256), 0, c.stream, feats, joints, P(e, "mean"), P(e, "std"), T,
+               e->cfg.nfeats, e->cfg.njoints);
+  }
+  count(c);
+  check_launch(c, "feats2joints");
+}
+
+// Everything mld.py:232-240,264 does after the text encoder.  The reverse loop is latency bound (a few
+// hundred rows per launch), and samples never interact, so the batch is cut into `nchains` sub-batches
+// whose 50-step chains run on parallel branches (side streams forked from / joined to `stream`; inside
+// a capture they become parallel branches of the hipGraph).  The MFMA-bound decode runs on the whole batch.
+// rows of token 2 for an action CFG batch of R rows -> dst[R][D] (labels already in labels_dev)
+void action_rows(Ctx& c, int R, int nuncond, float* dst) {
+  E* e = c.e;
+  MLD_LAUNCH(action_rows_kernel, dim3(R), dim3(256), 0, c.stream, dst, P(e, "denoiser.emb_proj.action_embedding"),
+             P(e, "denoiser.query_pos.pe") + 2 * e->cfg.latent_dim, (const int*)e->labels_dev, nuncond);
+  count(c);
+  check_launch(c, "action_rows");
+}
+
+// `text` == nullptr selects the action condition (labels_dev holds the 2B labels).
+int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* init_lat, int B, int T,
+                   float* lat_out, float* feats_out, float* joints_out) {
+  Ctx c{e, stream};
+  const int D = e->cfg.latent_dim, n = e->cfg.num_inference_steps;
+  // guidance_scale <= 1: the reference runs the conditional batch alone (mld.py:300,316-340); u + 1*(c-u) is that batch
+  const float guidance = e->cfg.guidance_scale > 1.0f ? e->cfg.guidance_scale : 1.0f;
+  e->launches[0] = e->launches[1] = e->launches[2] = 0;
+  e->phase = 0;
+  if (text) text_projection(c, text, 2 * B, e->TP);
+  else action_rows(c, 2 * B, B, e->TP);
+  int nch = std::min(e->nchains, B);
+  const int Bc = (B + nch - 1) / nch;
+  nch = (B + Bc - 1) / Bc;
+#if !defined(MLDHIP_SIM)
+  if (nch > 1) {
+    hipError_t s = hipEventRecord(e->ev_fork, stream);
+    for (int ch = 1; ch < nch && s == hipSuccess; ++ch) s = hipStreamWaitEvent(e->side[ch - 1], e->ev_fork, 0);
+    if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "fork: %s", hipGetErrorString(s));
+  }
+#endif
+  int rc = 0;
+  for (int ch = 0; ch < nch; ++ch) {
+    const int b0 = ch * Bc, bc = std::min(Bc, B - b0);
+#if !defined(MLDHIP_SIM)
+    Ctx cc{e, ch == 0 ? stream : e->side[ch - 1]};
+#else
+    Ctx cc{e, stream};
+#endif
+    const DenView v = den_view(e, 6 * b0, b0, 2 * bc);
+    MLD_LAUNCH(init_chain_kernel, dim3(bc), dim3(256), 0, cc.stream, init_lat + (size_t)b0 * D, v.lat, v.X0,
+               P(e, "denoiser.query_pos.pe"), (const float*)e->T1, (const float*)e->TP, B, b0, bc, 1.0f /* init_noise_sigma */);
+    count(cc);
+    check_launch(cc, "init_chain");
+    for (int s = 0; s < n && !cc.rc; ++s) {
+      denoiser_body(cc, v);
+      const float* t1n = (s + 1 < n) ? e->T1 + (size_t)(s + 1) * D : nullptr;
+      MLD_LAUNCH(den_final_step_kernel, dim3(bc), dim3(256), 0, cc.stream, den_final_args(e, v), v.lat, v.X0,
+                 P(e, "denoiser.query_pos.pe"), t1n, bc, guidance, ddim_coef(e, e->timesteps[s]));
+      count(cc);
+      check_launch(cc, "den_final_step");
+    }
+    if (cc.rc && !rc) rc = cc.rc;
+#if !defined(MLDHIP_SIM)
+    if (ch > 0) {   // join (also on error paths, so a capture can always be closed)
+      hipError_t s = hipEventRecord(e->ev_join[ch - 1], e->side[ch - 1]);
+      if (s == hipSuccess) s = hipStreamWaitEvent(stream, e->ev_join[ch - 1], 0);
+      if (s != hipSuccess && !rc) rc = e->fail(MLDHIP_EHIP, "join: %s", hipGetErrorString(s));
+    }
+#endif
+  }
+  if (rc) return rc;
+  if (lat_out) {
+    hipError_t s = hipMemcpyAsync(lat_out, e->lat, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream);
+    if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "latents copy: %s", hipGetErrorString(s));
+  }
+  if (feats_out || joints_out) {
+    e->phase = 1;
+    float* f = feats_out ? feats_out : e->feats_int;
+    decode_body(c, e->lat, B, T, f);
+    if (joints_out) {
+      e->phase = 2;
+      joints_body(c, f, B, T, joints_out);
+    }
+  }
+  return c.rc;
+}
+
+int validate_lengths(E* e, const int32_t* lengths, int B, int* Tmax) {
+  if (!lengths) return e->fail(MLDHIP_EINVAL, "lengths_host is NULL");
+  if (B < 1 || B > e->cfg.max_batch) return e->fail(MLDHIP_EINVAL, "batch %d outside [1, max_batch=%d]", B, e->cfg.max_batch);
+  int t = 0;
+  for (int i = 0; i < B; ++i) {
+    if (lengths[i] < 1 || lengths[i] > e->cfg.max_frames)
+      return e->fail(MLDHIP_EINVAL, "lengths[%d]=%d outside [1, max_frames=%d]", i, lengths[i], e->cfg.max_frames);
+    t = std::max(t, lengths[i]);
+  }
+  *Tmax = t;
+  return 0;
+}
+
+}  // namespace

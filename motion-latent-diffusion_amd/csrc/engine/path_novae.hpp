@@ -1,0 +1,123 @@
+// Diffusion-only path (config 4): trans_dec denoiser on raw motion + DDPM.
+// Part of libmldhip's single translation unit (included by ../mldhip.hip, in this order: state, params, dispatch,
+// path_latent, path_novae).  Internal linkage throughout (anonymous namespace) except the handle type itself.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// Diffusion-only variant (BASELINE config 4): trans_dec denoiser on raw motion, d = 512 (kernels/novae.hpp).
+// Row layout: sample-major rows r*T + t of the CFG batch (r < R = 2B), 512 floats per row.
+void novae_ln(Ctx& c, const float* x, const float* res, const float* g, const float* b, float* y, int M) {
+  MLD_LAUNCH((add_layernorm_rows_kernel<512>), dim3((M + 3) / 4), dim3(256), 0, c.stream, x, res, g, b, y, M);
+  count(c);
+  check_launch(c, "add_layernorm_rows");
+}
+
+void novae_self_attention(Ctx& c, int R, int T) {
+  E* e = c.e;
+  const int H = e->cfg.num_heads, nkt = pick_nkt(T), nqt = (T + 15) / 16;
+  const size_t shmem = (size_t)nkt * 16 * 132 * sizeof(float);
+  dim3 grid(R * H, (nqt + 7) / 8), block(512);
+  const int* nolens = nullptr;    // the reference passes no key-padding mask to the trans_dec denoiser (mld_denoiser.py:215)
+  switch (nkt) {
+    case 4: MLD_LAUNCH((attn_seq_kernel<4, 128>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
+    case 7: MLD_LAUNCH((attn_seq_kernel<7, 128>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
+    case 13: MLD_LAUNCH((attn_seq_kernel<13, 128>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
+    default: MLD_LAUNCH((attn_seq_kernel<18, 128>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
+  }
+  count(c);
+  check_launch(c, "attn_seq");
+}
+
+// K|V of the memory tokens for all layers at once (blockIdx.z = layer): dst[l][rows][2D] = src · Wkv_l^T + bkv_l
+void novae_memory_kv(Ctx& c, const float* src, int rows, float* dst, long long dst_layer_stride) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim;
+  GemmArgs g = lin_args(src, D, D, e->ndec[0].cin_w + (size_t)D * D, e->ndec[0].cin_b + D, dst, 2 * D, rows, 2 * D);
+  g.sW = (long long)e->ndec_layer_stride; g.sBias = (long long)e->ndec_layer_stride; g.sY = dst_layer_stride;
+  gemm(c, g, e->cfg.num_layers);
+}
+
+// MldDenoiser.forward, trans_dec branch, for the M = R*T rows whose zero-padded features are in e->FF [M][KP].
+// tkv: K|V of the time token, layer l at tkv + l*tkv_stride; text-token K|V in e->XKV [L][2*max_batch][2D].
+void novae_denoiser_body(Ctx& c, int R, int T, const float* tkv, long long tkv_stride, float* eps_out) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim, F = e->cfg.ff_size, NF = e->cfg.nfeats, KP = novae_kp(e), M = R * T;
+  gemm(c, lin_args(e->FF, KP, KP, e->WskelP, P(e, "denoiser.pose_embd.bias"), e->X0, D, M, D));
+  MLD_LAUNCH(add_pe_mod_kernel, dim3(std::min(4096, (M * (D / 4) + 255) / 256)), dim3(256), 0, c.stream, e->X0,
+             P(e, "denoiser.query_pos.pe"), (long long)M, T, D);
+  count(c);
+  check_launch(c, "add_pe_mod");
+  for (int l = 0; l < e->cfg.num_layers && !c.rc; ++l) {
+    const DecLayerP& L = e->ndec[l];
+    gemm(c, lin_args(e->X0, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
+    novae_self_attention(c, R, T);
+    gemm(c, lin_args(e->AO, D, D, L.out_w, L.out_b, e->Ha, D, M, D));
+    novae_ln(c, e->Ha, e->X0, L.n1_w, L.n1_b, e->H1, M);
+    gemm(c, lin_args(e->H1, D, D, L.cin_w, L.cin_b, e->Hb, D, M, D));                    // cross-attention queries
+    MLD_LAUNCH((cross2_kernel<512, 128>), dim3((M + 3) / 4), dim3(256), 0, c.stream, (const float*)e->Hb, tkv + (size_t)l * tkv_stride,
+               (const float*)(e->XKV + (size_t)l * 2 * e->cfg.max_batch * 2 * D), e->AO, M, T);
+    count(c);
+    check_launch(c, "cross2");
+    gemm(c, lin_args(e->AO, D, D, L.cout_w, L.cout_b, e->Ha, D, M, D));
+    novae_ln(c, e->Ha, e->H1, L.n2_w, L.n2_b, e->X0, M);
+    GemmArgs f1 = lin_args(e->X0, D, D, L.l1_w, L.l1_b, e->FF, F, M, F);
+    f1.act = ACT_GELU;
+    gemm(c, f1);
+    gemm(c, lin_args(e->FF, F, F, L.l2_w, L.l2_b, e->Ha, D, M, D));
+    novae_ln(c, e->Ha, e->X0, L.n3_w, L.n3_b, e->X0, M);       // in place: a wave reads its whole row before writing it
+  }
+  novae_ln(c, e->X0, nullptr, P(e, "denoiser.decoder.norm.weight"), P(e, "denoiser.decoder.norm.bias"), e->H1, M);
+  GemmArgs f = lin_args(e->H1, D, D, P(e, "denoiser.pose_proj.weight"), P(e, "denoiser.pose_proj.bias"), eps_out, NF, M, NF);
+  f.lens = e->lens_dev; f.rows_per_group = T;                   // sample[~mask.T] = 0 (mld_denoiser.py:219-221)
+  gemm(c, f);
+}
+
+void novae_pad_input(Ctx& c, const float* x, long long rows, int dup) {
+  E* e = c.e;
+  const int KP = novae_kp(e);
+  MLD_LAUNCH(dup_pad_rows_kernel, dim3((unsigned)std::min<long long>(8192, (rows * KP + 255) / 256)), dim3(256), 0, c.stream, x, e->FF, rows,
+             e->cfg.nfeats, KP, dup);
+  count(c);
+  check_launch(c, "dup_pad_rows");
+}
+
+// text token of the memory: emb_proj(text) + mem_pos.pe[1] -> TP [rows][D], then its K|V for every layer -> XKV
+void novae_text_memory(Ctx& c, const float* text, int rows) {
+  E* e = c.e;
+  text_projection(c, text, rows, e->TP);
+  novae_memory_kv(c, e->TP, rows, e->XKV, (long long)2 * e->cfg.max_batch * 2 * e->cfg.latent_dim);
+}
+
+// MLD.forward after the text encoder with vae_type 'no' (mld.py:232-242,264,290-360).  lens_dev holds lengths ++ lengths.
+int enqueue_sample_novae(E* e, hipStream_t stream, const float* text, const float* init_lat, int B, int T, const float* step_noise,
+                         unsigned long long seed, float* feats_out, float* joints_out) {
+  Ctx c{e, stream};
+  const int D = e->cfg.latent_dim, NF = e->cfg.nfeats, n = e->cfg.num_inference_steps;
+  const long long nel = (long long)B * T * NF;
+  const float guidance = e->cfg.guidance_scale > 1.0f ? e->cfg.guidance_scale : 1.0f;
+  e->launches[0] = e->launches[1] = e->launches[2] = 0;
+  e->phase = 0;
+  HIP_TRY(e, hipMemcpyAsync(e->lat, init_lat, nel * sizeof(float), hipMemcpyDeviceToDevice, stream));   // init_noise_sigma = 1
+  novae_text_memory(c, text, 2 * B);
+  for (int s = 0; s < n && !c.rc; ++s) {
+    novae_pad_input(c, e->lat, (long long)B * T, 2);                                      // torch.cat([latents] * 2)
+    novae_denoiser_body(c, 2 * B, T, e->TKV + (size_t)s * 2 * D, (long long)n * 2 * D, e->feats_int);
+    MLD_LAUNCH(cfg_ddpm_step_kernel, dim3((unsigned)std::min<long long>(4096, (nel / 4 + 255) / 256)), dim3(256), 0, stream,
+               (const float*)e->feats_int, (const float*)(e->feats_int + nel), (const float*)e->lat,
+               step_noise ? step_noise + (size_t)s * nel : (const float*)nullptr, e->lat, nel, guidance,
+               ddpm_coef(e, e->timesteps[s]), seed, (unsigned)s);
+    count(c);
+    check_launch(c, "cfg_ddpm_step");
+  }
+  if (c.rc) return c.rc;
+  if (feats_out) HIP_TRY(e, hipMemcpyAsync(feats_out, e->lat, nel * sizeof(float), hipMemcpyDeviceToDevice, stream));   // "decode" = identity (mld.py:241-242)
+  if (joints_out) {
+    e->phase = 2;
+    joints_body(c, e->lat, B, T, joints_out);
+  }
+  return c.rc;
+}
+
+}  // namespace

@@ -1,0 +1,121 @@
+// Engine state: parameter table entries, per-layer weight views, workspace contexts, the handle struct.
+// Part of libmldhip's single translation unit (included by ../mldhip.hip, in this order: state, params, dispatch,
+// path_latent, path_novae).  Internal linkage throughout (anonymous namespace) except the handle type itself.
+#pragma once
+
+namespace {
+
+std::string g_last_error;   // for failures before a handle exists
+
+struct Param {
+  std::string key;
+  std::vector<int64_t> shape;
+  size_t offset = 0;   // floats into the arena
+  size_t numel = 0;
+  bool loaded = false;
+  int group = 0;       // 0 denoiser, 1 vae decoder, 2 dataset statistics
+};
+
+struct EncLayerP {   // TransformerEncoderLayer (cross_attention.py:236-272)
+  const float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
+};
+struct DecLayerP {   // TransformerDecoderLayer (cross_attention.py:297-345)
+  const float *in_w, *in_b, *out_w, *out_b;
+  const float *cin_w, *cin_b, *cout_w, *cout_b;   // multihead_attn (only the V rows + out_proj are read)
+  const float *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b, *n3_w, *n3_b;
+};
+
+// A captured sample() is independent of the caller's buffers: inputs are copied into engine-owned staging before
+// the replay and outputs copied out after it (<= 17 MB of D2D copies, ~0.1 % of a batch), so a caller that allocates
+// fresh output tensors on every call (as MLD.forward does) replays instead of re-capturing ~2 000 nodes.
+struct GraphKey {
+  int B, T;
+  bool feats, joints;
+  bool operator<(const GraphKey& o) const { return std::tie(B, T, feats, joints) < std::tie(o.B, o.T, o.feats, o.joints); }
+};
+
+}  // namespace
+
+// One activation workspace.  cfg.max_in_flight of them share the weight arena: consecutive calls rotate through them,
+// so calls issued on different streams overlap on the GPU (the reverse loop of one batch leaves most CUs idle most of
+// the time: 1.6-1.8x throughput with 2-3 batches in flight, DESIGN.md §3 point 11).  A context is reused only after
+// the stream of its new call has waited on the event recorded at the end of its previous call.
+struct WsContext {
+  float* ws = nullptr;
+  int32_t *lens = nullptr, *lens2 = nullptr, *labels = nullptr;
+  bool used = false;
+#if !defined(MLDHIP_SIM)
+  hipEvent_t done = nullptr;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+#endif
+};
+
+struct mldhip_engine {
+  mldhip_config cfg;
+  int device = 0;
+  std::string err;
+  bool finalized = false;
+  bool group_ready[4] = {false, false, false, false};   // denoiser, vae decoder, mean/std, vae encoder
+
+  // ---- parameters
+  std::vector<Param> params;
+  std::map<std::string, int> index;
+  float* arena = nullptr;
+  size_t arena_floats = 0;
+  std::vector<EncLayerP> den;      // execution order
+  std::vector<DecLayerP> dec;
+  std::vector<EncLayerP> venc;     // VAE encoder layers (same layer type as the denoiser's)
+  std::vector<DecLayerP> ndec;     // no-VAE variant: denoiser.decoder.layers.* (TransformerDecoder, cross_attention.py:195-233)
+  size_t ndec_layer_stride = 0;
+  float *TKV = nullptr, *XKV = nullptr, *TKV_one = nullptr;   // memory-token K|V per layer: time [L][n][2D], text [L][2*max_batch][2D]
+  size_t dec_layer_stride = 0;     // floats between consecutive decoder layers' tensors
+
+  // ---- schedule
+  std::vector<int32_t> timesteps;
+  std::vector<float> alphas_cumprod, betas;
+  float final_alpha_cumprod = 1.f;
+
+  // ---- workspace (the pointers below are those of the currently bound context)
+  std::vector<WsContext> ctxs;
+  std::vector<std::pair<float**, size_t>> carve;   // (member pointer, offset in floats) of every workspace buffer
+  int cur_ctx = 0;
+  unsigned next_ctx = 0;
+  size_t ws_floats = 0;
+  int32_t* lens_dev = nullptr;
+  // denoiser
+  float *X0, *Ha, *Hb, *H1, *S[8], *QKV, *AO, *FF, *lat, *T1, *temb0, *tmid, *text_bias, *t1_one, *temb0_one, *time_b2pe;
+  // decode
+  float *cv1, *cvec, *LNO, *feats_int, *joints_int, *zbuf;
+  float *Po, *Pf, *Ps;   // denoiser split-K slabs: out-proj [1], FFN2 [4], skip-linear [2], each [6*max_batch][256]
+  unsigned long long* trace_buf = nullptr;   // measurement only (mldhip_profile_trace)
+  unsigned long long* trace_on = nullptr;    // non-null while a traced launch is being built
+  float* WskelP = nullptr;   // skel_embedding.weight padded to [D][KP]
+  int32_t* labels_dev = nullptr; // action labels of the CFG batch [2*max_batch] (uncond half first, ignored there)
+  int32_t* lens2_dev = nullptr;  // lengths + 2 (encoder key-padding mask incl. the two distribution tokens)
+  std::vector<int32_t> lens2_host;
+  float *text_in = nullptr, *lat_in = nullptr;   // graph staging of the caller's inputs
+  float* TP;             // text projection rows [2*max_batch][256] (+pe[2]), gathered per chain
+  bool fused_ffn = false; // MLDHIP_FUSED_FFN=1: linear1+GELU+linear2 in one launch (measured slower: DESIGN.md §3 point 9)
+  int t32_kh = 1;        // MLDHIP_T32_KH=2: tile32 kernels pass K through LDS in two pieces (two workgroups per CU)
+  bool tile16 = true;    // MLDHIP_TILE16=0 disables the 16-row K-split tiles (A/B runs)
+  int nchains = 1;       // independent sub-batch chains of the reverse loop (parallel graph branches)
+
+  int launches[3] = {0, 0, 0};
+  int phase = 0;
+
+#if !defined(MLDHIP_SIM)
+  hipStream_t cap_stream = nullptr;
+  hipStream_t side[7] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[7] = {};
+#endif
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+};
