@@ -120,6 +120,31 @@ def bench_a2m(local, dev, stream, warmup, steps, B=256, T=60, nfl=2):
     return out
 
 
+def bench_text_encoder(dev, n_texts=2 * BATCH, iters=10):
+    """the frozen CLIP ViT-L/14 text tower is OUTSIDE the measured path (it stays on PyTorch-ROCm); this
+    times a random-init tower of the same architecture (123.7 M parameters; no weights or tokenizer reachable offline) on the
+    2B = 128 prompts of one bs-64 CFG batch, so the metric can also be read with text encoding included."""
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    cfg = CLIPTextConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12, projection_dim=768,
+                         vocab_size=49408, max_position_embeddings=77)
+    model = CLIPTextModelWithProjection(cfg).eval().to(dev)
+    ids = torch.randint(0, 49407, (n_texts, 77), device=dev)
+    ids[:, -1] = 49407                                      # the EOS id the pooled output is read at
+    with torch.no_grad():
+        for _ in range(3):
+            model(input_ids=ids)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            model(input_ids=ids)
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    del model
+    torch.cuda.empty_cache()
+    return {"ms_per_128_prompts": round(ms, 3), "dtype": "f32", "weights": "random init (architecture of openai/clip-vit-large-patch14 text tower)",
+            "backend": "PyTorch-ROCm (not part of libmldhip)"}
+
+
 def bench_novae(local, dev, stream, B=64, T=196, steps=1000):
     """BASELINE config 4 shape (config_novae_humanml3d.yaml: raw-motion diffusion, trans_dec denoiser d=512, DDPM x1000,
     bs=64, T=196): ONE full 1000-step batch, timed like the headline (a secondary line, never `value`).  MFMA-bound:
@@ -163,6 +188,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MLD_BENCH_IN_FLIGHT", "4")),
                     help="bs-64 batches in flight per GPU: consecutive steps rotate over this many HIP streams / engine workspaces")
     ap.add_argument("--no-a2m", action="store_true", help="skip the secondary action-to-motion (config 5) measurement")
+    ap.add_argument("--no-clip", action="store_true", help="skip timing a random-init CLIP text tower on PyTorch-ROCm (reported beside the metric)")
     ap.add_argument("--no-novae", action="store_true", help="skip the secondary diffusion-only (config 4, 1000-step DDPM) measurement")
     ap.add_argument("--precision", choices=["f32", "bf16x3_decode"], default=os.environ.get("MLD_BENCH_PRECISION", "f32"),
                     help="f32: exact-fp32 MFMA everywhere; bf16x3_decode: split-bf16 MFMA in the VAE-decoder GEMMs")
@@ -315,10 +341,33 @@ def main():
                 alt["max_abs_joints_vs_oracle"] = float(np.abs(j2.cpu().numpy() - cj).max())
             out["alt_mode"] = alt
             eng2.close()
+        if world == 1 and not a.eager:
+            # also a realistic length mix -- uniform in {40, 44, ..., 196}, seed 1234 (same Tmax, ragged masks)
+            rng = np.random.Generator(np.random.PCG64(1234))
+            mix = [[int(v) for v in rng.choice(np.arange(40, 197, 4), BATCH)] for _ in range(nfl)]
+            for ln in mix:
+                ln[0] = FRAMES                                  # keep Tmax = 196 so buffers / graphs are the same
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                s_ = slots[i % nfl]
+                eng.sample(s_["text"], s_["lat0"], mix[i % nfl], s_["lat"], s_["feats"], s_["joints"], s_["stream"].cuda_stream)
+            torch.cuda.synchronize()
+            dtm = time.perf_counter() - t0
+            out["length_mix"] = {"value": round(BATCH * a.steps / dtm, 2), "unit": "motions/s", "ms_per_step": round(dtm / a.steps * 1e3, 4),
+                                 "lengths": "uniform in {40..196 step 4}, seed 1234, Tmax 196; mean %.1f frames" % float(np.mean(mix))}
         if world == 1 and not a.eager and not a.no_a2m:
             out["other_workloads"] = [bench_a2m(local, dev, stream, max(2, a.warmup), max(3, a.steps // 2))]
             if not a.no_novae:
                 out["other_workloads"].append(bench_novae(local, dev, stream))
+        if world == 1 and not a.no_clip:
+            try:
+                te = bench_text_encoder(dev)
+                te["single_stream_motions_per_s_incl_text"] = round(BATCH / (out["single_stream"]["ms_per_step"] + te["ms_per_128_prompts"]) * 1e3, 1)
+                te["note"] = "text encoding of a batch can overlap the sampling of the batches already in flight; this is the strictly serial view"
+                out["text_encoder"] = te
+            except Exception as ex:  # transformers missing / API drift: report, never fail the bench
+                out["text_encoder"] = {"error": repr(ex)[:200]}
         print(json.dumps(out))
     if dist:
         dist.barrier()

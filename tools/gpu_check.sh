@@ -17,7 +17,7 @@ echo "== rocprofv3" | tee -a gpurun_out/check_${TAG}.log
 # overlap and each one's wall duration is longer; the secondary workloads reuse the same kernels at other shapes).
 prof() {  # $1 = suffix, rest = bench flags
   local sfx=$1; shift
-  cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${sfx} -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-a2m --no-novae "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${sfx}.log 2>&1
+  cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${sfx} -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-a2m --no-novae --no-clip "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${sfx}.log 2>&1
   cd $GRAFT_REPO_ROOT
   find gpurun_out/prof_${TAG}_${sfx} -name "*kernel_trace*.csv" -size +20M -delete
 }
