@@ -208,23 +208,24 @@ void dec_layer(Ctx& c, int l, const float* xin, float* xout, int B, int T) {
   E* e = c.e;
   const DecLayerP& L = e->dec[l];
   const int D = e->cfg.latent_dim, F = e->cfg.ff_size, M = B * T;
-  gemm(c, lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
+  auto ragged = [&](GemmArgs g) { g.skip_lens = e->lens_dev; g.skip_rpg = T; return g; };   // skip all-padding row tiles
+  gemm(c, ragged(lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D)));
   dec_attention(c, B, T);
   // out-proj + residual + norm1, then the 1-key cross-attention (a per-sample vector) + norm2
   GemmArgs o = lin_args(e->AO, D, D, L.out_w, L.out_b, e->H1, D, M, D);
   o.res = xin; o.ldres = D; o.g1 = L.n1_w; o.b1 = L.n1_b;
   o.cvec = e->cvec + (size_t)l * e->cfg.max_batch * D; o.ldcvec = D; o.rows_per_group = T;
   o.g2 = L.n2_w; o.b2 = L.n2_b;
-  gemm_ln(c, o);
+  gemm_ln(c, ragged(o));
   GemmArgs f1 = lin_args(e->H1, D, D, L.l1_w, L.l1_b, e->FF, F, M, F);
   f1.act = ACT_GELU;
-  gemm(c, f1);
+  gemm(c, ragged(f1));
   GemmArgs f2 = lin_args(e->FF, F, F, L.l2_w, L.l2_b, xout, D, M, D);
   f2.res = e->H1; f2.ldres = D; f2.g1 = L.n3_w; f2.b1 = L.n3_b;
-  gemm_ln(c, f2);
+  gemm_ln(c, ragged(f2));
 }
 
-void skip_linear(Ctx& c, const std::string& prefix, int i, const float* x, const float* skip, float* y, int M) {
+void skip_linear(Ctx& c, const std::string& prefix, int i, const float* x, const float* skip, float* y, int M, int ragged_T = 0) {
   E* e = c.e;
   const int D = e->cfg.latent_dim;
   GemmArgs g;
@@ -232,6 +233,7 @@ void skip_linear(Ctx& c, const std::string& prefix, int i, const float* x, const
   g.W = P(e, prefix + ".linear_blocks." + std::to_string(i) + ".weight"); g.ldw = 2 * D;
   g.bias = P(e, prefix + ".linear_blocks." + std::to_string(i) + ".bias");
   g.Y = y; g.ldy = D; g.M = M; g.N = D;
+  if (ragged_T > 0) { g.skip_lens = e->lens_dev; g.skip_rpg = ragged_T; }   // decoder: skip all-padding row tiles
   gemm(c, g);
 }
 
@@ -278,7 +280,7 @@ void decode_body(Ctx& c, const float* z, int B, int T, float* feats_out) {
   }
   dec_layer(c, nb, x, e->Ha, B, T);
   for (int i = 0; i < nb; ++i) {
-    skip_linear(c, "vae.decoder", i, e->Ha, e->S[nb - 1 - i], e->Hb, M);
+    skip_linear(c, "vae.decoder", i, e->Ha, e->S[nb - 1 - i], e->Hb, M, T);
     dec_layer(c, nb + 1 + i, e->Hb, e->Ha, B, T);
   }
   MLD_LAUNCH(layernorm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, c.stream, (const float*)e->Ha, e->LNO,

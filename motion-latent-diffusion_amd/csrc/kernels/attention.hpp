@@ -43,7 +43,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* __res
   const int r = lane & 15, g = lane >> 4;
   const int len = lens[b] < T ? lens[b] : T;
   const int nkt = (len + 15) >> 4;          // key tiles that contain at least one valid key
-  const int nqt = (T + 15) >> 4;            // query tiles (padded queries are computed, as the reference does)
+  const int nqt = (len + 15) >> 4;          // query tiles: queries at padded frames are not computed (their rows are
+                                            // never read by a valid row and the final layer zeroes them)
   float* Ks = smem;
   float* Vs = smem + (size_t)NKT * 16 * LDS_STRIDE;
 

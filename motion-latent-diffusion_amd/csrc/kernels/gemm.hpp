@@ -33,6 +33,7 @@ struct GemmArgs {
   int relu_in = 0;                                       // ReLU on A while loading (mld_denoiser.py:65-68)
   int act = ACT_NONE;
   const int* lens = nullptr; int rows_per_group = 1;     // zero rows with (row % rpg) >= lens[row / rpg]
+  const int* skip_lens = nullptr; int skip_rpg = 1;      // skip row tiles made only of rows (row % rpg) >= skip_lens[row / rpg]
   long long sA = 0, sW = 0, sBias = 0, sY = 0;           // blockIdx.z strides (elements)
   // LayerNorm epilogue (N must equal the block's BN)
   const float* res = nullptr; int ldres = 0;
@@ -121,6 +122,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   const int KC = K / 32;
   const bool relu = p.relu_in != 0;
 
+  if (p.skip_lens) {
+    // Padded frames of a ragged batch: their rows never reach a valid row (attention masks them as keys, everything else
+    // is row-wise) and the final layer zeroes them, so a tile made only of such rows is not computed at all.  Uniform exit.
+    const int t0 = blockIdx.x * BM, t1 = (t0 + BM < p.M ? t0 + BM : p.M) - 1;
+    bool all_padding = true;
+    for (int b = t0 / p.skip_rpg; b <= t1 / p.skip_rpg; ++b) {
+      const int first = (t0 > b * p.skip_rpg ? t0 : b * p.skip_rpg) - b * p.skip_rpg;
+      if (first < p.skip_lens[b]) { all_padding = false; break; }
+    }
+    if (all_padding) return;
+  }
   unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, rt0 = 0;
   if constexpr (TRACE) { rt0 = realtime_100mhz(); ts[0] = clock_pinned(); }
   f32x4 acc[MREP][NREP];
