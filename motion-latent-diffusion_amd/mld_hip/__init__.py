@@ -6,4 +6,4 @@ See DESIGN.md / INTEGRATION.md at the repository root.
 """
 from . import synthetic  # noqa: F401  (pure numpy; safe to import anywhere)
 
-__all__ = ["synthetic", "config", "engine", "denoiser", "vae", "scheduler", "mld", "text_encoder", "datamodule", "dp"]
+__all__ = ["synthetic", "config", "engine", "denoiser", "vae", "scheduler", "mld", "text_encoder", "datamodule", "dp", "checkpoint", "demo"]

@@ -7,7 +7,7 @@ Variants: "text" = config_mld_humanml3d (MldDenoiser text condition + MldVae), "
 when constructed and verify them against the live engine before every use (``check_arch``)."""
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict
 
 from . import _lib
 

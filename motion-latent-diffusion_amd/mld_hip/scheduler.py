@@ -9,7 +9,6 @@ coefficients are computed inside libmldhip and applied by the step-final kernel.
 """
 from __future__ import annotations
 
-import math
 from types import SimpleNamespace
 
 import numpy as np

@@ -48,7 +48,7 @@ Two array backends share the code: ``NumpyOps`` (float32 or float64; the checker
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 
