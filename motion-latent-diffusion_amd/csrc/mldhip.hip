@@ -209,6 +209,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
 void mldhip_destroy(mldhip_handle* e) {
   if (!e) return;
 #if !defined(MLDHIP_SIM)
+  (void)hipDeviceSynchronize();      // calls may still be in flight on other streams; their buffers are freed below
   for (auto& x : e->ctxs) {
     for (auto& kv : x.graphs) (void)hipGraphExecDestroy(kv.second);
     if (x.done) (void)hipEventDestroy(x.done);
