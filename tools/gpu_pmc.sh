@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 TAG=${1:-pmc}
 for C in FETCH_SIZE WRITE_SIZE; do
-  cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$C -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$C.log 2>&1
+  cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$C -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-a2m --no-novae --no-clip --in-flight 1 > $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$C.log 2>&1
   cd $GRAFT_REPO_ROOT
   ls gpurun_out/pmc_${TAG}_$C | head
 done
