@@ -26,14 +26,14 @@ class HipMldDenoiser(HipModule):
         abl = ablation if isinstance(ablation, dict) else vars(ablation) if not hasattr(ablation, "get") else ablation
         get = (lambda k, d=None: abl.get(k, d)) if hasattr(abl, "get") else (lambda k, d=None: getattr(ablation, k, d))
         unsupported = []
-        if condition not in ("text", "action"):
-            unsupported.append(f"condition={condition!r} (text_uncond is a training-only ablation)")
+        if condition not in ("text", "text_uncond", "action"):
+            unsupported.append(f"condition={condition!r} (the reference knows text, text_uncond, action; mld_denoiser.py:57-79)")
         novae = get("VAE_TYPE", "mld") == "no"
         if novae != (arch == "trans_dec") or arch not in ("trans_enc", "trans_dec"):
             unsupported.append(f"arch={arch!r} with VAE_TYPE={get('VAE_TYPE')!r} (built: trans_enc on VAE latents, trans_dec on raw motion)")
         if not novae and not get("SKIP_CONNECT", False):
             unsupported.append("SKIP_CONNECT=False (only the skip trans_enc of the shipped configs)")
-        if novae and condition != "text":
+        if novae and condition not in ("text", "text_uncond"):
             unsupported.append("the diffusion-only variant is text-conditioned (config_novae_humanml3d.yaml)")
         if get("DIFF_PE_TYPE", "mld") != "mld" or position_embedding != "learned":
             unsupported.append("only DIFF_PE_TYPE='mld' with learned positional embeddings")

@@ -75,7 +75,7 @@ class DataParallelSampler:
         chunks = [(s, min(hi, s + self.batch_size)) for s in range(lo, hi, self.batch_size)]
         m = self.model
         overlap = (self.in_flight > 1 and torch.cuda.is_available() and getattr(m, "fused", False)
-                   and getattr(m, "condition", None) == "text" and getattr(m, "vae_type", "") != "no")
+                   and getattr(m, "condition", None) == "text" and getattr(m, "vae_type", "") != "no")   # plain text-to-motion only
         out = []
         if not overlap:
             for s, e in chunks:

@@ -44,17 +44,18 @@ class MLD(nn.Module):
             self.vae_type = cfg.model.vae_type
         except (KeyError, AttributeError):
             self.vae_type = cfg.model.motion_vae.target.split(".")[-1].lower().replace("hip", "").replace("vae", "")
-        if self.condition not in ("text", "action") or self.stage not in ("diffusion", "vae_diffusion"):
+        if self.condition not in ("text", "text_uncond", "action") or self.stage not in ("diffusion", "vae_diffusion"):
             raise NotImplementedError(f"mld_hip.MLD covers text-/action-to-motion sampling (condition={self.condition!r}, stage={self.stage!r})")
         self._engine_key = engine_key
-        self.variant = "novae" if self.vae_type == "no" else self.condition      # engine registry variant
+        # engine registry variant ("text_uncond" is the text network fed with empty prompts on both CFG halves, mld.py:228-229)
+        self.variant = "novae" if self.vae_type == "no" else ("action" if self.condition == "action" else "text")
         if engine_key is None:
             _engine.configure(self.variant, num_inference_steps=cfg.model.scheduler.num_inference_timesteps,
                               guidance_scale=float(self.guidance_scale))
         if hasattr(datamodule, "variant") and datamodule.variant is None:
             datamodule.variant = self.variant
         # the reference builds CLIP for every condition (mld.py:60); the action path never calls it, so it is skipped there
-        self.text_encoder = text_encoder if (text_encoder is not None or self.condition != "text") \
+        self.text_encoder = text_encoder if (text_encoder is not None or self.condition == "action") \
             else instantiate_from_config(cfg.model.text_encoder)
         self.vae = instantiate_from_config(cfg.model.motion_vae) if self.vae_type != "no" else None      # mld.py:58-59
         self.denoiser = instantiate_from_config(cfg.model.denoiser)
@@ -185,8 +186,8 @@ class MLD(nn.Module):
     @torch.no_grad()
     def forward(self, batch, init_latents: Optional[torch.Tensor] = None, step_noise: Optional[torch.Tensor] = None):
         texts, lengths = list(batch["text"]), list(batch["length"])
-        if self.do_classifier_free_guidance:
-            texts = [""] * len(texts) + texts                                   # mld.py:224-230: uncond first
+        if self.do_classifier_free_guidance:                                    # mld.py:224-230: uncond half first
+            texts = [""] * len(texts) + ([""] * len(texts) if self.condition == "text_uncond" else texts)
         text_emb = self.text_encoder(texts)
         if self.vae_type == "no":
             if self.fused:

@@ -102,7 +102,7 @@ def test_state_dict_keys_match_the_reference_modules(golden_dir):
 def test_unsupported_configurations_fail_loudly():
     abl = dict(SKIP_CONNECT=True, VAE_TYPE="mld", DIFF_PE_TYPE="mld", PE_TYPE="mld", MLP_DIST=False)
     with pytest.raises(NotImplementedError):
-        HipMldDenoiser(ablation=abl, condition="text_uncond", num_layers=9)
+        HipMldDenoiser(ablation=abl, condition="image", num_layers=9)
     with pytest.raises(NotImplementedError):
         HipMldDenoiser(ablation={**abl, "VAE_TYPE": "no"}, num_layers=9)          # raw motion needs arch trans_dec + d=512
     with pytest.raises(NotImplementedError):
@@ -183,6 +183,12 @@ def test_mld_forward_fused_and_modular_agree_with_oracle(sim_key):
     feats = model.vae.decode(z.contiguous(), lengths)
     j2 = model.feats2joints(feats)
     assert np.abs(j2.numpy() - jr).max() < 1e-4
+    # condition 'text_uncond' (mld.py:228-229): the same network, empty prompts on both CFG halves -> text-independent motions
+    cfg_u = C.load_config(overrides={"model.scheduler.num_inference_timesteps": 2, "model.condition": "text_uncond"})
+    mu = MLD(cfg_u, dm, text_encoder=enc, engine_key=sim_key).eval()
+    ja = mu({"text": texts, "length": lengths}, init_latents=lat0)
+    jb = mu({"text": ["something else entirely", "x"], "length": lengths}, init_latents=lat0)
+    assert all(torch.equal(a, b) for a, b in zip(ja, jb))
     # recon_from_motion (mld.py:277-288): encode -> decode -> joints, plus the joints of the reference motion
     fr = torch.randn(2, 24, 263) * 0.3
     fr[1, 17:] = 0
