@@ -46,7 +46,8 @@ struct WsContext {
   bool used = false;
 #if !defined(MLDHIP_SIM)
   hipEvent_t done = nullptr;
-  std::map<GraphKey, hipGraphExec_t> graphs;
+  std::map<GraphKey, hipGraphExec_t> graphs;   // captured sample() graphs of this workspace, evicted least-recently-used
+  std::vector<GraphKey> graph_lru;             // most recent last
 #endif
 };
 

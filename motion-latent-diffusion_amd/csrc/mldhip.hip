@@ -47,6 +47,8 @@ using namespace mld;
 
 // ======================================================================================= C ABI
 
+namespace { constexpr size_t kGraphCacheCapacity = 48; }   // captured graphs kept per workspace context
+
 extern "C" {
 
 int mldhip_abi_version(void) { return MLDHIP_ABI_VERSION; }
@@ -321,6 +323,7 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
   for (auto& x : e->ctxs) {
     for (auto& kv : x.graphs) (void)hipGraphExecDestroy(kv.second);
     x.graphs.clear();
+    x.graph_lru.clear();
     x.used = false;
   }
 #endif
@@ -365,10 +368,19 @@ int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* acti
     GraphKey key{B, T, want_f, want_j};
     auto& graphs = e->ctxs[e->cur_ctx].graphs;
     auto it = graphs.find(key);
+    auto& lru = e->ctxs[e->cur_ctx].graph_lru;
+    auto same = [&](const GraphKey& k) { return !(k < key) && !(key < k); };
+    lru.erase(std::remove_if(lru.begin(), lru.end(), same), lru.end());
+    lru.push_back(key);
     if (it == graphs.end()) {
-      if (graphs.size() >= 16) {
-        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
-        graphs.clear();
+      // one graph per (B, Tmax, outputs): a serving loop with ragged batches sees many Tmax values, so keep a generous
+      // number (each exec holds ~2 100 kernel nodes, a few MB) and evict the least recently used one beyond it
+      while (graphs.size() >= kGraphCacheCapacity) {
+        auto victim = graphs.find(lru.front());
+        lru.erase(lru.begin());
+        if (victim == graphs.end()) continue;
+        (void)hipGraphExecDestroy(victim->second);
+        graphs.erase(victim);
       }
       hipGraph_t graph = nullptr;
       HIP_TRY(e, hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
