@@ -11,7 +11,7 @@ e4, e1 = mk(4), mk(1)
 streams = [torch.cuda.Stream() for _ in range(5)]          # 5 streams on 4 contexts: contexts get reused across streams
 rng = np.random.default_rng(0)
 jobs = []
-for i in range(40):
+for i in range(int(os.environ.get("STRESS_JOBS", "40"))):
     B = int(rng.integers(1, 33)); lens = [int(v) for v in rng.integers(1, 121, B)]
     b = syn.make_batch(B, lens, seed=500 + i)
     jobs.append((b, torch.from_numpy(b.text_emb).to(dev), torch.from_numpy(b.init_latents).to(dev), torch.empty(B, max(lens), 22, 3, device=dev)))
