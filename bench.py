@@ -7,7 +7,9 @@
 One "step" = one pass of the hot path over one batch: 50-step DDIM latent sampling with
 classifier-free guidance -> motion-VAE decode -> (T,22,3) joints for B=64 synthetic HumanML3D-shaped
 prompts (config_mld_humanml3d.yaml, T=196), inputs resident in HBM, text embeddings precomputed
-(the frozen CLIP encoder is outside this path).  Ranks are pure data parallel: weights are broadcast
+(the frozen CLIP encoder is outside this path).  Consecutive steps rotate over --in-flight (default 4) HIP streams /
+engine workspaces, so up to four independent bs-64 steps overlap on the chip; `single_stream` in the JSON is the same
+K steps issued one after another.  Ranks are pure data parallel: weights are broadcast
 once from rank 0 (one RCCL broadcast of the packed blob), every rank samples its own 64 prompts, no
 data-path collective.  Rank 0 prints ONE JSON line.
 """
