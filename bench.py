@@ -31,6 +31,7 @@ import torch  # noqa: E402
 from mld_hip import _lib  # noqa: E402
 from mld_hip import synthetic as syn  # noqa: E402
 
+METRIC = "motions/sec (50-step DDIM + VAE decode), HumanML3D bs64, 1/2/4/8 GPU"      # BASELINE.json "metric", verbatim
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 BATCH, FRAMES, STEPS_DDIM = 64, 196, 50
 
@@ -265,7 +266,7 @@ def main():
     dt1 = timed(a.steps, single_stream=True) if nfl > 1 else dt      # the same steps strictly one after another
 
     out = {
-        "metric": "motions/sec (50-step DDIM + VAE decode), HumanML3D bs64", "value": round(value, 2),
+        "metric": METRIC, "value": round(value, 2),
         "unit": "motions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {0: "f32", 1: "f32 (reverse loop, attention, norms) + split-bf16 x3 MFMA, fp32 accumulate (decoder GEMMs)"}[prec],
