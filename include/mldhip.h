@@ -17,8 +17,9 @@
  *     a failed create).
  *   - work is enqueued on the caller's `stream` (a hipStream_t passed as void*, NULL = the null
  *     stream) and is stream-ordered: no implicit device synchronisation.
- *   - the caller owns every I/O buffer; the engine owns weights, workspace and the hipGraph.
- *   - one handle per device; a handle is not thread-safe.
+ *   - the caller owns every I/O buffer; the engine owns weights, workspaces and the captured hipGraphs.
+ *   - one handle per device and model variant; a handle is not thread-safe (issue its calls from one host thread).
+ *     Calls on DIFFERENT streams overlap on the GPU when the handle was created with max_in_flight > 1.
  */
 #ifndef MLDHIP_H_
 #define MLDHIP_H_
