@@ -96,8 +96,7 @@ def bench_a2m(local, dev, stream, warmup, steps, B=256, T=60, nfl=2):
     slots = []
     for sl in range(nfl):
         acts, lat0, lens = syn.make_action_batch(B, nframes=T, seed=1234 + sl)
-        slots.append((acts, torch.from_numpy(lat0).to(dev), lens, torch.empty(B, T, 150, device=dev),
-                      stream if sl == 0 else torch.cuda.Stream(device=dev)))
+        slots.append((acts, torch.from_numpy(lat0).to(dev), lens, torch.empty(B, T, 150, device=dev), torch.cuda.Stream(device=dev)))
 
     def run(n, single):
         torch.cuda.synchronize()
@@ -360,7 +359,8 @@ def main():
             out["length_mix"] = {"value": round(BATCH * a.steps / dtm, 2), "unit": "motions/s", "ms_per_step": round(dtm / a.steps * 1e3, 4),
                                  "lengths": "uniform in {40..196 step 4}, seed 1234, Tmax 196; mean %.1f frames" % float(np.mean(mix))}
         if world == 1 and not a.eager and not a.no_a2m:
-            out["other_workloads"] = [bench_a2m(local, dev, stream, max(2, a.warmup), max(3, a.steps // 2))]
+            out["other_workloads"] = [bench_a2m(local, dev, stream, max(2, a.warmup), max(4, a.steps // 2),
+                                               nfl=int(os.environ.get("MLD_BENCH_A2M_IN_FLIGHT", "4")))]
             if not a.no_novae:
                 out["other_workloads"].append(bench_novae(local, dev, stream))
         if world == 1 and not a.no_clip:
