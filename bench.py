@@ -147,13 +147,13 @@ def bench_text_encoder(dev, n_texts=2 * BATCH, iters=10):
             "backend": "PyTorch-ROCm (not part of libmldhip)"}
 
 
-def bench_novae(local, dev, stream, B=64, T=196, steps=1000, nfl=1):
+def bench_novae(local, dev, stream, B=64, T=196, steps=1000, nfl=2):
     """BASELINE config 4 shape (config_novae_humanml3d.yaml: raw-motion diffusion, trans_dec denoiser d=512, DDPM x1000,
     bs=64, T=196): `nfl` full 1000-step batches in flight on `nfl` streams, timed like the headline (a secondary line,
     never `value`).  MFMA-bound: 1.29 TFLOP per step, noise from the in-kernel Philox stream.
-    nfl = 1: a 1000-step call is 114 k eager launches issued by one host thread, so a second call only starts being enqueued
-    when the first is nearly done -- two batches overlap in a 20-step probe (13.3 -> 11.7 ms per step, tools/novae_in_flight.py)
-    but not here until the step loop is captured in graph chunks."""
+    The engine replays the step loop from graphs of 20 DDPM steps each, so two 1000-step batches on two streams overlap:
+    13.3 -> 11.8 ms per step and batch in steady state (tools/novae_in_flight.py); the line below is ONE cold call per
+    stream, i.e. it includes capturing those graphs."""
     eng = _lib.Engine(device=local, max_batch=B, max_frames=T, latent_dim=512, vae_arch=_lib.VAE_NONE, denoiser_arch=_lib.ARCH_TRANS_DEC,
                       scheduler_type=_lib.SCHED_DDPM, num_inference_steps=steps, steps_offset=0, max_in_flight=nfl)
     eng.load_state_dict(syn.make_novae_denoiser_state_dict(), "denoiser.")
@@ -167,7 +167,7 @@ def bench_novae(local, dev, stream, B=64, T=196, steps=1000, nfl=1):
     joints = [torch.empty(B, T, 22, 3, device=dev) for _ in range(nfl)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()             # includes the one-time capture of the 50 step-chunk graphs of each workspace (~5 %)
     for i in range(nfl):
         eng.sample_novae(text, x0[i], b.lengths, None, 1234 + i, None, joints[i], streams[i].cuda_stream)
     torch.cuda.synchronize()

@@ -90,28 +90,43 @@ void novae_text_memory(Ctx& c, const float* text, int rows) {
   novae_memory_kv(c, e->TP, rows, e->XKV, (long long)2 * e->cfg.max_batch * 2 * e->cfg.latent_dim);
 }
 
-// MLD.forward after the text encoder with vae_type 'no' (mld.py:232-242,264,290-360).  lens_dev holds lengths ++ lengths.
-int enqueue_sample_novae(E* e, hipStream_t stream, const float* text, const float* init_lat, int B, int T, const float* step_noise,
-                         unsigned long long seed, float* feats_out, float* joints_out) {
+// MLD.forward after the text encoder with vae_type 'no' (mld.py:232-242,264,290-360), in three pieces so that the step
+// loop can be captured in graph chunks.  lens_dev holds lengths ++ lengths.
+int novae_prologue(E* e, hipStream_t stream, const float* text, const float* init_lat, int B, int T) {
   Ctx c{e, stream};
-  const int D = e->cfg.latent_dim, NF = e->cfg.nfeats, n = e->cfg.num_inference_steps;
-  const long long nel = (long long)B * T * NF;
-  const float guidance = e->cfg.guidance_scale > 1.0f ? e->cfg.guidance_scale : 1.0f;
+  const long long nel = (long long)B * T * e->cfg.nfeats;
   e->launches[0] = e->launches[1] = e->launches[2] = 0;
   e->phase = 0;
   HIP_TRY(e, hipMemcpyAsync(e->lat, init_lat, nel * sizeof(float), hipMemcpyDeviceToDevice, stream));   // init_noise_sigma = 1
   novae_text_memory(c, text, 2 * B);
-  for (int s = 0; s < n && !c.rc; ++s) {
+  return c.rc;
+}
+
+// DDPM steps [s0, s1): CFG batch through the trans_dec denoiser, guidance, ancestral step.  The per-step Gaussian draw is
+// step_noise[s] when injected, else Philox(seed, s, element) with the seed taken from *seed_dev when that is non-null.
+int novae_steps(E* e, hipStream_t stream, int B, int T, int s0, int s1, const float* step_noise, unsigned long long seed,
+                const unsigned long long* seed_dev) {
+  Ctx c{e, stream};
+  const int D = e->cfg.latent_dim, NF = e->cfg.nfeats, n = e->cfg.num_inference_steps;
+  const long long nel = (long long)B * T * NF;
+  const float guidance = e->cfg.guidance_scale > 1.0f ? e->cfg.guidance_scale : 1.0f;
+  e->phase = 0;
+  for (int s = s0; s < s1 && !c.rc; ++s) {
     novae_pad_input(c, e->lat, (long long)B * T, 2);                                      // torch.cat([latents] * 2)
     novae_denoiser_body(c, 2 * B, T, e->TKV + (size_t)s * 2 * D, (long long)n * 2 * D, e->feats_int);
     MLD_LAUNCH(cfg_ddpm_step_kernel, dim3((unsigned)std::min<long long>(4096, (nel / 4 + 255) / 256)), dim3(256), 0, stream,
                (const float*)e->feats_int, (const float*)(e->feats_int + nel), (const float*)e->lat,
                step_noise ? step_noise + (size_t)s * nel : (const float*)nullptr, e->lat, nel, guidance,
-               ddpm_coef(e, e->timesteps[s]), seed, (unsigned)s);
+               ddpm_coef(e, e->timesteps[s]), seed, (unsigned)s, seed_dev);
     count(c);
     check_launch(c, "cfg_ddpm_step");
   }
-  if (c.rc) return c.rc;
+  return c.rc;
+}
+
+int novae_epilogue(E* e, hipStream_t stream, int B, int T, float* feats_out, float* joints_out) {
+  Ctx c{e, stream};
+  const long long nel = (long long)B * T * e->cfg.nfeats;
   if (feats_out) HIP_TRY(e, hipMemcpyAsync(feats_out, e->lat, nel * sizeof(float), hipMemcpyDeviceToDevice, stream));   // "decode" = identity (mld.py:241-242)
   if (joints_out) {
     e->phase = 2;

@@ -44,10 +44,12 @@ struct WsContext {
   float* ws = nullptr;
   int32_t *lens = nullptr, *lens2 = nullptr, *labels = nullptr;
   bool used = false;
+  unsigned long long seed_host = 0;   // stable host copy of the Philox seed while it is uploaded to seed_slot
 #if !defined(MLDHIP_SIM)
   hipEvent_t done = nullptr;
   std::map<GraphKey, hipGraphExec_t> graphs;   // captured sample() graphs of this workspace, evicted least-recently-used
   std::vector<GraphKey> graph_lru;             // most recent last
+  std::map<std::tuple<int, int, int>, hipGraphExec_t> step_graphs;   // diffusion-only variant: (B, Tmax, chunk) -> captured DDPM steps
 #endif
 };
 
@@ -68,6 +70,7 @@ struct mldhip_engine {
   std::vector<EncLayerP> venc;     // VAE encoder layers (same layer type as the denoiser's)
   std::vector<DecLayerP> ndec;     // no-VAE variant: denoiser.decoder.layers.* (TransformerDecoder, cross_attention.py:195-233)
   size_t ndec_layer_stride = 0;
+  float* seed_slot = nullptr;     // 8 bytes of workspace: the Philox seed of the call whose captured step graphs are running
   float *TKV = nullptr, *XKV = nullptr, *TKV_one = nullptr;   // memory-token K|V per layer: time [L][n][2D], text [L][2*max_batch][2D]
   size_t dec_layer_stride = 0;     // floats between consecutive decoder layers' tensors
 

@@ -300,7 +300,9 @@ struct DdpmCoef { float sqrt_ab, sqrt_1mab, c_x0, c_x, sigma; };
 __global__ __launch_bounds__(256) void cfg_ddpm_step_kernel(const float* __restrict__ eps_u, const float* __restrict__ eps_c,
                                                             const float* __restrict__ x, const float* __restrict__ noise,
                                                             float* __restrict__ out, long long n, float guidance, DdpmCoef k,
-                                                            unsigned long long seed, unsigned step) {
+                                                            unsigned long long seed, unsigned step,
+                                                            const unsigned long long* __restrict__ seed_ptr = nullptr) {
+  if (seed_ptr) seed = *seed_ptr;        // captured step graphs take the call's seed from device memory (uniform load)
   const long long nq = (n + 3) / 4;
   for (long long qd = (long long)blockIdx.x * blockDim.x + threadIdx.x; qd < nq; qd += (long long)gridDim.x * blockDim.x) {
     float z[4] = {0.f, 0.f, 0.f, 0.f};

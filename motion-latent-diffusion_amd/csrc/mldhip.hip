@@ -47,6 +47,7 @@ using namespace mld;
 
 // ======================================================================================= C ABI
 
+namespace { constexpr int kStepChunk = 20; }                // DDPM steps per captured graph (diffusion-only variant)
 namespace { constexpr size_t kGraphCacheCapacity = 48; }   // captured graphs kept per workspace context
 
 extern "C" {
@@ -152,6 +153,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
     want(&e->WskelP, D * KPn);
     want(&e->feats_int, 2 * Bm * Tm * NF); want(&e->joints_int, Bm * Tm * cfg->njoints * 3);
     want(&e->TKV, L * n * 2 * D); want(&e->XKV, L * 2 * Bm * 2 * D); want(&e->TKV_one, L * 2 * D);
+    want(&e->seed_slot, 2);
   } else {
   want(&e->X0, rows * D); want(&e->Ha, rows * D); want(&e->Hb, rows * D); want(&e->H1, rows * D); want(&e->LNO, rows * D);
   for (int i = 0; i < 8; ++i) want(&e->S[i], (i < (int)(L - 1) / 2) ? rows * D : 0);
@@ -214,6 +216,7 @@ void mldhip_destroy(mldhip_handle* e) {
   (void)hipDeviceSynchronize();      // calls may still be in flight on other streams; their buffers are freed below
   for (auto& x : e->ctxs) {
     for (auto& kv : x.graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : x.step_graphs) (void)hipGraphExecDestroy(kv.second);
     if (x.done) (void)hipEventDestroy(x.done);
   }
   if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
@@ -324,6 +327,8 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
     for (auto& kv : x.graphs) (void)hipGraphExecDestroy(kv.second);
     x.graphs.clear();
     x.graph_lru.clear();
+    for (auto& kv : x.step_graphs) (void)hipGraphExecDestroy(kv.second);
+    x.step_graphs.clear();
     x.used = false;
   }
 #endif
@@ -500,8 +505,46 @@ int mldhip_sample_novae(mldhip_handle* e, const float* text_emb_dev, const float
   if (use.rc) return use.rc;
   HIP_TRY(e, hipMemcpyAsync(e->lens_dev, lengths_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   HIP_TRY(e, hipMemcpyAsync(e->lens_dev + B, lengths_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));   // lengths * 2 (mld.py:327-328)
-  // ~114 launches of 0.1-2 ms each per step: the GPU, not the host, is the bottleneck -> plain stream launches, no graph
-  return enqueue_sample_novae(e, stream, text_emb_dev, init_latents_dev, B, T, step_noise_dev, seed, feats_out_dev, joints_out_dev);
+  if (int rc = novae_prologue(e, stream, text_emb_dev, init_latents_dev, B, T)) return rc;
+  const int n = e->cfg.num_inference_steps;
+#if !defined(MLDHIP_SIM)
+  if (e->cfg.use_graph && !step_noise_dev) {
+    // ~114 launches per step: a 1000-step call is 114 k launches.  Issued eagerly they keep one host thread busy for the
+    // whole call, so a second call on another stream cannot even be enqueued before the first is nearly done.  The steps
+    // are therefore captured once per (B, Tmax) in chunks of kStepChunk and replayed; everything a step needs is a
+    // constant of (weights, step index) except the Philox seed, which the step kernel reads from the workspace.
+    e->ctxs[e->cur_ctx].seed_host = seed;
+    HIP_TRY(e, hipMemcpyAsync(e->seed_slot, &e->ctxs[e->cur_ctx].seed_host, sizeof seed, hipMemcpyHostToDevice, stream));
+    auto& graphs = e->ctxs[e->cur_ctx].step_graphs;
+    const int nchunks = (n + kStepChunk - 1) / kStepChunk;
+    if (graphs.size() + nchunks > 512) {
+      for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+      graphs.clear();
+    }
+    for (int ch = 0; ch < nchunks; ++ch) {
+      auto key = std::make_tuple((int)B, T, ch);
+      auto it = graphs.find(key);
+      if (it == graphs.end()) {
+        hipGraph_t graph = nullptr;
+        HIP_TRY(e, hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
+        int rc = novae_steps(e, e->cap_stream, B, T, ch * kStepChunk, std::min(n, (ch + 1) * kStepChunk), nullptr, 0,
+                             reinterpret_cast<const unsigned long long*>(e->seed_slot));
+        hipError_t st = hipStreamEndCapture(e->cap_stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (st != hipSuccess) return e->fail(MLDHIP_EHIP, "hipStreamEndCapture(steps): %s", hipGetErrorString(st));
+        hipGraphExec_t exec = nullptr;
+        st = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (st != hipSuccess) return e->fail(MLDHIP_EHIP, "hipGraphInstantiate(steps): %s", hipGetErrorString(st));
+        it = graphs.emplace(key, exec).first;
+      }
+      HIP_TRY(e, hipGraphLaunch(it->second, stream));
+    }
+    return novae_epilogue(e, stream, B, T, feats_out_dev, joints_out_dev);
+  }
+#endif
+  if (int rc = novae_steps(e, stream, B, T, 0, n, step_noise_dev, seed, nullptr)) return rc;
+  return novae_epilogue(e, stream, B, T, feats_out_dev, joints_out_dev);
 }
 
 int mldhip_denoiser_forward_novae(mldhip_handle* e, const float* sample_dev, int32_t timestep, const float* text_emb_dev,

@@ -2,8 +2,8 @@ import sys, os, time, json
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"]); sys.path.insert(0, os.path.join(os.environ["GRAFT_REPO_ROOT"], "motion-latent-diffusion_amd"))
 import torch
 from mld_hip import _lib, synthetic as syn
-steps = 20
-for nfl in (1, 2, 3, 4):
+steps = int(os.environ.get("NOVAE_STEPS", "20"))
+for nfl in (1, 2):
     eng = _lib.Engine(device=0, max_batch=64, max_frames=196, latent_dim=512, vae_arch=_lib.VAE_NONE, denoiser_arch=_lib.ARCH_TRANS_DEC,
                       scheduler_type=_lib.SCHED_DDPM, num_inference_steps=steps, steps_offset=0, max_in_flight=nfl)
     eng.load_state_dict(syn.make_novae_denoiser_state_dict(), "denoiser.")
