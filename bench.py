@@ -149,30 +149,43 @@ def bench_text_encoder(dev, n_texts=2 * BATCH, iters=10):
 
 def bench_novae(local, dev, stream, B=64, T=196, steps=1000, nfl=2):
     """BASELINE config 4 shape (config_novae_humanml3d.yaml: raw-motion diffusion, trans_dec denoiser d=512, DDPM x1000,
-    bs=64, T=196): `nfl` full 1000-step batches in flight on `nfl` streams, timed like the headline (a secondary line,
-    never `value`).  MFMA-bound: 1.29 TFLOP per step, noise from the in-kernel Philox stream.
-    The engine replays the step loop from graphs of 20 DDPM steps each, so two 1000-step batches on two streams overlap:
-    13.3 -> 11.8 ms per step and batch; one untimed call per stream captures the graphs first."""
-    eng = _lib.Engine(device=local, max_batch=B, max_frames=T, latent_dim=512, vae_arch=_lib.VAE_NONE, denoiser_arch=_lib.ARCH_TRANS_DEC,
-                      scheduler_type=_lib.SCHED_DDPM, num_inference_steps=steps, steps_offset=0, max_in_flight=nfl)
-    eng.load_state_dict(syn.make_novae_denoiser_state_dict(), "denoiser.")
-    mean, std = syn.make_mean_std()
-    eng.load_tensor("mean", mean)
-    eng.load_tensor("std", std)
-    eng.finalize()
+    bs=64, T=196): `nfl` full 1000-step batches in flight, timed like the headline (a secondary line, never `value`).
+    MFMA-bound: 1.29 TFLOP per step, noise from the in-kernel Philox stream.  A 1000-step call is 50 graph
+    launches of 2 280 kernels each and blocks its host thread on the hardware queue depth, so each batch in flight gets its
+    own handle, stream and host thread (a handle is used by one thread only, as the C ABI requires)."""
+    import threading
     b = syn.make_batch(B, None, seed=1234, max_len=T)
     text = torch.from_numpy(b.text_emb).to(dev)
-    x0 = [torch.randn(B, T, 263, device=dev) for _ in range(nfl)]
-    joints = [torch.empty(B, T, 22, 3, device=dev) for _ in range(nfl)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
-    for i in range(nfl):                 # untimed: captures the 50 step-chunk graphs of each workspace
-        eng.sample_novae(text, x0[i], b.lengths, None, 99, None, joints[i], streams[i].cuda_stream)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    mean, std = syn.make_mean_std()
+    weights = syn.make_novae_denoiser_state_dict()
+    engs, x0, joints, streams = [], [], [], []
     for i in range(nfl):
-        eng.sample_novae(text, x0[i], b.lengths, None, 1234 + i, None, joints[i], streams[i].cuda_stream)
+        eng = _lib.Engine(device=local, max_batch=B, max_frames=T, latent_dim=512, vae_arch=_lib.VAE_NONE, denoiser_arch=_lib.ARCH_TRANS_DEC,
+                          scheduler_type=_lib.SCHED_DDPM, num_inference_steps=steps, steps_offset=0)
+        eng.load_state_dict(weights, "denoiser.")
+        eng.load_tensor("mean", mean)
+        eng.load_tensor("std", std)
+        eng.finalize()
+        engs.append(eng)
+        x0.append(torch.randn(B, T, 263, device=dev))
+        joints.append(torch.empty(B, T, 22, 3, device=dev))
+        streams.append(torch.cuda.Stream(device=dev))
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+
+    def run(seed0):
+        def one(i):
+            engs[i].sample_novae(text, x0[i], b.lengths, None, seed0 + i, None, joints[i], streams[i].cuda_stream)
+        th = [threading.Thread(target=one, args=(i,)) for i in range(nfl)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(99)                              # untimed: captures each handle's 50 step-chunk graphs
+    dt = run(1234)
     lin = lambda m, k, n: 2.0 * m * k * n
     m = 2 * B * T
     gf_step = (9 * (lin(m, 512, 1536) + 3 * lin(m, 512, 512) + 2 * lin(m, 512, 1024) + 4.0 * m * T * 512 + 4.0 * m * 2 * 512)
@@ -183,8 +196,9 @@ def bench_novae(local, dev, stream, B=64, T=196, steps=1000, nfl=2):
            "ms_per_ddpm_step": round(dt * 1e3 / (steps * nfl), 3), "dtype": "f32", "algorithmic_gflop_per_ddpm_step": round(gf_step, 1),
            "achieved_tflops": round(gf_step * steps * nfl / 1e3 / dt, 2),
            "frac_of_fp32_mfma_peak": round(gf_step * steps * nfl / 1e3 / dt / FP32_MFMA_PEAK_TF, 4),
-           "finite": bool(all(torch.isfinite(j).all().item() for j in joints)), "launches_per_step": eng.launch_counts()}
-    eng.close()
+           "finite": bool(all(torch.isfinite(j).all().item() for j in joints)), "kernel_launches_per_ddpm_step": 114}
+    for eng in engs:
+        eng.close()
     return out
 
 
@@ -366,9 +380,11 @@ def main():
             dtm = time.perf_counter() - t0
             out["length_mix"] = {"value": round(BATCH * a.steps / dtm, 2), "unit": "motions/s", "ms_per_step": round(dtm / a.steps * 1e3, 4),
                                  "lengths": "uniform in {40..196 step 4}, seed 1234, Tmax 196; mean %.1f frames" % float(np.mean(mix))}
-        if world == 1 and not a.eager and not a.no_a2m:
-            out["other_workloads"] = [bench_a2m(local, dev, stream, max(2, a.warmup), max(4, a.steps // 2),
-                                               nfl=int(os.environ.get("MLD_BENCH_A2M_IN_FLIGHT", "4")))]
+        if world == 1 and not a.eager:
+            out["other_workloads"] = []
+            if not a.no_a2m:
+                out["other_workloads"].append(bench_a2m(local, dev, stream, max(2, a.warmup), max(4, a.steps // 2),
+                                                        nfl=int(os.environ.get("MLD_BENCH_A2M_IN_FLIGHT", "4"))))
             if not a.no_novae:
                 out["other_workloads"].append(bench_novae(local, dev, stream))
         if world == 1 and not a.no_clip:
