@@ -53,8 +53,20 @@ def pack_and_broadcast_weights(rank, world, dev):
     template = {**{"denoiser." + k: v for k, v in syn.make_denoiser_state_dict().items()},
                 **{"vae." + k: v for k, v in syn.make_vae_state_dict().items()}}
     template["mean"], template["std"] = syn.make_mean_std()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     state = dp.broadcast_state(template if rank == 0 else {}, template, dev, src=0)
-    return state, sum(v.size for v in template.values()) * 4
+    torch.cuda.synchronize()
+    return state, sum(v.size for v in template.values()) * 4, time.perf_counter() - t0
+
+
+def device_identity(local):
+    """(uuid or PCI bus id, name) of this rank's GPU -- all-gathered so the JSON proves N distinct devices took part."""
+    pr = torch.cuda.get_device_properties(local)
+    ident = getattr(pr, "uuid", None)
+    if ident is None:
+        ident = "pci:%s:%s:%s" % (getattr(pr, "pci_domain_id", "?"), getattr(pr, "pci_bus_id", "?"), getattr(pr, "pci_device_id", "?"))
+    return str(ident), pr.name
 
 
 def time_kernel(eng, name, B, T, iters, stream):
@@ -218,10 +230,26 @@ def main():
                     help="f32: exact-fp32 MFMA everywhere; bf16x3_decode: split-bf16 MFMA in the VAE-decoder GEMMs")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, same flags
+        import socket
+        import subprocess
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            sys.exit(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) are visible")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {a.gpus}, or without torchrun)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -234,7 +262,12 @@ def main():
     prec = {"f32": 0, "bf16x3_decode": 1}[a.precision]
     nfl = max(1, min(8, a.in_flight))
     eng = _lib.Engine(device=local, max_batch=BATCH, max_frames=FRAMES, use_graph=0 if a.eager else 1, precision=prec, max_in_flight=nfl)
-    weights, weight_bytes = pack_and_broadcast_weights(rank, world, dev)
+    weights, weight_bytes, bcast_s = pack_and_broadcast_weights(rank, world, dev)
+    ident = (rank, local) + device_identity(local)
+    ranks_seen = [ident]
+    if dist:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, ident)
     eng.load_state_dict(weights)
     eng.finalize()
 
@@ -268,23 +301,28 @@ def main():
         for i in range(nsteps):
             step(i, single_stream)
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0           # this rank's own K steps (before waiting for the slowest rank)
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        per_rank = [own]
         if dist:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt
+            g = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(g, torch.tensor([own], device=dev, dtype=torch.float64))
+            per_rank = [float(x.item()) for x in g]
+        return dt, per_rank
 
     torch.cuda.synchronize()                     # inputs were uploaded on the default stream
     for i in range(max(a.warmup, nfl)):          # at least one call per workspace, so every graph is captured untimed
         step(i)
-    dt = timed(a.steps)
+    dt, per_rank_s = timed(a.steps)
     ms_per_step = dt / a.steps * 1e3
     value = world * BATCH * a.steps / dt
-    dt1 = timed(a.steps, single_stream=True) if nfl > 1 else dt      # the same steps strictly one after another
+    dt1 = timed(a.steps, single_stream=True)[0] if nfl > 1 else dt      # the same steps strictly one after another
 
     out = {
         "metric": METRIC, "value": round(value, 2),
@@ -298,6 +336,13 @@ def main():
                    "weights": "synthetic (seeded numpy), one broadcast of %.1f MB" % (weight_bytes / 1e6),
                    "launches_per_step": eng.launch_counts()},
     }
+    per_rank_v = [BATCH * a.steps / t for t in per_rank_s]
+    out["distributed"] = {"backend": "nccl (RCCL)" if dist else "none (single process)", "world_size": world,
+                          "ranks_seen": [list(r) for r in ranks_seen], "distinct_devices": len({r[2] for r in ranks_seen}),
+                          "weight_broadcast": {"bytes": weight_bytes, "seconds": round(bcast_s, 4), "collectives": 1 if dist else 0,
+                                               "note": "one packed broadcast from rank 0 (includes host->device staging on rank 0)"},
+                          "per_rank_motions_per_s": {"min": round(min(per_rank_v), 2), "max": round(max(per_rank_v), 2)},
+                          "data_path_collectives": 0}
     out["single_stream"] = {"value": round(world * BATCH * a.steps / dt1, 2), "unit": "motions/s", "ms_per_step": round(dt1 / a.steps * 1e3, 4),
                             "note": "the same K steps issued on ONE stream (one batch in flight): per-batch latency"}
     if rank == 0:

@@ -22,7 +22,8 @@ void bind_context(E* e, int k) {
 }
 
 // Scope of one workspace-using call on `stream`: picks the next context round-robin, orders the stream behind the
-// context's previous user, binds its buffers; on exit records the context's "done" event on the stream.
+// context's previous user (ALWAYS, also with a single context: two calls on different streams must never share a
+// workspace concurrently), binds its buffers; on exit records the context's "done" event on the stream.
 struct CtxUse {
   E* e;
   hipStream_t stream;
@@ -31,7 +32,7 @@ struct CtxUse {
     const int k = int(e->next_ctx++ % e->ctxs.size());
 #if !defined(MLDHIP_SIM)
     WsContext& x = e->ctxs[k];
-    if (x.used && e->ctxs.size() > 1) {
+    if (x.used) {
       hipError_t st = hipStreamWaitEvent(stream, x.done, 0);
       if (st != hipSuccess) rc = e->fail(MLDHIP_EHIP, "hipStreamWaitEvent(context): %s", hipGetErrorString(st));
     }
@@ -41,11 +42,40 @@ struct CtxUse {
   ~CtxUse() {
 #if !defined(MLDHIP_SIM)
     WsContext& x = e->ctxs[e->cur_ctx];
-    if (e->ctxs.size() > 1) (void)hipEventRecord(x.done, stream);
+    (void)hipEventRecord(x.done, stream);
     x.used = true;
 #endif
   }
 };
+
+// Selects the engine's device for the duration of one C-ABI call and restores the caller's current device on exit
+// (two engines on different GPUs in one process, or a host that switched devices since mldhip_create).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int want) {
+#if !defined(MLDHIP_SIM)
+    if (hipGetDevice(&prev) == hipSuccess && prev != want) switched = hipSetDevice(want) == hipSuccess;
+#endif
+    (void)want;
+  }
+  ~DeviceGuard() {
+#if !defined(MLDHIP_SIM)
+    if (switched) (void)hipSetDevice(prev);
+#endif
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// A captured graph exec may still be running on the context's last stream: wait for the context's completion event
+// before destroying it (HIP does not promise deferred destruction of an in-flight exec).
+void drain_context(WsContext& x) {
+#if !defined(MLDHIP_SIM)
+  if (x.used && x.done) (void)hipEventSynchronize(x.done);
+#endif
+  (void)x;
+}
 
 bool is_action(const E* e) { return e->cfg.condition == MLDHIP_COND_ACTION; }
 bool is_actor(const E* e) { return e->cfg.vae_arch == MLDHIP_VAE_ACTOR; }

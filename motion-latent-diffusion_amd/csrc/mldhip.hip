@@ -105,13 +105,13 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_last_error = "no HIP device visible (libmldhip has no CPU path)"; return MLDHIP_ENODEV; }
   if (device < 0 || device >= ndev) return bad("device index out of range");
-  if (hipSetDevice(device) != hipSuccess) { g_last_error = "hipSetDevice failed"; return MLDHIP_EHIP; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
     g_last_error = std::string("libmldhip is built for gfx950 only; device is ") + prop.gcnArchName;
     return MLDHIP_ENODEV;
   }
 #endif
+  DeviceGuard dg(device);      // allocations below land on `device`; the caller's current device is restored on return
   auto* e = new mldhip_engine();
   const char* m_gemm = std::getenv("MLDHIP_GEMM");        // process-wide A/B knobs, re-read at every create
   g_staged_gemm = !(m_gemm && std::strcmp(m_gemm, "direct") == 0);
@@ -212,6 +212,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
 
 void mldhip_destroy(mldhip_handle* e) {
   if (!e) return;
+  DeviceGuard dg(e->device);
 #if !defined(MLDHIP_SIM)
   (void)hipDeviceSynchronize();      // calls may still be in flight on other streams; their buffers are freed below
   for (auto& x : e->ctxs) {
@@ -237,6 +238,7 @@ void mldhip_destroy(mldhip_handle* e) {
 int mldhip_load_tensor(mldhip_handle* e, const char* key, const void* data, const int64_t* shape, int32_t ndim,
                        int32_t dtype, int32_t src_is_device) {
   if (!e || !key || !data || (!shape && ndim > 0)) return e ? e->fail(MLDHIP_EINVAL, "null argument") : MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (dtype != MLDHIP_F32) return e->fail(MLDHIP_EINVAL, "tensor %s: only float32 tensors are accepted", key);
   auto it = e->index.find(key);
   if (it == e->index.end()) {
@@ -277,6 +279,7 @@ int mldhip_missing_keys(mldhip_handle* e, char* buf, int64_t buflen) {
 
 int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   // A group (denoiser / vae decoder / mean+std) must be loaded completely or not at all; ops of an
   // absent group fail with MLDHIP_ESTATE, sample() needs all three.
   int have[4] = {0, 0, 0, 0}, total[4] = {0, 0, 0, 0};
@@ -384,6 +387,7 @@ int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* acti
         auto victim = graphs.find(lru.front());
         lru.erase(lru.begin());
         if (victim == graphs.end()) continue;
+        drain_context(e->ctxs[e->cur_ctx]);               // the victim may still be replaying on this context's last stream
         (void)hipGraphExecDestroy(victim->second);
         graphs.erase(victim);
       }
@@ -417,6 +421,7 @@ extern "C" {
 int mldhip_sample(mldhip_handle* e, const float* text_emb_dev, const float* init_latents_dev, const int32_t* lengths_host,
                   int32_t B, float* latents_out_dev, float* feats_out_dev, float* joints_out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (is_action(e)) return e->fail(MLDHIP_ESTATE, "engine was created with the action condition: use mldhip_sample_action");
   if (is_novae(e)) return e->fail(MLDHIP_ESTATE, "engine was created for the diffusion-only variant: use mldhip_sample_novae");
   if (joints_out_dev && is_actor(e)) return e->fail(MLDHIP_ESTATE, "joints of the ActorVae feature layout need SMPL (out of scope)");
@@ -427,6 +432,7 @@ int mldhip_sample(mldhip_handle* e, const float* text_emb_dev, const float* init
 int mldhip_sample_action(mldhip_handle* e, const int32_t* actions_host, const float* init_latents_dev, const int32_t* lengths_host,
                          int32_t B, float* latents_out_dev, float* feats_out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (!is_action(e)) return e->fail(MLDHIP_ESTATE, "engine was created with the text condition: use mldhip_sample");
   if (!actions_host) return e->fail(MLDHIP_EINVAL, "null input pointer");
   return sample_impl(e, nullptr, actions_host, init_latents_dev, lengths_host, B, latents_out_dev, feats_out_dev, nullptr, stream_);
@@ -477,6 +483,7 @@ extern "C" {
 int mldhip_denoiser_forward(mldhip_handle* e, const float* sample_dev, int32_t timestep, const float* text_emb_dev,
                             int32_t R, float* out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (is_action(e)) return e->fail(MLDHIP_ESTATE, "engine was created with the action condition: use mldhip_denoiser_forward_action");
   if (is_novae(e)) return e->fail(MLDHIP_ESTATE, "engine was created for the diffusion-only variant: use mldhip_denoiser_forward_novae");
   if (!text_emb_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
@@ -486,6 +493,7 @@ int mldhip_denoiser_forward(mldhip_handle* e, const float* sample_dev, int32_t t
 int mldhip_denoiser_forward_action(mldhip_handle* e, const float* sample_dev, int32_t timestep, const int32_t* actions_host,
                                    int32_t R, float* out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (!is_action(e)) return e->fail(MLDHIP_ESTATE, "engine was created with the text condition: use mldhip_denoiser_forward");
   if (!actions_host) return e->fail(MLDHIP_EINVAL, "null pointer");
   return denoiser_forward_impl(e, sample_dev, timestep, nullptr, actions_host, R, out_dev, stream_);
@@ -494,6 +502,7 @@ int mldhip_denoiser_forward_action(mldhip_handle* e, const float* sample_dev, in
 int mldhip_sample_novae(mldhip_handle* e, const float* text_emb_dev, const float* init_latents_dev, const int32_t* lengths_host,
                         int32_t B, const float* step_noise_dev, uint64_t seed, float* feats_out_dev, float* joints_out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (!is_novae(e)) return e->fail(MLDHIP_ESTATE, "engine was not created for the diffusion-only variant (vae_arch = MLDHIP_VAE_NONE)");
   if (!e->finalized || !e->group_ready[0] || (joints_out_dev && !e->group_ready[2]))
     return e->fail(MLDHIP_ESTATE, "mldhip_sample_novae needs finalize and denoiser.* (and mean/std for joints) loaded");
@@ -518,6 +527,7 @@ int mldhip_sample_novae(mldhip_handle* e, const float* text_emb_dev, const float
     auto& graphs = e->ctxs[e->cur_ctx].step_graphs;
     const int nchunks = (n + kStepChunk - 1) / kStepChunk;
     if (graphs.size() + nchunks > 512) {
+      drain_context(e->ctxs[e->cur_ctx]);
       for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
       graphs.clear();
     }
@@ -550,6 +560,7 @@ int mldhip_sample_novae(mldhip_handle* e, const float* text_emb_dev, const float
 int mldhip_denoiser_forward_novae(mldhip_handle* e, const float* sample_dev, int32_t timestep, const float* text_emb_dev,
                                   const int32_t* lengths_host, int32_t R, int32_t T, float* out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (!is_novae(e)) return e->fail(MLDHIP_ESTATE, "engine was not created for the diffusion-only variant (vae_arch = MLDHIP_VAE_NONE)");
   if (!e->finalized || !e->group_ready[0]) return e->fail(MLDHIP_ESTATE, "denoiser_forward_novae before finalize / denoiser.* not loaded");
   if (!sample_dev || !text_emb_dev || !lengths_host || !out_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
@@ -580,6 +591,7 @@ int mldhip_denoiser_forward_novae(mldhip_handle* e, const float* sample_dev, int
 int mldhip_ddpm_step(mldhip_handle* e, const float* eps_dev, int32_t timestep, const float* sample_dev, const float* noise_dev,
                      uint64_t seed, int32_t step_index, float* prev_dev, int64_t n, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (!is_ddpm(e)) return e->fail(MLDHIP_ESTATE, "engine was created with the DDIM scheduler: use mldhip_ddim_step");
   if (!eps_dev || !sample_dev || !prev_dev || n < 1) return e->fail(MLDHIP_EINVAL, "null pointer / n < 1");
   if (timestep < 0 || timestep >= e->cfg.num_train_timesteps) return e->fail(MLDHIP_EINVAL, "timestep %d out of range", timestep);
@@ -592,6 +604,7 @@ int mldhip_ddpm_step(mldhip_handle* e, const float* eps_dev, int32_t timestep, c
 
 int mldhip_philox_normal(mldhip_handle* e, float* out_dev, int64_t n, uint64_t seed, int32_t step_index, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (!out_dev || n < 1) return e->fail(MLDHIP_EINVAL, "null pointer / n < 1");
   Ctx c{e, (hipStream_t)stream_};
   MLD_LAUNCH(philox_normal_kernel, dim3((unsigned)std::min<long long>(4096, (n / 4 + 256) / 256)), dim3(256), 0, c.stream, out_dev, (long long)n,
@@ -602,6 +615,7 @@ int mldhip_philox_normal(mldhip_handle* e, float* out_dev, int64_t n, uint64_t s
 int mldhip_vae_decode(mldhip_handle* e, const float* z_dev, const int32_t* lengths_host, int32_t B, float* feats_out_dev,
                       void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (!e->finalized || !e->group_ready[1]) return e->fail(MLDHIP_ESTATE, "vae_decode before finalize / vae.* not loaded");
   if (!z_dev || !feats_out_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
   int T = 0;
@@ -619,6 +633,7 @@ int mldhip_vae_decode(mldhip_handle* e, const float* z_dev, const int32_t* lengt
 int mldhip_vae_encode(mldhip_handle* e, const float* feats_dev, const int32_t* lengths_host, int32_t B, int32_t T,
                       const float* eps_dev, float* latent_out_dev, float* mu_out_dev, float* logvar_out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (!e->finalized || !e->group_ready[3]) return e->fail(MLDHIP_ESTATE, "vae_encode before finalize / vae.encoder.* not loaded");
   if (!feats_dev || !mu_out_dev || !logvar_out_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
   if (eps_dev && !latent_out_dev) return e->fail(MLDHIP_EINVAL, "eps given but latent_out is NULL");
@@ -647,6 +662,7 @@ __global__ void ddim_step_kernel(const float* eps, const float* x, float* out, l
 int mldhip_ddim_step(mldhip_handle* e, const float* eps_dev, int32_t timestep, const float* sample_dev, float* prev_dev,
                      int64_t n, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (!eps_dev || !sample_dev || !prev_dev || n < 0) return e->fail(MLDHIP_EINVAL, "bad argument");
   if (timestep < 0 || timestep >= e->cfg.num_train_timesteps) return e->fail(MLDHIP_EINVAL, "timestep %d out of range", timestep);
   if (n == 0) return MLDHIP_OK;
@@ -658,6 +674,7 @@ int mldhip_ddim_step(mldhip_handle* e, const float* eps_dev, int32_t timestep, c
 
 int mldhip_feats2joints(mldhip_handle* e, const float* feats_dev, int32_t B, int32_t T, float* joints_out_dev, void* stream_) {
   if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (is_actor(e) || e->cfg.nfeats < 67) return e->fail(MLDHIP_ESTATE, "feats2joints implements the HumanML3D layout only (SMPL-based layouts are out of scope)");
   if (!e->finalized || !e->group_ready[2]) return e->fail(MLDHIP_ESTATE, "feats2joints before finalize / mean,std not loaded");
   if (!feats_dev || !joints_out_dev) return e->fail(MLDHIP_EINVAL, "null pointer");
@@ -675,6 +692,7 @@ int mldhip_profile_kernel(mldhip_handle* e, const char* name, int32_t B, int32_t
   // shape, on the engine's own buffers (call after a sample() so they hold real activations).  The
   // caller brackets the call with events on the same stream (bench.py does) -- no timing happens here.
   if (!e || !name || !flops_per_launch) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   if (!e->finalized || !e->group_ready[0] || !e->group_ready[1]) return e->fail(MLDHIP_ESTATE, "profile before finalize");
   if (B < 1 || B > e->cfg.max_batch || T < 1 || T > e->cfg.max_frames || iters < 1) return e->fail(MLDHIP_EINVAL, "bad B/T/iters");
   CtxUse use(e, (hipStream_t)stream_);
@@ -747,6 +765,7 @@ int mldhip_profile_trace(mldhip_handle* e, const char* name, int32_t B, int32_t 
   // wave: [0] start [1] loads landed + prologue [2] LDS written [3] barrier passed [4] MFMAs done
   // [5] stores drained (shader clock), [6]/[7] start/end on the 100 MHz realtime counter.
   if (!e || !name || !out_host) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
   constexpr int64_t kMax = 512 * 8 * 8;
   if (!e->trace_buf && hipMalloc((void**)&e->trace_buf, kMax * sizeof(uint64_t)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(trace)");
   double fl = 0;

@@ -159,6 +159,11 @@ class Engine:
             array = array.detach().contiguous().float()
             shape = tuple(array.shape)
             on_device = array.is_cuda
+            if on_device:
+                # mldhip_load_tensor copies on the null stream; torch side streams are non-blocking, so a parameter that was
+                # just written on the caller's current stream (.to(device), load_state_dict) must have landed first
+                import torch
+                torch.cuda.current_stream(array.device).synchronize()
         shp = (C.c_int64 * len(shape))(*shape)
         rc = self._check(self.lib.mldhip_load_tensor(self._h, key.encode(), _ptr(array), shp, len(shape), 0,
                                                      1 if on_device else 0))

@@ -24,6 +24,7 @@ class HipModule(nn.Module):
     def __init__(self):
         super().__init__()
         self._arch: Dict[str, object] = {}           # mldhip_config fields this module's weights imply
+        self._shared_arch: Dict[str, object] = {}    # fields of the other parts of the same model (set by MLD)
         self._engine_key: Optional[str] = None      # set by tests to an injected (simulator) engine
         self._synced_sig = None
 
@@ -50,12 +51,11 @@ class HipModule(nn.Module):
     def engine(self):
         if self._engine_key is not None:
             return _engine.get_engine(self._engine_key)
-        return _engine.get_engine(next(self.parameters()).device, self._variant)
+        return _engine.get_engine(next(self.parameters()).device, self._variant, want={**self._shared_arch, **self._arch})
 
     def _set_arch(self, variant: str, **fields):
         self._variant = variant
         self._arch = dict(fields)
-        _engine.configure(variant, **fields)
 
     def _signature(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())

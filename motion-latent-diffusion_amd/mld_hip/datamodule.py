@@ -41,10 +41,12 @@ class HipDataModule:
         self.std = np.asarray(std, np.float32)
         self.hparams = type("H", (), {"mean": self.mean, "std": self.std})()
         self._engine_key = engine_key
+        self._shared_arch = {}          # architecture fields of the model this datamodule serves (set by MLD)
         self._loaded_on = None
 
     def _engine(self, device):
-        eng = _engine.get_engine(self._engine_key if self._engine_key is not None else device, self.variant or "text")
+        eng = _engine.get_engine(self._engine_key if self._engine_key is not None else device, self.variant or "text",
+                                 want=self._shared_arch)
         if self._loaded_on is not eng:
             eng.load_tensor("mean", self.mean)
             eng.load_tensor("std", self.std)

@@ -44,7 +44,7 @@ def broadcast_state(tensors: Dict[str, np.ndarray], index_template: Dict[str, np
         blob = torch.from_numpy(blob_np).to(device)
     else:
         blob = torch.empty(total, dtype=torch.float32, device=device)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():        # also at world size 1: the collective path is the same code at every N
         dist.broadcast(blob, src=src, group=group)
     return {k: blob[o:o + int(np.prod(s))].view(*s) for k, s, o in index}
 
@@ -58,9 +58,9 @@ class DataParallelSampler:
     chunks of `batch_size` and returns (global_indices, joints_list) for its block.
 
     in_flight > 1 (text-to-motion models on the fused engine path): consecutive chunks are issued on `in_flight` rotating
-    HIP streams, so several batches overlap on the GPU (the engine must have been configured with
-    ``mld_hip.engine.configure("text", max_in_flight=in_flight)`` before its first use; with fewer workspaces the calls
-    simply serialise).  Results are identical either way."""
+    HIP streams, so several batches overlap on the GPU (configure the engine with ``mld_hip.engine.configure("text", max_in_flight=in_flight)`` before
+    its first use; with fewer workspaces the engine orders the calls behind each other on the device -- a workspace is
+    never shared by two calls at once).  Results are identical either way."""
 
     def __init__(self, model, batch_size: int = 64, in_flight: int = 1):
         self.model = model

@@ -2,9 +2,14 @@
 instantiated separately from YAML (as the reference does, mld.py:56-83) all talk to ONE ``libmldhip``
 handle per (device, model variant), because the fused ``sample()`` needs every weight group in one place.
 
+Engines are looked up by (device, variant) AND by the architecture fields the asking module needs (`want`): a second
+model of the same variant with other hyper-parameters gets its own engine instead of silently changing -- or failing
+against -- the first one's.  ``configure`` only sets defaults (capacity: max_batch / max_frames / max_in_flight ...) for
+engines created later.
+
 Variants: "text" = config_mld_humanml3d (MldDenoiser text condition + MldVae), "action" = config_mld_humanact12
-(MldDenoiser action condition + ActorVae), "novae" = config_novae_humanml3d (trans_dec MldDenoiser on raw motion, DDPM).  Modules push their architecture fields with ``configure(variant, ...)``
-when constructed and verify them against the live engine before every use (``check_arch``)."""
+(MldDenoiser action condition + ActorVae), "novae" = config_novae_humanml3d (trans_dec MldDenoiser on raw motion, DDPM).  Modules keep their own architecture fields (``HipModule._arch``; ``MLD`` merges those of its parts with the
+scheduler / guidance fields into one shared dict) and pass them as `want`; ``check_arch`` re-verifies them before every use."""
 from __future__ import annotations
 
 from typing import Dict
@@ -44,13 +49,27 @@ def device_index(device) -> int:
     return d.index if d.index is not None else torch.cuda.current_device()
 
 
-def get_engine(device, variant: str = "text", **cfg) -> "_lib.Engine":
+def _matches(engine, want) -> bool:
+    for k, v in want.items():
+        have = getattr(engine.cfg, k)
+        if (abs(have - v) > 1e-6 * max(1.0, abs(v))) if isinstance(v, float) else have != v:
+            return False
+    return True
+
+
+def get_engine(device, variant: str = "text", want=None, **cfg) -> "_lib.Engine":
+    """The engine of (device, variant) whose config has every field of `want`; created (defaults + want + cfg) if none does."""
     if isinstance(device, str) and device.startswith("inject:"):
         return _engines[device]
-    key = (device_index(device), variant)
-    if key not in _engines:
-        _engines[key] = _lib.Engine(device=key[0], **{**_defaults[variant], **cfg})
-        _engines[key]._dirty = True
+    dev = device_index(device)
+    want = dict(want or {})
+    mine = [k for k in _engines if isinstance(k, tuple) and k[:2] == (dev, variant)]
+    for k in mine:
+        if _matches(_engines[k], want):
+            return _engines[k]
+    key = (dev, variant, len(mine))
+    _engines[key] = _lib.Engine(device=dev, **{**_defaults[variant], **want, **cfg})
+    _engines[key]._dirty = True
     return _engines[key]
 
 

@@ -49,9 +49,6 @@ class MLD(nn.Module):
         self._engine_key = engine_key
         # engine registry variant ("text_uncond" is the text network fed with empty prompts on both CFG halves, mld.py:228-229)
         self.variant = "novae" if self.vae_type == "no" else ("action" if self.condition == "action" else "text")
-        if engine_key is None:
-            _engine.configure(self.variant, num_inference_steps=cfg.model.scheduler.num_inference_timesteps,
-                              guidance_scale=float(self.guidance_scale))
         if hasattr(datamodule, "variant") and datamodule.variant is None:
             datamodule.variant = self.variant
         # the reference builds CLIP for every condition (mld.py:60); the action path never calls it, so it is skipped there
@@ -63,6 +60,17 @@ class MLD(nn.Module):
         for m in (self.vae, self.denoiser):
             if engine_key is not None and m is not None and hasattr(m, "use_engine"):
                 m.use_engine(engine_key)
+        # ONE engine for all parts of this model: every part asks the registry for the union of the architecture fields
+        # (the fused sample() needs every weight group in one handle); another model with other fields gets its own engine
+        shared = {}
+        for m in (self.denoiser, self.vae):
+            shared.update(getattr(m, "_arch", {}) or {})
+        if hasattr(self.scheduler, "engine_config"):
+            shared.update(self.scheduler.engine_config(cfg.model.scheduler.num_inference_timesteps))
+        shared["guidance_scale"] = float(self.guidance_scale)
+        for m in (self.denoiser, self.vae, datamodule):
+            if m is not None and hasattr(m, "_shared_arch"):
+                m._shared_arch = shared
         self.sample_mean = False
         self.fact = None
         self.do_classifier_free_guidance = self.guidance_scale > 1.0

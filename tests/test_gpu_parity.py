@@ -607,3 +607,82 @@ def test_actor_encode_vs_golden(aeng, dev, golden_dir):
     torch.cuda.synchronize()
     assert np.abs(mu.cpu().numpy() - g["mu"]).max() < 1e-4
     assert np.abs(np.sqrt(np.exp(lv.cpu().numpy())) - g["std"]).max() < 1e-4
+
+
+def test_one_workspace_two_streams_never_share_it(dev, eng):
+    """with max_in_flight = 1 two calls on different streams must be ordered behind each other on the device
+    (one activation workspace).  Interleave many calls on two non-default streams and compare with serial results."""
+    e = _lib.Engine(device=0, max_batch=8, max_frames=64, max_in_flight=1, num_inference_steps=10)
+    _load(e)
+    b1, b2 = syn.make_batch(8, [64] * 8, seed=5), syn.make_batch(8, [40, 64, 33, 64, 12, 64, 64, 50], seed=6)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ins = [(_cuda(b.text_emb, dev), _cuda(b.init_latents, dev), b.lengths) for b in (b1, b2)]
+    ref = []
+    for text, lat0, lens in ins:                                # serial reference on the default stream
+        j = torch.empty(8, 64, 22, 3, device=dev)
+        e.sample(text, lat0, lens, None, None, j)
+        torch.cuda.synchronize()
+        ref.append(j.clone())
+    torch.cuda.synchronize()
+    outs = [[torch.empty(8, 64, 22, 3, device=dev) for _ in range(6)] for _ in range(2)]
+    for it in range(6):                                         # no host sync in between: the streams race unless the engine orders them
+        for k, st in enumerate((s1, s2)):
+            text, lat0, lens = ins[k]
+            e.sample(text, lat0, lens, None, None, outs[k][it], st.cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(2):
+        for it in range(6):
+            assert torch.equal(outs[k][it], ref[k]), f"stream {k} iteration {it} differs: workspace shared by two calls"
+    e.close()
+
+
+def test_nccl_broadcast_and_dp_sampler(tmp_path):
+    """RCCL path end to end at world_size = number of visible GPUs (1 on the test box, 8 on a full node): the NCCL-backend
+    dist.broadcast of the packed weights is EXECUTED at every world size, each rank samples its shard on its own GPU."""
+    import json
+    import subprocess
+    import sys
+    world = torch.cuda.device_count()
+    out = str(tmp_path / "nccl.json")
+    here = os.path.dirname(os.path.abspath(__file__))
+    nprompts = 6 * world + 1
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(here, "dp_worker_nccl.py"), out, str(nprompts)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    got = json.load(open(out))
+    assert got["backend"] == "nccl" and got["world"] == world
+    assert len({tuple(x) for x in got["ranks"]}) == world and len({x[2] for x in got["ranks"]}) == world    # distinct devices
+    assert sorted(i for idx in got["indices"] for i in idx) == list(range(nprompts))                         # every prompt exactly once
+    assert all(got["ok"])
+
+
+def test_mld_forward_through_clip_adapter_on_gpu(dev, tmp_path, oracle_weights):
+    """MLD.forward with the real CLIP adapter class (random-init CLIPModel directory, see test_text_encoder.py) on the GPU:
+    text -> CLIP on PyTorch-ROCm -> [2B,1,768] -> libmldhip sample() -> joints, vs the oracle fed the same embeddings."""
+    from test_text_encoder import make_clip_dir
+    from mld_hip import config as C
+    from mld_hip import engine as E
+    from mld_hip.datamodule import HipDataModule
+    from mld_hip.mld import MLD
+    from mld_hip.text_encoder import MldTextEncoder
+
+    E.drop_engines()
+    d, _ = make_clip_dir(tmp_path)
+    cfg = C.load_config()
+    E.configure("text", max_batch=4, max_frames=64)
+    enc = MldTextEncoder(d)
+    model = MLD(cfg, HipDataModule(cfg), text_encoder=enc).to(dev).eval()
+    assert model.fused and next(enc.text_model.parameters()).is_cuda
+    texts, lengths = ["a man walks.", "a person runs.", ""], [40, 33, 64]
+    lat0 = _cuda(syn.make_batch(3, lengths).init_latents, dev)
+    joints = model({"text": texts, "length": lengths}, init_latents=lat0)
+    emb = enc([""] * 3 + texts)
+    assert emb.is_cuda and tuple(emb.shape) == (6, 1, 768)
+    ops, bd, bv = oracle_weights
+    mean, std = syn.make_mean_std()
+    jr = O.sample(ops, bd, bv, emb.cpu().numpy(), lat0.cpu().numpy(), lengths, mean, std)
+    for i, n in enumerate(lengths):
+        assert tuple(joints[i].shape) == (n, 22, 3) and np.abs(joints[i].numpy() - jr[i, :n]).max() < 1e-3
+    E.drop_engines()
