@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MLDHIP_ABI_VERSION 2
+#define MLDHIP_ABI_VERSION 3
 
 enum {
   MLDHIP_OK = 0,
@@ -117,6 +117,16 @@ int mldhip_load_tensor(mldhip_handle* h, const char* key, const void* data, cons
  * time-MLP outputs for the scheduler's timesteps, PE-folded biases).  Runs on `stream`. */
 int mldhip_finalize_weights(mldhip_handle* h, void* stream);
 
+/* Per-handle tuning options (ABI 3; no reference counterpart, no process-wide environment knobs).  Changing one drops the
+ * handle's captured graphs.  Names:
+ *   "loop_kernel"     0 = auto (default), 1 = latency kernels (kernels/tile32.hpp: one request of <= ~128 motions),
+ *                     2 = throughput kernels (kernels/strip.hpp: several requests coalesced into one call)
+ *   "strip_min_rows"  auto picks the throughput kernels when the reverse loop has >= this many token rows
+ *                     (6 x batch; default 768 = 128 motions)
+ *   "gemm_small_m"    row count up to which one-off GEMMs use the register-direct 16x64 shape (default 256; tests set 0
+ *                     to drive the LDS-staged kernels at simulator-sized shapes) */
+int mldhip_set_option(mldhip_handle* h, const char* name, int64_t value);
+
 /* Number of tensors the engine requires / names of those still missing (NUL-separated list
  * written to buf, returns the count missing). */
 int mldhip_missing_keys(mldhip_handle* h, char* buf, int64_t buflen);
@@ -132,6 +142,24 @@ int mldhip_missing_keys(mldhip_handle* h, char* buf, int64_t buflen);
 int mldhip_sample(mldhip_handle* h, const float* text_emb_dev, const float* init_latents_dev,
                   const int32_t* lengths_host, int32_t B, float* latents_out_dev, float* feats_out_dev,
                   float* joints_out_dev, void* stream);
+
+/* Serving entry (ABI 3): several independent requests as ONE reverse-diffusion chain and ONE decode.  Replaces: a loop
+ * of MLD.forward calls, one per batch (demo.py:171-186 iterates the batches of a prompt file; test.py does the same over
+ * the dataloader).  The reverse loop at bs 64 is a chain of ~2 000 launches with a few hundred rows each; four requests
+ * coalesced run the same chain once at 4x the rows on the throughput kernels (kernels/strip.hpp).  Motions never
+ * interact, so every request gets what mldhip_sample / mldhip_sample_action would have given it (up to fp32 summation
+ * order).  Sum of B <= max_batch.  Output shapes are those of mldhip_sample with Tmax = max(lengths) of THAT request. */
+typedef struct mldhip_request {
+  const float* text_emb_dev;      /* [2B, 1, text_dim], unconditional half first (NULL on action engines) */
+  const int32_t* actions_host;    /* [B] class labels (action engines; NULL otherwise) */
+  const float* init_latents_dev;  /* [B, latent_size, latent_dim] */
+  const int32_t* lengths_host;    /* [B] */
+  int32_t B;
+  float* latents_out_dev;         /* [B, latent_size, latent_dim] or NULL */
+  float* feats_out_dev;           /* [B, Tmax, nfeats] or NULL */
+  float* joints_out_dev;          /* [B, Tmax, njoints, 3] or NULL */
+} mldhip_request;
+int mldhip_sample_many(mldhip_handle* h, const mldhip_request* reqs, int32_t nreq, void* stream);
 
 /* Replaces: MldDenoiser.forward(sample, timestep, encoder_hidden_states)[0]
  * (mld/models/architectures/mld_denoiser.py:135-228).  sample [R,1,D], text [R,1,text_dim],
@@ -215,7 +243,7 @@ int mldhip_get_alphas_cumprod(mldhip_handle* h, float* out_host, int32_t n);
 
 /* Measurement hook (no reference counterpart): enqueue ONE named kernel of the path `iters` times on
  * `stream` at its production shape for batch B / Tmax T; writes its algorithmic FLOPs per launch.
- * names: den_{qkv,outproj,ffn,ffn1,ffn2,final}, dec_{qkv,attn,outproj_ln,ffn1,ffn2_ln}.  The caller times it with events on `stream`. */
+ * names: den_{qkv,outproj,ffn1,ffn2,final}, dec_{qkv,attn,outproj_ln,ffn1,ffn2_ln}.  The caller times it with events on `stream`. */
 int mldhip_profile_kernel(mldhip_handle* h, const char* name, int32_t B, int32_t T, int32_t iters,
                           double* flops_per_launch, void* stream);
 

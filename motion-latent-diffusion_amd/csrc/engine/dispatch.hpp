@@ -24,11 +24,9 @@ int check_launch(Ctx& c, const char* what) {
   return c.rc;
 }
 
-// Tile configurations.  "small" targets the latency-bound denoiser (M = 6B rows): one 16x16 tile per
-// wave so a GEMM spreads over as many SIMDs as possible; "large" targets the MFMA-bound decoder.
-int g_small_m = 256;         // MLDHIP_SMALL_M: row count up to which the 16x64 one-tile-per-wave shape is used (tiny one-off GEMMs)
-bool g_gemm8 = true;         // MLDHIP_GEMM8=0: the 4-wave variants of the staged fp32 GEMM tiles (A/B runs)
-bool g_staged_gemm = true;   // MLDHIP_GEMM=direct selects the first-version register-direct main loop (A/B runs)
+// Tile configurations.  Tiny one-off GEMMs (time MLP, text projection, per-sample cross-attention vectors; M up to
+// e->small_m rows) use the register-direct 16x64 one-tile-per-wave shape; everything else streams both panels through LDS
+// (64x128 tiles on 8 waves, 64x256 with the LayerNorm epilogue; 32x64 on 4 waves for the loop's K = 1024 GEMM at large M).
 
 // staged (LDS, prefetch ring) launch of one tile shape; K / 32 is a template parameter
 template <int WM, int WN, int MREP, int NREP, bool LN, int PREC>
@@ -55,39 +53,33 @@ void launch_staged(Ctx& c, const GemmArgs& a, dim3 grid) {
 }
 void gemm(Ctx& c, const GemmArgs& a, int nz = 1) {
   const int K = a.K1 + a.K2;
-  const bool small = a.M <= g_small_m || (K != 256 && K != 384 && K != 512 && K != 1024);
+  const bool small = a.M <= c.e->small_m || (K != 256 && K != 384 && K != 512 && K != 1024);
   const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_DECODE && c.e->phase == 1 && K != 384;   // decoder GEMMs only
   if (small) {
     dim3 grid((a.M + 15) / 16, (a.N + 63) / 64, nz);
     MLD_LAUNCH((gemm_kernel<1, 4, 1, 1, false>), grid, dim3(256), 0, c.stream, a);
-  } else if (!g_staged_gemm) {
-    dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);
-    MLD_LAUNCH((gemm_kernel<2, 2, 2, 4, false>), grid, dim3(256), 0, c.stream, a);
   } else {
     dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);
-    if (x3 && g_gemm8) launch_staged<2, 4, 2, 2, false, 1>(c, a, grid);
-    else if (x3) launch_staged<2, 2, 2, 4, false, 1>(c, a, grid);
-    else if (g_gemm8) launch_staged<2, 4, 2, 2, false, 0>(c, a, grid);   // same 64x128 tile on 8 waves (2 per SIMD)
-    else launch_staged<2, 2, 2, 4, false, 0>(c, a, grid);
+    if (x3) launch_staged<2, 4, 2, 2, false, 1>(c, a, grid);
+    else launch_staged<2, 4, 2, 2, false, 0>(c, a, grid);      // 64x128 tile on 8 waves (2 per SIMD)
   }
   count(c);
   check_launch(c, "gemm");
 }
 
-void gemm_ln(Ctx& c, const GemmArgs& a) {   // N == 256; full rows per workgroup (32 x 256 tile)
-  dim3 grid((a.M + 31) / 32, 1, 1);
+// 32x64 tiles on 4 waves (27.6 KB of LDS: several workgroups per CU): the loop's FFN2 at M >= 768, where N = 256 gives
+// only M/64 x 2 of the big tiles.  K in {256, 512, 1024}; fp32.
+void gemm_tile_32x64(Ctx& c, const GemmArgs& a) {
+  launch_staged<2, 2, 1, 2, false, 0>(c, a, dim3((a.M + 31) / 32, (a.N + 63) / 64, 1));
+  count(c);
+  check_launch(c, "gemm_32x64");
+}
+
+void gemm_ln(Ctx& c, const GemmArgs& a) {   // N == 256; full rows per workgroup (64 x 256 tile on 8 waves)
   const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_DECODE && c.e->phase == 1;
-  if (!g_staged_gemm) {
-    MLD_LAUNCH((gemm_kernel<1, 4, 2, 4, true>), grid, dim3(256), 0, c.stream, a);
-  } else if (x3 && g_gemm8) {
-    launch_staged<2, 4, 2, 4, true, 1>(c, a, dim3((a.M + 63) / 64, 1, 1));
-  } else if (x3) {
-    launch_staged<1, 4, 2, 4, true, 1>(c, a, grid);
-  } else if (g_gemm8) {
-    launch_staged<2, 4, 2, 4, true, 0>(c, a, dim3((a.M + 63) / 64, 1, 1));   // 64 x 256 tile on 8 waves
-  } else {
-    launch_staged<1, 4, 2, 4, true, 0>(c, a, grid);
-  }
+  const dim3 grid((a.M + 63) / 64, 1, 1);
+  if (x3) launch_staged<2, 4, 2, 4, true, 1>(c, a, grid);
+  else launch_staged<2, 4, 2, 4, true, 0>(c, a, grid);
   count(c);
   check_launch(c, "gemm_ln");
 }

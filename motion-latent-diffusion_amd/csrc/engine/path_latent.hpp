@@ -5,21 +5,26 @@
 
 namespace {
 
-// ---- denoiser layer pipeline on the tile32 kernels (4 launches per encoder layer) ----------------
-constexpr int t32_lds_bytes(int mt, int kh = 1) { return (mt + 64) * (256 / kh + 4) * 4; }
+// ---- denoiser layer pipeline (4 launches per encoder layer) on one of two kernel families -------------------------
+//   latency    (kernels/tile32.hpp): everything loaded before the first MFMA, split-K slabs summed by the consumer;
+//              M = 6B <= a few hundred rows (one bs-64 request: 384).
+//   throughput (kernels/strip.hpp + the 32x64 staged GEMM): A strip resident, weights streamed, 3 workgroups per CU,
+//              no split-K (one raw slab per GEMM); M >= strip_min_rows (several requests coalesced into one chain).
+// Both use the same data flow: a GEMM with K > 256 or a following LayerNorm leaves RAW fp32 partial slabs, and the
+// consumer's A prologue applies slab sum + bias + residual + LayerNorm (or the 3-token attention).
+constexpr int t32_lds_bytes(int mt) { return (mt + 64) * (256 + 4) * 4; }
 
 void tile32(Ctx& c, const Tile32Args& a_, int nz) {
   Tile32Args a = a_;
   a.trace = c.e->trace_on;
   // 16-row K-split tiles for the narrow (N = 256) GEMMs: more workgroups, fewer bytes and MFMAs per CU
-  const bool mt16 = a.N <= 256 && ((a.M + 15) / 16) * ((a.N + 63) / 64) * nz <= 256 && c.e->tile16;
+  const bool mt16 = a.N <= 256 && ((a.M + 15) / 16) * ((a.N + 63) / 64) * nz <= 256;
   const int mt = mt16 ? 16 : 32;
   dim3 grid((a.M + mt - 1) / mt, (a.N + 63) / 64, nz);
   const int ns = a.src[0].attn_R > 0 ? 0 : a.src[0].nsplit;
 #define MLD_T32(MT, NS)                                                                                          \
   do {                                                                                                           \
     if (a.trace) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, true>), grid, dim3(512), t32_lds_bytes(MT), c.stream, a); }  \
-    else if (c.e->t32_kh == 2) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, 2>), grid, dim3(512), t32_lds_bytes(MT, 2), c.stream, a); } \
     else { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false>), grid, dim3(512), t32_lds_bytes(MT), c.stream, a); }         \
   } while (0)
 #define MLD_T32_NS(MT)                                                                                           \
@@ -28,7 +33,6 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
     case 1: MLD_T32(MT, 1); break;                                                                               \
     case 2: MLD_T32(MT, 2); break;                                                                               \
     case 4: MLD_T32(MT, 4); break;                                                                               \
-    case 8: MLD_T32(MT, 8); break;                                                                               \
     default: c.rc = c.e->fail(MLDHIP_EINVAL, "tile32: unsupported slab count %d", ns); return;                   \
   }
   if (mt16) { MLD_T32_NS(16) } else { MLD_T32_NS(32) }
@@ -36,6 +40,20 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
 #undef MLD_T32
   count(c);
   check_launch(c, "gemm_tile32");
+}
+
+// throughput family: K = 256 (one source) or 512 (skip linear: src[0] | src[1]); src[0] plain, 1-slab combine or attention
+void strip(Ctx& c, const Tile32Args& a, int nsrc) {
+  const dim3 grid((a.M + 31) / 32, (a.N + 63) / 64, 1);
+  const bool attn = a.src[0].attn_R > 0;
+  const int ns = attn ? 0 : a.src[0].nsplit;
+  if (attn && nsrc == 1) { MLD_LAUNCH((gemm_strip_kernel<0, 1, true>), grid, dim3(256), strip_lds_bytes<1>(), c.stream, a); }
+  else if (ns == 0 && nsrc == 1) { MLD_LAUNCH((gemm_strip_kernel<0, 1, false>), grid, dim3(256), strip_lds_bytes<1>(), c.stream, a); }
+  else if (ns == 1 && nsrc == 1) { MLD_LAUNCH((gemm_strip_kernel<1, 1, false>), grid, dim3(256), strip_lds_bytes<1>(), c.stream, a); }
+  else if (ns == 1 && nsrc == 2) { MLD_LAUNCH((gemm_strip_kernel<1, 2, false>), grid, dim3(256), strip_lds_bytes<2>(), c.stream, a); }
+  else { c.rc = c.e->fail(MLDHIP_EINVAL, "strip: unsupported source (slabs %d, segments %d)", ns, nsrc); return; }
+  count(c);
+  check_launch(c, "gemm_strip");
 }
 
 ASrc plain_src(const float* base, int ld) {
@@ -51,20 +69,28 @@ ASrc combine_src(const float* slabs, int nsplit, long long pstride, const float*
   return s;
 }
 
-// One chain's slice of the denoiser workspace: rows [row0, row0 + 3R) of every row-indexed buffer.
+// The denoiser workspace as one chain sees it: rows [0, 3R) of every row-indexed buffer.
 struct DenView {
   float *X0, *QKV, *FF, *H1, *Ha, *Po, *Pf, *Ps, *S[8], *lat;
-  int R;            // samples in this chain's CFG batch (uncond half first)
+  int R;            // samples in the CFG batch (uncond half first)
+  bool strip;       // throughput kernel family (see above)
+  int ffn_slabs, skip_slabs;   // raw partial slabs FFN2 / the skip linear leave behind
 };
 
-DenView den_view(E* e, int row0, int b0, int R) {
+bool use_strip(const E* e, int rows) {
+  return e->loop_kernel == 2 || (e->loop_kernel == 0 && rows >= e->strip_min_rows);
+}
+
+DenView den_view(E* e, int R) {
   DenView v;
-  const size_t D = e->cfg.latent_dim, F = e->cfg.ff_size, r0 = (size_t)row0;
-  v.X0 = e->X0 + r0 * D; v.QKV = e->QKV + r0 * 3 * D; v.FF = e->FF + r0 * F; v.H1 = e->H1 + r0 * D; v.Ha = e->Ha + r0 * D;
-  v.Po = e->Po + r0 * D; v.Pf = e->Pf + r0 * D; v.Ps = e->Ps + r0 * D;
-  for (int i = 0; i < 8; ++i) v.S[i] = e->S[i] ? e->S[i] + r0 * D : nullptr;
-  v.lat = e->lat + (size_t)b0 * D;
+  v.X0 = e->X0; v.QKV = e->QKV; v.FF = e->FF; v.H1 = e->H1; v.Ha = e->Ha;
+  v.Po = e->Po; v.Pf = e->Pf; v.Ps = e->Ps;
+  for (int i = 0; i < 8; ++i) v.S[i] = e->S[i];
+  v.lat = e->lat;
   v.R = R;
+  v.strip = use_strip(e, 3 * R);
+  v.ffn_slabs = v.strip ? 1 : e->cfg.ff_size / 256;
+  v.skip_slabs = v.strip ? 1 : 2;
   return v;
 }
 long long den_slab(const E* e) { return (long long)6 * e->cfg.max_batch * 256; }
@@ -73,14 +99,14 @@ long long den_slab(const E* e) { return (long long)6 * e->cfg.max_batch * 256; }
 void den_qkv(Ctx& c, const DenView& v, const EncLayerP& L, const ASrc& x) {
   Tile32Args a;
   a.src[0] = x; a.nz0 = 1; a.W = L.in_w; a.ldw = 256; a.bias = L.in_b; a.Y = v.QKV; a.ldy = 768; a.M = 3 * v.R; a.N = 768;
-  tile32(c, a, 1);
+  if (v.strip) strip(c, a, 1); else tile32(c, a, 1);
 }
 // out-projection of the 3-token self-attention (computed while the A tile is assembled) -> raw slab Po
 void den_outproj(Ctx& c, const DenView& v, const EncLayerP& L) {
   Tile32Args a;
   a.src[0].base = v.QKV; a.src[0].attn_R = v.R;
   a.nz0 = 1; a.W = L.out_w; a.ldw = 256; a.P = v.Po; a.pstride = 0; a.M = 3 * v.R; a.N = 256;
-  tile32(c, a, 1);
+  if (v.strip) strip(c, a, 1); else tile32(c, a, 1);
 }
 // h1 = LN1(x + out_proj) assembled on load (written to H1), FF = gelu(h1 W1^T + b1)
 void den_ffn1(Ctx& c, const DenView& v, const EncLayerP& L, const float* xn) {
@@ -88,30 +114,23 @@ void den_ffn1(Ctx& c, const DenView& v, const EncLayerP& L, const float* xn) {
   Tile32Args a;
   a.src[0] = combine_src(v.Po, 1, 0, L.out_b, xn, L.n1_w, L.n1_b, v.H1);
   a.nz0 = 1; a.W = L.l1_w; a.ldw = 256; a.bias = L.l1_b; a.act = 1; a.Y = v.FF; a.ldy = F; a.M = 3 * v.R; a.N = F;
-  tile32(c, a, 1);
+  if (v.strip) strip(c, a, 1); else tile32(c, a, 1);
 }
-// FFN2 as ff_size/256 K-slices -> raw slabs Pf; bias, residual and norm2 are applied by whoever reads them
+// FFN2 -> raw slabs Pf (ff_size/256 K-slices on the latency kernels, one full-K slab on the throughput kernels);
+// bias, residual and norm2 are applied by whoever reads them
 void den_ffn2(Ctx& c, const DenView& v, const EncLayerP& L) {
   const int F = c.e->cfg.ff_size;
+  if (v.strip) {
+    gemm_tile_32x64(c, lin_args(v.FF, F, F, L.l2_w, nullptr, v.Pf, 256, 3 * v.R, 256));
+    return;
+  }
   Tile32Args a;
   a.src[0] = plain_src(v.FF, F);
   a.nz0 = F / 256; a.W = L.l2_w; a.ldw = F; a.P = v.Pf; a.pstride = den_slab(c.e); a.M = 3 * v.R; a.N = 256;
   tile32(c, a, F / 256);
 }
-int den_ffn_slabs(const E* e) { return e->fused_ffn ? e->cfg.ff_size / kFfnHS : e->cfg.ff_size / 256; }
 ASrc den_layer_output(E* e, const DenView& v, const EncLayerP& L, float* write_back) {   // LN2(sum Pf + b2 + h1)
-  return combine_src(v.Pf, den_ffn_slabs(e), den_slab(e), L.l2_b, v.H1, L.n2_w, L.n2_b, write_back);
-}
-// linear1 + GELU + linear2 in one launch (kernels/fused_layer.hpp): h1 = LN1(x + out_proj) assembled on load (written
-// to H1), raw FFN2 partial slabs -> Pf[ff_size/128]
-void den_ffn_fused(Ctx& c, const DenView& v, const EncLayerP& L, const float* xn) {
-  FfnFusedArgs a;
-  a.src = combine_src(v.Po, 1, 0, L.out_b, xn, L.n1_w, L.n1_b, v.H1);
-  a.W1 = L.l1_w; a.b1 = L.l1_b; a.W2 = L.l2_w; a.P = v.Pf; a.pstride = den_slab(c.e); a.M = 3 * v.R; a.F = c.e->cfg.ff_size;
-  dim3 grid((a.M + 15) / 16, a.F / kFfnHS);
-  MLD_LAUNCH((den_ffn_fused_kernel<1>), grid, dim3(512), kFfnLdsBytes, c.stream, a);
-  count(c);
-  check_launch(c, "den_ffn_fused");
+  return combine_src(v.Pf, v.ffn_slabs, den_slab(e), L.l2_b, v.H1, L.n2_w, L.n2_b, write_back);
 }
 
 // SkipTransformerEncoder over the 3-token sequences (cross_attention.py:41-64).  Leaves the last layer's
@@ -125,20 +144,16 @@ void denoiser_body(Ctx& c, const DenView& v) {
     const EncLayerP& P_ = e->den[l];
     den_qkv(c, v, P_, x);
     den_outproj(c, v, P_);
-    if (e->fused_ffn) {
-      den_ffn_fused(c, v, P_, xn);
-    } else {
-      den_ffn1(c, v, P_, xn);
-      den_ffn2(c, v, P_);
-    }
+    den_ffn1(c, v, P_, xn);
+    den_ffn2(c, v, P_);
     if (l + 1 == L) break;
     if (l < nb) {
       // next layer input = LN2(...), kept in S[l] for the skip connection (written by the next QKV prologue)
       x = den_layer_output(e, v, P_, v.S[l]);
       xn = v.S[l];
     } else {
-      // Linear(cat[x, skip]) as two K slices (cross_attention.py:56-58): slice 0 assembles x = LN2(...) on load,
-      // slice 1 reads the stored skip activation; the sum + bias is assembled by the next QKV prologue.
+      // Linear(cat[x, skip]) as two K segments (cross_attention.py:56-58): segment 0 assembles x = LN2(...) on load,
+      // segment 1 reads the stored skip activation; the bias is added by the next QKV prologue.
       const int i = l - nb;
       Tile32Args a;
       a.src[0] = den_layer_output(e, v, P_, nullptr);
@@ -146,9 +161,9 @@ void denoiser_body(Ctx& c, const DenView& v) {
       a.nz0 = 1;
       a.W = P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".weight"); a.ldw = 512;
       a.P = v.Ps; a.pstride = den_slab(e); a.M = 3 * v.R; a.N = 256;
-      tile32(c, a, 2);
-      x = combine_src(v.Ps, 2, den_slab(e), P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".bias"), nullptr, nullptr,
-                      nullptr, v.Ha);
+      if (v.strip) strip(c, a, 2); else tile32(c, a, 2);
+      x = combine_src(v.Ps, v.skip_slabs, den_slab(e), P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".bias"), nullptr,
+                      nullptr, nullptr, v.Ha);
       xn = v.Ha;
     }
   }
@@ -157,7 +172,7 @@ void denoiser_body(Ctx& c, const DenView& v) {
 FinalArgs den_final_args(E* e, const DenView& v) {
   const EncLayerP& L = e->den.back();
   FinalArgs f;
-  f.P = v.Pf; f.nsplit = den_ffn_slabs(e); f.pstride = den_slab(e);
+  f.P = v.Pf; f.nsplit = v.ffn_slabs; f.pstride = den_slab(e);
   f.b2 = L.l2_b; f.H1 = v.H1; f.g2 = L.n2_w; f.be2 = L.n2_b;
   f.gf = P(e, "denoiser.encoder.norm.weight"); f.bef = P(e, "denoiser.encoder.norm.bias");
   return f;
@@ -376,10 +391,9 @@ void joints_body(Ctx& c, const float* feats, int B, int T, float* joints) {
   check_launch(c, "feats2joints");
 }
 
-// Everything mld.py:232-240,264 does after the text encoder.  The reverse loop is latency bound (a few
-// hundred rows per launch), and samples never interact, so the batch is cut into `nchains` sub-batches
-// whose 50-step chains run on parallel branches (side streams forked from / joined to `stream`; inside
-// a capture they become parallel branches of the hipGraph).  The MFMA-bound decode runs on the whole batch.
+// Everything mld.py:232-240,264 does after the text encoder (enqueue_sample below).  The whole CFG batch runs as ONE
+// chain of dependent launches (splitting a batch into sub-batch chains on parallel graph branches was measured: the
+// sequential depth per chain is what costs, no gain -- profiles/r01_v3_chains*; removed).
 // rows of token 2 for an action CFG batch of R rows -> dst[R][D] (labels already in labels_dev)
 void action_rows(Ctx& c, int R, int nuncond, float* dst) {
   E* e = c.e;
@@ -400,47 +414,22 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
   e->phase = 0;
   if (text) text_projection(c, text, 2 * B, e->TP);
   else action_rows(c, 2 * B, B, e->TP);
-  int nch = std::min(e->nchains, B);
-  const int Bc = (B + nch - 1) / nch;
-  nch = (B + Bc - 1) / Bc;
-#if !defined(MLDHIP_SIM)
-  if (nch > 1) {
-    hipError_t s = hipEventRecord(e->ev_fork, stream);
-    for (int ch = 1; ch < nch && s == hipSuccess; ++ch) s = hipStreamWaitEvent(e->side[ch - 1], e->ev_fork, 0);
-    if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "fork: %s", hipGetErrorString(s));
-  }
-#endif
-  int rc = 0;
-  for (int ch = 0; ch < nch; ++ch) {
-    const int b0 = ch * Bc, bc = std::min(Bc, B - b0);
-#if !defined(MLDHIP_SIM)
-    Ctx cc{e, ch == 0 ? stream : e->side[ch - 1]};
-#else
-    Ctx cc{e, stream};
-#endif
-    const DenView v = den_view(e, 6 * b0, b0, 2 * bc);
-    MLD_LAUNCH(init_chain_kernel, dim3(bc), dim3(256), 0, cc.stream, init_lat + (size_t)b0 * D, v.lat, v.X0,
-               P(e, "denoiser.query_pos.pe"), (const float*)e->T1, (const float*)e->TP, B, b0, bc, 1.0f /* init_noise_sigma */);
-    count(cc);
-    check_launch(cc, "init_chain");
-    for (int s = 0; s < n && !cc.rc; ++s) {
-      denoiser_body(cc, v);
+  {
+    const DenView v = den_view(e, 2 * B);
+    MLD_LAUNCH(init_chain_kernel, dim3(B), dim3(256), 0, stream, init_lat, v.lat, v.X0, P(e, "denoiser.query_pos.pe"),
+               (const float*)e->T1, (const float*)e->TP, B, 0, B, 1.0f /* init_noise_sigma */);
+    count(c);
+    check_launch(c, "init_chain");
+    for (int s = 0; s < n && !c.rc; ++s) {
+      denoiser_body(c, v);
       const float* t1n = (s + 1 < n) ? e->T1 + (size_t)(s + 1) * D : nullptr;
-      MLD_LAUNCH(den_final_step_kernel, dim3(bc), dim3(256), 0, cc.stream, den_final_args(e, v), v.lat, v.X0,
-                 P(e, "denoiser.query_pos.pe"), t1n, bc, guidance, ddim_coef(e, e->timesteps[s]));
-      count(cc);
-      check_launch(cc, "den_final_step");
+      MLD_LAUNCH(den_final_step_kernel, dim3(B), dim3(256), 0, stream, den_final_args(e, v), v.lat, v.X0,
+                 P(e, "denoiser.query_pos.pe"), t1n, B, guidance, ddim_coef(e, e->timesteps[s]));
+      count(c);
+      check_launch(c, "den_final_step");
     }
-    if (cc.rc && !rc) rc = cc.rc;
-#if !defined(MLDHIP_SIM)
-    if (ch > 0) {   // join (also on error paths, so a capture can always be closed)
-      hipError_t s = hipEventRecord(e->ev_join[ch - 1], e->side[ch - 1]);
-      if (s == hipSuccess) s = hipStreamWaitEvent(stream, e->ev_join[ch - 1], 0);
-      if (s != hipSuccess && !rc) rc = e->fail(MLDHIP_EHIP, "join: %s", hipGetErrorString(s));
-    }
-#endif
   }
-  if (rc) return rc;
+  if (c.rc) return c.rc;
   if (lat_out) {
     hipError_t s = hipMemcpyAsync(lat_out, e->lat, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream);
     if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "latents copy: %s", hipGetErrorString(s));

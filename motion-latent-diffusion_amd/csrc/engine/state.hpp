@@ -99,18 +99,16 @@ struct mldhip_engine {
   std::vector<int32_t> lens2_host;
   float *text_in = nullptr, *lat_in = nullptr;   // graph staging of the caller's inputs
   float* TP;             // text projection rows [2*max_batch][256] (+pe[2]), gathered per chain
-  bool fused_ffn = false; // MLDHIP_FUSED_FFN=1: linear1+GELU+linear2 in one launch (measured slower: DESIGN.md §3 point 9)
-  int t32_kh = 1;        // MLDHIP_T32_KH=2: tile32 kernels pass K through LDS in two pieces (two workgroups per CU)
-  bool tile16 = true;    // MLDHIP_TILE16=0 disables the 16-row K-split tiles (A/B runs)
-  int nchains = 1;       // independent sub-batch chains of the reverse loop (parallel graph branches)
+  // per-handle options (mldhip_set_option)
+  int small_m = 256;         // "gemm_small_m": row count up to which the register-direct tiny-GEMM shape is used
+  int loop_kernel = 0;       // "loop_kernel": 0 auto (by rows), 1 latency kernels (tile32.hpp), 2 throughput kernels (strip.hpp)
+  int strip_min_rows = 768;  // "strip_min_rows": auto switches to the throughput kernels at 6B >= this many token rows
 
   int launches[3] = {0, 0, 0};
   int phase = 0;
 
 #if !defined(MLDHIP_SIM)
   hipStream_t cap_stream = nullptr;
-  hipStream_t side[7] = {};
-  hipEvent_t ev_fork = nullptr, ev_join[7] = {};
 #endif
 
   int fail(int code, const char* fmt, ...) {

@@ -334,10 +334,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
     // All epilogue loads are unconditional (clamped indices) and issued as one batch: a `cond ? load : 0`
     // becomes a branch + vmcnt(0) per load in hipcc's output (four serialised bias latencies before this).
     float bv[NREP];
+    if (bias) {                        // uniform: one branch around the whole block of loads (raw split-K slabs have none)
 #pragma unroll
-    for (int b = 0; b < NREP; ++b) {
-      const int col = n0 + b * 16 + r;
-      bv[b] = bias[col < p.N ? col : p.N - 1];
+      for (int b = 0; b < NREP; ++b) {
+        const int col = n0 + b * 16 + r;
+        bv[b] = bias[col < p.N ? col : p.N - 1];
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < NREP; ++b) bv[b] = 0.f;
     }
     bool rowok[MREP][4];
     float rowmask[MREP][4];

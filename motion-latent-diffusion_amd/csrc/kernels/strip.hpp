@@ -1,0 +1,250 @@
+// Throughput-oriented GEMM for the denoiser loop when several bs-64 requests run as ONE chain (M = 6B >= ~768 token
+// rows): Y[32 x 64] per workgroup, the A strip (32 rows x all of K) resident in LDS after the same "A prologue" the
+// latency kernels use (split-K slab sum + bias + residual + post-norm LayerNorm, or the 3-token self-attention,
+// kernels/tile32.hpp), the weight panel streamed through a double-buffered LDS ring in 32-wide K chunks behind a
+// 4-deep register prefetch ring, so chunk k's MFMAs run while chunks k+1..k+4 are in flight.
+//
+// Why a second kernel next to tile32.hpp: tile32 parks A AND W whole in LDS (99.8 KB -> one 8-wave workgroup per CU,
+// every load issued before the first MFMA): right when one launch has <= 192 workgroups and the only goal is a short
+// dependent chain (M = 384), but at M = 1 536 its 576-768 workgroups run in three serial rounds with no overlap of one
+// round's loads and another's MFMAs (measured r01: 24 TF on FFN1).  Here a workgroup is 4 waves with <= 52 KB of LDS
+// and <= 168 VGPRs, so three are resident per CU and their load / MFMA / store phases overlap each other.
+//
+// Row layout and the meaning of every ASrc / Tile32Args field are those of tile32.hpp (token-major rows, 256 floats).
+// Replaces the same reference code: cross_attention.py:259-272 (encoder layer), :56-58 (skip linear).
+#pragma once
+#include "tile32.hpp"
+
+namespace mld {
+
+constexpr int kStripWStride = 36;                        // floats per staged W row: one 32-wide K chunk + 4 pad
+template <int NSRC>
+constexpr int strip_lds_bytes() { return (32 * (256 * NSRC + 4) + 2 * 64 * kStripWStride) * 4; }   // 51 712 / 84 480 B
+
+// grid = (ceil(M/32), ceil(N/64)); block = 256 (4 waves).  Wave w owns output columns [16w, 16w+16) of the tile, both
+// 16-row tiles.  K = 256 * NSRC: columns [0, 256) come from src[0] (plain rows, combine, or attention), columns
+// [256, 512) from src[1] (plain rows; the skip connection's second K segment).
+// NS0 = compile-time slab count of src[0] in combine mode (0: plain rows or attention).
+template <int NS0, int NSRC, bool ATTN>
+__global__ __launch_bounds__(256, ATTN ? 2 : 3) void gemm_strip_kernel(Tile32Args p) {
+  static_assert(NSRC == 1 || NSRC == 2, "one or two 256-wide K segments");
+  static_assert(!(ATTN && (NS0 != 0 || NSRC != 1)), "the attention prologue feeds the out-projection only");
+  constexpr int K = 256 * NSRC, ST = K + 4, KCS = K / 32, RPW = 8;
+#if defined(MLDHIP_SIM)
+  float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
+#else
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+#endif
+  float* As = smem;                          // [32][ST]
+  float* Ws = smem + 32 * ST;                // [2][64][kStripWStride]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
+  const ASrc& src = p.src[0];
+
+  // ---- weight ring: thread t stages rows (t>>3) and (t>>3)+32 of the panel, 16 bytes at column 4*(t&7) of the chunk
+  const int wrow = tid >> 3, wc4 = tid & 7;
+  int wn0 = n0 + wrow, wn1 = n0 + wrow + 32;
+  wn0 = wn0 < p.N ? wn0 : p.N - 1;
+  wn1 = wn1 < p.N ? wn1 : p.N - 1;
+  const float* wp0 = p.W + (long long)wn0 * p.ldw + wc4 * 4;
+  const float* wp1 = p.W + (long long)wn1 * p.ldw + wc4 * 4;
+  F4 ring[4][2];
+  auto gload = [&](int c) {                  // c is a constant after unrolling
+    ring[c & 3][0] = ld4(wp0 + c * 32);
+    ring[c & 3][1] = ld4(wp1 + c * 32);
+  };
+  auto lstore = [&](int c) {
+    float* dst = Ws + (c & 1) * 64 * kStripWStride + wc4 * 4;
+    st4(dst + wrow * kStripWStride, ring[c & 3][0]);
+    st4(dst + (wrow + 32) * kStripWStride, ring[c & 3][1]);
+  };
+
+  // epilogue bias of this lane's output column, fetched now (clamped, unconditional)
+  const int ecol = n0 + wave * 16 + (lane & 15);
+  float ebias = 0.f;
+  if (p.bias) ebias = p.bias[ecol < p.N ? ecol : p.N - 1];
+
+  // ---- A prologue: wave w assembles rows w, w+4, ..., w+28 of the strip; lane l owns columns 4l..4l+3
+  int rows[RPW];
+  bool live[RPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int row = m0 + wave + i * 4;
+    live[i] = row < p.M;
+    rows[i] = live[i] ? row : p.M - 1;
+  }
+  F4 areg[RPW];
+  if constexpr (ATTN) {
+    // 3-token self-attention on load (tile32.hpp, cross_attention.py:265-266), four rows at a time to bound registers;
+    // the weight ring is started once the last pass's loads are out
+    const int R = src.attn_R;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      F4 q[4], k[4][3], v[4][3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = rows[h * 4 + i], tok = row / R, smp = row - tok * R;
+        q[i] = ld4(src.base + (long long)row * 768 + lane * 4);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float* kr = src.base + (long long)(j * R + smp) * 768 + 256 + lane * 4;
+          k[i][j] = ld4(kr);
+          v[i][j] = ld4(kr + 256);
+        }
+      }
+      if (h == 1) { gload(0); gload(1); gload(2); gload(3); }
+      float sc[12];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float d = q[i].x * k[i][j].x;
+          d = fmaf(q[i].y, k[i][j].y, d);
+          d = fmaf(q[i].z, k[i][j].z, d);
+          d = fmaf(q[i].w, k[i][j].w, d);
+          sc[i * 3 + j] = d;
+        }
+      sum16xn<12>(sc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float s0 = sc[i * 3] * 0.125f, s1 = sc[i * 3 + 1] * 0.125f, s2 = sc[i * 3 + 2] * 0.125f;
+        const float m = fmaxf(s0, fmaxf(s1, s2));
+        const float e0 = expf(s0 - m), e1 = expf(s1 - m), e2 = expf(s2 - m);
+        const float inv = 1.0f / (e0 + e1 + e2);
+        const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
+        F4 o;
+        o.x = p0 * v[i][0].x + p1 * v[i][1].x + p2 * v[i][2].x;
+        o.y = p0 * v[i][0].y + p1 * v[i][1].y + p2 * v[i][2].y;
+        o.z = p0 * v[i][0].z + p1 * v[i][1].z + p2 * v[i][2].z;
+        o.w = p0 * v[i][0].w + p1 * v[i][1].w + p2 * v[i][2].w;
+        areg[h * 4 + i] = o;
+      }
+    }
+  } else if constexpr (NS0 == 0) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) areg[i] = ld4(src.base + (long long)rows[i] * src.ld + lane * 4);
+    gload(0); gload(1); gload(2); gload(3);
+  } else {
+    // combine: sum of NS0 slabs + bias (+ residual), optional LayerNorm; one wave owns a row (tile32.hpp)
+    F4 sl[RPW][NS0], rs[RPW];
+    const bool has_res = src.res != nullptr, has_ln = src.gamma != nullptr;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+      for (int s = 0; s < NS0; ++s) sl[i][s] = ld4(src.base + s * src.pstride + (long long)rows[i] * 256 + lane * 4);
+    if (has_res) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) rs[i] = ld4(src.res + (long long)rows[i] * src.ldres + lane * 4);
+    }
+    const F4 bias = ld4(src.bias + lane * 4);
+    F4 gm = F4{1.f, 1.f, 1.f, 1.f}, bt = F4{0.f, 0.f, 0.f, 0.f};
+    if (has_ln) { gm = ld4(src.gamma + lane * 4); bt = ld4(src.beta + lane * 4); }
+    gload(0); gload(1); gload(2); gload(3);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      F4 v = sl[i][0];
+#pragma unroll
+      for (int s = 1; s < NS0; ++s) v = f4add(v, sl[i][s]);
+      v = f4add(v, bias);
+      if (has_res) v = f4add(v, rs[i]);
+      areg[i] = v;
+    }
+    if (has_ln) {
+      float s[RPW];
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) s[i] = areg[i].x + areg[i].y + areg[i].z + areg[i].w;
+      sum64xn<RPW>(s);
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const float mean = s[i] * (1.0f / 256.0f);
+        areg[i] = F4{areg[i].x - mean, areg[i].y - mean, areg[i].z - mean, areg[i].w - mean};
+        s[i] = areg[i].x * areg[i].x + areg[i].y * areg[i].y + areg[i].z * areg[i].z + areg[i].w * areg[i].w;
+      }
+      sum64xn<RPW>(s);
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const float rstd = rsqrtf(s[i] * (1.0f / 256.0f) + kLnEps);
+        areg[i] = F4{areg[i].x * rstd * gm.x + bt.x, areg[i].y * rstd * gm.y + bt.y, areg[i].z * rstd * gm.z + bt.z,
+                     areg[i].w * rstd * gm.w + bt.w};
+      }
+    }
+    if (src.out && blockIdx.y == 0) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i)
+        if (live[i]) st4(src.out + (long long)rows[i] * src.ldout + lane * 4, areg[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) st4(As + (wave + i * 4) * ST + lane * 4, areg[i]);
+  if constexpr (NSRC == 2) {                 // second K segment: plain rows (the stored skip activation)
+    const ASrc& s1 = p.src[1];
+    F4 breg[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) breg[i] = ld4(s1.base + (long long)rows[i] * s1.ld + lane * 4);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) st4(As + (wave + i * 4) * ST + 256 + lane * 4, breg[i]);
+  }
+
+  // ---- main loop: one barrier per K chunk; chunk kc multiplies while kc+1 is written to the other LDS buffer and
+  //      kc+2..kc+4 are in flight (straight-line after unrolling: KCS is a compile-time constant)
+  const int r = lane & 15, g = lane >> 4;
+  const float* ap = As + r * ST + g * 8;
+  const float* wp = Ws + (wave * 16 + r) * kStripWStride + g * 8;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  lstore(0);
+  if (4 < KCS) gload(4);
+  __syncthreads();
+#pragma unroll
+  for (int kc = 0; kc < KCS; ++kc) {
+    const float* wb = wp + (kc & 1) * 64 * kStripWStride;
+    const F4 b0 = ld4(wb), b1 = ld4(wb + 4);
+    const F4 a0 = ld4(ap + kc * 32), a1 = ld4(ap + kc * 32 + 4);
+    const F4 c0 = ld4(ap + 16 * ST + kc * 32), c1 = ld4(ap + 16 * ST + kc * 32 + 4);
+    acc0 = mfma_f32_16x16x4(a0.x, b0.x, acc0);
+    acc1 = mfma_f32_16x16x4(c0.x, b0.x, acc1);
+    acc0 = mfma_f32_16x16x4(a0.y, b0.y, acc0);
+    acc1 = mfma_f32_16x16x4(c0.y, b0.y, acc1);
+    acc0 = mfma_f32_16x16x4(a0.z, b0.z, acc0);
+    acc1 = mfma_f32_16x16x4(c0.z, b0.z, acc1);
+    acc0 = mfma_f32_16x16x4(a0.w, b0.w, acc0);
+    acc1 = mfma_f32_16x16x4(c0.w, b0.w, acc1);
+    acc0 = mfma_f32_16x16x4(a1.x, b1.x, acc0);
+    acc1 = mfma_f32_16x16x4(c1.x, b1.x, acc1);
+    acc0 = mfma_f32_16x16x4(a1.y, b1.y, acc0);
+    acc1 = mfma_f32_16x16x4(c1.y, b1.y, acc1);
+    acc0 = mfma_f32_16x16x4(a1.z, b1.z, acc0);
+    acc1 = mfma_f32_16x16x4(c1.z, b1.z, acc1);
+    acc0 = mfma_f32_16x16x4(a1.w, b1.w, acc0);
+    acc1 = mfma_f32_16x16x4(c1.w, b1.w, acc1);
+    if (kc + 1 < KCS) {
+      lstore(kc + 1);
+      if (kc + 5 < KCS) gload(kc + 5);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: 16 lanes write 64 contiguous bytes per row (raw partial slab, or bias + activation)
+  const int col = n0 + wave * 16 + r;
+  if (col < p.N) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 acc = t == 0 ? acc0 : acc1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + t * 16 + g * 4 + i;
+        if (row < p.M) {
+          if (p.P) {
+            p.P[(long long)row * p.N + col] = acc[i];
+          } else {
+            float v = acc[i] + ebias;
+            if (p.act == 1) v = gelu_erf(v);
+            else if (p.act == 2) v = silu(v);
+            p.Y[(long long)row * p.ldy + col] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace mld

@@ -76,16 +76,13 @@ __device__ __forceinline__ F4 f4add(F4 a, F4 b) { return F4{a.x + b.x, a.y + b.y
 // NS0 = compile-time slab count of src[0] when it is a combine source (0: src[0] is plain / attention):
 // keeps every load unconditional and straight-line (a per-load `cond ? load : 0` makes hipcc branch and
 // wait per element -- cdna_hip_programming.md, "three .s-level traps" (c)).
-// KH = number of K pieces that pass through LDS one after the other (1: the whole 256-wide slice is resident, 99.8 KB
-// for MT = 32; 2: 128 columns at a time, 50.7 KB, and the register budget is capped at 128 so that TWO workgroups fit a
-// CU -- with several batches in flight (DESIGN.md §3 point 11) another chain's kernel can then run its MFMAs while this
-// one waits for its loads).  The global loads are identical (all issued up front, full K in registers).
-template <int MT, int NS0, bool TRACE, int KH = 1>
-__global__ __launch_bounds__(512, KH == 2 ? 4 : 2) void gemm_tile32_kernel(Tile32Args p) {
+// (Passing K through LDS in two 128-wide pieces so that two workgroups fit a CU was measured: +2.9 % with four batches in
+// flight, -10 % for one batch; removed -- kernels/strip.hpp is the throughput form.  profiles/r01_v17_xcd_kh_ab.txt.)
+template <int MT, int NS0, bool TRACE>
+__global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
   static_assert(MT == 16 || MT == 32, "row tile");
-  static_assert(KH == 1 || KH == 2, "K pieces");
   constexpr int RPW = MT / 8;                 // A rows assembled per wave
-  constexpr int KW = 256 / KH, ST = KW + 4;   // K columns resident in LDS, LDS row stride (floats)
+  constexpr int KW = 256, ST = KW + 4;        // K columns resident in LDS, LDS row stride (floats)
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
 #else
@@ -228,22 +225,18 @@ __global__ __launch_bounds__(512, KH == 2 ? 4 : 2) void gemm_tile32_kernel(Tile3
   const int ct = wave & 3;
   const int rt = MT == 32 ? (wave >> 2) : 0;          // row tile (MT = 32)
   const int kh = MT == 16 ? (wave >> 2) : 0;          // K half of the resident piece (MT = 16)
-  constexpr int KCH = (MT == 32 ? 8 : 4) / KH;        // 32-wide K chunks per wave and resident piece
+  constexpr int KCH = MT == 32 ? 8 : 4;               // 32-wide K chunks per wave
   const float* ap = As + (rt * 16 + r) * ST + g * 8 + kh * (KW / 2);
   const float* wp = Ws + (ct * 16 + r) * ST + g * 8 + kh * (KW / 2);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  {
 #pragma unroll
-  for (int h = 0; h < KH; ++h) {
-    if (h > 0) __syncthreads();                       // the previous piece's MFMAs have read their fragments
-    if (KH == 1 || (lane * 4) / KW == h) {            // lane l owns columns 4l..4l+3 of its rows: piece (4l / KW)
+    for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * ST + lane * 4, wreg[i]);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * ST + lane * 4 - h * KW, wreg[i]);
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) st4(As + (wave + i * 8) * ST + lane * 4 - h * KW, areg[i]);
-    }
-    if constexpr (tracing) { if (h == 0) ts[2] = clock_pinned(); }      // tile parked in LDS (this wave)
+    for (int i = 0; i < RPW; ++i) st4(As + (wave + i * 8) * ST + lane * 4, areg[i]);
+    if constexpr (tracing) ts[2] = clock_pinned();      // tile parked in LDS (this wave)
     __syncthreads();
-    if constexpr (tracing) { if (h == 0) ts[3] = clock_pinned(); }      // barrier passed
+    if constexpr (tracing) ts[3] = clock_pinned();      // barrier passed
 #pragma unroll
     for (int kc = 0; kc < KCH; ++kc) {
       const F4 a0 = ld4(ap + kc * 32), a1 = ld4(ap + kc * 32 + 4);

@@ -34,7 +34,7 @@
 #include "kernels/novae.hpp"
 #include "kernels/rt.hpp"
 #include "kernels/tile32.hpp"
-#include "kernels/fused_layer.hpp"
+#include "kernels/strip.hpp"
 
 using namespace mld;
 
@@ -113,17 +113,6 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
 #endif
   DeviceGuard dg(device);      // allocations below land on `device`; the caller's current device is restored on return
   auto* e = new mldhip_engine();
-  const char* m_gemm = std::getenv("MLDHIP_GEMM");        // process-wide A/B knobs, re-read at every create
-  g_staged_gemm = !(m_gemm && std::strcmp(m_gemm, "direct") == 0);
-  const char* m_g8 = std::getenv("MLDHIP_GEMM8");
-  g_gemm8 = !(m_g8 && std::atoi(m_g8) == 0);
-  const char* m_small = std::getenv("MLDHIP_SMALL_M");
-  g_small_m = m_small ? std::atoi(m_small) : 256;
-  if (const char* m = std::getenv("MLDHIP_TILE16")) e->tile16 = std::atoi(m) != 0;
-  if (const char* m = std::getenv("MLDHIP_FUSED_FFN")) e->fused_ffn = std::atoi(m) != 0;
-  if (const char* m = std::getenv("MLDHIP_T32_KH")) e->t32_kh = std::atoi(m) == 2 ? 2 : 1;
-  e->nchains = 1;   // measured: parallel chains do not shorten the sequential depth
-  if (const char* m = std::getenv("MLDHIP_CHAINS")) e->nchains = std::max(1, std::min(8, std::atoi(m)));
   e->cfg = *cfg;
   e->device = device;
   declare_params(e);
@@ -181,11 +170,6 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   bind_context(e, 0);
 #if !defined(MLDHIP_SIM)
   if (hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) { e->err = "hipStreamCreate failed"; return fail_create(MLDHIP_EHIP); }
-  for (int i = 0; i < 7; ++i) {
-    if (hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) != hipSuccess) { e->err = "side stream/event create failed"; return fail_create(MLDHIP_EHIP); }
-  }
-  if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) { e->err = "event create failed"; return fail_create(MLDHIP_EHIP); }
   // the decoder attention keeps K and V of one (sample, head) in LDS: up to 2*18*16*68*4 = 153 KiB
   const int big = 2 * 18 * 16 * 68 * 4;
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -201,9 +185,9 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<32, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);  \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
-  MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4) MLD_T32_ATTR(8)
-  (void)hipFuncSetAttribute((const void*)den_ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLdsBytes);
+  MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4)
 #undef MLD_T32_ATTR
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<1, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds_bytes<2>());
   (void)hipGetLastError();
 #endif
   *out = e;
@@ -221,8 +205,6 @@ void mldhip_destroy(mldhip_handle* e) {
     if (x.done) (void)hipEventDestroy(x.done);
   }
   if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
-  for (int i = 0; i < 7; ++i) { if (e->side[i]) (void)hipStreamDestroy(e->side[i]); if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]); }
-  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
 #endif
   if (e->arena) (void)hipFree(e->arena);
   for (auto& x : e->ctxs) {
@@ -258,6 +240,36 @@ int mldhip_load_tensor(mldhip_handle* e, const char* key, const void* data, cons
   HIP_TRY(e, hipMemcpy(e->arena + p.offset, data, p.numel * sizeof(float), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   p.loaded = true;
   e->finalized = false;
+  return MLDHIP_OK;
+}
+
+int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
+  if (!e || !name) return MLDHIP_EINVAL;
+  const std::string n = name;
+  if (n == "loop_kernel") {
+    if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "loop_kernel must be 0 (auto), 1 (latency) or 2 (throughput)");
+    e->loop_kernel = (int)value;
+  } else if (n == "strip_min_rows") {
+    if (value < 1) return e->fail(MLDHIP_EINVAL, "strip_min_rows must be >= 1");
+    e->strip_min_rows = (int)std::min<int64_t>(value, 1 << 30);
+  } else if (n == "gemm_small_m") {
+    if (value < 0) return e->fail(MLDHIP_EINVAL, "gemm_small_m must be >= 0");
+    e->small_m = (int)std::min<int64_t>(value, 1 << 30);
+  } else {
+    return e->fail(MLDHIP_EINVAL, "unknown option %s", name);
+  }
+#if !defined(MLDHIP_SIM)
+  // captured graphs bake the kernel choice in: drop them (nothing may be in flight on a context while it is rebuilt)
+  DeviceGuard dg(e->device);
+  for (auto& x : e->ctxs) {
+    drain_context(x);
+    for (auto& kv : x.graphs) (void)hipGraphExecDestroy(kv.second);
+    x.graphs.clear();
+    x.graph_lru.clear();
+    for (auto& kv : x.step_graphs) (void)hipGraphExecDestroy(kv.second);
+    x.step_graphs.clear();
+  }
+#endif
   return MLDHIP_OK;
 }
 
@@ -344,6 +356,46 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
 }  // extern "C"
 
 namespace {
+#if !defined(MLDHIP_SIM)
+// The captured graph of (B, Tmax, requested outputs) on the bound workspace context: looked up, or captured now.  Graphs
+// read the engine's staging buffers (text_in / lat_in / labels / lens) and write lat / feats_int / joints_int, so they
+// are independent of the caller's buffers and of how many requests make up the B motions.
+int graph_for(mldhip_handle* e, const GraphKey& key, bool text_condition, hipGraphExec_t* out) {
+  auto& graphs = e->ctxs[e->cur_ctx].graphs;
+  auto& lru = e->ctxs[e->cur_ctx].graph_lru;
+  auto same = [&](const GraphKey& k) { return !(k < key) && !(key < k); };
+  lru.erase(std::remove_if(lru.begin(), lru.end(), same), lru.end());
+  lru.push_back(key);
+  auto it = graphs.find(key);
+  if (it == graphs.end()) {
+    // one graph per (B, Tmax, outputs): a serving loop with ragged batches sees many Tmax values, so keep a generous
+    // number (each exec holds ~2 100 kernel nodes, a few MB) and evict the least recently used one beyond it
+    while (graphs.size() >= kGraphCacheCapacity) {
+      auto victim = graphs.find(lru.front());
+      lru.erase(lru.begin());
+      if (victim == graphs.end()) continue;
+      drain_context(e->ctxs[e->cur_ctx]);               // the victim may still be replaying on this context's last stream
+      (void)hipGraphExecDestroy(victim->second);
+      graphs.erase(victim);
+    }
+    hipGraph_t graph = nullptr;
+    HIP_TRY(e, hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
+    int rc = enqueue_sample(e, e->cap_stream, text_condition ? e->text_in : nullptr, e->lat_in, key.B, key.T, nullptr,
+                            key.feats ? e->feats_int : nullptr, key.joints ? e->joints_int : nullptr);
+    hipError_t s = hipStreamEndCapture(e->cap_stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(s));
+    hipGraphExec_t exec = nullptr;
+    s = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(s));
+    it = graphs.emplace(key, exec).first;
+  }
+  *out = it->second;
+  return MLDHIP_OK;
+}
+#endif
+
 // shared body of mldhip_sample / mldhip_sample_action (text_emb_dev == nullptr <=> action labels given)
 int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* actions_host, const float* init_latents_dev,
                 const int32_t* lengths_host, int32_t B, float* latents_out_dev, float* feats_out_dev, float* joints_out_dev,
@@ -373,38 +425,9 @@ int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* acti
     if (text_emb_dev)
       HIP_TRY(e, hipMemcpyAsync(e->text_in, text_emb_dev, (size_t)2 * B * e->cfg.text_dim * sizeof(float), hipMemcpyDeviceToDevice, stream));
     HIP_TRY(e, hipMemcpyAsync(e->lat_in, init_latents_dev, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    GraphKey key{B, T, want_f, want_j};
-    auto& graphs = e->ctxs[e->cur_ctx].graphs;
-    auto it = graphs.find(key);
-    auto& lru = e->ctxs[e->cur_ctx].graph_lru;
-    auto same = [&](const GraphKey& k) { return !(k < key) && !(key < k); };
-    lru.erase(std::remove_if(lru.begin(), lru.end(), same), lru.end());
-    lru.push_back(key);
-    if (it == graphs.end()) {
-      // one graph per (B, Tmax, outputs): a serving loop with ragged batches sees many Tmax values, so keep a generous
-      // number (each exec holds ~2 100 kernel nodes, a few MB) and evict the least recently used one beyond it
-      while (graphs.size() >= kGraphCacheCapacity) {
-        auto victim = graphs.find(lru.front());
-        lru.erase(lru.begin());
-        if (victim == graphs.end()) continue;
-        drain_context(e->ctxs[e->cur_ctx]);               // the victim may still be replaying on this context's last stream
-        (void)hipGraphExecDestroy(victim->second);
-        graphs.erase(victim);
-      }
-      hipGraph_t graph = nullptr;
-      HIP_TRY(e, hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
-      int rc = enqueue_sample(e, e->cap_stream, text_emb_dev ? e->text_in : nullptr, e->lat_in, B, T, nullptr,
-                              want_f ? e->feats_int : nullptr, want_j ? e->joints_int : nullptr);
-      hipError_t s = hipStreamEndCapture(e->cap_stream, &graph);
-      if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-      if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(s));
-      hipGraphExec_t exec = nullptr;
-      s = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(s));
-      it = graphs.emplace(key, exec).first;
-    }
-    HIP_TRY(e, hipGraphLaunch(it->second, stream));
+    hipGraphExec_t exec = nullptr;
+    if (int rc = graph_for(e, GraphKey{B, T, want_f, want_j}, text_emb_dev != nullptr, &exec)) return rc;
+    HIP_TRY(e, hipGraphLaunch(exec, stream));
     if (latents_out_dev) HIP_TRY(e, hipMemcpyAsync(latents_out_dev, e->lat, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (feats_out_dev) HIP_TRY(e, hipMemcpyAsync(feats_out_dev, e->feats_int, (size_t)B * T * NF * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (joints_out_dev)
@@ -416,7 +439,95 @@ int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* acti
 }
 }  // namespace
 
+namespace {
+// Several independent requests as ONE reverse-diffusion chain + ONE decode (mldhip_sample_many): inputs are gathered into
+// the engine's staging buffers (unconditional halves first, as one big CFG batch), outputs scattered per request with
+// each request's own Tmax as its row pitch.  Motions never interact (attention is per sample), so results equal the
+// per-request calls up to the summation order of the kernel family picked for the larger row count.
+int sample_many_impl(mldhip_handle* e, const mldhip_request* rq, int nreq, hipStream_t stream) {
+  if (!e->finalized) return e->fail(MLDHIP_ESTATE, "mldhip_sample_many before mldhip_finalize_weights");
+  const bool action = is_action(e);
+  bool want_j = false, want_f = false;
+  int Btot = 0, T = 0;
+  std::vector<int32_t> lens, tmax(nreq, 0);
+  for (int i = 0; i < nreq; ++i) {
+    const mldhip_request& r = rq[i];
+    if (!r.init_latents_dev || (action ? !r.actions_host : !r.text_emb_dev)) return e->fail(MLDHIP_EINVAL, "request %d: null input pointer", i);
+    if (r.joints_out_dev && is_actor(e)) return e->fail(MLDHIP_ESTATE, "joints of the ActorVae feature layout need SMPL (out of scope)");
+    if (int rc = validate_lengths(e, r.lengths_host, r.B, &tmax[i])) return rc;
+    if (action)
+      for (int k = 0; k < r.B; ++k)
+        if (r.actions_host[k] < 0 || r.actions_host[k] >= e->cfg.nclasses)
+          return e->fail(MLDHIP_EINVAL, "request %d: actions[%d]=%d outside [0, nclasses=%d)", i, k, r.actions_host[k], e->cfg.nclasses);
+    lens.insert(lens.end(), r.lengths_host, r.lengths_host + r.B);
+    Btot += r.B;
+    T = std::max(T, tmax[i]);
+    want_j = want_j || r.joints_out_dev;
+    want_f = want_f || r.feats_out_dev || r.joints_out_dev;
+  }
+  if (Btot > e->cfg.max_batch) return e->fail(MLDHIP_EINVAL, "requests hold %d motions, max_batch is %d", Btot, e->cfg.max_batch);
+  if (!e->group_ready[0] || !e->group_ready[1] || (want_j && !e->group_ready[2]))
+    return e->fail(MLDHIP_ESTATE, "mldhip_sample_many needs denoiser.*, vae.decoder.* (and mean/std for joints) loaded");
+  CtxUse use(e, stream);
+  if (use.rc) return use.rc;
+  const size_t D = e->cfg.latent_dim, NF = e->cfg.nfeats, TD = e->cfg.text_dim, NJ = (size_t)e->cfg.njoints * 3;
+  HIP_TRY(e, hipMemcpyAsync(e->lens_dev, lens.data(), (size_t)Btot * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  if (action) {
+    std::vector<int32_t> lab(2 * (size_t)Btot, 0);        // cond = cat(zeros_like(actions), actions) (mld.py:722-725)
+    int o = 0;
+    for (int i = 0; i < nreq; ++i) { std::copy(rq[i].actions_host, rq[i].actions_host + rq[i].B, lab.begin() + Btot + o); o += rq[i].B; }
+    HIP_TRY(e, hipMemcpyAsync(e->labels_dev, lab.data(), lab.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  }
+  int o = 0;
+  for (int i = 0; i < nreq; ++i) {
+    const mldhip_request& r = rq[i];
+    const size_t b = (size_t)r.B;
+    if (!action) {
+      HIP_TRY(e, hipMemcpyAsync(e->text_in + (size_t)o * TD, r.text_emb_dev, b * TD * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      HIP_TRY(e, hipMemcpyAsync(e->text_in + ((size_t)Btot + o) * TD, r.text_emb_dev + b * TD, b * TD * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->lat_in + (size_t)o * D, r.init_latents_dev, b * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    o += r.B;
+  }
+  const float* text = action ? nullptr : e->text_in;
+  bool replayed = false;
+#if !defined(MLDHIP_SIM)
+  if (e->cfg.use_graph) {
+    hipGraphExec_t exec = nullptr;
+    if (int rc = graph_for(e, GraphKey{Btot, T, want_f, want_j}, text != nullptr, &exec)) return rc;
+    HIP_TRY(e, hipGraphLaunch(exec, stream));
+    replayed = true;
+  }
+#endif
+  if (!replayed) {
+    if (int rc = enqueue_sample(e, stream, text, e->lat_in, Btot, T, nullptr, want_f ? e->feats_int : nullptr, want_j ? e->joints_int : nullptr)) return rc;
+  }
+  o = 0;
+  for (int i = 0; i < nreq; ++i) {
+    const mldhip_request& r = rq[i];
+    const size_t b = (size_t)r.B, ti = (size_t)tmax[i];
+    if (r.latents_out_dev) HIP_TRY(e, hipMemcpyAsync(r.latents_out_dev, e->lat + (size_t)o * D, b * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (r.feats_out_dev)
+      HIP_TRY(e, hipMemcpy2DAsync(r.feats_out_dev, ti * NF * sizeof(float), e->feats_int + (size_t)o * T * NF, (size_t)T * NF * sizeof(float),
+                                  ti * NF * sizeof(float), b, hipMemcpyDeviceToDevice, stream));
+    if (r.joints_out_dev)
+      HIP_TRY(e, hipMemcpy2DAsync(r.joints_out_dev, ti * NJ * sizeof(float), e->joints_int + (size_t)o * T * NJ, (size_t)T * NJ * sizeof(float),
+                                  ti * NJ * sizeof(float), b, hipMemcpyDeviceToDevice, stream));
+    o += r.B;
+  }
+  return MLDHIP_OK;
+}
+}  // namespace
+
 extern "C" {
+
+int mldhip_sample_many(mldhip_handle* e, const mldhip_request* reqs, int32_t nreq, void* stream_) {
+  if (!e) return MLDHIP_EINVAL;
+  DeviceGuard dg(e->device);
+  if (is_novae(e)) return e->fail(MLDHIP_ESTATE, "mldhip_sample_many serves the latent models (text or action condition)");
+  if (!reqs || nreq < 1 || nreq > 64) return e->fail(MLDHIP_EINVAL, "1..64 requests expected");
+  return sample_many_impl(e, reqs, nreq, (hipStream_t)stream_);
+}
 
 int mldhip_sample(mldhip_handle* e, const float* text_emb_dev, const float* init_latents_dev, const int32_t* lengths_host,
                   int32_t B, float* latents_out_dev, float* feats_out_dev, float* joints_out_dev, void* stream_) {
@@ -464,7 +575,7 @@ int denoiser_forward_impl(mldhip_handle* e, const float* sample_dev, int32_t tim
   HIP_TRY(e, hipMemcpyAsync(e->temb0_one, host.data(), TD * sizeof(float), hipMemcpyHostToDevice, stream));
   HIP_TRY(e, hipStreamSynchronize(stream));   // `host` is a stack temporary
   time_mlp(c, e->temb0_one, e->temb0_one + TD, e->t1_one, 1);
-  const DenView v = den_view(e, 0, 0, R);
+  const DenView v = den_view(e, R);
   if (text_emb_dev) text_projection(c, text_emb_dev, R, e->X0 + (size_t)2 * R * D);
   else action_rows(c, R, e->cfg.guidance_scale > 1.0f ? R / 2 : 0, e->X0 + (size_t)2 * R * D);   // mld_denoiser.py:253-257
   // token 0 rows: sample + pe[0]; token 1 rows: the time-MLP row (pe[1] already folded in)
@@ -707,7 +818,7 @@ int mldhip_profile_kernel(mldhip_handle* e, const char* name, int32_t B, int32_t
   int saved_phase = e->phase;
   e->phase = dec ? 1 : 0;
   const EncLayerP& DL = e->den[mid];
-  const DenView v = den_view(e, 0, 0, R);
+  const DenView v = den_view(e, R);
   for (int it = 0; it < iters && !c.rc; ++it) {
     if (n == "den_qkv") {            // with the LN2-on-load prologue of a typical layer (sums the 4 FFN2 slabs)
       den_qkv(c, v, DL, den_layer_output(e, v, e->den[mid - 1], v.S[mid - 1]));
@@ -715,9 +826,6 @@ int mldhip_profile_kernel(mldhip_handle* e, const char* name, int32_t B, int32_t
     } else if (n == "den_outproj") {
       den_outproj(c, v, DL);
       *flops_per_launch = 2.0 * M * D * D + 4.0 * M * 3 * D;
-    } else if (n == "den_ffn") {      // linear1 + GELU + linear2 fused (kernels/fused_layer.hpp)
-      den_ffn_fused(c, v, DL, v.S[mid - 1]);
-      *flops_per_launch = 4.0 * M * D * F;
     } else if (n == "den_ffn1") {
       den_ffn1(c, v, DL, v.S[mid - 1]);
       *flops_per_launch = 2.0 * M * D * F;

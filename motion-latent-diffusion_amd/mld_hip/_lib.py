@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libmldhip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MldHipError(RuntimeError):
@@ -37,6 +37,13 @@ class Config(C.Structure):
     ]
 
 
+class Request(C.Structure):
+    """Mirror of ``mldhip_request`` (include/mldhip.h): one request of ``mldhip_sample_many``."""
+    _fields_ = [("text_emb_dev", C.c_void_p), ("actions_host", C.POINTER(C.c_int32)), ("init_latents_dev", C.c_void_p),
+                ("lengths_host", C.POINTER(C.c_int32)), ("B", C.c_int32), ("latents_out_dev", C.c_void_p),
+                ("feats_out_dev", C.c_void_p), ("joints_out_dev", C.c_void_p)]
+
+
 COND_TEXT, COND_ACTION = 0, 1            # MLDHIP_COND_*
 VAE_MLD, VAE_ACTOR, VAE_NONE = 0, 1, 2   # MLDHIP_VAE_*
 ARCH_TRANS_ENC, ARCH_TRANS_DEC = 0, 1    # MLDHIP_ARCH_*
@@ -51,9 +58,11 @@ _SYMBOLS = {
     "mldhip_destroy": (None, [C.c_void_p]),
     "mldhip_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32]),
     "mldhip_finalize_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mldhip_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "mldhip_missing_keys": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "mldhip_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mldhip_sample_many": (C.c_int, [C.c_void_p, C.POINTER(Request), C.c_int32, C.c_void_p]),
     "mldhip_denoiser_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mldhip_sample_action": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
@@ -183,6 +192,10 @@ class Engine:
             return []
         return [s.decode() for s in buf.raw.split(b"\0") if s][:n]
 
+    def set_option(self, name: str, value: int):
+        """Per-handle tuning option (include/mldhip.h: loop_kernel, strip_min_rows, gemm_small_m)."""
+        self._check(self.lib.mldhip_set_option(self._h, name.encode(), int(value)))
+
     def finalize(self, stream: int = 0):
         self._check(self.lib.mldhip_finalize_weights(self._h, stream))
 
@@ -192,6 +205,26 @@ class Engine:
         lens = (C.c_int32 * len(lengths))(*[int(x) for x in lengths])
         self._check(self.lib.mldhip_sample(self._h, _ptr(text_emb), _ptr(init_latents), lens, len(lengths),
                                            _ptr(latents_out), _ptr(feats_out), _ptr(joints_out), stream))
+
+    def sample_many(self, requests: Sequence[dict], stream: int = 0):
+        """Several requests as ONE chain (mldhip_sample_many).  Each request is a dict with ``lengths`` and ``init_latents``,
+        ``text_emb`` (text engines) or ``actions`` (action engines), and optional ``latents_out`` / ``feats_out`` / ``joints_out``."""
+        arr = (Request * len(requests))()
+        keep = []
+        for r, q in zip(arr, requests):
+            lens = (C.c_int32 * len(q["lengths"]))(*[int(x) for x in q["lengths"]])
+            keep.append(lens)
+            r.lengths_host, r.B = lens, len(q["lengths"])
+            r.text_emb_dev = _ptr(q.get("text_emb")) or None
+            if q.get("actions") is not None:
+                acts = (C.c_int32 * len(q["actions"]))(*[int(x) for x in q["actions"]])
+                keep.append(acts)
+                r.actions_host = acts
+            r.init_latents_dev = _ptr(q["init_latents"]) or None
+            r.latents_out_dev = _ptr(q.get("latents_out")) or None
+            r.feats_out_dev = _ptr(q.get("feats_out")) or None
+            r.joints_out_dev = _ptr(q.get("joints_out")) or None
+        self._check(self.lib.mldhip_sample_many(self._h, arr, len(requests), stream))
 
     def denoiser_forward(self, sample, timestep: int, text_emb, R: int, out, stream: int = 0):
         self._check(self.lib.mldhip_denoiser_forward(self._h, _ptr(sample), int(timestep), _ptr(text_emb), R, _ptr(out), stream))

@@ -139,6 +139,10 @@ inline hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(1, n ? n : 1)
 inline hipError_t hipFree(void* p) { std::free(p); return 0; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return 0; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return 0; }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t) {
+  for (size_t r = 0; r < height; ++r) std::memmove(static_cast<char*>(d) + r * dpitch, static_cast<const char*>(s) + r * spitch, width);
+  return 0;
+}
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }

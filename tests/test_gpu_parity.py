@@ -686,3 +686,64 @@ def test_mld_forward_through_clip_adapter_on_gpu(dev, tmp_path, oracle_weights):
     for i, n in enumerate(lengths):
         assert tuple(joints[i].shape) == (n, 22, 3) and np.abs(joints[i].numpy() - jr[i, :n]).max() < 1e-3
     E.drop_engines()
+
+
+def test_sample_many_coalesced_requests_vs_reference_golden(dev, golden_dir, oracle_weights):
+    """mldhip_sample_many: four requests as ONE chain (256 motions -> 1 536 token rows: the throughput kernels of
+    kernels/strip.hpp are picked automatically).  Request 0 is the reference-generated B=64 / T=196 fixture; the others are
+    ragged (own Tmax each, scattered with their own row pitch) and must equal their own mldhip_sample calls within the
+    re-association noise of the two kernel families."""
+    big = _lib.Engine(device=0, max_batch=160, max_frames=196)
+    _load(big)
+    small = _lib.Engine(device=0, max_batch=64, max_frames=196)
+    _load(small)
+    g = _gold(golden_dir, "pipeline_b64.npz")
+    batches = [syn.make_batch(64), syn.make_batch(40, "ragged", seed=3), syn.make_batch(7, [33, 1, 196, 64, 65, 12, 100], seed=4),
+               syn.make_batch(49, None, seed=5, max_len=120)]
+    reqs = []
+    for b in batches:
+        B, T = len(b.lengths), max(b.lengths)
+        reqs.append(dict(text_emb=_cuda(b.text_emb, dev), init_latents=_cuda(b.init_latents, dev), lengths=b.lengths,
+                         latents_out=torch.empty(B, 1, 256, device=dev), feats_out=torch.empty(B, T, 263, device=dev),
+                         joints_out=torch.empty(B, T, 22, 3, device=dev)))
+    for _ in range(2):                                  # second call replays the captured graph of (160, 196)
+        big.sample_many(reqs)
+    torch.cuda.synchronize()
+    q = reqs[0]
+    assert np.abs(q["latents_out"].cpu().numpy() - g["latents"]).max() < 5e-3
+    assert np.abs(q["feats_out"].cpu().numpy()[:, -1] - g["feats_frame_last"]).max() < 2e-4
+    assert np.abs(q["joints_out"].cpu().numpy()[:, ::4] - g["joints_every4"]).max() < 1e-3
+    for b, q in zip(batches[1:], reqs[1:]):
+        B, T = len(b.lengths), max(b.lengths)
+        lat, feats, joints = torch.empty(B, 1, 256, device=dev), torch.empty(B, T, 263, device=dev), torch.empty(B, T, 22, 3, device=dev)
+        small.sample(q["text_emb"], q["init_latents"], b.lengths, lat, feats, joints)
+        torch.cuda.synchronize()
+        assert (q["latents_out"] - lat).abs().max().item() < 5e-3
+        assert (q["joints_out"] - joints).abs().max().item() < 1e-3 and (q["feats_out"] - feats).abs().max().item() < 1e-3
+        for i, n in enumerate(b.lengths):
+            assert torch.all(q["feats_out"][i, n:] == 0)
+    with pytest.raises(_lib.MldHipError):
+        big.sample_many(reqs + reqs[:1])                # 224 motions > max_batch
+    big.close()
+    small.close()
+
+
+def test_throughput_kernels_single_call_vs_oracle(dev, oracle_weights):
+    """The two loop-kernel families on the same 8-motion batch vs the oracle (loop_kernel option, graphs dropped in between)."""
+    ops, bd, bv = oracle_weights
+    mean, std = syn.make_mean_std()
+    e = _lib.Engine(device=0, max_batch=8, max_frames=64, num_inference_steps=10)
+    _load(e)
+    b = syn.make_batch(8, [64, 40, 33, 64, 12, 1, 64, 50], seed=8)
+    jr, fr, lr = O.sample(ops, bd, bv, b.text_emb, b.init_latents, b.lengths, mean, std, steps=10, return_intermediates=True)
+    outs = []
+    for fam in (1, 2):
+        e.set_option("loop_kernel", fam)
+        lat, joints = torch.empty(8, 1, 256, device=dev), torch.empty(8, 64, 22, 3, device=dev)
+        for _ in range(2):
+            e.sample(_cuda(b.text_emb, dev), _cuda(b.init_latents, dev), b.lengths, lat, None, joints)
+        torch.cuda.synchronize()
+        assert np.abs(lat.cpu().numpy() - lr).max() < 2e-3 and np.abs(joints.cpu().numpy() - jr).max() < 1e-3
+        outs.append(joints.clone())
+    assert not torch.equal(outs[0], outs[1])            # the option really switched kernels (different summation order)
+    e.close()

@@ -130,22 +130,6 @@ def test_full_sample_sim(eng, ow):
     assert den == 1 + 1 * (1 + 2 * (9 * 4 + 4 + 1)) and dec == 2 + 1 + 9 * 5 + 4 + 2 and jn == 1
 
 
-@pytest.mark.parametrize("nch", [2, 3])
-def test_chain_split_is_exact_sim(monkeypatch, ow, nch):
-    """Sub-batch chains (parallel graph branches on the GPU) must not change any value."""
-    ops, bd, bv = ow
-    monkeypatch.setenv("MLDHIP_CHAINS", str(nch))
-    e = simlib.sim_engine(max_batch=4, max_frames=24, num_inference_steps=2)
-    b = syn.make_batch(3, [20, 13, 7])
-    mean, std = syn.make_mean_std()
-    joints = np.zeros((3, 20, 22, 3), np.float32)
-    e.sample(b.text_emb, b.init_latents, b.lengths, None, None, joints)
-    jr = O.sample(ops, bd, bv, b.text_emb, b.init_latents, b.lengths, mean, std, steps=2)
-    assert np.abs(joints - jr).max() < 1e-4
-    assert e.launch_counts()[0] == 1 + nch * (1 + 2 * 41)
-    e.close()
-
-
 def test_abi_errors_sim(eng):
     b = syn.make_batch(2, [10, 10])
     with pytest.raises(_lib.MldHipError) as ei:
@@ -312,11 +296,11 @@ def test_novae_full_sample_sim(neng, now):
     assert den == 2 + 4 * (1 + 2 + 2 * 11 + 2 + 1) and dec == 0 and jn == 1
 
 
-def test_novae_denoiser_forward_staged_gemms_sim(monkeypatch, now):
+def test_novae_denoiser_forward_staged_gemms_sim(now):
     """Same check with the LDS-staged GEMM pipeline forced (production shape: K = 384 / 512 / 1024 chunk pipelines)."""
     ops, bd = now
-    monkeypatch.setenv("MLDHIP_SMALL_M", "0")
     e = simlib.sim_novae_engine(num_layers=2, max_batch=2, max_frames=40, num_inference_steps=4)
+    e.set_option("gemm_small_m", 0)
     g = syn._rng(11, "nv")
     R, T = 3, 21
     x = g.standard_normal((R, T, 263)).astype(np.float32)
@@ -326,21 +310,6 @@ def test_novae_denoiser_forward_staged_gemms_sim(monkeypatch, now):
     e.denoiser_forward_novae(x, 999, te, lens, T, out)
     ref = O.denoiser_forward_novae(ops, bd, x, 999, te, lens)
     assert np.abs(out - ref).max() < 5e-5
-    e.close()
-
-
-def test_fused_ffn_knob_is_exact_sim(monkeypatch, ow):
-    """MLDHIP_FUSED_FFN=1 (linear1 + GELU + linear2 in one launch, 8 partial slabs; an A/B knob, default off)."""
-    ops, bd, bv = ow
-    monkeypatch.setenv("MLDHIP_FUSED_FFN", "1")
-    e = simlib.sim_engine(max_batch=4, max_frames=24, num_inference_steps=2)
-    b = syn.make_batch(3, [20, 13, 7])
-    mean, std = syn.make_mean_std()
-    joints = np.zeros((3, 20, 22, 3), np.float32)
-    e.sample(b.text_emb, b.init_latents, b.lengths, None, None, joints)
-    jr = O.sample(ops, bd, bv, b.text_emb, b.init_latents, b.lengths, mean, std, steps=2)
-    assert np.abs(joints - jr).max() < 1e-4
-    assert e.launch_counts()[0] == 1 + 1 + 2 * (9 * 3 + 4 + 1)
     e.close()
 
 
@@ -360,34 +329,16 @@ def test_contexts_rotate_and_stay_exact_sim(ow):
     e.close()
 
 
-@pytest.mark.parametrize("g8", ["1", "0"])
-def test_staged_gemm_tiles_are_exact_sim(monkeypatch, ow, g8):
-    """The staged fp32 GEMM tiles on 8 waves (default: 64x128 plain, 64x256 with the LayerNorm epilogue) and on 4 waves
-    (MLDHIP_GEMM8=0: 64x128 / 32x256), forced at simulator-sized M."""
+def test_staged_gemm_tiles_are_exact_sim(ow):
+    """The staged fp32 GEMM tiles on 8 waves (64x128 plain, 64x256 with the LayerNorm epilogue), forced at simulator-sized M."""
     ops, _, bv = ow
-    monkeypatch.setenv("MLDHIP_GEMM8", g8)
-    monkeypatch.setenv("MLDHIP_SMALL_M", "0")          # force the staged kernels at simulator-sized M
     e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2)
+    e.set_option("gemm_small_m", 0)                     # force the staged kernels at simulator-sized M
     z = syn._rng(7, "g8").standard_normal((3, 1, 256)).astype(np.float32)
     lens = [40, 23, 7]
     feats = np.zeros((3, 40, 263), np.float32)
     e.vae_decode(z, lens, feats)
     assert np.abs(feats - O.vae_decode(ops, bv, z, lens)).max() < 5e-5
-    e.close()
-
-
-def test_tile32_two_k_pieces_knob_is_exact_sim(monkeypatch, ow):
-    """MLDHIP_T32_KH=2: the loop GEMMs pass K through LDS in two 128-wide pieces (half the LDS, two workgroups per CU)."""
-    ops, bd, bv = ow
-    monkeypatch.setenv("MLDHIP_T32_KH", "2")
-    e = simlib.sim_engine(max_batch=4, max_frames=24, num_inference_steps=2)
-    b = syn.make_batch(3, [20, 13, 7])
-    mean, std = syn.make_mean_std()
-    joints = np.zeros((3, 20, 22, 3), np.float32)
-    lat = np.zeros((3, 1, 256), np.float32)
-    e.sample(b.text_emb, b.init_latents, b.lengths, lat, None, joints)
-    jr, _, lr = O.sample(ops, bd, bv, b.text_emb, b.init_latents, b.lengths, mean, std, steps=2, return_intermediates=True)
-    assert np.abs(lat - lr).max() < 5e-4 and np.abs(joints - jr).max() < 1e-4
     e.close()
 
 
@@ -406,14 +357,12 @@ def test_actor_encode_sim(aeng, aow):
     assert np.abs(lat - lr[:, 0]).max() < 1e-4
 
 
-@pytest.mark.parametrize("g8", ["1", "0"])
-def test_split_bf16_decoder_gemms_sim(monkeypatch, ow, g8):
+def test_split_bf16_decoder_gemms_sim(ow):
     """precision = BF16X3_DECODE on the simulator's v_mfma_f32_16x16x32_bf16 model: x = hi + lo in bf16, three MFMAs per
     K chunk (hi*hi + hi*lo + lo*hi), fp32 accumulate -- decoder features stay within ~1e-4 of the fp32 oracle."""
     ops, _, bv = ow
-    monkeypatch.setenv("MLDHIP_GEMM8", g8)
-    monkeypatch.setenv("MLDHIP_SMALL_M", "0")          # force the staged (split-capable) kernels at simulator-sized M
     e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2, precision=1)
+    e.set_option("gemm_small_m", 0)                     # force the staged (split-capable) kernels at simulator-sized M
     z = syn._rng(7, "g8").standard_normal((3, 1, 256)).astype(np.float32)
     lens = [40, 23, 7]
     feats = np.zeros((3, 40, 263), np.float32)
@@ -421,4 +370,103 @@ def test_split_bf16_decoder_gemms_sim(monkeypatch, ow, g8):
     ref = O.vae_decode(ops, bv, z, lens)
     err = np.abs(feats - ref).max()
     assert 1e-7 < err < 2e-4                            # not bit-equal to fp32 (the split really ran), yet well inside tolerance
+    e.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# throughput kernel family (kernels/strip.hpp + the 32x64 staged GEMM): same data flow, one raw slab per GEMM
+def test_strip_family_sample_is_exact_sim(ow):
+    """loop_kernel = 2 forces the throughput kernels at simulator-sized M: ragged batch (M = 18 rows: one partial strip),
+    2 steps, against the oracle; launch counts are those of the latency family."""
+    ops, bd, bv = ow
+    e = simlib.sim_engine(max_batch=4, max_frames=24, num_inference_steps=2)
+    e.set_option("loop_kernel", 2)
+    b = syn.make_batch(3, [20, 13, 7])
+    mean, std = syn.make_mean_std()
+    lat = np.zeros((3, 1, 256), np.float32)
+    joints = np.zeros((3, 20, 22, 3), np.float32)
+    e.sample(b.text_emb, b.init_latents, b.lengths, lat, None, joints)
+    jr, _, lr = O.sample(ops, bd, bv, b.text_emb, b.init_latents, b.lengths, mean, std, steps=2, return_intermediates=True)
+    assert np.abs(lat - lr).max() < 5e-4 and np.abs(joints - jr).max() < 1e-4
+    assert e.launch_counts()[0] == 1 + 1 + 2 * (9 * 4 + 4 + 1)
+    with pytest.raises(_lib.MldHipError):
+        e.set_option("loop_kernel", 3)
+    with pytest.raises(_lib.MldHipError):
+        e.set_option("no_such_option", 1)
+    e.close()
+
+
+def test_strip_family_denoiser_forward_matches_latency_family_sim(ow):
+    """One MldDenoiser.forward at R = 22 (M = 66 rows: two full strips + a partial one) on both kernel families and vs the
+    oracle; auto mode switches families at strip_min_rows."""
+    ops, bd, _ = ow
+    e = simlib.sim_engine(max_batch=11, max_frames=8, num_inference_steps=2)
+    g = syn._rng(21, "strip")
+    R = 22
+    x = g.standard_normal((R, 1, 256)).astype(np.float32)
+    te = g.standard_normal((R, 1, 768)).astype(np.float32)
+    ref = np.asarray(O.denoiser_forward(ops, bd, x, 741, te))
+    outs = {}
+    for name, opts in (("latency", {"loop_kernel": 1}), ("throughput", {"loop_kernel": 2}), ("auto", {"loop_kernel": 0, "strip_min_rows": 60})):
+        for k, v in opts.items():
+            e.set_option(k, v)
+        out = np.zeros((R, 1, 256), np.float32)
+        e.denoiser_forward(x, 741, te, R, out)
+        assert np.abs(out - ref).max() < 5e-5, name
+        outs[name] = out
+    assert np.array_equal(outs["auto"], outs["throughput"])            # 66 rows >= 60: auto picked the throughput kernels
+    assert np.abs(outs["latency"] - outs["throughput"]).max() < 2e-5   # different summation order only
+    e.close()
+
+
+def test_strip_family_action_variant_sim(aow):
+    """15-layer action denoiser (7 skip linears: the two-segment K = 512 strip kernel) on the throughput family."""
+    ops, bd, bv = aow
+    e = simlib.sim_action_engine(max_batch=4, max_frames=20, num_inference_steps=2)
+    e.set_option("loop_kernel", 2)
+    acts, lat0, lens = syn.make_action_batch(3, nframes=20, seed=5)
+    lat = np.zeros((3, 1, 256), np.float32)
+    feats = np.zeros((3, 20, 150), np.float32)
+    e.sample_action(acts, lat0, lens, lat, feats)
+    fr, lr = O.sample_action(ops, bd, bv, acts, lat0, lens, steps=2, return_intermediates=True)
+    assert np.abs(lat - np.asarray(lr)).max() < 5e-4 and np.abs(feats - np.asarray(fr)).max() < 2e-4
+    e.close()
+
+
+def test_sample_many_equals_per_request_calls_sim(ow):
+    """mldhip_sample_many: three requests (ragged, different Tmax, one without joints) coalesced into one chain give every
+    request what its own mldhip_sample call gives (same kernel family forced, so bit-identical here)."""
+    e = simlib.sim_engine(max_batch=6, max_frames=24, num_inference_steps=2)
+    e.set_option("loop_kernel", 1)
+    reqs, solo = [], []
+    for seed, lens in ((1, [20, 13]), (2, [9]), (3, [24, 5, 17])):
+        b = syn.make_batch(len(lens), lens, seed=seed)
+        B, T = len(lens), max(lens)
+        q = dict(text_emb=b.text_emb, init_latents=b.init_latents, lengths=lens, latents_out=np.zeros((B, 1, 256), np.float32),
+                 feats_out=np.zeros((B, T, 263), np.float32), joints_out=None if seed == 2 else np.zeros((B, T, 22, 3), np.float32))
+        reqs.append(q)
+        lat, feats, joints = np.zeros((B, 1, 256), np.float32), np.zeros((B, T, 263), np.float32), np.zeros((B, T, 22, 3), np.float32)
+        e.sample(b.text_emb, b.init_latents, lens, lat, feats, joints)
+        solo.append((lat, feats, joints))
+    e.sample_many(reqs)
+    for q, (lat, feats, joints) in zip(reqs, solo):
+        assert np.array_equal(q["latents_out"], lat) and np.array_equal(q["feats_out"], feats)
+        if q["joints_out"] is not None:
+            assert np.array_equal(q["joints_out"], joints)
+    with pytest.raises(_lib.MldHipError):
+        e.sample_many(reqs + reqs)                                   # 12 motions > max_batch 6
+    e.close()
+
+
+def test_sample_many_action_sim(aow):
+    ops, bd, bv = aow
+    e = simlib.sim_action_engine(max_batch=4, max_frames=20, num_inference_steps=2)
+    reqs = []
+    for seed, n in ((5, 2), (6, 1)):
+        acts, lat0, lens = syn.make_action_batch(n, nframes=20, seed=seed)
+        reqs.append(dict(actions=acts, init_latents=lat0, lengths=lens, feats_out=np.zeros((n, max(lens), 150), np.float32)))
+    e.sample_many(reqs)
+    for q in reqs:
+        fr = O.sample_action(ops, bd, bv, q["actions"], q["init_latents"], q["lengths"], steps=2)
+        assert np.abs(q["feats_out"] - np.asarray(fr)).max() < 2e-4
     e.close()
