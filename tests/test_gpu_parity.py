@@ -747,3 +747,61 @@ def test_throughput_kernels_single_call_vs_oracle(dev, oracle_weights):
         outs.append(joints.clone())
     assert not torch.equal(outs[0], outs[1])            # the option really switched kernels (different summation order)
     e.close()
+
+
+def test_novae_full_length_1000_steps_vs_reference_golden(dev, golden_dir):
+    """BASELINE config 4 at its real length (configs/modules_novae/scheduler.yaml:16-29: 1000 DDPM steps; loop mld.py:323-346):
+    B = 2, lengths [196, 150], noise from the in-kernel Philox stream (seed, step) -- the same stream the fixture's generator
+    regenerated (oracle/make_golden_novae1000.py; reference MldDenoiser in the loop, fp32).  The fixture stores how far a
+    float64 evaluation drifts from the reference's float32 one on this 1000-step map (features |x| ~ 148: 4e-4; joints, which
+    integrate 196 frames of yaw / root velocity on top: 2e-2); the engine must stay within a small multiple of that floor."""
+    g = _gold(golden_dir, "novae_pipeline_1000.npz")
+    lens = [int(x) for x in g["lengths"]]
+    B, T = len(lens), max(lens)
+    e = _lib.Engine(device=0, max_batch=B, max_frames=T, latent_dim=512, vae_arch=_lib.VAE_NONE, denoiser_arch=_lib.ARCH_TRANS_DEC,
+                    scheduler_type=_lib.SCHED_DDPM, num_inference_steps=int(g["steps"]), steps_offset=0)
+    e.load_state_dict(syn.make_novae_denoiser_state_dict(), "denoiser.")
+    mean, std = syn.make_mean_std()
+    e.load_tensor("mean", mean)
+    e.load_tensor("std", std)
+    e.finalize()
+    b = syn.make_batch(B, lens, seed=int(g["batch_seed"]))
+    lat0 = syn._rng(int(g["lat0_seed"]), "nv1000").standard_normal((B, T, 263)).astype(np.float32)
+    feats, joints = torch.empty(B, T, 263, device=dev), torch.empty(B, T, 22, 3, device=dev)
+    e.sample_novae(_cuda(b.text_emb, dev), _cuda(lat0, dev), lens, None, int(g["seed"]), feats, joints)
+    torch.cuda.synchronize()
+    f, j = feats.cpu().numpy(), joints.cpu().numpy()
+    ef = max(np.abs(f[i, :n] - g["feats"][i, :n]).max() for i, n in enumerate(lens))
+    ej = max(np.abs(j[i, :n] - g["joints"][i, :n]).max() for i, n in enumerate(lens))
+    print("novae 1000 steps: feats err %.3e (f64 floor %.3e, |x| max %.1f)  joints err %.3e (floor %.3e)"
+          % (ef, float(g["f64_diff_feats"]), float(g["feats_absmax"]), ej, float(g["f64_diff_joints"])))
+    assert np.isfinite(f).all() and np.isfinite(j).all()
+    assert ef < 10 * float(g["f64_diff_feats"]) and ej < 10 * float(g["f64_diff_joints"])
+    e.close()
+
+
+def test_ragged_bs64_uniform_length_mix_vs_oracle(eng, dev):
+    """BASELINE config 2 batch size with the realistic length mix of SURVEY.md §8(d) (uniform in {40..196 step 4}, seed 1234,
+    one motion at 196): the decoder skips every all-padding row tile (gemm.hpp) and key tile (attention.hpp) -- exactness of
+    that shortcut at full size, against the oracle (torch-CPU backend: same arithmetic as the numpy one, multi-threaded)."""
+    rng = np.random.Generator(np.random.PCG64(1234))
+    lens = [int(v) for v in rng.choice(np.arange(40, 197, 4), 64)]
+    lens[0] = 196
+    b = syn.make_batch(64, lens, seed=1234)
+    lat, feats, joints = torch.empty(64, 1, 256, device=dev), torch.empty(64, 196, 263, device=dev), torch.empty(64, 196, 22, 3, device=dev)
+    eng.sample(_cuda(b.text_emb, dev), _cuda(b.init_latents, dev), lens, lat, feats, joints)
+    torch.cuda.synchronize()
+    ops = O.TorchOps("float32")
+    mean, std = syn.make_mean_std()
+    jr, fr, lr = O.sample(ops, O.to_backend(ops, syn.make_denoiser_state_dict()), O.to_backend(ops, syn.make_vae_state_dict()),
+                          ops.asarray(b.text_emb), ops.asarray(b.init_latents), lens, ops.asarray(mean), ops.asarray(std),
+                          return_intermediates=True)
+    jr, fr, lr = (ops.to_numpy(x) for x in (jr, fr, lr))
+    f, j = feats.cpu().numpy(), joints.cpu().numpy()
+    assert np.abs(lat.cpu().numpy() - lr).max() < 5e-3
+    ej = max(np.abs(j[i, :n] - jr[i, :n]).max() for i, n in enumerate(lens))
+    ef = max(np.abs(f[i, :n] - fr[i, :n]).max() for i, n in enumerate(lens))
+    print("ragged bs64: feats err %.3e joints err %.3e (mean length %.1f)" % (ef, ej, float(np.mean(lens))))
+    assert ef < 1e-3 and ej < 1e-3
+    for i, n in enumerate(lens):
+        assert np.all(f[i, n:] == 0)
