@@ -43,12 +43,21 @@ enum {
 
 enum { MLDHIP_F32 = 0 };   /* dtype codes for mldhip_load_tensor */
 
-enum {                     /* arithmetic mode of the matrix kernels */
+enum {                     /* arithmetic mode of the matrix kernels.  In EVERY mode accumulation, bias, residual,
+                              LayerNorm, softmax, the attention kernels, the scheduler step and all stored activations
+                              are fp32; the modes differ in the operand format fed to the MFMAs of the GEMMs. */
   MLDHIP_PREC_F32 = 0,            /* exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere: the parity mode */
-  MLDHIP_PREC_BF16X3_DECODE = 1   /* VAE-decoder GEMMs on split-bf16 (3 x v_mfma_f32_16x16x32_bf16, fp32 accumulate,
-                                     ~1e-5 relative per product); reverse loop, attention, LayerNorm, joints stay fp32.
-                                     (Split-bf16 in the reverse loop was measured and rejected: joint error 1.1e-3 at
-                                     T=196 -- over the 1e-3 contract -- and no faster; profiles/r01_v9.) */
+  MLDHIP_PREC_BF16X3_DECODE = 1,  /* split-bf16 (x = hi + lo; 3 x v_mfma_f32_16x16x32_bf16, ~1e-5 relative per product) in the
+                                     MFMA-bound large-M GEMMs: VAE decoder / encoder of the latent models, every GEMM of the
+                                     diffusion-only variant; the reverse loop of the latent models stays fp32.  Meets the
+                                     1e-3 joint contract (tests).  (Split-bf16 inside the latent reverse loop was measured
+                                     and rejected: joint error 1.1e-3 at T=196 and no faster; profiles/r01_v9.) */
+  MLDHIP_PREC_BF16 = 2,           /* operands of EVERY GEMM rounded to bf16 (one v_mfma_f32_16x16x32_bf16 per tile and K chunk):
+                                     the "bf16" of BASELINE.json configs[1].  Does NOT meet the 1e-3 joint contract on the
+                                     synthetic weights; bench.py reports its measured error next to its throughput. */
+  MLDHIP_PREC_FP8_DENOISER = 3    /* BASELINE.json configs[4]: the reverse-loop GEMMs on v_mfma_f32_16x16x32_fp8_fp8 (OCP e4m3;
+                                     weights scaled per tensor, activation rows per row, powers of two), decoder GEMMs
+                                     split-bf16.  Latent models only.  Error reported by bench.py, not asserted. */
 };
 
 /* Mirrors the keys of configs/config_mld_humanml3d.yaml + configs/modules/{denoiser,motion_vae,

@@ -43,7 +43,7 @@ void launch_staged(Ctx& c, const GemmArgs& a, dim3 grid) {
   switch (kcs) {
     case 8: MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 8>), grid, dim3(WM * WN * 64), lds, c.stream, a); break;
     case 12:   // K = 384: the 263-wide motion features padded to the chunk pipeline (pose_embd of the no-VAE denoiser)
-      if constexpr (!LN && PREC == 0) { MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 12>), grid, dim3(WM * WN * 64), lds, c.stream, a); }
+      if constexpr (!LN && PREC == PREC_F32) { MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 12>), grid, dim3(WM * WN * 64), lds, c.stream, a); }
       else c.rc = c.e->fail(MLDHIP_EINVAL, "staged GEMM: K=384 is built for the plain fp32 tile only");
       break;
     case 16: MLD_LAUNCH((gemm_kernel<WM, WN, MREP, NREP, LN, true, PREC, 16>), grid, dim3(WM * WN * 64), lds, c.stream, a); break;
@@ -51,17 +51,34 @@ void launch_staged(Ctx& c, const GemmArgs& a, dim3 grid) {
     default: c.rc = c.e->fail(MLDHIP_EINVAL, "staged GEMM: K=%d not in {256,384,512,1024}", a.K1 + a.K2);
   }
 }
+// Operand format of the LDS-staged GEMMs outside the latent reverse loop (mldhip.h MLDHIP_PREC_*): the decoder / encoder
+// GEMMs (phase 1) and every GEMM of the diffusion-only variant.
+int staged_prec(const E* e) {
+  const bool big = e->phase == 1 || e->cfg.vae_arch == MLDHIP_VAE_NONE;
+  switch (e->cfg.precision) {
+    case MLDHIP_PREC_BF16X3_DECODE: return big ? PREC_BF16X3 : PREC_F32;
+    case MLDHIP_PREC_BF16: return PREC_BF16;
+    case MLDHIP_PREC_FP8_DENOISER: return big ? PREC_BF16X3 : PREC_F32;
+    default: return PREC_F32;
+  }
+}
+// Operand format of the latent reverse loop's GEMMs (tile32.hpp / strip.hpp / the 32x64 staged FFN2)
+int loop_prec(const E* e) {
+  return e->cfg.precision == MLDHIP_PREC_BF16 ? PREC_BF16 : e->cfg.precision == MLDHIP_PREC_FP8_DENOISER ? PREC_FP8 : PREC_F32;
+}
+
 void gemm(Ctx& c, const GemmArgs& a, int nz = 1) {
   const int K = a.K1 + a.K2;
   const bool small = a.M <= c.e->small_m || (K != 256 && K != 384 && K != 512 && K != 1024);
-  const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_DECODE && c.e->phase == 1 && K != 384;   // decoder GEMMs only
+  const int prec = K == 384 ? PREC_F32 : staged_prec(c.e);     // K = 384 (padded 263-wide features): fp32 tile only
   if (small) {
     dim3 grid((a.M + 15) / 16, (a.N + 63) / 64, nz);
     MLD_LAUNCH((gemm_kernel<1, 4, 1, 1, false>), grid, dim3(256), 0, c.stream, a);
   } else {
-    dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);
-    if (x3) launch_staged<2, 4, 2, 2, false, 1>(c, a, grid);
-    else launch_staged<2, 4, 2, 2, false, 0>(c, a, grid);      // 64x128 tile on 8 waves (2 per SIMD)
+    dim3 grid((a.M + 63) / 64, (a.N + 127) / 128, nz);         // 64x128 tile on 8 waves (2 per SIMD)
+    if (prec == PREC_BF16X3) launch_staged<2, 4, 2, 2, false, PREC_BF16X3>(c, a, grid);
+    else if (prec == PREC_BF16) launch_staged<2, 4, 2, 2, false, PREC_BF16>(c, a, grid);
+    else launch_staged<2, 4, 2, 2, false, PREC_F32>(c, a, grid);
   }
   count(c);
   check_launch(c, "gemm");
@@ -69,17 +86,21 @@ void gemm(Ctx& c, const GemmArgs& a, int nz = 1) {
 
 // 32x64 tiles on 4 waves (27.6 KB of LDS: several workgroups per CU): the loop's FFN2 at M >= 768, where N = 256 gives
 // only M/64 x 2 of the big tiles.  K in {256, 512, 1024}; fp32.
-void gemm_tile_32x64(Ctx& c, const GemmArgs& a) {
-  launch_staged<2, 2, 1, 2, false, 0>(c, a, dim3((a.M + 31) / 32, (a.N + 63) / 64, 1));
+void gemm_tile_32x64(Ctx& c, const GemmArgs& a, int prec) {
+  const dim3 grid((a.M + 31) / 32, (a.N + 63) / 64, 1);
+  if (prec == PREC_BF16) launch_staged<2, 2, 1, 2, false, PREC_BF16>(c, a, grid);
+  else if (prec == PREC_FP8) launch_staged<2, 2, 1, 2, false, PREC_FP8>(c, a, grid);
+  else launch_staged<2, 2, 1, 2, false, PREC_F32>(c, a, grid);
   count(c);
   check_launch(c, "gemm_32x64");
 }
 
 void gemm_ln(Ctx& c, const GemmArgs& a) {   // N == 256; full rows per workgroup (64 x 256 tile on 8 waves)
-  const bool x3 = c.e->cfg.precision >= MLDHIP_PREC_BF16X3_DECODE && c.e->phase == 1;
+  const int prec = staged_prec(c.e);
   const dim3 grid((a.M + 63) / 64, 1, 1);
-  if (x3) launch_staged<2, 4, 2, 4, true, 1>(c, a, grid);
-  else launch_staged<2, 4, 2, 4, true, 0>(c, a, grid);
+  if (prec == PREC_BF16X3) launch_staged<2, 4, 2, 4, true, PREC_BF16X3>(c, a, grid);
+  else if (prec == PREC_BF16) launch_staged<2, 4, 2, 4, true, PREC_BF16>(c, a, grid);
+  else launch_staged<2, 4, 2, 4, true, PREC_F32>(c, a, grid);
   count(c);
   check_launch(c, "gemm_ln");
 }

@@ -12,7 +12,6 @@ namespace {
 //              no split-K (one raw slab per GEMM); M >= strip_min_rows (several requests coalesced into one chain).
 // Both use the same data flow: a GEMM with K > 256 or a following LayerNorm leaves RAW fp32 partial slabs, and the
 // consumer's A prologue applies slab sum + bias + residual + LayerNorm (or the 3-token attention).
-constexpr int t32_lds_bytes(int mt) { return (mt + 64) * (256 + 4) * 4; }
 
 void tile32(Ctx& c, const Tile32Args& a_, int nz) {
   Tile32Args a = a_;
@@ -22,10 +21,13 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
   const int mt = mt16 ? 16 : 32;
   dim3 grid((a.M + mt - 1) / mt, (a.N + 63) / 64, nz);
   const int ns = a.src[0].attn_R > 0 ? 0 : a.src[0].nsplit;
+  const int prec = loop_prec(c.e);
 #define MLD_T32(MT, NS)                                                                                          \
   do {                                                                                                           \
-    if (a.trace) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, true>), grid, dim3(512), t32_lds_bytes(MT), c.stream, a); }  \
-    else { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false>), grid, dim3(512), t32_lds_bytes(MT), c.stream, a); }         \
+    if (a.trace) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, true>), grid, dim3(512), kT32LdsBytes, c.stream, a); }       \
+    else if (prec == PREC_BF16) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, PREC_BF16>), grid, dim3(512), kT32LdsBytes, c.stream, a); } \
+    else if (prec == PREC_FP8) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, PREC_FP8>), grid, dim3(512), kT32LdsBytes, c.stream, a); }   \
+    else { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false>), grid, dim3(512), kT32LdsBytes, c.stream, a); }              \
   } while (0)
 #define MLD_T32_NS(MT)                                                                                           \
   switch (ns) {                                                                                                  \
@@ -47,11 +49,19 @@ void strip(Ctx& c, const Tile32Args& a, int nsrc) {
   const dim3 grid((a.M + 31) / 32, (a.N + 63) / 64, 1);
   const bool attn = a.src[0].attn_R > 0;
   const int ns = attn ? 0 : a.src[0].nsplit;
-  if (attn && nsrc == 1) { MLD_LAUNCH((gemm_strip_kernel<0, 1, true>), grid, dim3(256), strip_lds_bytes<1>(), c.stream, a); }
-  else if (ns == 0 && nsrc == 1) { MLD_LAUNCH((gemm_strip_kernel<0, 1, false>), grid, dim3(256), strip_lds_bytes<1>(), c.stream, a); }
-  else if (ns == 1 && nsrc == 1) { MLD_LAUNCH((gemm_strip_kernel<1, 1, false>), grid, dim3(256), strip_lds_bytes<1>(), c.stream, a); }
-  else if (ns == 1 && nsrc == 2) { MLD_LAUNCH((gemm_strip_kernel<1, 2, false>), grid, dim3(256), strip_lds_bytes<2>(), c.stream, a); }
+  const int prec = loop_prec(c.e);
+#define MLD_STRIP(NS, NSRC, ATTN)                                                                                                  \
+  do {                                                                                                                             \
+    if (prec == PREC_BF16) { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_BF16>), grid, dim3(256), strip_lds_bytes<NSRC>(), c.stream, a); } \
+    else if (prec == PREC_FP8) { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_FP8>), grid, dim3(256), strip_lds_bytes<NSRC>(), c.stream, a); } \
+    else { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN>), grid, dim3(256), strip_lds_bytes<NSRC>(), c.stream, a); }                  \
+  } while (0)
+  if (attn && nsrc == 1) MLD_STRIP(0, 1, true);
+  else if (ns == 0 && nsrc == 1) MLD_STRIP(0, 1, false);
+  else if (ns == 1 && nsrc == 1) MLD_STRIP(1, 1, false);
+  else if (ns == 1 && nsrc == 2) MLD_STRIP(1, 2, false);
   else { c.rc = c.e->fail(MLDHIP_EINVAL, "strip: unsupported source (slabs %d, segments %d)", ns, nsrc); return; }
+#undef MLD_STRIP
   count(c);
   check_launch(c, "gemm_strip");
 }
@@ -99,6 +109,7 @@ long long den_slab(const E* e) { return (long long)6 * e->cfg.max_batch * 256; }
 void den_qkv(Ctx& c, const DenView& v, const EncLayerP& L, const ASrc& x) {
   Tile32Args a;
   a.src[0] = x; a.nz0 = 1; a.W = L.in_w; a.ldw = 256; a.bias = L.in_b; a.Y = v.QKV; a.ldy = 768; a.M = 3 * v.R; a.N = 768;
+  a.wscale = L.s_in;
   if (v.strip) strip(c, a, 1); else tile32(c, a, 1);
 }
 // out-projection of the 3-token self-attention (computed while the A tile is assembled) -> raw slab Po
@@ -106,6 +117,7 @@ void den_outproj(Ctx& c, const DenView& v, const EncLayerP& L) {
   Tile32Args a;
   a.src[0].base = v.QKV; a.src[0].attn_R = v.R;
   a.nz0 = 1; a.W = L.out_w; a.ldw = 256; a.P = v.Po; a.pstride = 0; a.M = 3 * v.R; a.N = 256;
+  a.wscale = L.s_out;
   if (v.strip) strip(c, a, 1); else tile32(c, a, 1);
 }
 // h1 = LN1(x + out_proj) assembled on load (written to H1), FF = gelu(h1 W1^T + b1)
@@ -114,6 +126,7 @@ void den_ffn1(Ctx& c, const DenView& v, const EncLayerP& L, const float* xn) {
   Tile32Args a;
   a.src[0] = combine_src(v.Po, 1, 0, L.out_b, xn, L.n1_w, L.n1_b, v.H1);
   a.nz0 = 1; a.W = L.l1_w; a.ldw = 256; a.bias = L.l1_b; a.act = 1; a.Y = v.FF; a.ldy = F; a.M = 3 * v.R; a.N = F;
+  a.wscale = L.s_l1;
   if (v.strip) strip(c, a, 1); else tile32(c, a, 1);
 }
 // FFN2 -> raw slabs Pf (ff_size/256 K-slices on the latency kernels, one full-K slab on the throughput kernels);
@@ -121,12 +134,16 @@ void den_ffn1(Ctx& c, const DenView& v, const EncLayerP& L, const float* xn) {
 void den_ffn2(Ctx& c, const DenView& v, const EncLayerP& L) {
   const int F = c.e->cfg.ff_size;
   if (v.strip) {
-    gemm_tile_32x64(c, lin_args(v.FF, F, F, L.l2_w, nullptr, v.Pf, 256, 3 * v.R, 256));
+    GemmArgs g = lin_args(v.FF, F, F, L.l2_w, nullptr, v.Pf, 256, 3 * v.R, 256);
+    // fp8: the FFN activations (post-GELU, |x| <~ 10) get a static scale of 16 (saturation at 28); weights per tensor
+    g.ascale = 16.f; g.wscale = L.s_l2; g.oscale = 1.0f / (g.ascale * g.wscale);
+    gemm_tile_32x64(c, g, loop_prec(c.e));
     return;
   }
   Tile32Args a;
   a.src[0] = plain_src(v.FF, F);
   a.nz0 = F / 256; a.W = L.l2_w; a.ldw = F; a.P = v.Pf; a.pstride = den_slab(c.e); a.M = 3 * v.R; a.N = 256;
+  a.wscale = L.s_l2;
   tile32(c, a, F / 256);
 }
 ASrc den_layer_output(E* e, const DenView& v, const EncLayerP& L, float* write_back) {   // LN2(sum Pf + b2 + h1)
@@ -161,6 +178,7 @@ void denoiser_body(Ctx& c, const DenView& v) {
       a.nz0 = 1;
       a.W = P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".weight"); a.ldw = 512;
       a.P = v.Ps; a.pstride = den_slab(e); a.M = 3 * v.R; a.N = 256;
+      a.wscale = e->den_skip_scale.empty() ? 1.f : e->den_skip_scale[i];
       if (v.strip) strip(c, a, 2); else tile32(c, a, 2);
       x = combine_src(v.Ps, v.skip_slabs, den_slab(e), P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".bias"), nullptr,
                       nullptr, nullptr, v.Ha);

@@ -18,6 +18,7 @@ struct Param {
 
 struct EncLayerP {   // TransformerEncoderLayer (cross_attention.py:236-272)
   const float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
+  float s_in = 1.f, s_out = 1.f, s_l1 = 1.f, s_l2 = 1.f;   // MLDHIP_PREC_FP8_DENOISER: per-tensor power-of-two weight scales
 };
 struct DecLayerP {   // TransformerDecoderLayer (cross_attention.py:297-345)
   const float *in_w, *in_b, *out_w, *out_b;
@@ -66,6 +67,7 @@ struct mldhip_engine {
   float* arena = nullptr;
   size_t arena_floats = 0;
   std::vector<EncLayerP> den;      // execution order
+  std::vector<float> den_skip_scale;   // fp8 weight scales of denoiser.encoder.linear_blocks.i
   std::vector<DecLayerP> dec;
   std::vector<EncLayerP> venc;     // VAE encoder layers (same layer type as the denoiser's)
   std::vector<DecLayerP> ndec;     // no-VAE variant: denoiser.decoder.layers.* (TransformerDecoder, cross_attention.py:195-233)

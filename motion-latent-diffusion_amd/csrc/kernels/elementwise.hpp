@@ -40,6 +40,17 @@ __global__ __launch_bounds__(256) void init_chain_kernel(const float* __restrict
   X0[(long long)(2 * Rc + Bc + b) * 256 + d] = TP[(long long)(B + b0 + b) * 256 + d];
 }
 
+// max |x| over n floats (one workgroup; finalize-time only: per-tensor fp8 weight scales)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float m = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+  m = max64(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
 struct DdimCoef { float sqrt_at, sqrt_1mat, sqrt_ap, sqrt_1map; };   // DDIM eta=0 coefficients of one step
 
 // LayerNorm over rows of width 256: one wave per row, 4 rows per workgroup.

@@ -40,6 +40,8 @@ struct GemmArgs {
   const float* g1 = nullptr; const float* b1 = nullptr;
   const float* cvec = nullptr; int ldcvec = 0;           // + cvec[row / rows_per_group] then LN(g2,b2)
   const float* g2 = nullptr; const float* b2 = nullptr;
+  float ascale = 1.f, wscale = 1.f, oscale = 1.f;        // PREC_FP8: operands are multiplied by a/wscale before the e4m3
+                                                         // conversion, the accumulator by oscale = 1/(ascale*wscale)
   unsigned long long* trace = nullptr;   // measurement only (staged kernels): 8 timestamps per wave
 };
 
@@ -97,15 +99,18 @@ constexpr int gemm_lds_bytes() { return 2 * (WM * MREP * 16 + WN * NREP * 16) * 
 //                 flight while chunk k's MFMAs run; one barrier per chunk.  (The register-direct form
 //                 reached only ~50 of 157 TF on the decoder: fragment-shaped loads saturate the TA path,
 //                 cdna_hip_programming.md "x through LDS in full lines".)
-// PREC (staged path only): 0 = exact fp32 MFMA, 1 = split-bf16 ("bf16x3", rt.hpp): operands are split into
+// PREC (staged path only): PREC_F32 = exact fp32 MFMA; PREC_BF16X3 = split-bf16 (rt.hpp): operands are split into
 //                 bf16 hi/lo planes while they are written to LDS (same LDS footprint as fp32), 3 bf16 MFMAs
-//                 per tile per K chunk.
+//                 per tile per K chunk; PREC_BF16 = operands rounded to bf16 (RNE) at the LDS store, one
+//                 v_mfma_f32_16x16x32_bf16 per tile and chunk; PREC_FP8 = operands scaled (per-tensor powers of two)
+//                 and rounded to OCP e4m3, one v_mfma_f32_16x16x32_fp8_fp8 per tile and chunk.  Accumulation, bias,
+//                 residual, LayerNorm and the stored result are fp32 in every mode.
 // KCS (staged path only): K / 32, compile time, so that the whole chunk pipeline is straight-line code: any
 //                 runtime branch around a prefetch load makes hipcc's vmcnt bookkeeping conservative and the
 //                 ring drains at every LDS store (seen in the ISA as vmcnt(5)..vmcnt(0) ladders).
 template <int WM, int WN, int MREP, int NREP, bool LN, bool STAGED = false, int PREC = 0, int KCS = 0, bool TRACE = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
-  static_assert(PREC == 0 || STAGED, "split-bf16 needs the LDS-staged main loop");
+  static_assert(PREC == PREC_F32 || STAGED, "reduced-precision operands need the LDS-staged main loop");
   constexpr int BM = WM * MREP * 16, BN = WN * NREP * 16;
   constexpr bool SPLIT = (MREP * NREP == 1);   // one tile per wave: split the k-chain over 2 accumulators
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,8 +223,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         const int idx = tid + j * NT, row = idx >> 3, c4 = idx & 7;
         F4 v = stage[j];
         if (j < NLA) { v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo); }
-        if constexpr (PREC == 0) {
+        if constexpr (PREC == PREC_F32) {
           st4(dst + row * kGemmLdsStride + c4 * 4, v);
+        } else if constexpr (PREC == PREC_BF16) {
+          // row image: [32 x bf16 | unused]; this thread owns k = 4*c4 .. 4*c4+3 -> words 2*c4, 2*c4+1
+          unsigned* rowp = reinterpret_cast<unsigned*>(dst + row * kGemmLdsStride);
+          *reinterpret_cast<uint2_t*>(rowp + c4 * 2) = uint2_t{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+        } else if constexpr (PREC == PREC_FP8) {
+          // row image: [32 x e4m3 | unused]; this thread owns word c4
+          const float sc = j < NLA ? p.ascale : p.wscale;
+          reinterpret_cast<unsigned*>(dst + row * kGemmLdsStride)[c4] = pack_fp8x4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
         } else {
           // row image: [32 x bf16 hi | 32 x bf16 lo | pad]; this thread owns k = 4*c4 .. 4*c4+3
           unsigned h0, l0, h1, l1;
@@ -264,6 +277,30 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         blo[t] = rp[4 + g];
       }
     };
+    U2 a8[MREP], b8[NREP];
+    auto mma_narrow = [&](int buf) {       // PREC_BF16 / PREC_FP8: one matrix instruction per tile and K chunk
+      const float* as = smem + buf * ROWS * kGemmLdsStride + (wm * MREP * 16 + r) * kGemmLdsStride;
+      const float* ws = smem + buf * ROWS * kGemmLdsStride + (BM + wn * NREP * 16 + r) * kGemmLdsStride;
+      if constexpr (PREC == PREC_BF16) {
+#pragma unroll
+        for (int t = 0; t < MREP; ++t) ahi[t] = reinterpret_cast<const U4*>(as + t * 16 * kGemmLdsStride)[g];
+#pragma unroll
+        for (int t = 0; t < NREP; ++t) bhi[t] = reinterpret_cast<const U4*>(ws + t * 16 * kGemmLdsStride)[g];
+#pragma unroll
+        for (int a = 0; a < MREP; ++a)
+#pragma unroll
+          for (int b = 0; b < NREP; ++b) acc[a][b] = mfma_bf16_16x16x32(ahi[a], bhi[b], acc[a][b]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < MREP; ++t) a8[t] = reinterpret_cast<const U2*>(as + t * 16 * kGemmLdsStride)[g];
+#pragma unroll
+        for (int t = 0; t < NREP; ++t) b8[t] = reinterpret_cast<const U2*>(ws + t * 16 * kGemmLdsStride)[g];
+#pragma unroll
+        for (int a = 0; a < MREP; ++a)
+#pragma unroll
+          for (int b = 0; b < NREP; ++b) acc[a][b] = mfma_fp8_16x16x32(a8[a], b8[b], acc[a][b]);
+      }
+    };
     auto compute_bf16 = [&]() {
 #pragma unroll
       for (int a = 0; a < MREP; ++a)
@@ -275,12 +312,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         }
     };
     auto mma = [&](int buf) {
-      if constexpr (PREC == 0) {
+      if constexpr (PREC == PREC_F32) {
         lfrags(buf);
         compute(fa0, fb0);
-      } else {
+      } else if constexpr (PREC == PREC_BF16X3) {
         lfrags_bf16(buf);
         compute_bf16();
+      } else {
+        mma_narrow(buf);
       }
     };
     static_assert(KCS >= 4 && KCS % 4 == 0, "staged GEMMs take K in {256, 512, 1024}");
@@ -316,6 +355,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
     }
   }
   if (SPLIT) acc[0][0] += acc2;
+  if constexpr (PREC == PREC_FP8) {
+#pragma unroll
+    for (int a = 0; a < MREP; ++a)
+#pragma unroll
+      for (int b = 0; b < NREP; ++b) acc[a][b] *= p.oscale;
+  }
   if constexpr (TRACE) ts[3] = clock_pinned();              // main loop done
   auto trace_out = [&]() {
     if constexpr (TRACE) {

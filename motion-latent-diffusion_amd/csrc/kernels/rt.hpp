@@ -102,6 +102,25 @@ __device__ __forceinline__ float sum64(float v) {
 #endif
 }
 
+// max over all 64 lanes, result in every lane (same DPP + readlane scheme as sum64)
+__device__ __forceinline__ float max64(float v) {
+#if defined(MLDHIP_SIM)
+  v = fmaxf(v, wave_xor(v, 1)); v = fmaxf(v, wave_xor(v, 2)); v = fmaxf(v, wave_xor(v, 4)); v = fmaxf(v, wave_xor(v, 8));
+  return max_groups(v);
+#else
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+#endif
+}
+
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26), branch free: the epilogue of the FFN1 GEMMs
 // evaluates it 4-32 times per lane and libm's erff is a divergent multi-branch routine.
 __device__ __forceinline__ float erf_as(float x) {
@@ -151,6 +170,52 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(U4 a, U4 b, f32x4 c) {
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 #endif
+}
+
+// ---- reduced-precision operand formats of the GEMM kernels (operands only: accumulation, bias, residual, LayerNorm,
+// softmax and every stored activation stay fp32).  PREC codes shared by gemm.hpp / tile32.hpp / strip.hpp:
+enum : int { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_FP8 = 3 };
+
+// two floats -> packed bf16 pair, round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950), element 0 in the low half
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+#if defined(MLDHIP_SIM)
+  return bf16_rne_bits(a) | (bf16_rne_bits(b) << 16);
+#else
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+#endif
+}
+// four floats -> four OCP e4m3 bytes (element 0 in the low byte), saturating at +-448
+constexpr float kFp8Max = 448.0f;
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+  a = fminf(fmaxf(a, -kFp8Max), kFp8Max); b = fminf(fmaxf(b, -kFp8Max), kFp8Max);
+  c = fminf(fmaxf(c, -kFp8Max), kFp8Max); d = fminf(fmaxf(d, -kFp8Max), kFp8Max);
+#if defined(MLDHIP_SIM)
+  return hipsim::fp8_e4m3_bits(a) | (hipsim::fp8_e4m3_bits(b) << 8) | (hipsim::fp8_e4m3_bits(c) << 16) | (hipsim::fp8_e4m3_bits(d) << 24);
+#else
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+#endif
+}
+// v_mfma_f32_16x16x32_fp8_fp8: lane l supplies A[row = l&15][k = 8*(l>>4) + j] and B[k][col = l&15], j = 0..7 as 8 bytes
+struct alignas(8) U2 { unsigned x, y; };
+__device__ __forceinline__ f32x4 mfma_fp8_16x16x32(U2 a, U2 b, f32x4 c) {
+#if defined(MLDHIP_SIM)
+  const unsigned av[2] = {a.x, a.y}, bv[2] = {b.x, b.y};
+  return hipsim::mfma_fp8_16x16x32(av, bv, c);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(__builtin_bit_cast(long, a), __builtin_bit_cast(long, b), c, 0, 0, 0);
+#endif
+}
+// largest power of two s with s * amax <= 256 (keeps e4m3's 3 mantissa bits on the big elements, headroom below 448);
+// amax == 0 -> 1.  Power-of-two scales make quantise / de-quantise exact.
+__device__ __forceinline__ float fp8_pow2_scale(float amax) {
+  if (!(amax > 0.f)) return 1.f;
+  int e;
+  (void)frexpf(amax, &e);            // amax = m * 2^e, m in [0.5, 1)
+  return ldexpf(1.f, 8 - e);          // s * amax = m * 256 in [128, 256)
 }
 
 // shader-clock timestamp pinned in program order (phase tracing of a kernel; measurement only)

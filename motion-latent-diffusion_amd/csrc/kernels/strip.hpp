@@ -19,13 +19,48 @@ namespace mld {
 
 constexpr int kStripWStride = 36;                        // floats per staged W row: one 32-wide K chunk + 4 pad
 template <int NSRC>
-constexpr int strip_lds_bytes() { return (32 * (256 * NSRC + 4) + 2 * 64 * kStripWStride) * 4; }   // 51 712 / 84 480 B
+constexpr int strip_lds_bytes() { return (32 * (256 * NSRC + 4) + 2 * 64 * kStripWStride + 32) * 4; }   // 51 840 / 84 608 B
+
+// one 32-wide K chunk for both 16-row tiles of the strip against one 16-column weight tile (operand formats: tile32.hpp)
+template <int PREC>
+__device__ __forceinline__ void strip_chunk(const float* a0, const float* a1, const float* w, int kc, int g, f32x4& acc0, f32x4& acc1) {
+  if constexpr (PREC == PREC_F32) {
+    const F4 b0 = ld4(w + g * 8), b1 = ld4(w + g * 8 + 4);
+    const F4 x0 = ld4(a0 + kc * 32 + g * 8), x1 = ld4(a0 + kc * 32 + g * 8 + 4);
+    const F4 y0 = ld4(a1 + kc * 32 + g * 8), y1 = ld4(a1 + kc * 32 + g * 8 + 4);
+    acc0 = mfma_f32_16x16x4(x0.x, b0.x, acc0);
+    acc1 = mfma_f32_16x16x4(y0.x, b0.x, acc1);
+    acc0 = mfma_f32_16x16x4(x0.y, b0.y, acc0);
+    acc1 = mfma_f32_16x16x4(y0.y, b0.y, acc1);
+    acc0 = mfma_f32_16x16x4(x0.z, b0.z, acc0);
+    acc1 = mfma_f32_16x16x4(y0.z, b0.z, acc1);
+    acc0 = mfma_f32_16x16x4(x0.w, b0.w, acc0);
+    acc1 = mfma_f32_16x16x4(y0.w, b0.w, acc1);
+    acc0 = mfma_f32_16x16x4(x1.x, b1.x, acc0);
+    acc1 = mfma_f32_16x16x4(y1.x, b1.x, acc1);
+    acc0 = mfma_f32_16x16x4(x1.y, b1.y, acc0);
+    acc1 = mfma_f32_16x16x4(y1.y, b1.y, acc1);
+    acc0 = mfma_f32_16x16x4(x1.z, b1.z, acc0);
+    acc1 = mfma_f32_16x16x4(y1.z, b1.z, acc1);
+    acc0 = mfma_f32_16x16x4(x1.w, b1.w, acc0);
+    acc1 = mfma_f32_16x16x4(y1.w, b1.w, acc1);
+  } else if constexpr (PREC == PREC_BF16) {
+    const U4 b = reinterpret_cast<const U4*>(w)[g];
+    acc0 = mfma_bf16_16x16x32(reinterpret_cast<const U4*>(a0)[kc * 4 + g], b, acc0);
+    acc1 = mfma_bf16_16x16x32(reinterpret_cast<const U4*>(a1)[kc * 4 + g], b, acc1);
+  } else {
+    const U2 b = reinterpret_cast<const U2*>(w)[g];
+    acc0 = mfma_fp8_16x16x32(reinterpret_cast<const U2*>(a0)[kc * 4 + g], b, acc0);
+    acc1 = mfma_fp8_16x16x32(reinterpret_cast<const U2*>(a1)[kc * 4 + g], b, acc1);
+  }
+}
 
 // grid = (ceil(M/32), ceil(N/64)); block = 256 (4 waves).  Wave w owns output columns [16w, 16w+16) of the tile, both
 // 16-row tiles.  K = 256 * NSRC: columns [0, 256) come from src[0] (plain rows, combine, or attention), columns
 // [256, 512) from src[1] (plain rows; the skip connection's second K segment).
 // NS0 = compile-time slab count of src[0] in combine mode (0: plain rows or attention).
-template <int NS0, int NSRC, bool ATTN>
+// PREC = operand format of the MFMAs (rt.hpp); prologue, accumulation and epilogue are fp32 in every mode.
+template <int NS0, int NSRC, bool ATTN, int PREC = PREC_F32>
 __global__ __launch_bounds__(256, ATTN ? 2 : 3) void gemm_strip_kernel(Tile32Args p) {
   static_assert(NSRC == 1 || NSRC == 2, "one or two 256-wide K segments");
   static_assert(!(ATTN && (NS0 != 0 || NSRC != 1)), "the attention prologue feeds the out-projection only");
@@ -37,6 +72,7 @@ __global__ __launch_bounds__(256, ATTN ? 2 : 3) void gemm_strip_kernel(Tile32Arg
 #endif
   float* As = smem;                          // [32][ST]
   float* Ws = smem + 32 * ST;                // [2][64][kStripWStride]
+  float* rsc = Ws + 2 * 64 * kStripWStride;  // [32] 1 / (row scale * wscale) (PREC_FP8)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
   const ASrc& src = p.src[0];
@@ -54,9 +90,9 @@ __global__ __launch_bounds__(256, ATTN ? 2 : 3) void gemm_strip_kernel(Tile32Arg
     ring[c & 3][1] = ld4(wp1 + c * 32);
   };
   auto lstore = [&](int c) {
-    float* dst = Ws + (c & 1) * 64 * kStripWStride + wc4 * 4;
-    st4(dst + wrow * kStripWStride, ring[c & 3][0]);
-    st4(dst + (wrow + 32) * kStripWStride, ring[c & 3][1]);
+    float* dst = Ws + (c & 1) * 64 * kStripWStride;
+    st_operand<PREC>(dst + wrow * kStripWStride, wc4, ring[c & 3][0], p.wscale);        // "lane" = the 16-byte slot within the chunk
+    st_operand<PREC>(dst + (wrow + 32) * kStripWStride, wc4, ring[c & 3][1], p.wscale);
   };
 
   // epilogue bias of this lane's output column, fetched now (clamped, unconditional)
@@ -174,48 +210,45 @@ __global__ __launch_bounds__(256, ATTN ? 2 : 3) void gemm_strip_kernel(Tile32Arg
         if (live[i]) st4(src.out + (long long)rows[i] * src.ldout + lane * 4, areg[i]);
     }
   }
-#pragma unroll
-  for (int i = 0; i < RPW; ++i) st4(As + (wave + i * 4) * ST + lane * 4, areg[i]);
+  F4 breg[RPW];
   if constexpr (NSRC == 2) {                 // second K segment: plain rows (the stored skip activation)
     const ASrc& s1 = p.src[1];
-    F4 breg[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) breg[i] = ld4(s1.base + (long long)rows[i] * s1.ld + lane * 4);
+  }
+  float ascale[RPW];
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) st4(As + (wave + i * 4) * ST + 256 + lane * 4, breg[i]);
+  for (int i = 0; i < RPW; ++i) ascale[i] = 1.f;
+  if constexpr (PREC == PREC_FP8) {          // per-row power-of-two scale over the whole K of the row
+    float am[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) am[i] = max64(NSRC == 2 ? fmaxf(f4absmax(areg[i]), f4absmax(breg[i])) : f4absmax(areg[i]));
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      ascale[i] = fp8_pow2_scale(am[i]);
+      if (lane == 0) rsc[wave + i * 4] = 1.0f / (ascale[i] * p.wscale);
+    }
+  }
+  constexpr int SEG = PREC == PREC_F32 ? 256 : PREC == PREC_BF16 ? 128 : 64;   // words one 256-wide K segment takes in a row
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * 4) * ST, lane, areg[i], ascale[i]);
+  if constexpr (NSRC == 2) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * 4) * ST + SEG, lane, breg[i], ascale[i]);
   }
 
   // ---- main loop: one barrier per K chunk; chunk kc multiplies while kc+1 is written to the other LDS buffer and
   //      kc+2..kc+4 are in flight (straight-line after unrolling: KCS is a compile-time constant)
   const int r = lane & 15, g = lane >> 4;
-  const float* ap = As + r * ST + g * 8;
-  const float* wp = Ws + (wave * 16 + r) * kStripWStride + g * 8;
+  const float* ap = As + r * ST;
+  const float* wp = Ws + (wave * 16 + r) * kStripWStride;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   lstore(0);
   if (4 < KCS) gload(4);
   __syncthreads();
 #pragma unroll
   for (int kc = 0; kc < KCS; ++kc) {
-    const float* wb = wp + (kc & 1) * 64 * kStripWStride;
-    const F4 b0 = ld4(wb), b1 = ld4(wb + 4);
-    const F4 a0 = ld4(ap + kc * 32), a1 = ld4(ap + kc * 32 + 4);
-    const F4 c0 = ld4(ap + 16 * ST + kc * 32), c1 = ld4(ap + 16 * ST + kc * 32 + 4);
-    acc0 = mfma_f32_16x16x4(a0.x, b0.x, acc0);
-    acc1 = mfma_f32_16x16x4(c0.x, b0.x, acc1);
-    acc0 = mfma_f32_16x16x4(a0.y, b0.y, acc0);
-    acc1 = mfma_f32_16x16x4(c0.y, b0.y, acc1);
-    acc0 = mfma_f32_16x16x4(a0.z, b0.z, acc0);
-    acc1 = mfma_f32_16x16x4(c0.z, b0.z, acc1);
-    acc0 = mfma_f32_16x16x4(a0.w, b0.w, acc0);
-    acc1 = mfma_f32_16x16x4(c0.w, b0.w, acc1);
-    acc0 = mfma_f32_16x16x4(a1.x, b1.x, acc0);
-    acc1 = mfma_f32_16x16x4(c1.x, b1.x, acc1);
-    acc0 = mfma_f32_16x16x4(a1.y, b1.y, acc0);
-    acc1 = mfma_f32_16x16x4(c1.y, b1.y, acc1);
-    acc0 = mfma_f32_16x16x4(a1.z, b1.z, acc0);
-    acc1 = mfma_f32_16x16x4(c1.z, b1.z, acc1);
-    acc0 = mfma_f32_16x16x4(a1.w, b1.w, acc0);
-    acc1 = mfma_f32_16x16x4(c1.w, b1.w, acc1);
+    strip_chunk<PREC>(ap, ap + 16 * ST, wp + (kc & 1) * 64 * kStripWStride, kc, g, acc0, acc1);
     if (kc + 1 < KCS) {
       lstore(kc + 1);
       if (kc + 5 < KCS) gload(kc + 5);
@@ -225,6 +258,10 @@ __global__ __launch_bounds__(256, ATTN ? 2 : 3) void gemm_strip_kernel(Tile32Arg
 
   // ---- epilogue: 16 lanes write 64 contiguous bytes per row (raw partial slab, or bias + activation)
   const int col = n0 + wave * 16 + r;
+  if constexpr (PREC == PREC_FP8) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc0[i] *= rsc[g * 4 + i]; acc1[i] *= rsc[16 + g * 4 + i]; }
+  }
   if (col < p.N) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {

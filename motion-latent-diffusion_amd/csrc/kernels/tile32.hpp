@@ -46,12 +46,53 @@ struct Tile32Args {
   float* P = nullptr;            // partial epilogue when non-null: P[z][M][N] = acc (raw)
   long long pstride = 0;
   int M = 0, N = 0;
+  float wscale = 1.f;            // PREC_FP8: per-tensor power-of-two scale of W (the A rows are scaled per row in-kernel)
   unsigned long long* trace = nullptr;   // measurement only: 8 timestamps per wave (see mldhip_profile_trace)
 };
 
 constexpr int kT32Stride = 260;                         // LDS row stride (floats): 256 + 4 pad
-constexpr int kT32LdsFloats = (32 + 64) * kT32Stride;   // A tile + W tile
-constexpr int kT32LdsBytes = kT32LdsFloats * 4;         // 99,840 B -> one workgroup per CU
+constexpr int kT32LdsFloats = (32 + 64) * kT32Stride + 32;   // A tile + W tile + per-row operand scales (PREC_FP8)
+constexpr int kT32LdsBytes = kT32LdsFloats * 4;              // 99,968 B -> one workgroup per CU
+
+// ---- operand formats shared by the loop kernels (tile32 / strip): an LDS row holds 256 K-values of one A or W row as
+// fp32 (256 words), bf16 (128 words) or e4m3 (64 words); lane l of the storing wave owns k = 4l..4l+3; a fragment of the
+// 32-wide K chunk kc is lane (r, g)'s 8 values k = 32kc + 8g .. +7 in every format (rt.hpp MFMA operand layouts).
+template <int PREC>
+__device__ __forceinline__ void st_operand(float* row, int lane, F4 v, float scale) {
+  if constexpr (PREC == PREC_F32) {
+    st4(row + lane * 4, v);
+  } else if constexpr (PREC == PREC_BF16) {
+    *reinterpret_cast<U2*>(reinterpret_cast<unsigned*>(row) + lane * 2) = U2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+  } else {
+    reinterpret_cast<unsigned*>(row)[lane] = pack_fp8x4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+  }
+}
+// one 32-wide K chunk of a 16x16 tile: acc += A_frag . B_frag (fp32: 8 MFMAs alternating over two accumulators to hide
+// the dependent-issue latency; bf16 / fp8: one MFMA, accumulators alternate by chunk parity)
+template <int PREC>
+__device__ __forceinline__ void mma_chunk(const float* arow, const float* wrow, int kc, int g, f32x4& acc0, f32x4& acc1) {
+  if constexpr (PREC == PREC_F32) {
+    const F4 a0 = ld4(arow + kc * 32 + g * 8), a1 = ld4(arow + kc * 32 + g * 8 + 4);
+    const F4 b0 = ld4(wrow + kc * 32 + g * 8), b1 = ld4(wrow + kc * 32 + g * 8 + 4);
+    acc0 = mfma_f32_16x16x4(a0.x, b0.x, acc0);
+    acc1 = mfma_f32_16x16x4(a0.y, b0.y, acc1);
+    acc0 = mfma_f32_16x16x4(a0.z, b0.z, acc0);
+    acc1 = mfma_f32_16x16x4(a0.w, b0.w, acc1);
+    acc0 = mfma_f32_16x16x4(a1.x, b1.x, acc0);
+    acc1 = mfma_f32_16x16x4(a1.y, b1.y, acc1);
+    acc0 = mfma_f32_16x16x4(a1.z, b1.z, acc0);
+    acc1 = mfma_f32_16x16x4(a1.w, b1.w, acc1);
+  } else if constexpr (PREC == PREC_BF16) {
+    const U4 a = reinterpret_cast<const U4*>(arow)[kc * 4 + g], b = reinterpret_cast<const U4*>(wrow)[kc * 4 + g];
+    if (kc & 1) acc1 = mfma_bf16_16x16x32(a, b, acc1);
+    else acc0 = mfma_bf16_16x16x32(a, b, acc0);
+  } else {
+    const U2 a = reinterpret_cast<const U2*>(arow)[kc * 4 + g], b = reinterpret_cast<const U2*>(wrow)[kc * 4 + g];
+    if (kc & 1) acc1 = mfma_fp8_16x16x32(a, b, acc1);
+    else acc0 = mfma_fp8_16x16x32(a, b, acc0);
+  }
+}
+__device__ __forceinline__ float f4absmax(F4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 
 // Independent wave reductions issued back to back: the DPP chains of different rows interleave.
 template <int N>
@@ -78,9 +119,11 @@ __device__ __forceinline__ F4 f4add(F4 a, F4 b) { return F4{a.x + b.x, a.y + b.y
 // wait per element -- cdna_hip_programming.md, "three .s-level traps" (c)).
 // (Passing K through LDS in two 128-wide pieces so that two workgroups fit a CU was measured: +2.9 % with four batches in
 // flight, -10 % for one batch; removed -- kernels/strip.hpp is the throughput form.  profiles/r01_v17_xcd_kh_ab.txt.)
-template <int MT, int NS0, bool TRACE>
+// PREC: operand format of the MFMAs (rt.hpp PREC_F32 / PREC_BF16 / PREC_FP8; the A prologue and the epilogue stay fp32).
+template <int MT, int NS0, bool TRACE, int PREC = PREC_F32>
 __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
   static_assert(MT == 16 || MT == 32, "row tile");
+  static_assert(PREC == PREC_F32 || PREC == PREC_BF16 || PREC == PREC_FP8, "operand format");
   constexpr int RPW = MT / 8;                 // A rows assembled per wave
   constexpr int KW = 256, ST = KW + 4;        // K columns resident in LDS, LDS row stride (floats)
 #if defined(MLDHIP_SIM)
@@ -90,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
 #endif
   float* As = smem;                          // [MT][ST]
   float* Ws = smem + MT * ST;                // [64][ST]
+  float* rsc = smem + (MT + 64) * ST;        // [MT] 1 / (row scale * wscale) (PREC_FP8)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // (An XCD-aware tile order -- block b runs on XCD b % 8; give each XCD a contiguous range of column tiles so that it
   // pulls 1/8 of the weight panel instead of all of it -- was measured SLOWER: 6 825 vs 7 260 motions/s at 4 batches in
@@ -226,30 +270,32 @@ __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
   const int rt = MT == 32 ? (wave >> 2) : 0;          // row tile (MT = 32)
   const int kh = MT == 16 ? (wave >> 2) : 0;          // K half of the resident piece (MT = 16)
   constexpr int KCH = MT == 32 ? 8 : 4;               // 32-wide K chunks per wave
-  const float* ap = As + (rt * 16 + r) * ST + g * 8 + kh * (KW / 2);
-  const float* wp = Ws + (ct * 16 + r) * ST + g * 8 + kh * (KW / 2);
+  const float* ap = As + (rt * 16 + r) * ST;
+  const float* wp = Ws + (ct * 16 + r) * ST;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   {
+    float ascale[RPW];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * ST + lane * 4, wreg[i]);
+    for (int i = 0; i < RPW; ++i) ascale[i] = 1.f;
+    if constexpr (PREC == PREC_FP8) {          // per-row power-of-two scale of the assembled A rows (one wave owns a row)
+      float am[RPW];
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) st4(As + (wave + i * 8) * ST + lane * 4, areg[i]);
+      for (int i = 0; i < RPW; ++i) am[i] = max64(f4absmax(areg[i]));
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        ascale[i] = fp8_pow2_scale(am[i]);
+        if (lane == 0) rsc[wave + i * 8] = 1.0f / (ascale[i] * p.wscale);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st_operand<PREC>(Ws + (wave + i * 8) * ST, lane, wreg[i], p.wscale);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * 8) * ST, lane, areg[i], ascale[i]);
     if constexpr (tracing) ts[2] = clock_pinned();      // tile parked in LDS (this wave)
     __syncthreads();
     if constexpr (tracing) ts[3] = clock_pinned();      // barrier passed
 #pragma unroll
-    for (int kc = 0; kc < KCH; ++kc) {
-      const F4 a0 = ld4(ap + kc * 32), a1 = ld4(ap + kc * 32 + 4);
-      const F4 b0 = ld4(wp + kc * 32), b1 = ld4(wp + kc * 32 + 4);
-      acc0 = mfma_f32_16x16x4(a0.x, b0.x, acc0);
-      acc1 = mfma_f32_16x16x4(a0.y, b0.y, acc1);
-      acc0 = mfma_f32_16x16x4(a0.z, b0.z, acc0);
-      acc1 = mfma_f32_16x16x4(a0.w, b0.w, acc1);
-      acc0 = mfma_f32_16x16x4(a1.x, b1.x, acc0);
-      acc1 = mfma_f32_16x16x4(a1.y, b1.y, acc1);
-      acc0 = mfma_f32_16x16x4(a1.z, b1.z, acc0);
-      acc1 = mfma_f32_16x16x4(a1.w, b1.w, acc1);
-    }
+    for (int kc = 0; kc < KCH; ++kc) mma_chunk<PREC>(ap, wp, kh * KCH + kc, g, acc0, acc1);
   }
   f32x4 acc = acc0 + acc1;
   if constexpr (MT == 16) {
@@ -265,6 +311,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
   //      transposed the tile through LDS was measured SLOWER (+0.7-1.8 k cycles: two barriers + an LDS
   //      round trip cost more than the wider stores save; profiles/r01_v5).
   const int col = n0 + ct * 16 + r;
+  if constexpr (PREC == PREC_FP8) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] *= rsc[rt * 16 + g * 4 + i];
+  }
   if (col < p.N && kh == 0) {
     if (p.P) {
       float* P = p.P + z * p.pstride;

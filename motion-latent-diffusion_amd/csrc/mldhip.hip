@@ -99,7 +99,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   if (cfg->scheduler_type == MLDHIP_SCHED_DDIM &&
       (cfg->num_inference_steps - 1) * (cfg->num_train_timesteps / cfg->num_inference_steps) + cfg->steps_offset >= cfg->num_train_timesteps)
     return bad("steps_offset pushes the first timestep past num_train_timesteps");
-  if (cfg->precision != MLDHIP_PREC_F32 && cfg->precision != MLDHIP_PREC_BF16X3_DECODE) return bad("unsupported precision");
+  if (cfg->precision < MLDHIP_PREC_F32 || cfg->precision > MLDHIP_PREC_FP8_DENOISER) return bad("unsupported precision");
+  if (cfg->precision == MLDHIP_PREC_FP8_DENOISER && novae) return bad("MLDHIP_PREC_FP8_DENOISER applies to the latent models' reverse loop");
   if (cfg->max_in_flight < 1 || cfg->max_in_flight > 8) return bad("max_in_flight must be 1..8");
 #if !defined(MLDHIP_SIM)
   int ndev = 0;
@@ -180,14 +181,18 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)attn_seq_kernel<7, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, big128);
   (void)hipFuncSetAttribute((const void*)attn_seq_kernel<13, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, big128);
   (void)hipFuncSetAttribute((const void*)attn_seq_kernel<18, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, big128);
+#define MLD_T32_ATTR1(MT, NS, ...) \
+  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<MT, NS, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
 #define MLD_T32_ATTR(NS)                                                                                                    \
-  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<32, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
-  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<32, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);  \
-  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
-  (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<16, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
+  MLD_T32_ATTR1(32, NS, false) MLD_T32_ATTR1(32, NS, true) MLD_T32_ATTR1(16, NS, false) MLD_T32_ATTR1(16, NS, true)             \
+  MLD_T32_ATTR1(32, NS, false, PREC_BF16) MLD_T32_ATTR1(16, NS, false, PREC_BF16)                                             \
+  MLD_T32_ATTR1(32, NS, false, PREC_FP8) MLD_T32_ATTR1(16, NS, false, PREC_FP8)
   MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4)
 #undef MLD_T32_ATTR
+#undef MLD_T32_ATTR1
   (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<1, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds_bytes<2>());
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<1, 2, false, PREC_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds_bytes<2>());
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<1, 2, false, PREC_FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds_bytes<2>());
   (void)hipGetLastError();
 #endif
   *out = e;
@@ -305,6 +310,28 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
   Ctx c{e, stream};
   const int D = e->cfg.latent_dim, TD = time_width(e), n = e->cfg.num_inference_steps;
   HIP_TRY(e, hipDeviceSynchronize());                   // no call may be in flight on any context while tables are rebuilt
+  if (e->cfg.precision == MLDHIP_PREC_FP8_DENOISER && e->group_ready[0]) {
+    // per-tensor power-of-two scales of the loop GEMMs' weights: s * max|w| in [128, 256) (rt.hpp fp8_pow2_scale)
+    bind_context(e, 0);
+    const int nb = (e->cfg.num_layers - 1) / 2;
+    std::vector<std::pair<const float*, long long>> tens;
+    const long long DD = (long long)D * D, DF = (long long)D * e->cfg.ff_size;
+    for (auto& L : e->den) { tens.push_back({L.in_w, 3 * DD}); tens.push_back({L.out_w, DD}); tens.push_back({L.l1_w, DF}); tens.push_back({L.l2_w, DF}); }
+    for (int i = 0; i < nb; ++i) tens.push_back({P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".weight"), 2 * DD});
+    std::vector<float> amax(tens.size());
+    for (size_t i = 0; i < tens.size(); ++i) {
+      MLD_LAUNCH(absmax_kernel, dim3(1), dim3(256), 0, stream, tens[i].first, tens[i].second, e->temb0_one);
+      if (check_launch(c, "absmax")) return c.rc;
+      HIP_TRY(e, hipMemcpyAsync(&amax[i], e->temb0_one, sizeof(float), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(e, hipStreamSynchronize(stream));
+    }
+    auto sc = [](float a) { if (!(a > 0.f)) return 1.f; int ex; (void)std::frexp(a, &ex); return std::ldexp(1.f, 8 - ex); };
+    for (size_t l = 0; l < e->den.size(); ++l) {
+      e->den[l].s_in = sc(amax[4 * l]); e->den[l].s_out = sc(amax[4 * l + 1]); e->den[l].s_l1 = sc(amax[4 * l + 2]); e->den[l].s_l2 = sc(amax[4 * l + 3]);
+    }
+    e->den_skip_scale.clear();
+    for (int i = 0; i < nb; ++i) e->den_skip_scale.push_back(sc(amax[4 * e->den.size() + i]));
+  }
   for (int k = 0; k < (int)e->ctxs.size(); ++k) {       // the derived tables live in each context's workspace
   bind_context(e, k);
   if (e->group_ready[0]) {

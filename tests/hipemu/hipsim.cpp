@@ -107,6 +107,27 @@ static void compute_mfma_bf16(WaveState& w, int slot) {
   }
 }
 
+static void compute_mfma_fp8(WaveState& w, int slot) {
+  float A[16][32], B[32][16];
+  for (int l = 0; l < 64; ++l) {
+    const unsigned* p = reinterpret_cast<const unsigned*>(w.buf[slot][l]);
+    for (int j = 0; j < 8; ++j) {
+      A[l & 15][(l >> 4) * 8 + j] = fp8_e4m3_value((p[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+      B[(l >> 4) * 8 + j][l & 15] = fp8_e4m3_value((p[4 + (j >> 2)] >> (8 * (j & 3))) & 0xFFu);
+    }
+  }
+  for (int l = 0; l < 64; ++l) {
+    const float* cp = reinterpret_cast<const float*>(w.buf[slot][l]) + 8;
+    const int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+      const int row = (l >> 4) * 4 + r;
+      float d = cp[r];
+      for (int k = 0; k < 32; ++k) d = fmaf(A[row][k], B[k][col], d);   // products of e4m3 values are exact in fp32
+      w.res[slot][l][r] = d;
+    }
+  }
+}
+
 int wave_arrive(const void* payload, int nbytes, int is_mfma) {
   BlockState& b = g_blk;
   WaveState& w = b.waves[b.cur->wave];
@@ -118,7 +139,8 @@ int wave_arrive(const void* payload, int nbytes, int is_mfma) {
     if (is_mfma) {
       if (w.alive != 64) { std::fprintf(stderr, "hipsim: MFMA issued by a partial wave\n"); std::abort(); }
       if (is_mfma == 1) compute_mfma(w, slot);
-      else compute_mfma_bf16(w, slot);
+      else if (is_mfma == 2) compute_mfma_bf16(w, slot);
+      else compute_mfma_fp8(w, slot);
     }
     w.count = 0;
     w.gen++;

@@ -107,6 +107,40 @@ inline f32x4 mfma_bf16_16x16x32(const unsigned (&a)[4], const unsigned (&bq)[4],
   return d;
 }
 
+// OCP e4m3fn: 1-4-3, bias 7, max 448, no infinities; round-to-nearest-even (inputs are pre-clamped to +-448)
+inline float fp8_e4m3_value(unsigned b) {
+  const int sgn = (b >> 7) & 1, ex = (b >> 3) & 15, man = b & 7;
+  const float v = ex == 0 ? std::ldexp((float)man, -9) : std::ldexp(1.0f + man / 8.0f, ex - 7);
+  return sgn ? -v : v;
+}
+inline unsigned fp8_e4m3_bits(float x) {
+  const unsigned sgn = std::signbit(x) ? 0x80u : 0u;
+  float a = std::fabs(x);
+  if (!(a > 0.f)) return sgn;
+  if (a >= 448.f) return sgn | 0x7Eu;
+  int e;
+  (void)std::frexp(a, &e);                       // a = m * 2^e, m in [0.5, 1): value exponent e-1
+  int ex = e - 1 + 7;
+  float q;
+  if (ex <= 0) { q = std::nearbyint(std::ldexp(a, 9)); ex = 0; if (q >= 8.f) { ex = 1; q = 0.f; } return sgn | (unsigned)(ex << 3) | (unsigned)q; }
+  q = std::nearbyint(std::ldexp(a, 3 - (e - 1))) - 8.f;     // mantissa steps above 1.0 (ties to even under the default mode)
+  if (q >= 8.f) { q = 0.f; ++ex; }
+  if (ex > 15 || (ex == 15 && q > 6.f)) return sgn | 0x7Eu;
+  return sgn | (unsigned)(ex << 3) | (unsigned)q;
+}
+// v_mfma_f32_16x16x32_fp8_fp8: 8 e4m3 bytes of A and of B per lane (k = 8*(l>>4)+j), fp32 accumulate
+inline f32x4 mfma_fp8_16x16x32(const unsigned (&a)[2], const unsigned (&bq)[2], f32x4 c) {
+  BlockState& b = blk();
+  unsigned payload[12] = {a[0], a[1], 0, 0, bq[0], bq[1], 0, 0, 0, 0, 0, 0};
+  float cf[4] = {c[0], c[1], c[2], c[3]};
+  std::memcpy(&payload[8], cf, 16);
+  int slot = wave_arrive(payload, 48, 3);
+  WaveState& w = b.waves[b.cur->wave];
+  const float* r = w.res[slot][b.cur->lane];
+  f32x4 d = {r[0], r[1], r[2], r[3]};
+  return d;
+}
+
 }  // namespace hipsim
 
 // ------------------------------------------------------------------ HIP surface used by the kernels

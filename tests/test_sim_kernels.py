@@ -470,3 +470,39 @@ def test_sample_many_action_sim(aow):
         fr = O.sample_action(ops, bd, bv, q["actions"], q["init_latents"], q["lengths"], steps=2)
         assert np.abs(q["feats_out"] - np.asarray(fr)).max() < 2e-4
     e.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# reduced-precision operand formats (mldhip.h MLDHIP_PREC_BF16 / MLDHIP_PREC_FP8_DENOISER) on the simulator's models of
+# v_mfma_f32_16x16x32_bf16 / _fp8_fp8: the point here is that the kernels' fragment indexing and scaling are right -- the
+# result must be CLOSE to the fp32 oracle (error of the format, not garbage) and NOT equal to it (the mode really ran).
+@pytest.mark.parametrize("prec,fam,lo,hi", [(2, 1, 1e-6, 5e-2), (2, 2, 1e-6, 5e-2), (3, 1, 1e-4, 0.6), (3, 2, 1e-4, 0.6)])
+def test_reduced_precision_loop_kernels_sim(ow, prec, fam, lo, hi):
+    ops, bd, _ = ow
+    e = simlib.sim_engine(max_batch=11, max_frames=8, num_inference_steps=2, precision=prec)
+    e.set_option("loop_kernel", fam)
+    g = syn._rng(21, "strip")
+    R = 22
+    x = g.standard_normal((R, 1, 256)).astype(np.float32)
+    te = g.standard_normal((R, 1, 768)).astype(np.float32)
+    ref = np.asarray(O.denoiser_forward(ops, bd, x, 741, te))
+    out = np.zeros((R, 1, 256), np.float32)
+    e.denoiser_forward(x, 741, te, R, out)
+    err = np.abs(out - ref).max()
+    print("prec", prec, "family", fam, "denoiser max-abs err", err, "ref max", np.abs(ref).max())
+    assert lo < err < hi
+    e.close()
+
+
+def test_bf16_mode_decoder_gemms_sim(ow):
+    ops, _, bv = ow
+    e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2, precision=2)
+    e.set_option("gemm_small_m", 0)
+    z = syn._rng(7, "g8").standard_normal((3, 1, 256)).astype(np.float32)
+    lens = [40, 23, 7]
+    feats = np.zeros((3, 40, 263), np.float32)
+    e.vae_decode(z, lens, feats)
+    err = np.abs(feats - O.vae_decode(ops, bv, z, lens)).max()
+    print("bf16 decoder feats err", err)
+    assert 1e-5 < err < 5e-2
+    e.close()
