@@ -86,8 +86,8 @@ void gemm(Ctx& c, const GemmArgs& a, int nz = 1) {
 
 // 32x64 tiles on 4 waves (27.6 KB of LDS: several workgroups per CU): the loop's FFN2 at M >= 768, where N = 256 gives
 // only M/64 x 2 of the big tiles.  K in {256, 512, 1024}; fp32.
-void gemm_tile_32x64(Ctx& c, const GemmArgs& a, int prec) {
-  const dim3 grid((a.M + 31) / 32, (a.N + 63) / 64, 1);
+void gemm_tile_32x64(Ctx& c, const GemmArgs& a, int prec, int nz = 1) {
+  const dim3 grid((a.M + 31) / 32, (a.N + 63) / 64, nz);
   if (prec == PREC_BF16) launch_staged<2, 2, 1, 2, false, PREC_BF16>(c, a, grid);
   else if (prec == PREC_FP8) launch_staged<2, 2, 1, 2, false, PREC_FP8>(c, a, grid);
   else launch_staged<2, 2, 1, 2, false, PREC_F32>(c, a, grid);

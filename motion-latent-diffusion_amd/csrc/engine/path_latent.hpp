@@ -44,23 +44,31 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
   check_launch(c, "gemm_tile32");
 }
 
-// throughput family: K = 256 (one source) or 512 (skip linear: src[0] | src[1]); src[0] plain, 1-slab combine or attention
+// throughput family: K = 256 (one source) or 512 (skip linear: src[0] | src[1]); src[0] plain, 1- or 2-slab combine, or attention.
+// Wide GEMMs (N a multiple of 128, N >= 512: QKV, FFN1) take 32 x 128 tiles: half as many workgroups repeat one A prologue.
 void strip(Ctx& c, const Tile32Args& a, int nsrc) {
-  const dim3 grid((a.M + 31) / 32, (a.N + 63) / 64, 1);
   const bool attn = a.src[0].attn_R > 0;
   const int ns = attn ? 0 : a.src[0].nsplit;
+  const bool wide = !attn && nsrc == 1 && a.N % 128 == 0 && (c.e->strip_wide == 2 || (c.e->strip_wide == 0 && a.N >= 512));
+  const dim3 grid((a.M + 31) / 32, wide ? a.N / 128 : (a.N + 63) / 64, 1);
   const int prec = loop_prec(c.e);
-#define MLD_STRIP(NS, NSRC, ATTN)                                                                                                  \
+#define MLD_STRIP(NS, NSRC, ATTN, ACT, CT)                                                                                         \
   do {                                                                                                                             \
-    if (prec == PREC_BF16) { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_BF16>), grid, dim3(256), strip_lds_bytes<NSRC>(), c.stream, a); } \
-    else if (prec == PREC_FP8) { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_FP8>), grid, dim3(256), strip_lds_bytes<NSRC>(), c.stream, a); } \
-    else { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN>), grid, dim3(256), strip_lds_bytes<NSRC>(), c.stream, a); }                  \
+    if (prec == PREC_BF16) { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_BF16, ACT, CT>), grid, dim3(256), (strip_lds_bytes<NSRC, CT>()), c.stream, a); } \
+    else if (prec == PREC_FP8) { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_FP8, ACT, CT>), grid, dim3(256), (strip_lds_bytes<NSRC, CT>()), c.stream, a); } \
+    else { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_F32, ACT, CT>), grid, dim3(256), (strip_lds_bytes<NSRC, CT>()), c.stream, a); }       \
   } while (0)
-  if (attn && nsrc == 1) MLD_STRIP(0, 1, true);
-  else if (ns == 0 && nsrc == 1) MLD_STRIP(0, 1, false);
-  else if (ns == 1 && nsrc == 1) MLD_STRIP(1, 1, false);
-  else if (ns == 1 && nsrc == 2) MLD_STRIP(1, 2, false);
+#define MLD_STRIP_W(NS, NSRC, ATTN, ACT) do { if (wide) MLD_STRIP(NS, NSRC, ATTN, ACT, 2); else MLD_STRIP(NS, NSRC, ATTN, ACT, 1); } while (0)
+  if (a.act != 0 && !(a.act == 1 && ns == 1 && nsrc == 1 && !attn)) { c.rc = c.e->fail(MLDHIP_EINVAL, "strip: activation %d is built for the FFN1 shape only", a.act); return; }
+  if (attn && nsrc == 1) MLD_STRIP(0, 1, true, 0, 1);
+  else if (ns == 0 && nsrc == 1) MLD_STRIP_W(0, 1, false, 0);
+  else if (ns == 1 && nsrc == 1 && a.act == 1) MLD_STRIP_W(1, 1, false, 1);
+  else if (ns == 1 && nsrc == 1) MLD_STRIP_W(1, 1, false, 0);
+  else if (ns == 2 && nsrc == 1) MLD_STRIP_W(2, 1, false, 0);
+  else if (ns == 1 && nsrc == 2) MLD_STRIP(1, 2, false, 0, 1);
+  else if (ns == 2 && nsrc == 2) MLD_STRIP(2, 2, false, 0, 1);
   else { c.rc = c.e->fail(MLDHIP_EINVAL, "strip: unsupported source (slabs %d, segments %d)", ns, nsrc); return; }
+#undef MLD_STRIP_W
 #undef MLD_STRIP
   count(c);
   check_launch(c, "gemm_strip");
@@ -99,7 +107,7 @@ DenView den_view(E* e, int R) {
   v.lat = e->lat;
   v.R = R;
   v.strip = use_strip(e, 3 * R);
-  v.ffn_slabs = v.strip ? 1 : e->cfg.ff_size / 256;
+  v.ffn_slabs = v.strip ? e->strip_ffn2_split : e->cfg.ff_size / 256;
   v.skip_slabs = v.strip ? 1 : 2;
   return v;
 }
@@ -134,10 +142,14 @@ void den_ffn1(Ctx& c, const DenView& v, const EncLayerP& L, const float* xn) {
 void den_ffn2(Ctx& c, const DenView& v, const EncLayerP& L) {
   const int F = c.e->cfg.ff_size;
   if (v.strip) {
-    GemmArgs g = lin_args(v.FF, F, F, L.l2_w, nullptr, v.Pf, 256, 3 * v.R, 256);
+    // `ffn_slabs` K slices (blockIdx.z) -> as many raw slabs: with one slice the N = 256 GEMM has M/32 x 4 workgroups, fewer
+    // than CUs at M <= 2 048, each walking all 32 K chunks behind a 4-deep prefetch ring (latency bound: 51 TF measured)
+    const int nz = v.ffn_slabs, Kz = F / nz;
+    GemmArgs g = lin_args(v.FF, F, Kz, L.l2_w, nullptr, v.Pf, 256, 3 * v.R, 256);
+    g.ldw = F; g.sA = Kz; g.sW = Kz; g.sY = den_slab(c.e);
     // fp8: the FFN activations (post-GELU, |x| <~ 10) get a static scale of 16 (saturation at 28); weights per tensor
     g.ascale = 16.f; g.wscale = L.s_l2; g.oscale = 1.0f / (g.ascale * g.wscale);
-    gemm_tile_32x64(c, g, loop_prec(c.e));
+    gemm_tile_32x64(c, g, loop_prec(c.e), nz);
     return;
   }
   Tile32Args a;

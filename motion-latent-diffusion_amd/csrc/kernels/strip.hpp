@@ -18,8 +18,8 @@
 namespace mld {
 
 constexpr int kStripWStride = 36;                        // floats per staged W row: one 32-wide K chunk + 4 pad
-template <int NSRC>
-constexpr int strip_lds_bytes() { return (32 * (256 * NSRC + 4) + 2 * 64 * kStripWStride + 32) * 4; }   // 51 840 / 84 608 B
+template <int NSRC, int CT = 1>
+constexpr int strip_lds_bytes() { return (32 * (256 * NSRC + 4) + 2 * 64 * CT * kStripWStride + 32) * 4; }   // CT=1: 51 840 / 84 608 B; CT=2: 70 272 B
 
 // one 32-wide K chunk for both 16-row tiles of the strip against one 16-column weight tile (operand formats: tile32.hpp)
 template <int PREC>
@@ -55,13 +55,18 @@ __device__ __forceinline__ void strip_chunk(const float* a0, const float* a1, co
   }
 }
 
-// grid = (ceil(M/32), ceil(N/64)); block = 256 (4 waves).  Wave w owns output columns [16w, 16w+16) of the tile, both
-// 16-row tiles.  K = 256 * NSRC: columns [0, 256) come from src[0] (plain rows, combine, or attention), columns
+// grid = (ceil(M/32), ceil(N/(64 CT))); block = 256 (4 waves).  Wave w owns output columns [16w + 64c, 16w + 64c + 16),
+// c < CT, of the tile, both 16-row tiles.  CT = 2 (a 32 x 128 tile, 70 KB of LDS, two workgroups per CU) halves the number of
+// workgroups that repeat the same A prologue and keeps N = 1024 at 1 920 rows within one resident round.  K = 256 * NSRC: columns [0, 256) come from src[0] (plain rows, combine, or attention), columns
 // [256, 512) from src[1] (plain rows; the skip connection's second K segment).
 // NS0 = compile-time slab count of src[0] in combine mode (0: plain rows or attention).
 // PREC = operand format of the MFMAs (rt.hpp); prologue, accumulation and epilogue are fp32 in every mode.
-template <int NS0, int NSRC, bool ATTN, int PREC = PREC_F32>
-__global__ __launch_bounds__(256, ATTN ? 2 : 3) void gemm_strip_kernel(Tile32Args p) {
+// ACT  = epilogue activation of the direct (Y) output, compile time: 0 none, 1 erf-GELU (FFN1).  Besides saving a branch it
+//        gives QKV and FFN1 -- same prologue, same K -- distinct kernel names in a profile.
+template <int NS0, int NSRC, bool ATTN, int PREC = PREC_F32, int ACT = 0, int CT = 1>
+__global__ __launch_bounds__(256, (ATTN || CT == 2 || NS0 >= 2) ? 2 : 3) void gemm_strip_kernel(Tile32Args p) {
+  static_assert(CT == 1 || CT == 2, "one or two 16-column tiles per wave");
+  constexpr int BN = 64 * CT;
   static_assert(NSRC == 1 || NSRC == 2, "one or two 256-wide K segments");
   static_assert(!(ATTN && (NS0 != 0 || NSRC != 1)), "the attention prologue feeds the out-projection only");
   constexpr int K = 256 * NSRC, ST = K + 4, KCS = K / 32, RPW = 8;
@@ -71,34 +76,41 @@ __global__ __launch_bounds__(256, ATTN ? 2 : 3) void gemm_strip_kernel(Tile32Arg
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #endif
   float* As = smem;                          // [32][ST]
-  float* Ws = smem + 32 * ST;                // [2][64][kStripWStride]
-  float* rsc = Ws + 2 * 64 * kStripWStride;  // [32] 1 / (row scale * wscale) (PREC_FP8)
+  float* Ws = smem + 32 * ST;                // [2][BN][kStripWStride]
+  float* rsc = Ws + 2 * BN * kStripWStride;  // [32] 1 / (row scale * wscale) (PREC_FP8)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * BN;
   const ASrc& src = p.src[0];
 
-  // ---- weight ring: thread t stages rows (t>>3) and (t>>3)+32 of the panel, 16 bytes at column 4*(t&7) of the chunk
+  // ---- weight ring: thread t stages rows (t>>3) + 32j, j < 2 CT, of the panel, 16 bytes at column 4*(t&7) of the chunk
   const int wrow = tid >> 3, wc4 = tid & 7;
-  int wn0 = n0 + wrow, wn1 = n0 + wrow + 32;
-  wn0 = wn0 < p.N ? wn0 : p.N - 1;
-  wn1 = wn1 < p.N ? wn1 : p.N - 1;
-  const float* wp0 = p.W + (long long)wn0 * p.ldw + wc4 * 4;
-  const float* wp1 = p.W + (long long)wn1 * p.ldw + wc4 * 4;
-  F4 ring[4][2];
+  const float* wptr[2 * CT];
+#pragma unroll
+  for (int j = 0; j < 2 * CT; ++j) {
+    int n = n0 + wrow + 32 * j;
+    n = n < p.N ? n : p.N - 1;
+    wptr[j] = p.W + (long long)n * p.ldw + wc4 * 4;
+  }
+  F4 ring[4][2 * CT];
   auto gload = [&](int c) {                  // c is a constant after unrolling
-    ring[c & 3][0] = ld4(wp0 + c * 32);
-    ring[c & 3][1] = ld4(wp1 + c * 32);
+#pragma unroll
+    for (int j = 0; j < 2 * CT; ++j) ring[c & 3][j] = ld4(wptr[j] + c * 32);
   };
   auto lstore = [&](int c) {
-    float* dst = Ws + (c & 1) * 64 * kStripWStride;
-    st_operand<PREC>(dst + wrow * kStripWStride, wc4, ring[c & 3][0], p.wscale);        // "lane" = the 16-byte slot within the chunk
-    st_operand<PREC>(dst + (wrow + 32) * kStripWStride, wc4, ring[c & 3][1], p.wscale);
+    float* dst = Ws + (c & 1) * BN * kStripWStride;
+#pragma unroll
+    for (int j = 0; j < 2 * CT; ++j)       // "lane" = the 16-byte slot within the chunk
+      st_operand<PREC>(dst + (wrow + 32 * j) * kStripWStride, wc4, ring[c & 3][j], p.wscale);
   };
 
-  // epilogue bias of this lane's output column, fetched now (clamped, unconditional)
-  const int ecol = n0 + wave * 16 + (lane & 15);
-  float ebias = 0.f;
-  if (p.bias) ebias = p.bias[ecol < p.N ? ecol : p.N - 1];
+  // epilogue bias of this lane's output columns, fetched now (clamped, unconditional)
+  float ebias[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const int ecol = n0 + (wave + 4 * c) * 16 + (lane & 15);
+    ebias[c] = 0.f;
+    if (p.bias) ebias[c] = p.bias[ecol < p.N ? ecol : p.N - 1];
+  }
 
   // ---- A prologue: wave w assembles rows w, w+4, ..., w+28 of the strip; lane l owns columns 4l..4l+3
   int rows[RPW];
@@ -242,13 +254,17 @@ __global__ __launch_bounds__(256, ATTN ? 2 : 3) void gemm_strip_kernel(Tile32Arg
   const int r = lane & 15, g = lane >> 4;
   const float* ap = As + r * ST;
   const float* wp = Ws + (wave * 16 + r) * kStripWStride;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[CT][2];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) acc[c][0] = acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   lstore(0);
   if (4 < KCS) gload(4);
   __syncthreads();
 #pragma unroll
   for (int kc = 0; kc < KCS; ++kc) {
-    strip_chunk<PREC>(ap, ap + 16 * ST, wp + (kc & 1) * 64 * kStripWStride, kc, g, acc0, acc1);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      strip_chunk<PREC>(ap, ap + 16 * ST, wp + ((kc & 1) * BN + 64 * c) * kStripWStride, kc, g, acc[c][0], acc[c][1]);
     if (kc + 1 < KCS) {
       lstore(kc + 1);
       if (kc + 5 < KCS) gload(kc + 5);
@@ -257,26 +273,29 @@ __global__ __launch_bounds__(256, ATTN ? 2 : 3) void gemm_strip_kernel(Tile32Arg
   }
 
   // ---- epilogue: 16 lanes write 64 contiguous bytes per row (raw partial slab, or bias + activation)
-  const int col = n0 + wave * 16 + r;
   if constexpr (PREC == PREC_FP8) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { acc0[i] *= rsc[g * 4 + i]; acc1[i] *= rsc[16 + g * 4 + i]; }
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc[c][0][i] *= rsc[g * 4 + i]; acc[c][1][i] *= rsc[16 + g * 4 + i]; }
   }
-  if (col < p.N) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const f32x4 acc = t == 0 ? acc0 : acc1;
+  for (int c = 0; c < CT; ++c) {
+    const int col = n0 + (wave + 4 * c) * 16 + r;
+    if (col < p.N) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = m0 + t * 16 + g * 4 + i;
-        if (row < p.M) {
-          if (p.P) {
-            p.P[(long long)row * p.N + col] = acc[i];
-          } else {
-            float v = acc[i] + ebias;
-            if (p.act == 1) v = gelu_erf(v);
-            else if (p.act == 2) v = silu(v);
-            p.Y[(long long)row * p.ldy + col] = v;
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = m0 + t * 16 + g * 4 + i;
+          if (row < p.M) {
+            if (p.P) {
+              p.P[(long long)row * p.N + col] = acc[c][t][i];
+            } else {
+              float v = acc[c][t][i] + ebias[c];
+              if constexpr (ACT == 1) v = gelu_erf(v);
+              p.Y[(long long)row * p.ldy + col] = v;
+            }
           }
         }
       }

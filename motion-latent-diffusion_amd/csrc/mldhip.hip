@@ -190,9 +190,13 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4)
 #undef MLD_T32_ATTR
 #undef MLD_T32_ATTR1
-  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<1, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds_bytes<2>());
-  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<1, 2, false, PREC_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds_bytes<2>());
-  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<1, 2, false, PREC_FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, strip_lds_bytes<2>());
+#define MLD_STRIP_ATTR(NS, NSRC, ACT, CT)                                                                                   \
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, NSRC, false, PREC_F32, ACT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<NSRC, CT>())); \
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, NSRC, false, PREC_BF16, ACT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<NSRC, CT>())); \
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, NSRC, false, PREC_FP8, ACT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<NSRC, CT>()));
+  MLD_STRIP_ATTR(1, 2, 0, 1) MLD_STRIP_ATTR(2, 2, 0, 1)
+  MLD_STRIP_ATTR(0, 1, 0, 2) MLD_STRIP_ATTR(1, 1, 0, 2) MLD_STRIP_ATTR(1, 1, 1, 2) MLD_STRIP_ATTR(2, 1, 0, 2)
+#undef MLD_STRIP_ATTR
   (void)hipGetLastError();
 #endif
   *out = e;
@@ -257,6 +261,12 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "strip_min_rows") {
     if (value < 1) return e->fail(MLDHIP_EINVAL, "strip_min_rows must be >= 1");
     e->strip_min_rows = (int)std::min<int64_t>(value, 1 << 30);
+  } else if (n == "strip_wide") {
+    if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "strip_wide must be 0 (auto), 1 (never) or 2 (always)");
+    e->strip_wide = (int)value;
+  } else if (n == "strip_ffn2_split") {
+    if (value != 1 && value != 2) return e->fail(MLDHIP_EINVAL, "strip_ffn2_split must be 1 or 2");
+    e->strip_ffn2_split = (int)value;
   } else if (n == "gemm_small_m") {
     if (value < 0) return e->fail(MLDHIP_EINVAL, "gemm_small_m must be >= 0");
     e->small_m = (int)std::min<int64_t>(value, 1 << 30);

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--out", default="")
+    ap.add_argument("--lengths", default="", help="JSON file with one length per motion (default: all --frames)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -32,6 +33,8 @@ def main():
     bd = O.to_backend(ops, syn.make_denoiser_state_dict())
     bv = O.to_backend(ops, syn.make_vae_state_dict())
     b = syn.make_batch(a.batch, None, seed=a.seed, max_len=a.frames)
+    if a.lengths:                       # same text embeddings / start noise, ragged lengths (bench.py length_mix)
+        b.lengths[:] = [int(x) for x in json.load(open(a.lengths))]
     mean, std = syn.make_mean_std()
     args = (ops.asarray(b.text_emb), ops.asarray(b.init_latents), b.lengths, ops.asarray(mean), ops.asarray(std))
     with torch.no_grad():

@@ -506,3 +506,21 @@ def test_bf16_mode_decoder_gemms_sim(ow):
     print("bf16 decoder feats err", err)
     assert 1e-5 < err < 5e-2
     e.close()
+
+
+@pytest.mark.parametrize("wide,split", [(1, 1), (2, 1), (1, 2)])
+def test_strip_family_tile_and_split_options_sim(ow, wide, split):
+    """The throughput kernels' tile width (32x64 / 32x128) and FFN2 K-split (1 or 2 raw slabs) options vs the oracle."""
+    ops, bd, _ = ow
+    e = simlib.sim_engine(max_batch=11, max_frames=8, num_inference_steps=2)
+    e.set_option("loop_kernel", 2)
+    e.set_option("strip_wide", wide)
+    e.set_option("strip_ffn2_split", split)
+    g = syn._rng(21, "strip")
+    R = 22
+    x = g.standard_normal((R, 1, 256)).astype(np.float32)
+    te = g.standard_normal((R, 1, 768)).astype(np.float32)
+    out = np.zeros((R, 1, 256), np.float32)
+    e.denoiser_forward(x, 741, te, R, out)
+    assert np.abs(out - np.asarray(O.denoiser_forward(ops, bd, x, 741, te))).max() < 5e-5
+    e.close()

@@ -1,27 +1,24 @@
 #!/bin/bash
-# One gpurun call: smoke + GPU parity tests + bench + rocprofv3 kernel stats.  Everything lands in gpurun_out/.
+# One gpurun call: smoke + GPU parity tests + bench (with the rocprofv3 summary its roofline block was computed from) +
+# rocprofv3 kernel stats of the headline workload with 4 steps in flight.  Everything lands in gpurun_out/.
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-TAG=${1:-r01}
+TAG=${1:-r02}
 {
   echo "== nproc: $(nproc)"; lscpu | grep -E "Model name|^CPU\(s\)" ; rocm-smi --showproductname 2>/dev/null | head -8
   echo "== smoke"; timeout 600 python __graft_entry__.py smoke 2>&1 | tail -5
-  echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -25
-  echo "== bench"; timeout 900 python bench.py --steps 20 --warmup 3 2>gpurun_out/bench_${TAG}.err | tee gpurun_out/bench_${TAG}.json
+  echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -12
+  echo "== bench"
+  /usr/bin/time -v -o gpurun_out/bench_${TAG}.time env MLD_BENCH_KEEP_ROCPROF=$PWD/gpurun_out/${TAG}_kernel_stats_bench_child.csv \
+    timeout 900 python bench.py --steps 20 --warmup 3 2>gpurun_out/bench_${TAG}.err | tee gpurun_out/bench_${TAG}.json | cut -c1-3000
+  grep -E "Elapsed|Maximum resident" gpurun_out/bench_${TAG}.time
   tail -5 gpurun_out/bench_${TAG}.err
 } 2>&1 | tee gpurun_out/check_${TAG}.log
-echo "== rocprofv3" | tee -a gpurun_out/check_${TAG}.log
-# Kernel stats of the HEADLINE workload only, one step in flight: the per-kernel averages then correspond to the isolated
-# per-kernel timings bench.py reports in `kernels` / `roofline` (with 4 steps in flight kernels of different batches
-# overlap and each one's wall duration is longer; the secondary workloads reuse the same kernels at other shapes).
-prof() {  # $1 = suffix, rest = bench flags
-  local sfx=$1; shift
-  cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${sfx} -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-a2m --no-novae --no-clip "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_${sfx}.log 2>&1
-  cd $GRAFT_REPO_ROOT
-  find gpurun_out/prof_${TAG}_${sfx} -name "*kernel_trace*.csv" -size +20M -delete
-}
-prof inflight1 --in-flight 1
-prof inflight4 --in-flight 4
-f=$(find gpurun_out/prof_${TAG}_inflight1 -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && head -24 "$f" | tee -a gpurun_out/check_${TAG}.log
-tail -3 gpurun_out/prof_${TAG}_inflight1.log
+echo "== rocprofv3 (4 steps in flight)" | tee -a gpurun_out/check_${TAG}.log
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_inflight4 -o bench -- \
+  python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-alt --no-a2m --no-novae --no-clip --no-rocprof > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_inflight4.log 2>&1
+cd $GRAFT_REPO_ROOT
+find gpurun_out/prof_${TAG}_inflight4 -name "*kernel_trace*.csv" -size +20M -delete
+f=$(find gpurun_out/prof_${TAG}_inflight4 -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_kernel_stats_inflight4.csv
+head -14 gpurun_out/${TAG}_kernel_stats_bench_child.csv | cut -c1-160 | tee -a gpurun_out/check_${TAG}.log
