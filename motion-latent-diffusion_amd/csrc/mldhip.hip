@@ -84,7 +84,9 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
     if (cfg->condition != MLDHIP_COND_TEXT) return bad("diffusion-only variant: text condition only");
     if (cfg->num_layers < 1 || cfg->num_layers > 24) return bad("num_layers must be 1..24");
   } else {
-    if (cfg->latent_dim != 256 || cfg->latent_size != 1) return bad("latent models: latent_dim [1, 256] only");
+    if (cfg->latent_dim != 256 || cfg->latent_size != 1)
+      return bad("mldhip_config.latent_size / latent_dim (model.latent_dim in the YAML): only [1, 256] is built; the reference's [N, 256] ablations "
+                 "(N = 2, 5, 7, 10: N + 2 denoiser tokens, mld_denoiser.py:171,187; 2N global / N memory tokens, mld_vae.py:150-163) are not");
     if (cfg->num_heads * 64 != cfg->latent_dim) return bad("head_dim must be 64");
     if (cfg->num_layers < 3 || cfg->num_layers % 2 == 0 || cfg->num_layers > 17) return bad("num_layers must be odd, 3..17 (SkipTransformer)");
   }

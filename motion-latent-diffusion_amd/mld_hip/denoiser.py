@@ -42,8 +42,13 @@ class HipMldDenoiser(HipModule):
         if novae:
             if list(latent_dim) != [1, 512] or num_heads * 128 != 512:
                 unsupported.append(f"diffusion-only variant: latent_dim={latent_dim}, num_heads={num_heads} (built: [1, 512], 4 heads)")
-        elif list(latent_dim) != [1, 256] or num_heads * 64 != 256 or num_layers % 2 == 0:
-            unsupported.append(f"latent_dim={latent_dim}, num_heads={num_heads}, num_layers={num_layers}")
+        elif list(latent_dim) != [1, 256]:
+            unsupported.append("model.latent_dim = %s: only latent_dim: [1, 256] is built.  The reference's latent_dim: [N, 256] ablations (N = 2, 5, 7, 10) make the "
+                                   "denoiser attend over N + 2 tokens (mld_denoiser.py:171,187) and the VAE use 2N global tokens / N memory tokens "
+                                   "(mld_vae.py:150-163,224-236); the 3-token attention prologue and the 1-key cross-attention shortcut of this engine "
+                                   "do not cover them" % (list(latent_dim),))
+        elif num_heads * 64 != 256 or num_layers % 2 == 0:
+            unsupported.append(f"num_heads={num_heads} (built: 4 heads of 64), num_layers={num_layers} (SkipTransformer needs an odd count)")
         if unsupported:
             raise NotImplementedError("HipMldDenoiser: " + "; ".join(unsupported))
         self.diffusion_only = novae

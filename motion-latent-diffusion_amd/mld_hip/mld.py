@@ -68,9 +68,11 @@ class MLD(nn.Module):
         if hasattr(self.scheduler, "engine_config"):
             shared.update(self.scheduler.engine_config(cfg.model.scheduler.num_inference_timesteps))
         shared["guidance_scale"] = float(self.guidance_scale)
-        for m in (self.denoiser, self.vae, datamodule):
-            if m is not None and hasattr(m, "_shared_arch"):
+        for m in (self.denoiser, self.vae, datamodule, self.scheduler):
+            if m is not None and hasattr(m, "_shared_arch") and engine_key is None:
                 m._shared_arch = shared
+        if hasattr(self.scheduler, "_variant"):
+            self.scheduler._variant = self.variant
         self.sample_mean = False
         self.fact = None
         self.do_classifier_free_guidance = self.guidance_scale > 1.0

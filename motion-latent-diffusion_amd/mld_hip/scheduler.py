@@ -3,8 +3,9 @@
 
 Third-party arithmetic restated from the published algorithm (diffusers is not installed; SURVEY.md App.
 A.3, parity unpinned): float32 tables, scaled_linear betas, steps_offset, set_alpha_to_one=False, eta=0.
-The tables are host logic; ``step`` is four elementwise torch ops on whatever device the sample lives
-(PyTorch-ROCm plumbing for the per-op path).  The fused ``MLD.sample`` never calls ``step``: the same
+The tables are host logic.  ``step`` on device tensors goes through the C ABI (``mldhip_ddim_step`` / ``mldhip_ddpm_step`` of the
+engine of that device, whose tables are checked against this scheduler's fields by the registry); on CPU tensors it is the same
+four elementwise operations in torch (host logic, used by the CPU tests).  The fused ``MLD.sample`` never calls ``step``: the same
 coefficients are computed inside libmldhip and applied by the step-final kernel.
 """
 from __future__ import annotations
@@ -20,6 +21,9 @@ class SchedulerOutput(SimpleNamespace):
 
 
 class HipDDIMScheduler:
+    _variant = "text"        # engine registry variant / architecture fields of the model this scheduler serves (set by MLD)
+    _shared_arch: dict = {}
+
     def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
                  beta_schedule: str = "linear", clip_sample: bool = True, set_alpha_to_one: bool = True,
                  steps_offset: int = 0, prediction_type: str = "epsilon", **kwargs):
@@ -68,6 +72,12 @@ class HipDDIMScheduler:
         sa, sb = float(a_t ** 0.5), float((1 - a_t) ** 0.5)
         pa, pb = float(a_p ** 0.5), float((1 - a_p) ** 0.5)
         x0 = (sample - sb * model_output) / sa
+        if sample.is_cuda and sample.dtype == torch.float32 and model_output.dtype == torch.float32:
+            from . import engine as _engine          # device tensors: the step runs in libmldhip (mldhip_ddim_step)
+            eng = _engine.get_engine(sample.device, self._variant, want=self._shared_arch or self.engine_config(self.num_inference_steps))
+            out = torch.empty_like(sample, memory_format=torch.contiguous_format)
+            eng.ddim_step(model_output.contiguous(), t, sample.contiguous(), out, out.numel(), _engine.current_stream_handle(sample))
+            return SchedulerOutput(prev_sample=out, pred_original_sample=x0)
         return SchedulerOutput(prev_sample=pa * x0 + pb * model_output, pred_original_sample=x0)
 
     def add_noise(self, original_samples, noise, timesteps):
@@ -80,6 +90,9 @@ class HipDDPMScheduler:
     fixed_small, no clipping, epsilon prediction).  Third-party arithmetic restated from the published algorithm
     (PARITY UNPINNED).  ``step`` has no ``eta`` parameter -- the reference probes for it
     (mld.py:318-320) -- and draws its noise from torch's generator unless ``noise=`` is injected."""
+
+    _variant = "novae"
+    _shared_arch: dict = {}
 
     def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
                  beta_schedule: str = "linear", variance_type: str = "fixed_small", clip_sample: bool = True,
@@ -132,10 +145,21 @@ class HipDDPMScheduler:
     def step(self, model_output, timestep, sample, generator=None, noise=None, **kwargs):
         sa, sb, c0, c1, sg = self.coeffs(int(timestep))
         x0 = (sample - sb * model_output) / sa
+        if sg != 0.0 and noise is None:
+            noise = torch.randn(model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
+        if sample.is_cuda and sample.dtype == torch.float32 and model_output.dtype == torch.float32 \
+                and (self.num_inference_steps or self.config.num_train_timesteps) == self.config.num_train_timesteps:
+            from . import _lib, engine as _engine     # device tensors at the shipped setting (1000 steps): mldhip_ddpm_step
+            want = dict(self.engine_config(self.config.num_train_timesteps), vae_arch=_lib.VAE_NONE, denoiser_arch=_lib.ARCH_TRANS_DEC,
+                        scheduler_type=_lib.SCHED_DDPM, latent_dim=512)
+            eng = _engine.get_engine(sample.device, "novae", want=self._shared_arch or want)
+            out = torch.empty_like(sample, memory_format=torch.contiguous_format)
+            nz = noise.contiguous() if noise is not None else torch.zeros_like(out)      # t = 0: sigma is 0, the draw is unused
+            eng.ddpm_step(model_output.contiguous(), int(timestep), sample.contiguous(), nz, out, out.numel(),
+                          stream=_engine.current_stream_handle(sample))
+            return SchedulerOutput(prev_sample=out, pred_original_sample=x0)
         prev = c0 * x0 + c1 * sample
         if sg != 0.0:
-            if noise is None:
-                noise = torch.randn(model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
             prev = prev + sg * noise
         return SchedulerOutput(prev_sample=prev, pred_original_sample=x0)
 

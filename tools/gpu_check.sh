@@ -10,13 +10,14 @@ TAG=${1:-r02}
   echo "== smoke"; timeout 600 python __graft_entry__.py smoke 2>&1 | tail -5
   echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -12
   echo "== bench"
-  /usr/bin/time -v -o gpurun_out/bench_${TAG}.time env MLD_BENCH_KEEP_ROCPROF=$PWD/gpurun_out/${TAG}_kernel_stats_bench_child.csv \
-    timeout 900 python bench.py --steps 20 --warmup 3 2>gpurun_out/bench_${TAG}.err | tee gpurun_out/bench_${TAG}.json | cut -c1-3000
-  grep -E "Elapsed|Maximum resident" gpurun_out/bench_${TAG}.time
+  T0=$SECONDS
+  MLD_BENCH_KEEP_ROCPROF=$PWD/gpurun_out/${TAG}_kernel_stats_bench_child.csv \
+    timeout 600 python bench.py --steps 20 --warmup 3 2>gpurun_out/bench_${TAG}.err | tee gpurun_out/bench_${TAG}.json | cut -c1-3000
+  echo "bench wall seconds: $((SECONDS - T0))"
   tail -5 gpurun_out/bench_${TAG}.err
 } 2>&1 | tee gpurun_out/check_${TAG}.log
 echo "== rocprofv3 (4 steps in flight)" | tee -a gpurun_out/check_${TAG}.log
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_inflight4 -o bench -- \
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_inflight4 -o bench -- \
   python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-alt --no-a2m --no-novae --no-clip --no-rocprof > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_inflight4.log 2>&1
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof_${TAG}_inflight4 -name "*kernel_trace*.csv" -size +20M -delete

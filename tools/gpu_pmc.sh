@@ -6,8 +6,10 @@ set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 TAG=${1:-r02}
-for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
-  cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$C -o pmc -- \
+# (the TCC passes hung once for 900 s each with 8 hardware queues configured: keep the runtime's default of 4 here and a short timeout)
+export GPU_MAX_HW_QUEUES=${PMC_HW_QUEUES:-4}
+for C in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES}; do
+  cd /tmp && timeout ${PMC_TIMEOUT:-180} rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$C -o pmc -- \
     python $GRAFT_REPO_ROOT/bench.py --profile-child --precision ${PMC_PRECISION:-bf16x3_decode} --coalesce ${PMC_COALESCE:-5} > $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$C.log 2>&1
   cd $GRAFT_REPO_ROOT
 done
