@@ -227,7 +227,7 @@ def run_steps(call, n, streams, single=None):
     return time.perf_counter() - t0
 
 
-def bench_a2m(local, dev, warmup, steps, B=256, T=60, nfl=2):
+def bench_a2m(local, dev, warmup, steps, streams, B=256, T=60):
     """BASELINE config 5 shape (config_mld_humanact12.yaml: action condition, 15-layer denoiser, ActorVae decoder, bs=256,
     T=60) in every arithmetic mode incl. the fp8 denoiser GEMMs BASELINE.json names, each with its measured error against
     the reference-generated fixture (tests/golden/action_b256.npz: final latents).  Secondary line, never `value`."""
@@ -240,6 +240,7 @@ def bench_a2m(local, dev, warmup, steps, B=256, T=60, nfl=2):
     _, _, dec6 = algorithmic_gflop(B, T, L=6, NF=150)
     gflop = den15 * STEPS_DDIM + dec6 - (6 - 1) / 2 * 2.0 * B * T * 512 * 256 / 1e9   # ActorVae has no skip linears
     modes = {}
+    nfl = len(streams)          # the caller's streams: their hardware-queue placement is already known to be good (DESIGN.md §3 point 15)
     for prec in ("f32", "bf16x3_decode", "bf16", "fp8_denoiser"):
         eng = _lib.Engine(device=local, max_batch=B, max_frames=T, condition=_lib.COND_ACTION, nclasses=12, vae_arch=_lib.VAE_ACTOR,
                           vae_num_layers=6, num_layers=15, nfeats=150, max_in_flight=nfl, precision=PRECISIONS[prec])
@@ -248,7 +249,6 @@ def bench_a2m(local, dev, warmup, steps, B=256, T=60, nfl=2):
         eng.finalize()
         lat = torch.empty(B, 1, 256, device=dev)
         feats = [torch.empty(B, T, 150, device=dev) for _ in range(nfl)]
-        streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
         eng.sample_action(acts, x0, lens, lat, feats[0])
         torch.cuda.synchronize()
         err = float(np.abs(lat.cpu().numpy() - gold["latents"]).max())
@@ -292,12 +292,13 @@ def bench_text_encoder(dev, n_texts=2 * BATCH, iters=10):
             "backend": "PyTorch-ROCm (not part of libmldhip)"}
 
 
-def bench_novae(local, dev, full, B=64, T=196, nfl=2):
+def bench_novae(local, dev, full, streams, B=64, T=196):
     """BASELINE config 4 shape (config_novae_humanml3d.yaml: raw-motion diffusion, trans_dec denoiser d=512, bs=64, T=196,
     DDPM).  Default: 100 DDPM steps per batch (the same per-step work as the 1000-step sampler; `value` is then the
     EXTRAPOLATED 1000-step rate and says so); --full runs the real 1000 steps.  Per arithmetic mode, `nfl` batches in flight
     (own handle, stream and host thread each: a long call blocks its host thread on the hardware queue depth)."""
     import threading
+    nfl = len(streams)
     steps = 1000 if full else 100
     b = syn.make_batch(B, None, seed=1234, max_len=T)
     text = torch.from_numpy(b.text_emb).to(dev)
@@ -309,7 +310,7 @@ def bench_novae(local, dev, full, B=64, T=196, nfl=2):
                + lin(m, 263, 512) + lin(m, 512, 263)) / 1e9
     modes = {}
     for prec in ("f32", "bf16x3_decode", "bf16"):
-        engs, x0, joints, streams = [], [], [], []
+        engs, x0, joints = [], [], []
         for i in range(nfl):
             eng = _lib.Engine(device=local, max_batch=B, max_frames=T, latent_dim=512, vae_arch=_lib.VAE_NONE, denoiser_arch=_lib.ARCH_TRANS_DEC,
                               scheduler_type=_lib.SCHED_DDPM, num_inference_steps=steps, steps_offset=0, precision=PRECISIONS[prec])
@@ -320,7 +321,6 @@ def bench_novae(local, dev, full, B=64, T=196, nfl=2):
             engs.append(eng)
             x0.append(torch.randn(B, T, 263, device=dev))
             joints.append(torch.empty(B, T, 22, 3, device=dev))
-            streams.append(torch.cuda.Stream(device=dev))
         torch.cuda.synchronize()
 
         def run(seed0):
@@ -666,9 +666,9 @@ def main():
         if world == 1 and not a.eager:
             out["other_workloads"] = []
             if not a.no_a2m:
-                out["other_workloads"].append(bench_a2m(local, dev, 2, max(4, a.steps // 3)))
+                out["other_workloads"].append(bench_a2m(local, dev, 2, max(4, a.steps // 3), streams[:2]))
             if not a.no_novae:
-                out["other_workloads"].append(bench_novae(local, dev, a.full))
+                out["other_workloads"].append(bench_novae(local, dev, a.full, streams[:2]))
         if world == 1 and not a.no_clip:
             try:
                 te = bench_text_encoder(dev)
