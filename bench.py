@@ -352,8 +352,8 @@ def bench_novae(local, dev, full, streams, B=64, T=196):
 
 
 def profile_child(a):
-    """--profile-child: the headline call shape (a.coalesce bs-64 requests per mldhip_sample_many call), one call at a time, a
-    few calls; run under rocprofv3 by rocprof_child_stats() and tools/gpu_pmc.sh."""
+    """--profile-child: the headline call shape (a.coalesce bs-64 requests per mldhip_sample_many call; 1 = a plain mldhip_sample),
+    one call at a time, a few calls; run under rocprofv3 by rocprof_child_stats() and tools/gpu_pmc.sh."""
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     c = max(1, a.coalesce)
@@ -363,8 +363,11 @@ def profile_child(a):
         bt = syn.make_batch(BATCH, None, seed=1234 + 1000 * i, max_len=FRAMES)
         reqs.append(dict(text_emb=torch.from_numpy(bt.text_emb).to(dev), init_latents=torch.from_numpy(bt.init_latents).to(dev), lengths=bt.lengths,
                          joints_out=torch.empty(BATCH, FRAMES, 22, 3, device=dev)))
-    for _ in range(4):
-        eng.sample_many(reqs)
+    for _ in range(max(1, a.steps if a.steps < 20 else 4)):
+        if c == 1:
+            eng.sample(reqs[0]["text_emb"], reqs[0]["init_latents"], reqs[0]["lengths"], None, None, reqs[0]["joints_out"])
+        else:
+            eng.sample_many(reqs)
     torch.cuda.synchronize()
 
 
@@ -416,7 +419,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or "WORLD_SIZE" in os.environ:      # under torchrun the collective path runs at every world size, 1 included
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -541,7 +544,7 @@ def main():
             ms, fl = time_kernel(eng, name, PB, FRAMES, 100 if name.startswith("den") else max(6, 30 // coalesce), stream)
             kern[name] = {"interval_us": round(ms * 1e3, 2), "gflop": round(fl / 1e9, 4), "launches_per_call": cnt}
         # ---- ... and each kernel's duration inside the dependent chain: rocprofv3 dispatch averages of a child run of this call shape
-        stats, where = (None, "disabled") if (a.no_rocprof or world > 1 or a.eager) else rocprof_child_stats(a.precision, coalesce)
+        stats, where = (None, "disabled") if (a.no_rocprof or dist is not None or a.eager) else rocprof_child_stats(a.precision, coalesce)
         for name, (prefix, cnt) in table.items():
             k = kern[name]
             if stats:

@@ -6,11 +6,12 @@ set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 TAG=${1:-r02}
-# (the TCC passes hung once for 900 s each with 8 hardware queues configured: keep the runtime's default of 4 here and a short timeout)
+# (the TCC passes hung -- 900 s and 150 s timeouts -- when the child made FOUR coalesced calls; with ONE call (capture + first replay,
+#  450 launches of every loop kernel) each pass takes seconds.  Keep one call, the runtime's default of 4 hardware queues, a short timeout.)
 export GPU_MAX_HW_QUEUES=${PMC_HW_QUEUES:-4}
 for C in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES}; do
   cd /tmp && timeout ${PMC_TIMEOUT:-180} rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$C -o pmc -- \
-    python $GRAFT_REPO_ROOT/bench.py --profile-child --precision ${PMC_PRECISION:-bf16x3_decode} --coalesce ${PMC_COALESCE:-5} > $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$C.log 2>&1
+    python $GRAFT_REPO_ROOT/bench.py --profile-child --precision ${PMC_PRECISION:-bf16x3_decode} --coalesce ${PMC_COALESCE:-5} --steps ${PMC_CALLS:-1} > $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$C.log 2>&1
   cd $GRAFT_REPO_ROOT
 done
 python - "$TAG" <<'PY'
