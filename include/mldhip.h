@@ -44,8 +44,10 @@ enum {
 enum { MLDHIP_F32 = 0 };   /* dtype codes for mldhip_load_tensor */
 
 enum {                     /* arithmetic mode of the matrix kernels.  In EVERY mode accumulation, bias, residual,
-                              LayerNorm, softmax, the attention kernels, the scheduler step and all stored activations
-                              are fp32; the modes differ in the operand format fed to the MFMAs of the GEMMs. */
+                              LayerNorm, softmax, the 3-token attention of the reverse loop, the scheduler step and all
+                              stored activations are fp32; the modes differ in the operand format fed to the MFMAs of the
+                              GEMMs -- and modes 1..3 also run the frame-level self-attention (VAE decoder / encoder,
+                              diffusion-only denoiser) split-bf16 (QK^T and PV as hi + lo bf16 products, fp32 softmax). */
   MLDHIP_PREC_F32 = 0,            /* exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere: the parity mode */
   MLDHIP_PREC_BF16X3_DECODE = 1,  /* split-bf16 (x = hi + lo; 3 x v_mfma_f32_16x16x32_bf16, ~1e-5 relative per product) in the
                                      MFMA-bound large-M GEMMs: VAE decoder / encoder of the latent models, every GEMM of the

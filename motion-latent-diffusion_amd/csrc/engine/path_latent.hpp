@@ -237,8 +237,20 @@ void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr) {
   E* e = c.e;
   const int H = e->cfg.num_heads;
   const int nkt = pick_nkt(T);
-  const size_t shmem = (size_t)2 * nkt * 16 * 68 * sizeof(float);
   dim3 grid(B * H), block(512);
+  if (staged_prec(e) != PREC_F32) {
+    // the modes that run the decoder GEMMs on bf16 MFMAs run its attention split-bf16 as well (attention.hpp)
+    switch (nkt) {
+      case 4: MLD_LAUNCH((attn_decode_x3_kernel<4>), grid, block, attn_x3_lds_bytes<4>(), c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
+      case 7: MLD_LAUNCH((attn_decode_x3_kernel<7>), grid, block, attn_x3_lds_bytes<7>(), c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
+      case 13: MLD_LAUNCH((attn_decode_x3_kernel<13>), grid, block, attn_x3_lds_bytes<13>(), c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
+      default: MLD_LAUNCH((attn_decode_x3_kernel<18>), grid, block, attn_x3_lds_bytes<18>(), c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
+    }
+    count(c);
+    check_launch(c, "attn_decode_x3");
+    return;
+  }
+  const size_t shmem = (size_t)2 * nkt * 16 * 68 * sizeof(float);
   switch (nkt) {
     case 4: MLD_LAUNCH((attn_decode_kernel<4>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
     case 7: MLD_LAUNCH((attn_decode_kernel<7>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;

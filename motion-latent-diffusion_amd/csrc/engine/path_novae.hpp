@@ -17,9 +17,20 @@ void novae_ln(Ctx& c, const float* x, const float* res, const float* g, const fl
 void novae_self_attention(Ctx& c, int R, int T) {
   E* e = c.e;
   const int H = e->cfg.num_heads, nkt = pick_nkt(T), nqt = (T + 15) / 16;
-  const size_t shmem = (size_t)nkt * 16 * 132 * sizeof(float);
   dim3 grid(R * H, (nqt + 7) / 8), block(512);
   const int* nolens = nullptr;    // the reference passes no key-padding mask to the trans_dec denoiser (mld_denoiser.py:215)
+  if (staged_prec(e) != PREC_F32) {   // GEMMs on bf16 MFMAs: the attention runs split-bf16 too
+    switch (nkt) {
+      case 4: MLD_LAUNCH((attn_seq_x3_kernel<4, 128>), grid, block, (attn_seq_x3_lds_bytes<4, 128>()), c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
+      case 7: MLD_LAUNCH((attn_seq_x3_kernel<7, 128>), grid, block, (attn_seq_x3_lds_bytes<7, 128>()), c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
+      case 13: MLD_LAUNCH((attn_seq_x3_kernel<13, 128>), grid, block, (attn_seq_x3_lds_bytes<13, 128>()), c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
+      default: MLD_LAUNCH((attn_seq_x3_kernel<18, 128>), grid, block, (attn_seq_x3_lds_bytes<18, 128>()), c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
+    }
+    count(c);
+    check_launch(c, "attn_seq_x3");
+    return;
+  }
+  const size_t shmem = (size_t)nkt * 16 * 132 * sizeof(float);
   switch (nkt) {
     case 4: MLD_LAUNCH((attn_seq_kernel<4, 128>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;
     case 7: MLD_LAUNCH((attn_seq_kernel<7, 128>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;

@@ -151,4 +151,183 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* __res
   }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Split-bf16 form of attn_decode_kernel (MLDHIP_PREC_BF16X3_DECODE and the other modes that run the decoder GEMMs on
+// bf16 MFMAs): same one-workgroup-per-(sample, head) structure, same swapped QK^T / P-as-A-operand mapping, but every
+// product runs as x = hi + lo in bf16 on v_mfma_f32_16x16x32_bf16 (3 MFMAs per 32-wide contraction chunk: lo*hi, hi*lo,
+// hi*hi; fp32 accumulate) -- 6 + 6.5 MFMAs of 16 cycles per 16 x 16 score / 16 x 64 output tile pair instead of 16 + 16 fp32
+// ones of 32 cycles.  Softmax, the 1/sqrt(d) scaling and the normalisation stay fp32.
+//   K   in LDS as two bf16 planes [key][64 dims] (row stride 36 words): lane (r, g) reads dims 32c + 8g .. + 7 of key r.
+//   V^T in LDS as two bf16 planes [dim][keys]: the P.V contraction runs over 32 KEYS per MFMA; a lane's 8 k-slots are the
+//        keys it already holds scores for -- 16kt + 4g + {0..3} of the two key tiles (2kb, 2kb + 1) -- so P needs no shuffle,
+//        and the matching V operand is two 8-byte reads of 4 consecutive keys each from the transposed planes.
+constexpr int kAttnX3KStride = 36;   // words per K row: 64 bf16 = 32 words + 4 pad
+template <int NKT>
+constexpr int attn_x3_vt_stride() { return ((NKT + 1) / 2) * 16 + 4; }   // words per V^T row: an even number of key tiles of 16 bf16 (= 8 words) + pad
+template <int NKT>
+constexpr int attn_x3_lds_bytes() { return (2 * NKT * 16 * kAttnX3KStride + 2 * 64 * attn_x3_vt_stride<NKT>()) * 4; }
+
+__device__ __forceinline__ void split_hi_lo_x8(const float (&x)[8], U4& hi, U4& lo) {
+  split_bf16_pair(x[0], x[1], hi.x, lo.x);
+  split_bf16_pair(x[2], x[3], hi.y, lo.y);
+  split_bf16_pair(x[4], x[5], hi.z, lo.z);
+  split_bf16_pair(x[6], x[7], hi.w, lo.w);
+}
+
+template <int NKT, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                             const int* __restrict__ lens, int T, int H) {
+  constexpr int HD = 64, KST = kAttnX3KStride, VST = attn_x3_vt_stride<NKT>(), NKB = (NKT + 1) / 2;
+#if defined(MLDHIP_SIM)
+  unsigned* smem = reinterpret_cast<unsigned*>(hipsim::blk().dyn_smem.data());
+#else
+  extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
+  unsigned* smem = smem_u;
+#endif
+  unsigned* Kh = smem;                       // [NKT*16][KST]
+  unsigned* Kl = Kh + NKT * 16 * KST;
+  unsigned* Vh = Kl + NKT * 16 * KST;        // [64][VST]  (V^T: row = head dim, column = key)
+  unsigned* Vl = Vh + 64 * VST;
+  const int D = H * HD;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int len = lens[b] < T ? lens[b] : T;
+  const int nkt = (len + 15) >> 4, nkb = (nkt + 1) >> 1, nqt = nkt;
+
+  // ---- stage K (row-wise planes) and V (transposed planes); all global loads of an operand before its first LDS store,
+  //      clamped addresses, rows >= len zeroed by a multiply (tile32 / attn_decode_kernel rules)
+  {
+    constexpr int KPI = NW * 4, NIT = (NKB * 32 + KPI - 1) / KPI;
+    const int c4 = tid & 15, k0 = tid >> 4;
+    const float* base = qkv + (long long)b * T * 3 * D + h * HD + c4 * 4;
+    F4 v[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int key = j * KPI + k0;
+      const int kc = key < len ? key : len - 1;
+      v[j] = ld4(base + D + (long long)kc * 3 * D);
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int key = j * KPI + k0;
+      const float m = key < len ? 1.f : 0.f;
+      if (key < nkt * 16) {
+        unsigned h0, l0, h1, l1;
+        split_bf16_pair(v[j].x * m, v[j].y * m, h0, l0);
+        split_bf16_pair(v[j].z * m, v[j].w * m, h1, l1);
+        *reinterpret_cast<U2*>(Kh + key * KST + c4 * 2) = U2{h0, h1};
+        *reinterpret_cast<U2*>(Kl + key * KST + c4 * 2) = U2{l0, l1};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int key = j * KPI + k0;
+      const int kc = key < len ? key : len - 1;
+      v[j] = ld4(base + 2 * D + (long long)kc * 3 * D);
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int key = j * KPI + k0;
+      const float m = key < len ? 1.f : 0.f;
+      if (key < nkb * 32) {                  // keys of the (possibly half-empty) last 32-key block are zero
+        unsigned h0, l0, h1, l1;
+        split_bf16_pair(v[j].x * m, v[j].y * m, h0, l0);
+        split_bf16_pair(v[j].z * m, v[j].w * m, h1, l1);
+        unsigned short* vh = reinterpret_cast<unsigned short*>(Vh) + key;
+        unsigned short* vl = reinterpret_cast<unsigned short*>(Vl) + key;
+        const int d0 = c4 * 4;
+        vh[(d0 + 0) * VST * 2] = (unsigned short)(h0 & 0xFFFFu); vh[(d0 + 1) * VST * 2] = (unsigned short)(h0 >> 16);
+        vh[(d0 + 2) * VST * 2] = (unsigned short)(h1 & 0xFFFFu); vh[(d0 + 3) * VST * 2] = (unsigned short)(h1 >> 16);
+        vl[(d0 + 0) * VST * 2] = (unsigned short)(l0 & 0xFFFFu); vl[(d0 + 1) * VST * 2] = (unsigned short)(l0 >> 16);
+        vl[(d0 + 2) * VST * 2] = (unsigned short)(l1 & 0xFFFFu); vl[(d0 + 3) * VST * 2] = (unsigned short)(l1 >> 16);
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int qt = wave; qt < nqt; qt += NW) {
+    // Q fragments: query q0 + r, dims 32c + 8g .. + 7, pre-scaled by 1/sqrt(64), split hi / lo
+    int qrow = qt * 16 + r;
+    qrow = qrow < T ? qrow : T - 1;
+    const float* qp = qkv + (long long)(b * T + qrow) * 3 * D + h * HD + g * 8;
+    U4 qh[2], ql[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const F4 t0 = ld4(qp + c * 32), t1 = ld4(qp + c * 32 + 4);
+      const float x[8] = {t0.x * 0.125f, t0.y * 0.125f, t0.z * 0.125f, t0.w * 0.125f, t1.x * 0.125f, t1.y * 0.125f, t1.z * 0.125f, t1.w * 0.125f};
+      split_hi_lo_x8(x, qh[c], ql[c]);
+    }
+    f32x4 s[2 * NKB];
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKB; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt < NKT && kt < nkt) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const U4 kh = *reinterpret_cast<const U4*>(Kh + (kt * 16 + r) * KST + c * 16 + g * 4);
+          const U4 kl = *reinterpret_cast<const U4*>(Kl + (kt * 16 + r) * KST + c * 16 + g * 4);
+          s[kt] = mfma_bf16_16x16x32(kl, qh[c], s[kt]);
+          s[kt] = mfma_bf16_16x16x32(kh, ql[c], s[kt]);
+          s[kt] = mfma_bf16_16x16x32(kh, qh[c], s[kt]);
+        }
+      }
+    }
+    // masked softmax down each query column: this lane holds keys kt*16 + g*4 + i
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKB; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool valid = (kt < nkt) && (kt * 16 + g * 4 + i < len);
+        s[kt][i] = valid ? s[kt][i] : -INFINITY;
+        m = fmaxf(m, s[kt][i]);
+      }
+    m = max_groups(m);
+    float den = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKB; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float e = expf(s[kt][i] - m);   // exp(-inf) = 0 for masked keys
+        s[kt][i] = e;
+        den += e;
+      }
+    den = sum_groups(den);
+    const float inv = 1.0f / den;
+    // O = P . V over 32-key blocks: k-slot 8g + j <-> key (2kb + (j >> 2)) * 16 + 4g + (j & 3)
+    f32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb < nkb) {
+        const float pf[8] = {s[2 * kb][0] * inv, s[2 * kb][1] * inv, s[2 * kb][2] * inv, s[2 * kb][3] * inv,
+                             s[2 * kb + 1][0] * inv, s[2 * kb + 1][1] * inv, s[2 * kb + 1][2] * inv, s[2 * kb + 1][3] * inv};
+        U4 ph, pl;
+        split_hi_lo_x8(pf, ph, pl);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const unsigned* vh = Vh + (dt * 16 + r) * VST + kb * 16 + g * 2;     // keys 32kb + 4g .. + 3 (2 words), + 16 keys (8 words) for the second tile
+          const unsigned* vl = Vl + (dt * 16 + r) * VST + kb * 16 + g * 2;
+          const U2 a0 = *reinterpret_cast<const U2*>(vh), a1 = *reinterpret_cast<const U2*>(vh + 8);
+          const U2 b0 = *reinterpret_cast<const U2*>(vl), b1 = *reinterpret_cast<const U2*>(vl + 8);
+          const U4 vhh = U4{a0.x, a0.y, a1.x, a1.y}, vll = U4{b0.x, b0.y, b1.x, b1.y};
+          oacc[dt] = mfma_bf16_16x16x32(pl, vhh, oacc[dt]);
+          oacc[dt] = mfma_bf16_16x16x32(ph, vll, oacc[dt]);
+          oacc[dt] = mfma_bf16_16x16x32(ph, vhh, oacc[dt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = qt * 16 + g * 4 + i;
+        if (q < T) o[(long long)(b * T + q) * D + h * HD + dt * 16 + r] = oacc[dt][i];
+      }
+  }
+}
+
 }  // namespace mld

@@ -218,6 +218,172 @@ __global__ __launch_bounds__(NW * 64) void attn_seq_kernel(const float* __restri
 }
 
 // ----------------------------------------------------------------------------------------------
+// Split-bf16 form of attn_seq_kernel (the arithmetic modes that run this variant's GEMMs on bf16 MFMAs): same two-phase
+// structure -- K, then V, through ONE LDS buffer, a workgroup's NW query tiles keep their scores in registers across the
+// switch -- with the operand layouts of attn_decode_x3_kernel (attention.hpp): K as two bf16 planes [key][HD], V transposed
+// as two bf16 planes [dim][keys] so that a lane's eight k-slots of a 32-key block are the keys it already holds scores for.
+// 3 bf16 MFMAs (lo*hi, hi*lo, hi*hi) per 32-wide contraction chunk, fp32 accumulate; softmax and scaling in fp32.
+template <int NKT, int HD>
+constexpr int attn_seq_x3_lds_bytes() {
+  constexpr int kwords = 2 * NKT * 16 * (HD / 2 + 4), vwords = 2 * HD * (((NKT + 1) / 2) * 16 + 4);
+  return (kwords > vwords ? kwords : vwords) * 4;
+}
+
+template <int NKT, int HD, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void attn_seq_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                          const int* __restrict__ lens, int T, int H) {
+  constexpr int C4 = HD / 4, KST = HD / 2 + 4, NKB = (NKT + 1) / 2, VST = NKB * 16 + 4, NCH = HD / 32;
+#if defined(MLDHIP_SIM)
+  unsigned* KV = reinterpret_cast<unsigned*>(hipsim::blk().dyn_smem.data());
+#else
+  extern __shared__ __attribute__((aligned(16))) unsigned smem_seq[];
+  unsigned* KV = smem_seq;
+#endif
+  unsigned* Kh = KV;                         // phase 1: [NKT*16][KST] x 2 planes
+  unsigned* Kl = KV + NKT * 16 * KST;
+  unsigned* Vh = KV;                         // phase 2: [HD][VST] x 2 planes (V^T)
+  unsigned* Vl = KV + HD * VST;
+  const int D = H * HD;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  int len = T;
+  if (lens) len = lens[b] < T ? lens[b] : T;
+  const int nkt = (len + 15) >> 4, nkb = (nkt + 1) >> 1, nqt = (T + 15) >> 4;
+  const int qt = blockIdx.y * NW + wave;
+  const bool active = qt < nqt;                       // idle waves still take part in the barriers
+  const float scale = rsqrtf((float)HD);
+
+  // operand rows of this (sample, head) -> LDS planes; loads of a half-pass before its stores, clamped, rows >= len zeroed
+  auto stage = [&](bool vphase) {
+    constexpr int KPI = NW * 64 / C4, NIT = (NKB * 32 + KPI - 1) / KPI, UB = (NIT + 1) / 2;
+    const int c4 = tid % C4, k0 = tid / C4;
+    const float* base = qkv + (long long)b * T * 3 * D + (vphase ? 2 * D : D) + h * HD + c4 * 4;
+#pragma unroll
+    for (int j0 = 0; j0 < NIT; j0 += UB) {
+      F4 v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int key = (j0 + u) * KPI + k0;
+        const int kc = key < len ? key : len - 1;
+        v[u] = ld4(base + (long long)kc * 3 * D);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int key = (j0 + u) * KPI + k0;
+        const float m = key < len ? 1.f : 0.f;
+        if (j0 + u < NIT) {
+          unsigned h0, l0, h1, l1;
+          split_bf16_pair(v[u].x * m, v[u].y * m, h0, l0);
+          split_bf16_pair(v[u].z * m, v[u].w * m, h1, l1);
+          if (!vphase) {
+            if (key < nkt * 16) {
+              *reinterpret_cast<U2*>(Kh + key * KST + c4 * 2) = U2{h0, h1};
+              *reinterpret_cast<U2*>(Kl + key * KST + c4 * 2) = U2{l0, l1};
+            }
+          } else if (key < nkb * 32) {
+            unsigned short* vh = reinterpret_cast<unsigned short*>(Vh) + key;
+            unsigned short* vl = reinterpret_cast<unsigned short*>(Vl) + key;
+            const int d0 = c4 * 4;
+            vh[(d0 + 0) * VST * 2] = (unsigned short)(h0 & 0xFFFFu); vh[(d0 + 1) * VST * 2] = (unsigned short)(h0 >> 16);
+            vh[(d0 + 2) * VST * 2] = (unsigned short)(h1 & 0xFFFFu); vh[(d0 + 3) * VST * 2] = (unsigned short)(h1 >> 16);
+            vl[(d0 + 0) * VST * 2] = (unsigned short)(l0 & 0xFFFFu); vl[(d0 + 1) * VST * 2] = (unsigned short)(l0 >> 16);
+            vl[(d0 + 2) * VST * 2] = (unsigned short)(l1 & 0xFFFFu); vl[(d0 + 3) * VST * 2] = (unsigned short)(l1 >> 16);
+          }
+        }
+      }
+    }
+  };
+
+  stage(false);
+  __syncthreads();
+  f32x4 s[2 * NKB];
+#pragma unroll
+  for (int kt = 0; kt < 2 * NKB; ++kt) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float inv = 0.f;
+  if (active) {
+    int qrow = qt * 16 + r;
+    qrow = qrow < T ? qrow : T - 1;
+    const float* qp = qkv + (long long)(b * T + qrow) * 3 * D + h * HD + g * 8;
+    U4 qh[NCH], ql[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const F4 t0 = ld4(qp + c * 32), t1 = ld4(qp + c * 32 + 4);
+      const float x[8] = {t0.x * scale, t0.y * scale, t0.z * scale, t0.w * scale, t1.x * scale, t1.y * scale, t1.z * scale, t1.w * scale};
+      split_hi_lo_x8(x, qh[c], ql[c]);
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < nkt) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const U4 kh = *reinterpret_cast<const U4*>(Kh + (kt * 16 + r) * KST + c * 16 + g * 4);
+          const U4 kl = *reinterpret_cast<const U4*>(Kl + (kt * 16 + r) * KST + c * 16 + g * 4);
+          s[kt] = mfma_bf16_16x16x32(kl, qh[c], s[kt]);
+          s[kt] = mfma_bf16_16x16x32(kh, ql[c], s[kt]);
+          s[kt] = mfma_bf16_16x16x32(kh, qh[c], s[kt]);
+        }
+      }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKB; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool valid = (kt < nkt) && (kt * 16 + g * 4 + i < len);
+        s[kt][i] = valid ? s[kt][i] : -INFINITY;
+        m = fmaxf(m, s[kt][i]);
+      }
+    m = max_groups(m);
+    float den = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKB; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float e = expf(s[kt][i] - m);
+        s[kt][i] = e;
+        den += e;
+      }
+    den = sum_groups(den);
+    inv = 1.0f / den;
+  }
+  __syncthreads();                                    // every wave is done reading K
+  stage(true);
+  __syncthreads();
+  if (!active) return;
+  f32x4 oacc[HD / 16];
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    if (kb < nkb) {
+      const float pf[8] = {s[2 * kb][0] * inv, s[2 * kb][1] * inv, s[2 * kb][2] * inv, s[2 * kb][3] * inv,
+                           s[2 * kb + 1][0] * inv, s[2 * kb + 1][1] * inv, s[2 * kb + 1][2] * inv, s[2 * kb + 1][3] * inv};
+      U4 ph, pl;
+      split_hi_lo_x8(pf, ph, pl);
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        const unsigned* vh = Vh + (dt * 16 + r) * VST + kb * 16 + g * 2;
+        const unsigned* vl = Vl + (dt * 16 + r) * VST + kb * 16 + g * 2;
+        const U2 a0 = *reinterpret_cast<const U2*>(vh), a1 = *reinterpret_cast<const U2*>(vh + 8);
+        const U2 b0 = *reinterpret_cast<const U2*>(vl), b1 = *reinterpret_cast<const U2*>(vl + 8);
+        const U4 vhh = U4{a0.x, a0.y, a1.x, a1.y}, vll = U4{b0.x, b0.y, b1.x, b1.y};
+        oacc[dt] = mfma_bf16_16x16x32(pl, vhh, oacc[dt]);
+        oacc[dt] = mfma_bf16_16x16x32(ph, vll, oacc[dt]);
+        oacc[dt] = mfma_bf16_16x16x32(ph, vhh, oacc[dt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = qt * 16 + g * 4 + i;
+      if (q < T) o[(long long)(b * T + q) * D + h * HD + dt * 16 + r] = oacc[dt][i];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // Cross-attention of the trans_dec denoiser: every frame row attends to the TWO memory tokens [time, text]
 // (mld_denoiser.py:170-172,214-215; cross_attention.py:336-339).  K/V of the time token are the same for all rows of
 // a step (kv_time[2*D]: k then v), those of the text token are per sample (kv_text[sample][2*D]).

@@ -178,11 +178,17 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<18>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   (void)hipFuncSetAttribute((const void*)attn_decode_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  (void)hipFuncSetAttribute((const void*)attn_decode_x3_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_x3_lds_bytes<7>());
+  (void)hipFuncSetAttribute((const void*)attn_decode_x3_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_x3_lds_bytes<13>());
+  (void)hipFuncSetAttribute((const void*)attn_decode_x3_kernel<18>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_x3_lds_bytes<18>());
   const int big128 = 18 * 16 * 132 * 4;   // attn_seq_kernel<*,128>: one operand (K, then V) of up to 288 keys x 132 floats = 148.5 KiB
   (void)hipFuncSetAttribute((const void*)attn_seq_kernel<4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, big128);
   (void)hipFuncSetAttribute((const void*)attn_seq_kernel<7, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, big128);
   (void)hipFuncSetAttribute((const void*)attn_seq_kernel<13, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, big128);
   (void)hipFuncSetAttribute((const void*)attn_seq_kernel<18, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, big128);
+  (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<7, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<7, 128>()));
+  (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<13, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<13, 128>()));
+  (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<18, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<18, 128>()));
 #define MLD_T32_ATTR1(MT, NS, ...) \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<MT, NS, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
 #define MLD_T32_ATTR(NS)                                                                                                    \

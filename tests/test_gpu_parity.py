@@ -805,3 +805,39 @@ def test_ragged_bs64_uniform_length_mix_vs_oracle(eng, dev):
     assert ef < 1e-3 and ej < 1e-3
     for i, n in enumerate(lens):
         assert np.all(f[i, n:] == 0)
+
+
+def test_reduced_precision_modes_run_and_stay_sane(dev, golden_dir):
+    """MLDHIP_PREC_BF16 / MLDHIP_PREC_FP8_DENOISER are REPORTED modes (bench.py prints their error): here only that they run on
+    the hardware MFMA forms, produce finite motions of the right shape, and sit where the formats put them -- bf16 within a
+    few percent of the reference latents (|x| ~ 80), fp8 far off but finite; and that the split-bf16 mode of the
+    diffusion-only variant stays within 5e-3 of the reference on the 10-step fixture (|x| ~ 67; fp32: 2e-4)."""
+    g = _gold(golden_dir, "pipeline_b64.npz")
+    b = syn.make_batch(64)
+    errs = {}
+    for prec in (2, 3):
+        e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=prec)
+        _load(e)
+        lat, _, joints, _ = _run_sample(e, dev, b)
+        assert torch.isfinite(joints).all() and torch.isfinite(lat).all()
+        errs[prec] = float(np.abs(lat.cpu().numpy() - g["latents"]).max())
+        e.close()
+    print("latent error vs reference: bf16 %.3f, fp8 denoiser %.3f (|x| ~ 80)" % (errs[2], errs[3]))
+    assert 1e-3 < errs[2] < 5.0 and errs[2] < errs[3]
+    gn = _gold(golden_dir, "novae_pipeline_b3.npz")
+    lens = [int(x) for x in gn["lengths"]]
+    e = _lib.Engine(device=0, max_batch=3, max_frames=40, latent_dim=512, vae_arch=_lib.VAE_NONE, denoiser_arch=_lib.ARCH_TRANS_DEC,
+                    scheduler_type=_lib.SCHED_DDPM, num_inference_steps=10, steps_offset=0, precision=1)
+    e.load_state_dict(syn.make_novae_denoiser_state_dict(), "denoiser.")
+    mean, std = syn.make_mean_std()
+    e.load_tensor("mean", mean)
+    e.load_tensor("std", std)
+    e.finalize()
+    e.set_option("gemm_small_m", 0)                     # 240 rows: drive the staged (precision-aware) GEMMs as at full size
+    feats = torch.empty(3, 40, 263, device=dev)
+    e.sample_novae(_cuda(gn["text_emb"], dev), _cuda(gn["init_latents"], dev), lens, _cuda(gn["step_noise"], dev), 0, feats, None)
+    torch.cuda.synchronize()
+    ef = max(np.abs(feats.cpu().numpy()[i, :n] - gn["feats"][i, :n]).max() for i, n in enumerate(lens))
+    print("diffusion-only, split-bf16 GEMMs, 10 steps: feats err %.3e" % ef)
+    assert 2e-5 < ef < 5e-3
+    e.close()

@@ -524,3 +524,39 @@ def test_strip_family_tile_and_split_options_sim(ow, wide, split):
     e.denoiser_forward(x, 741, te, R, out)
     assert np.abs(out - np.asarray(O.denoiser_forward(ops, bd, x, 741, te))).max() < 5e-5
     e.close()
+
+
+def test_split_bf16_attention_odd_key_tiles_sim(ow):
+    """attn_decode_x3_kernel with an ODD number of key tiles (T = 100 -> 7 tiles: the last 32-key block of P.V is half empty)
+    and ragged lengths, inside the split-bf16 decoder: features within 2e-4 of the fp32 oracle."""
+    ops, _, bv = ow
+    e = simlib.sim_engine(max_batch=2, max_frames=100, num_inference_steps=2, precision=1)
+    e.set_option("gemm_small_m", 0)
+    z = syn._rng(8, "x3attn").standard_normal((2, 1, 256)).astype(np.float32)
+    lens = [100, 37]
+    feats = np.zeros((2, 100, 263), np.float32)
+    e.vae_decode(z, lens, feats)
+    err = np.abs(feats - O.vae_decode(ops, bv, z, lens)).max()
+    print("x3 decoder (7 key tiles) feats err", err)
+    assert 1e-7 < err < 2e-4
+    assert np.all(feats[1, 37:] == 0)
+    e.close()
+
+
+def test_novae_split_bf16_gemms_and_attention_sim(now):
+    """Diffusion-only denoiser with precision = BF16X3_DECODE: every staged GEMM split-bf16 and attn_seq_x3_kernel (head dim 128,
+    K then V^T planes through one LDS buffer; T = 37 -> 3 key tiles, an odd count) -- within 3e-4 of the fp32 oracle, not equal."""
+    ops, bd = now
+    e = simlib.sim_novae_engine(num_layers=2, max_batch=2, max_frames=40, num_inference_steps=4, precision=1)
+    e.set_option("gemm_small_m", 0)
+    g = syn._rng(12, "nvx3")
+    R, T = 2, 37
+    x = g.standard_normal((R, T, 263)).astype(np.float32)
+    te = g.standard_normal((R, 1, 768)).astype(np.float32)
+    lens = [37, 20]
+    out = np.zeros((R, T, 263), np.float32)
+    e.denoiser_forward_novae(x, 999, te, lens, T, out)
+    err = np.abs(out - O.denoiser_forward_novae(ops, bd, x, 999, te, lens)).max()
+    print("novae x3 denoiser err", err)
+    assert 1e-7 < err < 3e-4
+    e.close()
