@@ -73,7 +73,7 @@ KERNEL_LATENCY = {
     "den_ffn1": ("void mld::gemm_tile32_kernel<32, 1, false", 9 * STEPS_DDIM),
     "den_ffn2": ("void mld::gemm_tile32_kernel<32, 0, false", 9 * STEPS_DDIM),
     "den_final": ("mld::den_final_step_kernel", STEPS_DDIM)}
-KERNEL_THROUGHPUT = {   # strip.hpp template arguments: <slabs of src0, K segments, attention, PREC, ACT, column tiles per wave>
+KERNEL_THROUGHPUT = {   # strip.hpp template arguments: <slabs of src0, K segments, attention, PREC, ACT, column tiles per wave, waves>
     "den_qkv": ("void mld::gemm_strip_kernel<2, 1, false, 0, 0,", 9 * STEPS_DDIM),       # (<1,1,..> after a skip linear, <0,1,..> layer 0)
     "den_outproj": ("void mld::gemm_strip_kernel<0, 1, true, 0, 0,", 9 * STEPS_DDIM),
     "den_ffn1": ("void mld::gemm_strip_kernel<1, 1, false, 0, 1,", 9 * STEPS_DDIM),

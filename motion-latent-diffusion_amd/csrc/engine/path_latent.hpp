@@ -52,21 +52,28 @@ void strip(Ctx& c, const Tile32Args& a, int nsrc) {
   const bool wide = !attn && nsrc == 1 && a.N % 128 == 0 && (c.e->strip_wide == 2 || (c.e->strip_wide == 0 && a.N >= 512));
   const dim3 grid((a.M + 31) / 32, wide ? a.N / 128 : (a.N + 63) / 64, 1);
   const int prec = loop_prec(c.e);
-#define MLD_STRIP(NS, NSRC, ATTN, ACT, CT)                                                                                         \
+#define MLD_STRIP(NS, NSRC, ATTN, ACT, CT, NW)                                                                                     \
   do {                                                                                                                             \
-    if (prec == PREC_BF16) { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_BF16, ACT, CT>), grid, dim3(256), (strip_lds_bytes<NSRC, CT>()), c.stream, a); } \
-    else if (prec == PREC_FP8) { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_FP8, ACT, CT>), grid, dim3(256), (strip_lds_bytes<NSRC, CT>()), c.stream, a); } \
-    else { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_F32, ACT, CT>), grid, dim3(256), (strip_lds_bytes<NSRC, CT>()), c.stream, a); }       \
+    if (prec == PREC_BF16) { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_BF16, ACT, CT, NW>), grid, dim3(64 * NW), (strip_lds_bytes<NSRC, CT>()), c.stream, a); } \
+    else if (prec == PREC_FP8) { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_FP8, ACT, CT, NW>), grid, dim3(64 * NW), (strip_lds_bytes<NSRC, CT>()), c.stream, a); } \
+    else { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_F32, ACT, CT, NW>), grid, dim3(64 * NW), (strip_lds_bytes<NSRC, CT>()), c.stream, a); }       \
   } while (0)
-#define MLD_STRIP_W(NS, NSRC, ATTN, ACT) do { if (wide) MLD_STRIP(NS, NSRC, ATTN, ACT, 2); else MLD_STRIP(NS, NSRC, ATTN, ACT, 1); } while (0)
+  // 8 waves per workgroup (one 16-row tile per wave) unless "strip_waves" says 4
+#define MLD_STRIP_W(NS, NSRC, ATTN, ACT)                                            \
+  do {                                                                              \
+    if (wide && c.e->strip_waves == 8) MLD_STRIP(NS, NSRC, ATTN, ACT, 2, 8);        \
+    else if (wide) MLD_STRIP(NS, NSRC, ATTN, ACT, 2, 4);                            \
+    else if (c.e->strip_waves == 8) MLD_STRIP(NS, NSRC, ATTN, ACT, 1, 8);           \
+    else MLD_STRIP(NS, NSRC, ATTN, ACT, 1, 4);                                      \
+  } while (0)
   if (a.act != 0 && !(a.act == 1 && ns == 1 && nsrc == 1 && !attn)) { c.rc = c.e->fail(MLDHIP_EINVAL, "strip: activation %d is built for the FFN1 shape only", a.act); return; }
-  if (attn && nsrc == 1) MLD_STRIP(0, 1, true, 0, 1);
+  if (attn && nsrc == 1) { if (c.e->strip_waves == 8) MLD_STRIP(0, 1, true, 0, 1, 8); else MLD_STRIP(0, 1, true, 0, 1, 4); }
   else if (ns == 0 && nsrc == 1) MLD_STRIP_W(0, 1, false, 0);
   else if (ns == 1 && nsrc == 1 && a.act == 1) MLD_STRIP_W(1, 1, false, 1);
   else if (ns == 1 && nsrc == 1) MLD_STRIP_W(1, 1, false, 0);
   else if (ns == 2 && nsrc == 1) MLD_STRIP_W(2, 1, false, 0);
-  else if (ns == 1 && nsrc == 2) MLD_STRIP(1, 2, false, 0, 1);
-  else if (ns == 2 && nsrc == 2) MLD_STRIP(2, 2, false, 0, 1);
+  else if (ns == 1 && nsrc == 2) { if (c.e->strip_waves == 8) MLD_STRIP(1, 2, false, 0, 1, 8); else MLD_STRIP(1, 2, false, 0, 1, 4); }
+  else if (ns == 2 && nsrc == 2) { if (c.e->strip_waves == 8) MLD_STRIP(2, 2, false, 0, 1, 8); else MLD_STRIP(2, 2, false, 0, 1, 4); }
   else { c.rc = c.e->fail(MLDHIP_EINVAL, "strip: unsupported source (slabs %d, segments %d)", ns, nsrc); return; }
 #undef MLD_STRIP_W
 #undef MLD_STRIP

@@ -106,6 +106,7 @@ struct mldhip_engine {
   int loop_kernel = 0;       // "loop_kernel": 0 auto (by rows), 1 latency kernels (tile32.hpp), 2 throughput kernels (strip.hpp)
   int strip_min_rows = 768;  // "strip_min_rows": auto switches to the throughput kernels at 6B >= this many token rows
   int strip_wide = 0;        // "strip_wide": 32 x 128 strip tiles for the wide GEMMs: 0 auto (N >= 512), 1 never, 2 whenever N % 128 == 0
+  int strip_waves = 8;       // "strip_waves": waves per workgroup of the 32 x 128 strip tiles: 4 (two row tiles per wave) or 8 (one)
   int strip_ffn2_split = 2;  // "strip_ffn2_split": K slices (= raw slabs) of FFN2 on the throughput kernels: 1 or 2
 
   int launches[3] = {0, 0, 0};

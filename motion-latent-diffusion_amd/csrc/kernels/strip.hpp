@@ -7,8 +7,10 @@
 // Why a second kernel next to tile32.hpp: tile32 parks A AND W whole in LDS (99.8 KB -> one 8-wave workgroup per CU,
 // every load issued before the first MFMA): right when one launch has <= 192 workgroups and the only goal is a short
 // dependent chain (M = 384), but at M = 1 536 its 576-768 workgroups run in three serial rounds with no overlap of one
-// round's loads and another's MFMAs (measured r01: 24 TF on FFN1).  Here a workgroup is 4 waves with <= 52 KB of LDS
-// and <= 168 VGPRs, so three are resident per CU and their load / MFMA / store phases overlap each other.
+// round's loads and another's MFMAs (measured r01: 24 TF on FFN1).  Here a workgroup holds 52-70 KB of LDS and <= 128
+// VGPRs per lane, so two or three are resident per CU; with 8 waves each (one 16-row tile per wave: +4.5 % end to end over
+// 4 waves with two tiles each, profiles/r02_strip_options_ab.json) every SIMD has four waves to hide LDS and global latency.
+// (A 64 x 64 / 8-wave tile for FFN2 instead of 32 x 64 / 4 waves: 14.4 -> 13.5 us alone, nothing end to end; not kept.)
 //
 // Row layout and the meaning of every ASrc / Tile32Args field are those of tile32.hpp (token-major rows, 256 floats).
 // Replaces the same reference code: cross_attention.py:259-272 (encoder layer), :56-58 (skip linear).
@@ -21,55 +23,77 @@ constexpr int kStripWStride = 36;                        // floats per staged W 
 template <int NSRC, int CT = 1>
 constexpr int strip_lds_bytes() { return (32 * (256 * NSRC + 4) + 2 * 64 * CT * kStripWStride + 32) * 4; }   // CT=1: 51 840 / 84 608 B; CT=2: 70 272 B
 
-// one 32-wide K chunk for both 16-row tiles of the strip against one 16-column weight tile (operand formats: tile32.hpp)
-template <int PREC>
-__device__ __forceinline__ void strip_chunk(const float* a0, const float* a1, const float* w, int kc, int g, f32x4& acc0, f32x4& acc1) {
+// one 32-wide K chunk: RT 16-row tiles of the A strip against CT 16-column weight tiles (operand formats: tile32.hpp).
+// All fragments are read first, then the MFMAs run interleaved over the RT x CT independent accumulators, so consecutive
+// matrix instructions never depend on each other.  `a` = row r of the first row tile (next tile 16 * ast words on),
+// `w` = row r of the first column tile of the current LDS buffer (next tile 64 * wst words on).
+template <int PREC, int RT, int CT>
+__device__ __forceinline__ void strip_mma(const float* a, int ast, const float* w, int wst, int kc, int g, f32x4 (&acc)[CT][RT]) {
   if constexpr (PREC == PREC_F32) {
-    const F4 b0 = ld4(w + g * 8), b1 = ld4(w + g * 8 + 4);
-    const F4 x0 = ld4(a0 + kc * 32 + g * 8), x1 = ld4(a0 + kc * 32 + g * 8 + 4);
-    const F4 y0 = ld4(a1 + kc * 32 + g * 8), y1 = ld4(a1 + kc * 32 + g * 8 + 4);
-    acc0 = mfma_f32_16x16x4(x0.x, b0.x, acc0);
-    acc1 = mfma_f32_16x16x4(y0.x, b0.x, acc1);
-    acc0 = mfma_f32_16x16x4(x0.y, b0.y, acc0);
-    acc1 = mfma_f32_16x16x4(y0.y, b0.y, acc1);
-    acc0 = mfma_f32_16x16x4(x0.z, b0.z, acc0);
-    acc1 = mfma_f32_16x16x4(y0.z, b0.z, acc1);
-    acc0 = mfma_f32_16x16x4(x0.w, b0.w, acc0);
-    acc1 = mfma_f32_16x16x4(y0.w, b0.w, acc1);
-    acc0 = mfma_f32_16x16x4(x1.x, b1.x, acc0);
-    acc1 = mfma_f32_16x16x4(y1.x, b1.x, acc1);
-    acc0 = mfma_f32_16x16x4(x1.y, b1.y, acc0);
-    acc1 = mfma_f32_16x16x4(y1.y, b1.y, acc1);
-    acc0 = mfma_f32_16x16x4(x1.z, b1.z, acc0);
-    acc1 = mfma_f32_16x16x4(y1.z, b1.z, acc1);
-    acc0 = mfma_f32_16x16x4(x1.w, b1.w, acc0);
-    acc1 = mfma_f32_16x16x4(y1.w, b1.w, acc1);
+    F4 x[RT][2], y[CT][2];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) { x[t][0] = ld4(a + t * 16 * ast + kc * 32 + g * 8); x[t][1] = ld4(a + t * 16 * ast + kc * 32 + g * 8 + 4); }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { y[c][0] = ld4(w + c * 64 * wst + g * 8); y[c][1] = ld4(w + c * 64 * wst + g * 8 + 4); }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[c][t] = mfma_f32_16x16x4(x[t][h].x, y[c][h].x, acc[c][t]);
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[c][t] = mfma_f32_16x16x4(x[t][h].y, y[c][h].y, acc[c][t]);
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[c][t] = mfma_f32_16x16x4(x[t][h].z, y[c][h].z, acc[c][t]);
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[c][t] = mfma_f32_16x16x4(x[t][h].w, y[c][h].w, acc[c][t]);
+    }
   } else if constexpr (PREC == PREC_BF16) {
-    const U4 b = reinterpret_cast<const U4*>(w)[g];
-    acc0 = mfma_bf16_16x16x32(reinterpret_cast<const U4*>(a0)[kc * 4 + g], b, acc0);
-    acc1 = mfma_bf16_16x16x32(reinterpret_cast<const U4*>(a1)[kc * 4 + g], b, acc1);
+    U4 x[RT], y[CT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) x[t] = reinterpret_cast<const U4*>(a + t * 16 * ast)[kc * 4 + g];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) y[c] = reinterpret_cast<const U4*>(w + c * 64 * wst)[g];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[c][t] = mfma_bf16_16x16x32(x[t], y[c], acc[c][t]);
   } else {
-    const U2 b = reinterpret_cast<const U2*>(w)[g];
-    acc0 = mfma_fp8_16x16x32(reinterpret_cast<const U2*>(a0)[kc * 4 + g], b, acc0);
-    acc1 = mfma_fp8_16x16x32(reinterpret_cast<const U2*>(a1)[kc * 4 + g], b, acc1);
+    U2 x[RT], y[CT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) x[t] = reinterpret_cast<const U2*>(a + t * 16 * ast)[kc * 4 + g];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) y[c] = reinterpret_cast<const U2*>(w + c * 64 * wst)[g];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[c][t] = mfma_fp8_16x16x32(x[t], y[c], acc[c][t]);
   }
 }
 
-// grid = (ceil(M/32), ceil(N/(64 CT))); block = 256 (4 waves).  Wave w owns output columns [16w + 64c, 16w + 64c + 16),
-// c < CT, of the tile, both 16-row tiles.  CT = 2 (a 32 x 128 tile, 70 KB of LDS, two workgroups per CU) halves the number of
+// grid = (ceil(M/32), ceil(N/(64 CT))); block = 64 NW.  NW = 4: wave w owns output columns [16w + 64c, 16w + 64c + 16), c < CT,
+// of the tile, both 16-row tiles.  NW = 8: the same columns for waves w and w + 4, which take one 16-row tile each -- half the
+// dependent MFMA chain and half the prologue rows per wave, four waves per SIMD with two workgroups per CU.  CT = 2 (a 32 x 128 tile, 70 KB of LDS, two workgroups per CU) halves the number of
 // workgroups that repeat the same A prologue and keeps N = 1024 at 1 920 rows within one resident round.  K = 256 * NSRC: columns [0, 256) come from src[0] (plain rows, combine, or attention), columns
 // [256, 512) from src[1] (plain rows; the skip connection's second K segment).
 // NS0 = compile-time slab count of src[0] in combine mode (0: plain rows or attention).
 // PREC = operand format of the MFMAs (rt.hpp); prologue, accumulation and epilogue are fp32 in every mode.
 // ACT  = epilogue activation of the direct (Y) output, compile time: 0 none, 1 erf-GELU (FFN1).  Besides saving a branch it
 //        gives QKV and FFN1 -- same prologue, same K -- distinct kernel names in a profile.
-template <int NS0, int NSRC, bool ATTN, int PREC = PREC_F32, int ACT = 0, int CT = 1>
-__global__ __launch_bounds__(256, (ATTN || CT == 2 || NS0 >= 2) ? 2 : 3) void gemm_strip_kernel(Tile32Args p) {
+template <int NS0, int NSRC, bool ATTN, int PREC = PREC_F32, int ACT = 0, int CT = 1, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : (ATTN || CT == 2 || NS0 >= 2) ? 2 : 3) void gemm_strip_kernel(Tile32Args p) {
   static_assert(CT == 1 || CT == 2, "one or two 16-column tiles per wave");
-  constexpr int BN = 64 * CT;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  constexpr int BN = 64 * CT, RT = NW == 8 ? 1 : 2, WJ = BN / (NW * 8);
   static_assert(NSRC == 1 || NSRC == 2, "one or two 256-wide K segments");
   static_assert(!(ATTN && (NS0 != 0 || NSRC != 1)), "the attention prologue feeds the out-projection only");
-  constexpr int K = 256 * NSRC, ST = K + 4, KCS = K / 32, RPW = 8;
+  constexpr int K = 256 * NSRC, ST = K + 4, KCS = K / 32, RPW = 32 / NW;
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
 #else
@@ -82,42 +106,42 @@ __global__ __launch_bounds__(256, (ATTN || CT == 2 || NS0 >= 2) ? 2 : 3) void ge
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * BN;
   const ASrc& src = p.src[0];
 
-  // ---- weight ring: thread t stages rows (t>>3) + 32j, j < 2 CT, of the panel, 16 bytes at column 4*(t&7) of the chunk
+  // ---- weight ring: thread t stages rows (t>>3) + 8 NW j, j < WJ, of the panel, 16 bytes at column 4*(t&7) of the chunk
   const int wrow = tid >> 3, wc4 = tid & 7;
-  const float* wptr[2 * CT];
+  const float* wptr[WJ];
 #pragma unroll
-  for (int j = 0; j < 2 * CT; ++j) {
-    int n = n0 + wrow + 32 * j;
+  for (int j = 0; j < WJ; ++j) {
+    int n = n0 + wrow + 8 * NW * j;
     n = n < p.N ? n : p.N - 1;
     wptr[j] = p.W + (long long)n * p.ldw + wc4 * 4;
   }
-  F4 ring[4][2 * CT];
+  F4 ring[4][WJ];
   auto gload = [&](int c) {                  // c is a constant after unrolling
 #pragma unroll
-    for (int j = 0; j < 2 * CT; ++j) ring[c & 3][j] = ld4(wptr[j] + c * 32);
+    for (int j = 0; j < WJ; ++j) ring[c & 3][j] = ld4(wptr[j] + c * 32);
   };
   auto lstore = [&](int c) {
     float* dst = Ws + (c & 1) * BN * kStripWStride;
 #pragma unroll
-    for (int j = 0; j < 2 * CT; ++j)       // "lane" = the 16-byte slot within the chunk
-      st_operand<PREC>(dst + (wrow + 32 * j) * kStripWStride, wc4, ring[c & 3][j], p.wscale);
+    for (int j = 0; j < WJ; ++j)           // "lane" = the 16-byte slot within the chunk
+      st_operand<PREC>(dst + (wrow + 8 * NW * j) * kStripWStride, wc4, ring[c & 3][j], p.wscale);
   };
 
   // epilogue bias of this lane's output columns, fetched now (clamped, unconditional)
   float ebias[CT];
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    const int ecol = n0 + (wave + 4 * c) * 16 + (lane & 15);
+    const int ecol = n0 + ((wave & 3) + 4 * c) * 16 + (lane & 15);
     ebias[c] = 0.f;
     if (p.bias) ebias[c] = p.bias[ecol < p.N ? ecol : p.N - 1];
   }
 
-  // ---- A prologue: wave w assembles rows w, w+4, ..., w+28 of the strip; lane l owns columns 4l..4l+3
+  // ---- A prologue: wave w assembles rows w, w + NW, ... of the strip; lane l owns columns 4l..4l+3
   int rows[RPW];
   bool live[RPW];
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
-    const int row = m0 + wave + i * 4;
+    const int row = m0 + wave + i * NW;
     live[i] = row < p.M;
     rows[i] = live[i] ? row : p.M - 1;
   }
@@ -126,8 +150,9 @@ __global__ __launch_bounds__(256, (ATTN || CT == 2 || NS0 >= 2) ? 2 : 3) void ge
     // 3-token self-attention on load (tile32.hpp, cross_attention.py:265-266), four rows at a time to bound registers;
     // the weight ring is started once the last pass's loads are out
     const int R = src.attn_R;
+    constexpr int NP = RPW / 4;              // passes of four rows
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NP; ++h) {
       F4 q[4], k[4][3], v[4][3];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -140,7 +165,7 @@ __global__ __launch_bounds__(256, (ATTN || CT == 2 || NS0 >= 2) ? 2 : 3) void ge
           v[i][j] = ld4(kr + 256);
         }
       }
-      if (h == 1) { gload(0); gload(1); gload(2); gload(3); }
+      if (h == NP - 1) { gload(0); gload(1); gload(2); gload(3); }
       float sc[12];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -238,33 +263,34 @@ __global__ __launch_bounds__(256, (ATTN || CT == 2 || NS0 >= 2) ? 2 : 3) void ge
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       ascale[i] = fp8_pow2_scale(am[i]);
-      if (lane == 0) rsc[wave + i * 4] = 1.0f / (ascale[i] * p.wscale);
+      if (lane == 0) rsc[wave + i * NW] = 1.0f / (ascale[i] * p.wscale);
     }
   }
   constexpr int SEG = PREC == PREC_F32 ? 256 : PREC == PREC_BF16 ? 128 : 64;   // words one 256-wide K segment takes in a row
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * 4) * ST, lane, areg[i], ascale[i]);
+  for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * NW) * ST, lane, areg[i], ascale[i]);
   if constexpr (NSRC == 2) {
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * 4) * ST + SEG, lane, breg[i], ascale[i]);
+    for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * NW) * ST + SEG, lane, breg[i], ascale[i]);
   }
 
   // ---- main loop: one barrier per K chunk; chunk kc multiplies while kc+1 is written to the other LDS buffer and
   //      kc+2..kc+4 are in flight (straight-line after unrolling: KCS is a compile-time constant)
   const int r = lane & 15, g = lane >> 4;
-  const float* ap = As + r * ST;
-  const float* wp = Ws + (wave * 16 + r) * kStripWStride;
-  f32x4 acc[CT][2];
+  const int wc = wave & 3, wr = NW == 8 ? (wave >> 2) : 0;      // column tile; first row tile of this wave
+  const float* ap = As + (wr * 16 + r) * ST;
+  const float* wp = Ws + (wc * 16 + r) * kStripWStride;
+  f32x4 acc[CT][RT];
 #pragma unroll
-  for (int c = 0; c < CT; ++c) acc[c][0] = acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   lstore(0);
   if (4 < KCS) gload(4);
   __syncthreads();
 #pragma unroll
   for (int kc = 0; kc < KCS; ++kc) {
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-      strip_chunk<PREC>(ap, ap + 16 * ST, wp + ((kc & 1) * BN + 64 * c) * kStripWStride, kc, g, acc[c][0], acc[c][1]);
+    strip_mma<PREC, RT, CT>(ap, ST, wp + (kc & 1) * BN * kStripWStride, kStripWStride, kc, g, acc);
     if (kc + 1 < KCS) {
       lstore(kc + 1);
       if (kc + 5 < KCS) gload(kc + 5);
@@ -277,17 +303,19 @@ __global__ __launch_bounds__(256, (ATTN || CT == 2 || NS0 >= 2) ? 2 : 3) void ge
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { acc[c][0][i] *= rsc[g * 4 + i]; acc[c][1][i] *= rsc[16 + g * 4 + i]; }
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[c][t][i] *= rsc[(wr + t) * 16 + g * 4 + i];
   }
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    const int col = n0 + (wave + 4 * c) * 16 + r;
+    const int col = n0 + (wc + 4 * c) * 16 + r;
     if (col < p.N) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < RT; ++t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int row = m0 + t * 16 + g * 4 + i;
+          const int row = m0 + (wr + t) * 16 + g * 4 + i;
           if (row < p.M) {
             if (p.P) {
               p.P[(long long)row * p.N + col] = acc[c][t][i];

@@ -205,6 +205,18 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   MLD_STRIP_ATTR(1, 2, 0, 1) MLD_STRIP_ATTR(2, 2, 0, 1)
   MLD_STRIP_ATTR(0, 1, 0, 2) MLD_STRIP_ATTR(1, 1, 0, 2) MLD_STRIP_ATTR(1, 1, 1, 2) MLD_STRIP_ATTR(2, 1, 0, 2)
 #undef MLD_STRIP_ATTR
+#define MLD_STRIP_ATTR8(NS, ACT)                                                                                            \
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 1, false, PREC_F32, ACT, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<1, 2>())); \
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 1, false, PREC_BF16, ACT, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<1, 2>())); \
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 1, false, PREC_FP8, ACT, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<1, 2>()));
+  MLD_STRIP_ATTR8(0, 0) MLD_STRIP_ATTR8(1, 0) MLD_STRIP_ATTR8(1, 1) MLD_STRIP_ATTR8(2, 0)
+#undef MLD_STRIP_ATTR8
+#define MLD_STRIP_ATTR8S(NS)                                                                                                \
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 2, false, PREC_F32, 0, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<2, 1>())); \
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 2, false, PREC_BF16, 0, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<2, 1>())); \
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 2, false, PREC_FP8, 0, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<2, 1>()));
+  MLD_STRIP_ATTR8S(1) MLD_STRIP_ATTR8S(2)
+#undef MLD_STRIP_ATTR8S
   (void)hipGetLastError();
 #endif
   *out = e;
@@ -272,6 +284,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "strip_wide") {
     if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "strip_wide must be 0 (auto), 1 (never) or 2 (always)");
     e->strip_wide = (int)value;
+  } else if (n == "strip_waves") {
+    if (value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "strip_waves must be 4 or 8");
+    e->strip_waves = (int)value;
   } else if (n == "strip_ffn2_split") {
     if (value != 1 && value != 2) return e->fail(MLDHIP_EINVAL, "strip_ffn2_split must be 1 or 2");
     e->strip_ffn2_split = (int)value;

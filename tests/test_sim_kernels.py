@@ -560,3 +560,22 @@ def test_novae_split_bf16_gemms_and_attention_sim(now):
     print("novae x3 denoiser err", err)
     assert 1e-7 < err < 3e-4
     e.close()
+
+
+def test_strip_family_four_wave_workgroups_sim(ow):
+    """strip_waves = 4 (two 16-row tiles per wave) is the A/B twin of the default 8-wave workgroups: same tiles, same summation
+    order, hence bit-identical results."""
+    e = simlib.sim_engine(max_batch=11, max_frames=8, num_inference_steps=2)
+    e.set_option("loop_kernel", 2)
+    g = syn._rng(21, "strip")
+    R = 22
+    x = g.standard_normal((R, 1, 256)).astype(np.float32)
+    te = g.standard_normal((R, 1, 768)).astype(np.float32)
+    outs = []
+    for waves in (8, 4):
+        e.set_option("strip_waves", waves)
+        out = np.zeros((R, 1, 256), np.float32)
+        e.denoiser_forward(x, 741, te, R, out)
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1])
+    e.close()

@@ -26,9 +26,9 @@ def tk(name, iters=60):
     return [round(ms * 1e3, 2), round(fl / ms / 1e9, 1)]
 out = {}
 ref = None
-for wide in (1, 0, 2):
-    for split in (1, 2):
-        eng.set_option("strip_wide", wide); eng.set_option("strip_ffn2_split", split)
+for wide, split, waves in ((1, 2, 4), (0, 1, 4), (0, 2, 4), (0, 2, 8), (1, 2, 8)):
+    if True:
+        eng.set_option("strip_wide", wide); eng.set_option("strip_ffn2_split", split); eng.set_option("strip_waves", waves)
         call = lambda i: eng.sample_many(reqs[(i % NFL) * NREQ:(i % NFL + 1) * NREQ], streams[i % NFL].cuda_stream)
         for i in range(2 * NFL): call(i)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -37,6 +37,6 @@ for wide in (1, 0, 2):
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         j = reqs[0]["joints_out"].clone()
         if ref is None: ref = j
-        out["wide=%d ffn2_split=%d" % (wide, split)] = {"motions_per_s": round(64 * NREQ * n / dt, 1), "max_abs_vs_first": float((j - ref).abs().max()),
+        out["wide=%d ffn2_split=%d waves=%d" % (wide, split, waves)] = {"motions_per_s": round(64 * NREQ * n / dt, 1), "max_abs_vs_first": float((j - ref).abs().max()),
                                                         "us_gflops": {k: tk(k) for k in ("den_qkv", "den_outproj", "den_ffn1", "den_ffn2")}}
 print(json.dumps(out, indent=0))
