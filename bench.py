@@ -80,7 +80,7 @@ KERNEL_THROUGHPUT = {   # strip.hpp template arguments: <slabs of src0, K segmen
     "den_ffn2": ("void mld::gemm_kernel<2, 2, 1, 2, false, true, 0, 16, false>", 9 * STEPS_DDIM),
     "den_final": ("mld::den_final_step_kernel", STEPS_DDIM)}
 KERNEL_DECODE = {
-    "dec_qkv": ("void mld::gemm_kernel<2, 4, 2, 2, false, true", 9), "dec_attn": ("void mld::attn_decode_kernel<13", 9),
+    "dec_qkv": ("void mld::gemm_kernel<2, 4, 2, 2, false, true", 9), "dec_attn": ("void mld::attn_decode", 9),      # attn_decode_kernel (f32) / attn_decode_x3_kernel (the bf16-MFMA modes)
     "dec_outproj_ln": ("void mld::gemm_kernel<2, 4, 2, 4, true, true", 9), "dec_ffn1": ("void mld::gemm_kernel<2, 4, 2, 2, false, true", 9),
     "dec_ffn2_ln": ("void mld::gemm_kernel<2, 4, 2, 4, true, true", 9)}
 
