@@ -46,6 +46,8 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
 
 // throughput family: K = 256 (one source) or 512 (skip linear: src[0] | src[1]); src[0] plain, 1- or 2-slab combine, or attention.
 // Wide GEMMs (N a multiple of 128, N >= 512: QKV, FFN1) take 32 x 128 tiles: half as many workgroups repeat one A prologue.
+// (QKV alone is faster on 32 x 64 tiles at 1 920 rows -- 13.5 vs 14.9 us, one resident round of 720 workgroups -- but with four
+// calls in flight the end-to-end rate is 2 % LOWER: 12.77 vs 13.04 k motions/s, profiles/r02_strip_options_ab.json.)
 void strip(Ctx& c, const Tile32Args& a, int nsrc) {
   const bool attn = a.src[0].attn_R > 0;
   const int ns = attn ? 0 : a.src[0].nsplit;

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
   static_assert(NSRC == 1 || NSRC == 2, "one or two 256-wide K segments");
   static_assert(!(ATTN && (NS0 != 0 || NSRC != 1)), "the attention prologue feeds the out-projection only");
   constexpr int K = 256 * NSRC, ST = K + 4, KCS = K / 32, RPW = 32 / NW;
+  constexpr int RD = 4;   // register prefetch ring depth in chunks (8 = the whole K = 256 panel up front was measured 1 % slower end to end)
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
 #else
@@ -115,16 +116,20 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
     n = n < p.N ? n : p.N - 1;
     wptr[j] = p.W + (long long)n * p.ldw + wc4 * 4;
   }
-  F4 ring[4][WJ];
+  F4 ring[RD][WJ];
   auto gload = [&](int c) {                  // c is a constant after unrolling
 #pragma unroll
-    for (int j = 0; j < WJ; ++j) ring[c & 3][j] = ld4(wptr[j] + c * 32);
+    for (int j = 0; j < WJ; ++j) ring[c % RD][j] = ld4(wptr[j] + c * 32);
+  };
+  auto gload_first = [&]() {
+#pragma unroll
+    for (int c = 0; c < RD; ++c) gload(c);
   };
   auto lstore = [&](int c) {
     float* dst = Ws + (c & 1) * BN * kStripWStride;
 #pragma unroll
     for (int j = 0; j < WJ; ++j)           // "lane" = the 16-byte slot within the chunk
-      st_operand<PREC>(dst + (wrow + 8 * NW * j) * kStripWStride, wc4, ring[c & 3][j], p.wscale);
+      st_operand<PREC>(dst + (wrow + 8 * NW * j) * kStripWStride, wc4, ring[c % RD][j], p.wscale);
   };
 
   // epilogue bias of this lane's output columns, fetched now (clamped, unconditional)
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
           v[i][j] = ld4(kr + 256);
         }
       }
-      if (h == NP - 1) { gload(0); gload(1); gload(2); gload(3); }
+      if (h == NP - 1) gload_first();
       float sc[12];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
   } else if constexpr (NS0 == 0) {
 #pragma unroll
     for (int i = 0; i < RPW; ++i) areg[i] = ld4(src.base + (long long)rows[i] * src.ld + lane * 4);
-    gload(0); gload(1); gload(2); gload(3);
+    gload_first();
   } else {
     // combine: sum of NS0 slabs + bias (+ residual), optional LayerNorm; one wave owns a row (tile32.hpp)
     F4 sl[RPW][NS0], rs[RPW];
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
     const F4 bias = ld4(src.bias + lane * 4);
     F4 gm = F4{1.f, 1.f, 1.f, 1.f}, bt = F4{0.f, 0.f, 0.f, 0.f};
     if (has_ln) { gm = ld4(src.gamma + lane * 4); bt = ld4(src.beta + lane * 4); }
-    gload(0); gload(1); gload(2); gload(3);
+    gload_first();
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       F4 v = sl[i][0];
@@ -286,14 +291,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   lstore(0);
-  if (4 < KCS) gload(4);
+  if (RD < KCS) gload(RD);
   __syncthreads();
 #pragma unroll
   for (int kc = 0; kc < KCS; ++kc) {
     strip_mma<PREC, RT, CT>(ap, ST, wp + (kc & 1) * BN * kStripWStride, kStripWStride, kc, g, acc);
     if (kc + 1 < KCS) {
       lstore(kc + 1);
-      if (kc + 5 < KCS) gload(kc + 5);
+      if (kc + 1 + RD < KCS) gload(kc + 1 + RD);
       __syncthreads();
     }
   }

@@ -26,7 +26,7 @@ def tk(name, iters=60):
     return [round(ms * 1e3, 2), round(fl / ms / 1e9, 1)]
 out = {}
 ref = None
-for wide, split, waves in ((1, 2, 4), (0, 1, 4), (0, 2, 4), (0, 2, 8), (1, 2, 8)):
+for wide, split, waves in ((1, 2, 4), (2, 2, 4), (2, 2, 8), (1, 2, 8), (0, 1, 8), (0, 2, 8)):
     if True:
         eng.set_option("strip_wide", wide); eng.set_option("strip_ffn2_split", split); eng.set_option("strip_waves", waves)
         call = lambda i: eng.sample_many(reqs[(i % NFL) * NREQ:(i % NFL + 1) * NREQ], streams[i % NFL].cuda_stream)
