@@ -60,12 +60,17 @@ class DataParallelSampler:
     in_flight > 1 (text-to-motion models on the fused engine path): consecutive chunks are issued on `in_flight` rotating
     HIP streams, so several batches overlap on the GPU (configure the engine with ``mld_hip.engine.configure("text", max_in_flight=in_flight)`` before
     its first use; with fewer workspaces the engine orders the calls behind each other on the device -- a workspace is
-    never shared by two calls at once).  Results are identical either way."""
+    never shared by two calls at once).  Results are identical either way.
 
-    def __init__(self, model, batch_size: int = 64, in_flight: int = 1):
+    coalesce > 1: `coalesce` consecutive chunks go into ONE engine call (``MLD.sample_many`` -> ``mldhip_sample_many``: one chain over
+    coalesce x batch_size motions on the throughput kernels); combined with in_flight = 4 this is the serving shape bench.py's
+    headline measures (configure ``max_batch >= coalesce * batch_size``).  Set GPU_MAX_HW_QUEUES=8 before HIP initialises."""
+
+    def __init__(self, model, batch_size: int = 64, in_flight: int = 1, coalesce: int = 1):
         self.model = model
         self.batch_size = batch_size
         self.in_flight = max(1, int(in_flight))
+        self.coalesce = max(1, int(coalesce))
 
     def __call__(self, texts: Sequence[str], lengths: Sequence[int]):
         import torch.distributed as dist
@@ -74,7 +79,7 @@ class DataParallelSampler:
         lo, hi = shard_range(len(texts), rank, world)
         chunks = [(s, min(hi, s + self.batch_size)) for s in range(lo, hi, self.batch_size)]
         m = self.model
-        overlap = (self.in_flight > 1 and torch.cuda.is_available() and getattr(m, "fused", False)
+        overlap = ((self.in_flight > 1 or self.coalesce > 1) and torch.cuda.is_available() and getattr(m, "fused", False)
                    and getattr(m, "condition", None) == "text" and getattr(m, "vae_type", "") != "no")   # plain text-to-motion only
         out = []
         if not overlap:
@@ -85,12 +90,19 @@ class DataParallelSampler:
         for st in streams:
             st.wait_stream(torch.cuda.current_stream())
         pending = []
-        for i, (s, e) in enumerate(chunks):
+        groups = [chunks[g:g + self.coalesce] for g in range(0, len(chunks), self.coalesce)]
+        for i, grp in enumerate(groups):
             with torch.cuda.stream(streams[i % self.in_flight]):
-                tx, ln = list(texts[s:e]), [int(x) for x in lengths[s:e]]
-                emb = m.text_encoder([""] * len(tx) + tx)                      # mld.py:224-231: unconditional half first
-                joints, _, _ = m.sample(emb, ln)
-                pending.append((joints, ln))
+                reqs = []
+                for s, e in grp:
+                    tx, ln = list(texts[s:e]), [int(x) for x in lengths[s:e]]
+                    reqs.append((m.text_encoder([""] * len(tx) + tx), ln))      # mld.py:224-231: unconditional half first
+                if len(reqs) == 1:
+                    joints, _, _ = m.sample(*reqs[0])
+                    pending.append((joints, reqs[0][1]))
+                else:
+                    for (joints, _, _), (_, ln) in zip(m.sample_many(reqs), reqs):
+                        pending.append((joints, ln))
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
         for joints, ln in pending:

@@ -133,6 +133,36 @@ class MLD(nn.Module):
         return joints, feats, lat
 
     @torch.no_grad()
+    def sample_many(self, requests, init_latents=None):
+        """Several independent text-to-motion requests as ONE engine call (``mldhip_sample_many``: one reverse-diffusion chain +
+        one decode over all of them; the engine needs ``max_batch >= total motions``).  `requests` = [(text_emb [2B_i,1,768],
+        lengths_i), ...]; returns [(joints_i, feats_i, latents_i), ...] on device, each shaped as ``sample`` would return it."""
+        if self.vae_type == "no" or self.condition == "action":
+            raise NotImplementedError("sample_many serves the text-to-motion latent model")
+        eng = self._engine()
+        dev = requests[0][0].device
+        dm_eng = self.datamodule._engine(dev) if hasattr(self.datamodule, "_engine") else eng
+        if dm_eng is not eng:
+            raise RuntimeError("datamodule and network parts are bound to different engines")
+        stream = _engine.current_stream_handle(requests[0][0])
+        _engine.finalize_if_dirty(eng, stream)
+        reqs, outs, keep = [], [], []
+        for i, (text_emb, lengths) in enumerate(requests):
+            lengths = [int(x) for x in lengths]
+            B, T = len(lengths), max(lengths)
+            text_emb = text_emb.float().contiguous()
+            lat0 = init_latents[i] if init_latents is not None else torch.randn((B, self.latent_dim[0], self.latent_dim[-1]), device=dev)
+            lat0 = lat0.float().contiguous()
+            lat = torch.empty(B, self.latent_dim[0], self.latent_dim[-1], device=dev)
+            feats = torch.empty(B, T, self.nfeats, device=dev)
+            joints = torch.empty(B, T, self.njoints, 3, device=dev)
+            keep.append((text_emb, lat0))
+            reqs.append(dict(text_emb=text_emb, init_latents=lat0, lengths=lengths, latents_out=lat, feats_out=feats, joints_out=joints))
+            outs.append((joints, feats, lat))
+        eng.sample_many(reqs, stream)
+        return outs
+
+    @torch.no_grad()
     def sample_novae(self, text_emb: torch.Tensor, lengths: List[int], init_latents: Optional[torch.Tensor] = None,
                      step_noise: Optional[torch.Tensor] = None, seed: Optional[int] = None):
         """Diffusion-only sampling in ONE mldhip_sample_novae call: text_emb [2B, 1, 768] -> (joints [B,T,22,3], feats [B,T,nfeats]).

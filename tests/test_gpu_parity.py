@@ -841,3 +841,42 @@ def test_reduced_precision_modes_run_and_stay_sane(dev, golden_dir):
     print("diffusion-only, split-bf16 GEMMs, 10 steps: feats err %.3e" % ef)
     assert 2e-5 < ef < 5e-3
     e.close()
+
+
+def test_config3_shape_512_prompts_through_the_dp_sampler(dev):
+    """BASELINE config 3 on the ranks this box has (1): 512 synthetic prompts, bs 64, sharded by DataParallelSampler -- every
+    prompt exactly once and in order, and the coalesced + overlapped serving shape (4 chunks per engine call, 2 calls in flight)
+    returns the same motions as one chunk per call (start noise pinned per chunk)."""
+    from mld_hip import config as C
+    from mld_hip import engine as E
+    from mld_hip.datamodule import HipDataModule
+    from mld_hip.dp import DataParallelSampler
+    from mld_hip.mld import MLD
+    from mld_hip.text_encoder import SyntheticTextEncoder
+
+    E.drop_engines()
+    cfg = C.load_config()
+    E.configure("text", max_batch=256, max_frames=196, max_in_flight=2)
+    model = MLD(cfg, HipDataModule(cfg), text_encoder=SyntheticTextEncoder()).to(dev).eval()
+    n = 512
+    texts = [f"synthetic prompt {i}" for i in range(n)]
+    rng = np.random.Generator(np.random.PCG64(3))
+    lengths = [int(v) for v in rng.choice(np.arange(40, 197, 4), n)]
+
+    def noise(lens):                       # the same start noise for a chunk whichever call shape serves it
+        g = torch.Generator(device=dev).manual_seed(1000003 * lens[0] + sum(lens))
+        return torch.randn((len(lens), 1, 256), device=dev, generator=g)
+    orig_sample, orig_many = model.sample, model.sample_many
+    model.sample = lambda emb, lens, init_latents=None: orig_sample(emb, lens, noise(lens))
+    model.sample_many = lambda reqs, init_latents=None: orig_many(reqs, [noise(l) for _, l in reqs])
+    idx1, one = DataParallelSampler(model, batch_size=64, in_flight=1)(texts, lengths)
+    idx4, many = DataParallelSampler(model, batch_size=64, in_flight=2, coalesce=4)(texts, lengths)
+    assert idx1 == idx4 == list(range(n)) and len(one) == len(many) == n
+    worst = 0.0
+    for a, b, ln in zip(one, many, lengths):
+        assert a.shape == b.shape == (ln, 22, 3) and bool(torch.isfinite(b).all())
+        worst = max(worst, float((a - b).abs().max()))
+    print("512 prompts: coalesced x in-flight vs one chunk per call, max-abs joints difference %.3e" % worst)
+    assert worst < 1e-3                    # latency vs throughput kernel family: summation order only
+    E.configure("text", max_batch=64, max_in_flight=1)
+    E.drop_engines()
