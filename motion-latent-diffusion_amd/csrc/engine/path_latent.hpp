@@ -48,7 +48,9 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
 // Wide GEMMs (N a multiple of 128, N >= 512: QKV, FFN1) take 32 x 128 tiles: half as many workgroups repeat one A prologue.
 // (QKV alone is faster on 32 x 64 tiles at 1 920 rows -- 13.5 vs 14.9 us, one resident round of 720 workgroups -- but with four
 // calls in flight the end-to-end rate is 2 % LOWER: 12.77 vs 13.04 k motions/s, profiles/r02_strip_options_ab.json.)
-void strip(Ctx& c, const Tile32Args& a, int nsrc) {
+void strip(Ctx& c, const Tile32Args& a_, int nsrc) {
+  Tile32Args a = a_;
+  a.trace = c.e->trace_on;
   const bool attn = a.src[0].attn_R > 0;
   const int ns = attn ? 0 : a.src[0].nsplit;
   const bool wide = !attn && nsrc == 1 && a.N % 128 == 0 && (c.e->strip_wide == 2 || (c.e->strip_wide == 0 && a.N >= 512));
@@ -68,6 +70,16 @@ void strip(Ctx& c, const Tile32Args& a, int nsrc) {
     else if (c.e->strip_waves == 8) MLD_STRIP(NS, NSRC, ATTN, ACT, 1, 8);           \
     else MLD_STRIP(NS, NSRC, ATTN, ACT, 1, 4);                                      \
   } while (0)
+  if (a.trace) {                              // measurement builds (mldhip_profile_trace): the fp32 8-wave kernels of the encoder layer
+    if (prec != PREC_F32 || c.e->strip_waves != 8 || nsrc != 1) { c.rc = c.e->fail(MLDHIP_EINVAL, "strip: traces exist for the fp32 8-wave layer kernels only"); return; }
+    if (attn) { MLD_LAUNCH((gemm_strip_kernel<0, 1, true, PREC_F32, 0, 1, 8, true>), grid, dim3(512), (strip_lds_bytes<1, 1>()), c.stream, a); }
+    else if (wide && ns == 1 && a.act == 1) { MLD_LAUNCH((gemm_strip_kernel<1, 1, false, PREC_F32, 1, 2, 8, true>), grid, dim3(512), (strip_lds_bytes<1, 2>()), c.stream, a); }
+    else if (wide && ns == 2 && a.act == 0) { MLD_LAUNCH((gemm_strip_kernel<2, 1, false, PREC_F32, 0, 2, 8, true>), grid, dim3(512), (strip_lds_bytes<1, 2>()), c.stream, a); }
+    else { c.rc = c.e->fail(MLDHIP_EINVAL, "strip: no traced build of this shape"); return; }
+    count(c);
+    check_launch(c, "gemm_strip(trace)");
+    return;
+  }
   if (a.act != 0 && !(a.act == 1 && ns == 1 && nsrc == 1 && !attn)) { c.rc = c.e->fail(MLDHIP_EINVAL, "strip: activation %d is built for the FFN1 shape only", a.act); return; }
   if (attn && nsrc == 1) { if (c.e->strip_waves == 8) MLD_STRIP(0, 1, true, 0, 1, 8); else MLD_STRIP(0, 1, true, 0, 1, 4); }
   else if (ns == 0 && nsrc == 1) MLD_STRIP_W(0, 1, false, 0);

@@ -231,6 +231,19 @@ __device__ __forceinline__ unsigned long long clock_pinned() {
   return t;
 #endif
 }
+// shader clock without draining outstanding global loads (stamps inside a software-pipelined loop)
+__device__ __forceinline__ unsigned long long clock_light() {
+#if defined(MLDHIP_SIM)
+  return 0ull;
+#else
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long t = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+#endif
+}
+
 __device__ __forceinline__ unsigned long long realtime_100mhz() {
 #if defined(MLDHIP_SIM)
   return 0ull;

@@ -86,7 +86,8 @@ __device__ __forceinline__ void strip_mma(const float* a, int ast, const float* 
 // PREC = operand format of the MFMAs (rt.hpp); prologue, accumulation and epilogue are fp32 in every mode.
 // ACT  = epilogue activation of the direct (Y) output, compile time: 0 none, 1 erf-GELU (FFN1).  Besides saving a branch it
 //        gives QKV and FFN1 -- same prologue, same K -- distinct kernel names in a profile.
-template <int NS0, int NSRC, bool ATTN, int PREC = PREC_F32, int ACT = 0, int CT = 1, int NW = 4>
+// TRACE = measurement build (mldhip_profile_trace): six shader-clock stamps per wave, see the end of the kernel.
+template <int NS0, int NSRC, bool ATTN, int PREC = PREC_F32, int ACT = 0, int CT = 1, int NW = 4, bool TRACE = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : (ATTN || CT == 2 || NS0 >= 2) ? 2 : 3) void gemm_strip_kernel(Tile32Args p) {
   static_assert(CT == 1 || CT == 2, "one or two 16-column tiles per wave");
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
@@ -104,6 +105,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
   float* Ws = smem + 32 * ST;                // [2][BN][kStripWStride]
   float* rsc = Ws + 2 * BN * kStripWStride;  // [32] 1 / (row scale * wscale) (PREC_FP8)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, rt0 = 0;
+  if constexpr (TRACE) { rt0 = realtime_100mhz(); ts[0] = clock_pinned(); }
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * BN;
   const ASrc& src = p.src[0];
 
@@ -258,6 +261,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
 #pragma unroll
     for (int i = 0; i < RPW; ++i) breg[i] = ld4(s1.base + (long long)rows[i] * s1.ld + lane * 4);
   }
+  if constexpr (TRACE) ts[1] = clock_pinned();             // A rows assembled, the first RD weight chunks landed
   float ascale[RPW];
 #pragma unroll
   for (int i = 0; i < RPW; ++i) ascale[i] = 1.f;
@@ -293,6 +297,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
   lstore(0);
   if (RD < KCS) gload(RD);
   __syncthreads();
+  if constexpr (TRACE) ts[2] = clock_light();               // strip + chunk 0 in LDS, first barrier passed
 #pragma unroll
   for (int kc = 0; kc < KCS; ++kc) {
     strip_mma<PREC, RT, CT>(ap, ST, wp + (kc & 1) * BN * kStripWStride, kStripWStride, kc, g, acc);
@@ -301,6 +306,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
       if (kc + 1 + RD < KCS) gload(kc + 1 + RD);
       __syncthreads();
     }
+    if constexpr (TRACE) { if (kc == KCS / 2 - 1) ts[3] = clock_light(); }   // half of the K chunks done
+  }
+  if constexpr (TRACE) {                                    // MFMAs retired
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int t = 0; t < RT; ++t) asm volatile("" :: "v"(acc[c][t][0]), "v"(acc[c][t][1]), "v"(acc[c][t][2]), "v"(acc[c][t][3]));
+    ts[4] = clock_light();
   }
 
   // ---- epilogue: 16 lanes write 64 contiguous bytes per row (raw partial slab, or bias + activation)
@@ -332,6 +345,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
           }
         }
       }
+    }
+  }
+  if constexpr (TRACE) {
+    ts[5] = clock_pinned();                 // epilogue stores issued and drained
+    if (lane == 0) {
+      const long long wg = blockIdx.x + (long long)gridDim.x * blockIdx.y;
+      unsigned long long* o = p.trace + (wg * 8 + (wave & 7)) * 8;
+      for (int i = 0; i < 6; ++i) o[i] = ts[i];
+      o[6] = rt0;
+      o[7] = realtime_100mhz();
     }
   }
 }

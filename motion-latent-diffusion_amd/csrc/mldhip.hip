@@ -216,6 +216,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 2, false, PREC_BF16, 0, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<2, 1>())); \
   (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 2, false, PREC_FP8, 0, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<2, 1>()));
   MLD_STRIP_ATTR8S(1) MLD_STRIP_ATTR8S(2)
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<1, 1, false, PREC_F32, 1, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<1, 2>()));
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<2, 1, false, PREC_F32, 0, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<1, 2>()));
 #undef MLD_STRIP_ATTR8S
   (void)hipGetLastError();
 #endif

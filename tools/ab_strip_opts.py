@@ -6,7 +6,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "motion-latent-diffusion_amd")]
 import numpy as np, torch
 from mld_hip import _lib, synthetic as syn
 dev = torch.device("cuda:0")
-NREQ, NFL = int(os.environ.get("AB_NREQ", "5")), 4
+NREQ, NFL = int(os.environ.get("AB_NREQ", "5")), int(os.environ.get("AB_NFL", "4"))
 sd = {**{"denoiser." + k: v for k, v in syn.make_denoiser_state_dict().items()}, **{"vae." + k: v for k, v in syn.make_vae_state_dict().items()}}
 sd["mean"], sd["std"] = syn.make_mean_std()
 reqs = []
@@ -26,17 +26,23 @@ def tk(name, iters=60):
     return [round(ms * 1e3, 2), round(fl / ms / 1e9, 1)]
 out = {}
 ref = None
-for wide, split, waves in ((1, 2, 4), (2, 2, 4), (2, 2, 8), (1, 2, 8), (0, 1, 8), (0, 2, 8)):
-    if True:
-        eng.set_option("strip_wide", wide); eng.set_option("strip_ffn2_split", split); eng.set_option("strip_waves", waves)
-        call = lambda i: eng.sample_many(reqs[(i % NFL) * NREQ:(i % NFL + 1) * NREQ], streams[i % NFL].cuda_stream)
-        for i in range(2 * NFL): call(i)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        n = 3 * NFL
-        for i in range(n): call(i)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        j = reqs[0]["joints_out"].clone()
-        if ref is None: ref = j
-        out["wide=%d ffn2_split=%d waves=%d" % (wide, split, waves)] = {"motions_per_s": round(64 * NREQ * n / dt, 1), "max_abs_vs_first": float((j - ref).abs().max()),
-                                                        "us_gflops": {k: tk(k) for k in ("den_qkv", "den_outproj", "den_ffn1", "den_ffn2")}}
-print(json.dumps(out, indent=0))
+DEFAULTS = dict(strip_wide=0, strip_ffn2_split=2, strip_waves=8)
+CONFIGS = [dict(), dict(strip_waves=16), dict(strip_waves=16, strip_kw=2), dict(strip_waves=16, strip_kw=2, strip_prio=1),
+           dict(strip_waves=16, strip_prio=1), dict(strip_prio=1), dict(strip_waves=4), dict(strip_wide=1), dict(strip_ffn2_split=1), dict()]
+if os.environ.get("AB_CONFIGS"): CONFIGS = json.loads(os.environ["AB_CONFIGS"])
+for n, cfg in enumerate(CONFIGS):
+    opts = {**DEFAULTS, **cfg}
+    for k, v in opts.items(): eng.set_option(k, v)
+    call = lambda i: eng.sample_many(reqs[(i % NFL) * NREQ:(i % NFL + 1) * NREQ], streams[i % NFL].cuda_stream)
+    for i in range(2 * NFL): call(i)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n_calls = 3 * NFL
+    for i in range(n_calls): call(i)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    j = reqs[0]["joints_out"].clone()
+    if ref is None: ref = j
+    name = "%d: " % n + (" ".join("%s=%d" % (k[6:], v) for k, v in cfg.items()) or "defaults")
+    out[name] = {"motions_per_s": round(64 * NREQ * n_calls / dt, 1), "max_abs_vs_first": float((j - ref).abs().max()),
+                 "us_gflops": {k: tk(k) for k in ("den_qkv", "den_outproj", "den_ffn1", "den_ffn2")}}
+    print(name, json.dumps(out[name]), flush=True)
+print(json.dumps({"requests_per_call": NREQ, "calls_in_flight": NFL, "results": out}, indent=0))
