@@ -67,10 +67,20 @@ int loop_prec(const E* e) {
   return e->cfg.precision == MLDHIP_PREC_BF16 ? PREC_BF16 : e->cfg.precision == MLDHIP_PREC_FP8_DENOISER ? PREC_FP8 : PREC_F32;
 }
 
-void gemm(Ctx& c, const GemmArgs& a, int nz = 1) {
+// split-bf16 mode: read W from the pre-split image of the weight arena when it lives there (derived tables in a workspace do not)
+void use_split_weights(const E* e, GemmArgs& a, int prec) {
+  if (prec == PREC_BF16X3 && e->split_weights && e->arena_x3 && a.W >= e->arena && a.W < e->arena + e->arena_floats) {
+    a.W = e->arena_x3 + (a.W - e->arena);
+    a.w_split = 1;
+  }
+}
+
+void gemm(Ctx& c, const GemmArgs& a_, int nz = 1) {
+  GemmArgs a = a_;
   const int K = a.K1 + a.K2;
   const bool small = a.M <= c.e->small_m || (K != 256 && K != 384 && K != 512 && K != 1024);
   const int prec = K == 384 ? PREC_F32 : staged_prec(c.e);     // K = 384 (padded 263-wide features): fp32 tile only
+  if (!small) use_split_weights(c.e, a, prec);
   if (small) {
     dim3 grid((a.M + 15) / 16, (a.N + 63) / 64, nz);
     MLD_LAUNCH((gemm_kernel<1, 4, 1, 1, false>), grid, dim3(256), 0, c.stream, a);
@@ -95,8 +105,10 @@ void gemm_tile_32x64(Ctx& c, const GemmArgs& a, int prec, int nz = 1) {
   check_launch(c, "gemm_32x64");
 }
 
-void gemm_ln(Ctx& c, const GemmArgs& a) {   // N == 256; full rows per workgroup (64 x 256 tile on 8 waves)
+void gemm_ln(Ctx& c, const GemmArgs& a_) {   // N == 256; full rows per workgroup (64 x 256 tile on 8 waves)
+  GemmArgs a = a_;
   const int prec = staged_prec(c.e);
+  use_split_weights(c.e, a, prec);
   const dim3 grid((a.M + 63) / 64, 1, 1);
   if (prec == PREC_BF16X3) launch_staged<2, 4, 2, 4, true, PREC_BF16X3>(c, a, grid);
   else if (prec == PREC_BF16) launch_staged<2, 4, 2, 4, true, PREC_BF16>(c, a, grid);

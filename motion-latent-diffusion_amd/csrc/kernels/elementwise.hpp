@@ -51,6 +51,23 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
 }
 
+// Split-bf16 image of the weight arena (finalize-time; precision modes that run staged GEMMs on split-bf16 MFMAs): every aligned
+// group of 32 floats -- one 32-wide K chunk of one weight row, tensors start on 64-float boundaries and the staged GEMMs take K % 32 == 0
+// -- becomes the 32 words a staged GEMM keeps in LDS for it: 16 words of bf16 high parts (element 2w in the low half of word w), then
+// 16 words of bf16 low parts (rt.hpp split_bf16_pair; gemm.hpp lstore).  Same size and addressing as the fp32 arena, so a GEMM
+// reads W from it at the same offset and stores the 16-byte pieces to LDS untouched.  grid = ceil(groups / 16), block = 256.
+__global__ __launch_bounds__(256) void split_bf16_weights_kernel(const float* __restrict__ w, float* __restrict__ out, long long groups) {
+  const long long grp = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int pr = threadIdx.x & 15;                      // pair (2 pr, 2 pr + 1) of the group
+  if (grp >= groups) return;
+  const float a = w[grp * 32 + 2 * pr], b = w[grp * 32 + 2 * pr + 1];
+  unsigned hi, lo;
+  split_bf16_pair(a, b, hi, lo);
+  unsigned* o = reinterpret_cast<unsigned*>(out) + grp * 32;
+  o[pr] = hi;
+  o[16 + pr] = lo;
+}
+
 struct DdimCoef { float sqrt_at, sqrt_1mat, sqrt_ap, sqrt_1map; };   // DDIM eta=0 coefficients of one step
 
 // LayerNorm over rows of width 256: one wave per row, 4 rows per workgroup.

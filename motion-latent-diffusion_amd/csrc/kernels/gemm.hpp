@@ -43,6 +43,7 @@ struct GemmArgs {
   float ascale = 1.f, wscale = 1.f, oscale = 1.f;        // PREC_FP8: operands are multiplied by a/wscale before the e4m3
                                                          // conversion, the accumulator by oscale = 1/(ascale*wscale)
   unsigned long long* trace = nullptr;   // measurement only (staged kernels): 8 timestamps per wave
+  int w_split = 0;                       // PREC_BF16X3: W points into the pre-split copy of the weight arena (elementwise.hpp split_bf16_weights_kernel)
 };
 
 struct Frag { float v[8]; };
@@ -89,7 +90,10 @@ __device__ __forceinline__ void load_frags(Frag (&f)[REP], const float* base, in
 
 constexpr int kGemmLdsStride = 36;   // floats per staged row: one 32-wide K chunk + 4 pad (bank spread)
 template <int WM, int WN, int MREP, int NREP>
-constexpr int gemm_lds_bytes() { return 2 * (WM * MREP * 16 + WN * NREP * 16) * kGemmLdsStride * 4; }
+constexpr int gemm_lds_bytes() {    // the chunk double buffer, or the output tile parked for the 16-byte stores, whichever is larger
+  constexpr int loop = 2 * (WM * MREP * 16 + WN * NREP * 16) * kGemmLdsStride * 4, epi = WM * MREP * 16 * (WN * NREP * 16 + 4) * 4;
+  return loop > epi ? loop : epi;
+}
 
 // WM x WN waves per workgroup, each wave owns MREP x NREP tiles of 16x16.
 // STAGED = false: fragments are fetched straight from global memory (first version; kept for the tiny
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
           reinterpret_cast<unsigned*>(dst + row * kGemmLdsStride)[c4] = pack_fp8x4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
         } else {
           // row image: [32 x bf16 hi | 32 x bf16 lo | pad]; this thread owns k = 4*c4 .. 4*c4+3
+          if (p.w_split && j >= NLA) { st4(dst + row * kGemmLdsStride + c4 * 4, v); continue; }   // W was split at finalize (split_bf16_weights_kernel): already the row image
           unsigned h0, l0, h1, l1;
           split_bf16_pair(v.x, v.y, h0, l0);
           split_bf16_pair(v.z, v.w, h1, l1);

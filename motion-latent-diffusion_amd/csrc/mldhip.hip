@@ -238,6 +238,7 @@ void mldhip_destroy(mldhip_handle* e) {
   if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
 #endif
   if (e->arena) (void)hipFree(e->arena);
+  if (e->arena_x3) (void)hipFree(e->arena_x3);
   for (auto& x : e->ctxs) {
     if (x.ws) (void)hipFree(x.ws);
     if (x.lens) (void)hipFree(x.lens);
@@ -289,6 +290,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "strip_waves") {
     if (value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "strip_waves must be 4 or 8");
     e->strip_waves = (int)value;
+  } else if (n == "split_weights") {
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "split_weights must be 0 or 1");
+    e->split_weights = (int)value;
   } else if (n == "strip_ffn2_split") {
     if (value != 1 && value != 2) return e->fail(MLDHIP_EINVAL, "strip_ffn2_split must be 1 or 2");
     e->strip_ffn2_split = (int)value;
@@ -366,6 +370,13 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
     }
     e->den_skip_scale.clear();
     for (int i = 0; i < nb; ++i) e->den_skip_scale.push_back(sc(amax[4 * e->den.size() + i]));
+  }
+  if (e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE || e->cfg.precision == MLDHIP_PREC_FP8_DENOISER) {
+    // the staged GEMMs of these modes run on split-bf16 MFMAs: split the weights once, here, not in every workgroup
+    if (!e->arena_x3 && hipMalloc((void**)&e->arena_x3, e->arena_floats * sizeof(float)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(split weights)");
+    const long long groups = (long long)(e->arena_floats / 32);
+    MLD_LAUNCH(split_bf16_weights_kernel, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, stream, e->arena, e->arena_x3, groups);
+    if (check_launch(c, "split_bf16_weights")) return c.rc;
   }
   for (int k = 0; k < (int)e->ctxs.size(); ++k) {       // the derived tables live in each context's workspace
   bind_context(e, k);

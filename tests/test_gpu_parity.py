@@ -843,6 +843,26 @@ def test_reduced_precision_modes_run_and_stay_sane(dev, golden_dir):
     e.close()
 
 
+def test_presplit_weights_match_in_kernel_split_and_the_golden(dev, golden_dir):
+    """precision = BF16X3_DECODE (the bench headline mode): the decoder GEMMs read W from the split-bf16 image finalize builds
+    ("split_weights" = 1, default).  Bit-identical to splitting in every workgroup, and inside the joints contract on the
+    reference fixture of the benchmarked shape."""
+    g = _gold(golden_dir, "pipeline_b64.npz")
+    b = syn.make_batch(64)
+    e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=1)
+    _load(e)
+    outs = []
+    for sw in (1, 0):
+        e.set_option("split_weights", sw)
+        lat, feats, joints, _ = _run_sample(e, dev, b)
+        outs.append((feats.clone(), joints.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    err = float(np.abs(outs[0][1].cpu().numpy()[:, ::4] - g["joints_every4"]).max())
+    print("bf16x3_decode joints vs reference golden: %.2e" % err)
+    assert err < 1e-3
+    e.close()
+
+
 def test_config3_shape_512_prompts_through_the_dp_sampler(dev):
     """BASELINE config 3 on the ranks this box has (1): 512 synthetic prompts, bs 64, sharded by DataParallelSampler -- every
     prompt exactly once and in order, and the coalesced + overlapped serving shape (4 chunks per engine call, 2 calls in flight)

@@ -579,3 +579,33 @@ def test_strip_family_four_wave_workgroups_sim(ow):
         outs.append(out)
     assert np.array_equal(outs[0], outs[1])
     e.close()
+
+
+def test_split_bf16_weights_presplit_is_bit_identical_sim(ow, now):
+    """precision = BF16X3_DECODE: finalize builds a split-bf16 image of the weight arena (elementwise.hpp split_bf16_weights_kernel)
+    and the staged GEMMs copy its 16-byte pieces to LDS untouched; "split_weights" = 0 splits in every workgroup as before.
+    Same split routine, same operand image -> the decoder features and the diffusion-only denoiser output are bit-identical."""
+    e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2, precision=1)
+    e.set_option("gemm_small_m", 0)
+    z = syn._rng(7, "g8").standard_normal((3, 1, 256)).astype(np.float32)
+    outs = []
+    for sw in (1, 0):
+        e.set_option("split_weights", sw)
+        feats = np.zeros((3, 40, 263), np.float32)
+        e.vae_decode(z, [40, 23, 7], feats)
+        outs.append(feats)
+    assert np.abs(outs[0]).max() > 0.1 and np.array_equal(outs[0], outs[1])
+    e.close()
+    e = simlib.sim_novae_engine(num_layers=2, max_batch=2, max_frames=40, num_inference_steps=4, precision=1)
+    e.set_option("gemm_small_m", 0)
+    g = syn._rng(12, "nvx3")
+    x = g.standard_normal((2, 37, 263)).astype(np.float32)
+    te = g.standard_normal((2, 1, 768)).astype(np.float32)
+    outs = []
+    for sw in (1, 0):
+        e.set_option("split_weights", sw)
+        out = np.zeros((2, 37, 263), np.float32)
+        e.denoiser_forward_novae(x, 999, te, [37, 20], 37, out)
+        outs.append(out)
+    assert np.abs(outs[0]).max() > 0.1 and np.array_equal(outs[0], outs[1])
+    e.close()

@@ -26,7 +26,7 @@ def tk(name, iters=60):
     return [round(ms * 1e3, 2), round(fl / ms / 1e9, 1)]
 out = {}
 ref = None
-DEFAULTS = dict(strip_wide=0, strip_ffn2_split=2, strip_waves=8)
+DEFAULTS = json.loads(os.environ.get("AB_DEFAULTS", '{"strip_wide": 0, "strip_ffn2_split": 2, "strip_waves": 8}'))
 CONFIGS = [dict(), dict(strip_waves=16), dict(strip_waves=16, strip_kw=2), dict(strip_waves=16, strip_kw=2, strip_prio=1),
            dict(strip_waves=16, strip_prio=1), dict(strip_prio=1), dict(strip_waves=4), dict(strip_wide=1), dict(strip_ffn2_split=1), dict()]
 if os.environ.get("AB_CONFIGS"): CONFIGS = json.loads(os.environ["AB_CONFIGS"])
@@ -41,8 +41,8 @@ for n, cfg in enumerate(CONFIGS):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     j = reqs[0]["joints_out"].clone()
     if ref is None: ref = j
-    name = "%d: " % n + (" ".join("%s=%d" % (k[6:], v) for k, v in cfg.items()) or "defaults")
+    name = "%d: " % n + (" ".join("%s=%d" % (k.replace("strip_", ""), v) for k, v in cfg.items()) or "defaults")
     out[name] = {"motions_per_s": round(64 * NREQ * n_calls / dt, 1), "max_abs_vs_first": float((j - ref).abs().max()),
-                 "us_gflops": {k: tk(k) for k in ("den_qkv", "den_outproj", "den_ffn1", "den_ffn2")}}
+                 "us_gflops": {k: tk(k) for k in os.environ.get("AB_KERNELS", "den_qkv,den_outproj,den_ffn1,den_ffn2").split(",")}}
     print(name, json.dumps(out[name]), flush=True)
 print(json.dumps({"requests_per_call": NREQ, "calls_in_flight": NFL, "results": out}, indent=0))
