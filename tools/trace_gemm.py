@@ -1,14 +1,14 @@
 #!/usr/bin/env python
 """Phase breakdown of the decoder's staged GEMMs from in-kernel timestamps (run on the GPU box)."""
 import os, sys, json
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, "motion-latent-diffusion_amd")]
 import numpy as np, torch
 from mld_hip import _lib, synthetic as syn
 
-B, T = 64, 196
+B, T = int(os.environ.get("TRACE_B", "64")), 196
 out = {}
-for prec in (0, 1):
+for prec in [int(x) for x in os.environ.get("TRACE_PREC", "0,1").split(",")]:
     eng = _lib.Engine(device=0, max_batch=B, max_frames=T, precision=prec)
     eng.load_state_dict(syn.make_denoiser_state_dict(), "denoiser."); eng.load_state_dict(syn.make_vae_state_dict(), "vae.")
     m, s = syn.make_mean_std(); eng.load_tensor("mean", m); eng.load_tensor("std", s); eng.finalize()
