@@ -1,4 +1,7 @@
-"""GPU A/B of the throughput-kernel options at the headline call shape (5 x 64 motions per call, 4 calls in flight)."""
+"""GPU A/B of per-handle options (mldhip_set_option) at the headline call shape (5 x 64 motions per call, 4 calls in flight):
+end-to-end motions/s plus back-to-back per-kernel times.  Environment: AB_NREQ / AB_NFL (requests per call / calls in flight),
+AB_DEFAULTS and AB_CONFIGS (JSON: the baseline option values and the list of overrides to run; the first and last entries should be
+the baseline, the first one absorbs the clock ramp), AB_KERNELS (comma list of mldhip_profile_kernel names to time)."""
 import json, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,8 +30,7 @@ def tk(name, iters=60):
 out = {}
 ref = None
 DEFAULTS = json.loads(os.environ.get("AB_DEFAULTS", '{"strip_wide": 0, "strip_ffn2_split": 2, "strip_waves": 8}'))
-CONFIGS = [dict(), dict(strip_waves=16), dict(strip_waves=16, strip_kw=2), dict(strip_waves=16, strip_kw=2, strip_prio=1),
-           dict(strip_waves=16, strip_prio=1), dict(strip_prio=1), dict(strip_waves=4), dict(strip_wide=1), dict(strip_ffn2_split=1), dict()]
+CONFIGS = [dict(), dict(strip_wide=1), dict(strip_wide=2), dict(strip_waves=4), dict(strip_wide=1, strip_waves=4), dict(strip_ffn2_split=1), dict()]
 if os.environ.get("AB_CONFIGS"): CONFIGS = json.loads(os.environ["AB_CONFIGS"])
 for n, cfg in enumerate(CONFIGS):
     opts = {**DEFAULTS, **cfg}
