@@ -85,8 +85,14 @@ KERNEL_DECODE = {
     "dec_ffn2_ln": ("void mld::gemm_kernel<2, 4, 2, 4, true, true", 9)}
 
 
-def kernel_table(batch):
-    return {**(KERNEL_THROUGHPUT if 6 * batch >= 768 else KERNEL_LATENCY), **KERNEL_DECODE}
+KERNEL_DECODE_X3 = {   # split-bf16 modes: the feed-forward block is ONE launch (kernels/ffn_fused.hpp), the K = 256 staged GEMM serves QKV only
+    "dec_qkv": KERNEL_DECODE["dec_qkv"], "dec_attn": KERNEL_DECODE["dec_attn"], "dec_outproj_ln": KERNEL_DECODE["dec_outproj_ln"],
+    "dec_ffn": ("mld::ffn_x3_kernel", 9)}
+
+
+def kernel_table(batch, precision="bf16x3_decode"):
+    dec = KERNEL_DECODE_X3 if precision in ("bf16x3_decode", "fp8_denoiser") else KERNEL_DECODE
+    return {**(KERNEL_THROUGHPUT if 6 * batch >= 768 else KERNEL_LATENCY), **dec}
 
 
 def algorithmic_gflop(B, T, D=256, F=1024, L=9, NF=263, steps=STEPS_DDIM):
@@ -538,7 +544,7 @@ def main():
         # ---- per-kernel table at the shape of one headline call (coalesce x 64 motions): back-to-back launch interval
         #      (HIP events on the launch stream) ...
         PB = BATCH * coalesce
-        table = kernel_table(PB)
+        table = kernel_table(PB, a.precision)
         kern = {}
         for name, (_, cnt) in table.items():
             ms, fl = time_kernel(eng, name, PB, FRAMES, 100 if name.startswith("den") else max(6, 30 // coalesce), stream)
@@ -549,7 +555,7 @@ def main():
             k = kern[name]
             if stats:
                 hits = [(n, v) for n, v in stats.items() if n.startswith(prefix)]
-                if name.startswith("dec_") and name != "dec_attn":
+                if name.startswith("dec_") and name not in ("dec_attn", "dec_ffn"):
                     # decoder GEMMs share two templates: K = 256 vs K = 1024 differ in the KCS argument; QKV and FFN1 are one kernel (same tile, same K)
                     kcs = ", 32, false>" if name == "dec_ffn2_ln" else ", 8, false>"
                     hits = [(n, v) for n, v in hits if kcs in n]
@@ -560,7 +566,7 @@ def main():
                 k["chain_us"] = round(chain_marginal_us(eng, name, PB, FRAMES, 60, stream), 2)
             dur = k.get("rocprof_us") or k.get("chain_us") or k["interval_us"]
             k["clock"] = "rocprofv3" if "rocprof_us" in k else "chain_events" if "chain_us" in k else "interval"
-            if name in ("dec_qkv", "dec_ffn1") and "rocprof_us" in k:
+            if name in ("dec_qkv", "dec_ffn1") and "dec_ffn1" in table and "rocprof_us" in k:
                 # one kernel serves both: split its average by their FLOP ratio is not measurable -- report the interval clock for these two
                 dur, k["clock"] = k["interval_us"], "interval (shares its rocprofv3 row with the other K = 256 decoder GEMM)"
             k["tflops"] = round(k["gflop"] / (dur * 1e-6) / 1e3, 3) if dur else 0.0

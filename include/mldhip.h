@@ -137,6 +137,8 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "strip_wide"      throughput kernels: 32 x 128 tiles for the wide GEMMs: 0 = auto (N >= 512), 1 = never, 2 = whenever N % 128 == 0
  *   "strip_waves"     throughput kernels: waves per workgroup of the 32 x 128 tiles, 4 or 8 (default 8)
  *   "strip_ffn2_split" throughput kernels: K slices (raw slabs) of the FFN2 GEMM, 1 or 2 (default 2)
+ *   "fused_ffn"       split-bf16 modes: 1 (default) = linear1 + GELU + linear2 + residual + LayerNorm of a decoder / encoder layer as
+ *                     ONE launch (kernels/ffn_fused.hpp; the hidden activation stays in LDS), 0 = the two staged GEMMs (A/B knob)
  *   "split_weights"   precision modes whose staged GEMMs run on split-bf16 MFMAs: 1 (default) = read the weights from the bf16
  *                     high / low image finalize builds once, 0 = split them in every workgroup (bit-identical results; A/B knob)
  *   "gemm_small_m"    row count up to which one-off GEMMs use the register-direct 16x64 shape (default 256; tests set 0

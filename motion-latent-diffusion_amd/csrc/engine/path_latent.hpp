@@ -282,10 +282,40 @@ void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr) {
   check_launch(c, "attn_decode");
 }
 
+// linear1 + GELU + linear2 + residual + LayerNorm of a post-norm layer.  Split-bf16 modes with D = 256, FF = 1024: ONE launch
+// (kernels/ffn_fused.hpp) reading the pre-split weights; otherwise the two staged GEMMs.  ragged_T > 0: skip all-padding row tiles.
+void ffn_block(Ctx& c, const float* x, float* y, int M, const float* w1, const float* b1, const float* w2, const float* b2,
+               const float* gamma, const float* beta, int ragged_T) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim, F = e->cfg.ff_size;
+  auto in_arena = [&](const float* w) { return w >= e->arena && w < e->arena + e->arena_floats; };
+  if (staged_prec(e) == PREC_BF16X3 && e->fused_ffn && e->split_weights && e->arena_x3 && D == 256 && F == 1024 && M > e->small_m &&
+      !e->trace_on && in_arena(w1) && in_arena(w2)) {
+    FfnArgs a;
+    a.X = x; a.W1 = e->arena_x3 + (w1 - e->arena); a.b1 = b1; a.W2 = e->arena_x3 + (w2 - e->arena); a.b2 = b2;
+    a.gamma = gamma; a.beta = beta; a.Y = y; a.M = M;
+    if (ragged_T > 0) { a.skip_lens = e->lens_dev; a.skip_rpg = ragged_T; }
+    MLD_LAUNCH(ffn_x3_kernel, dim3((M + 63) / 64), dim3(512), kFfnLdsBytes, c.stream, a);
+    count(c);
+    check_launch(c, "ffn_x3");
+    return;
+  }
+  GemmArgs f1 = lin_args(x, D, D, w1, b1, e->FF, F, M, F);
+  f1.act = ACT_GELU;
+  GemmArgs f2 = lin_args(e->FF, F, F, w2, b2, y, D, M, D);
+  f2.res = x; f2.ldres = D; f2.g1 = gamma; f2.b1 = beta;
+  if (ragged_T > 0) {
+    f1.skip_lens = f2.skip_lens = e->lens_dev;
+    f1.skip_rpg = f2.skip_rpg = ragged_T;
+  }
+  gemm(c, f1);
+  gemm_ln(c, f2);
+}
+
 void dec_layer(Ctx& c, int l, const float* xin, float* xout, int B, int T) {
   E* e = c.e;
   const DecLayerP& L = e->dec[l];
-  const int D = e->cfg.latent_dim, F = e->cfg.ff_size, M = B * T;
+  const int D = e->cfg.latent_dim, M = B * T;
   auto ragged = [&](GemmArgs g) { g.skip_lens = e->lens_dev; g.skip_rpg = T; return g; };   // skip all-padding row tiles
   gemm(c, ragged(lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D)));
   dec_attention(c, B, T);
@@ -295,12 +325,7 @@ void dec_layer(Ctx& c, int l, const float* xin, float* xout, int B, int T) {
   o.cvec = e->cvec + (size_t)l * e->cfg.max_batch * D; o.ldcvec = D; o.rows_per_group = T;
   o.g2 = L.n2_w; o.b2 = L.n2_b;
   gemm_ln(c, ragged(o));
-  GemmArgs f1 = lin_args(e->H1, D, D, L.l1_w, L.l1_b, e->FF, F, M, F);
-  f1.act = ACT_GELU;
-  gemm(c, ragged(f1));
-  GemmArgs f2 = lin_args(e->FF, F, F, L.l2_w, L.l2_b, xout, D, M, D);
-  f2.res = e->H1; f2.ldres = D; f2.g1 = L.n3_w; f2.b1 = L.n3_b;
-  gemm_ln(c, ragged(f2));
+  ffn_block(c, e->H1, xout, M, L.l1_w, L.l1_b, L.l2_w, L.l2_b, L.n3_w, L.n3_b, T);
 }
 
 void skip_linear(Ctx& c, const std::string& prefix, int i, const float* x, const float* skip, float* y, int M, int ragged_T = 0) {
@@ -375,18 +400,13 @@ void decode_body(Ctx& c, const float* z, int B, int T, float* feats_out) {
 // on the decoder's kernels: packed in-proj GEMM, masked MFMA attention, out-proj + res + norm1, FFN.
 void venc_layer(Ctx& c, const EncLayerP& L, const float* xin, float* xout, int B, int S) {
   E* e = c.e;
-  const int D = e->cfg.latent_dim, F = e->cfg.ff_size, M = B * S;
+  const int D = e->cfg.latent_dim, M = B * S;
   gemm(c, lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
   dec_attention(c, B, S, e->lens2_dev);
   GemmArgs o = lin_args(e->AO, D, D, L.out_w, L.out_b, e->H1, D, M, D);
   o.res = xin; o.ldres = D; o.g1 = L.n1_w; o.b1 = L.n1_b;
   gemm_ln(c, o);
-  GemmArgs f1 = lin_args(e->H1, D, D, L.l1_w, L.l1_b, e->FF, F, M, F);
-  f1.act = ACT_GELU;
-  gemm(c, f1);
-  GemmArgs f2 = lin_args(e->FF, F, F, L.l2_w, L.l2_b, xout, D, M, D);
-  f2.res = e->H1; f2.ldres = D; f2.g1 = L.n2_w; f2.b1 = L.n2_b;
-  gemm_ln(c, f2);
+  ffn_block(c, e->H1, xout, M, L.l1_w, L.l1_b, L.l2_w, L.l2_b, L.n2_w, L.n2_b, 0);
 }
 
 // MldVae.encode (mld_vae.py:124-184): feats [B,T,nfeats] -> mu, logvar (and latent = mu + exp(logvar)^0.5 * eps).

@@ -35,6 +35,7 @@
 #include "kernels/rt.hpp"
 #include "kernels/tile32.hpp"
 #include "kernels/strip.hpp"
+#include "kernels/ffn_fused.hpp"
 
 using namespace mld;
 
@@ -189,6 +190,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<7, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<7, 128>()));
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<13, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<13, 128>()));
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<18, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<18, 128>()));
+  (void)hipFuncSetAttribute((const void*)ffn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLdsBytes);
 #define MLD_T32_ATTR1(MT, NS, ...) \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<MT, NS, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
 #define MLD_T32_ATTR(NS)                                                                                                    \
@@ -290,6 +292,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "strip_waves") {
     if (value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "strip_waves must be 4 or 8");
     e->strip_waves = (int)value;
+  } else if (n == "fused_ffn") {
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "fused_ffn must be 0 or 1");
+    e->fused_ffn = (int)value;
   } else if (n == "split_weights") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "split_weights must be 0 or 1");
     e->split_weights = (int)value;
@@ -918,6 +923,9 @@ int mldhip_profile_kernel(mldhip_handle* e, const char* name, int32_t B, int32_t
       f1.act = ACT_GELU;
       gemm(c, f1);
       *flops_per_launch = 2.0 * M * D * F;
+    } else if (n == "dec_ffn") {      // the whole feed-forward block as the layer runs it (one fused launch in the split-bf16 modes)
+      ffn_block(c, e->H1, e->Hb, (int)M, e->dec[mid].l1_w, e->dec[mid].l1_b, e->dec[mid].l2_w, e->dec[mid].l2_b, e->dec[mid].n3_w, e->dec[mid].n3_b, 0);
+      *flops_per_launch = 4.0 * M * D * F;
     } else if (n == "dec_ffn2_ln") {
       GemmArgs f2 = lin_args(e->FF, F, F, e->dec[mid].l2_w, e->dec[mid].l2_b, e->Hb, D, (int)M, D);
       f2.res = e->H1; f2.ldres = D; f2.g1 = e->dec[mid].n3_w; f2.b1 = e->dec[mid].n3_b;

@@ -851,6 +851,7 @@ def test_presplit_weights_match_in_kernel_split_and_the_golden(dev, golden_dir):
     b = syn.make_batch(64)
     e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=1)
     _load(e)
+    e.set_option("fused_ffn", 0)                         # the fused feed-forward block needs the split image: compare like with like
     outs = []
     for sw in (1, 0):
         e.set_option("split_weights", sw)
@@ -859,6 +860,30 @@ def test_presplit_weights_match_in_kernel_split_and_the_golden(dev, golden_dir):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     err = float(np.abs(outs[0][1].cpu().numpy()[:, ::4] - g["joints_every4"]).max())
     print("bf16x3_decode joints vs reference golden: %.2e" % err)
+    assert err < 1e-3
+    e.close()
+
+
+def test_fused_ffn_block_matches_the_two_staged_gemms_on_gpu(dev, golden_dir):
+    """precision = BF16X3_DECODE: the one-launch feed-forward block (kernels/ffn_fused.hpp) vs the two staged GEMMs
+    ("fused_ffn" = 0) on the benchmarked shape with ragged lengths (padded-frame tiles skipped in both): features within 2e-5
+    of each other (same products and summation order; the two builds contract a few epilogue operations differently), and the
+    fused path inside the joints contract on the reference fixture."""
+    g = _gold(golden_dir, "pipeline_b64.npz")
+    e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=1)
+    _load(e)
+    outs = {}
+    for name, b in (("full", syn.make_batch(64)), ("ragged", syn.make_batch(64, "ragged", seed=5))):
+        for ff in (1, 0):
+            e.set_option("fused_ffn", ff)
+            lat, feats, joints, _ = _run_sample(e, dev, b)
+            outs[name, ff] = (feats.clone(), joints.clone())
+        df = float((outs[name, 1][0] - outs[name, 0][0]).abs().max())
+        dj = float((outs[name, 1][1] - outs[name, 0][1]).abs().max())
+        print("%s: fused vs two-launch feed-forward: feats %.2e joints %.2e" % (name, df, dj))
+        assert df < 2e-5 and dj < 5e-5
+    err = float(np.abs(outs["full", 1][1].cpu().numpy()[:, ::4] - g["joints_every4"]).max())
+    print("fused feed-forward, joints vs reference golden: %.2e" % err)
     assert err < 1e-3
     e.close()
 

@@ -609,3 +609,44 @@ def test_split_bf16_weights_presplit_is_bit_identical_sim(ow, now):
         outs.append(out)
     assert np.abs(outs[0]).max() > 0.1 and np.array_equal(outs[0], outs[1])
     e.close()
+
+
+def test_fused_ffn_block_equals_the_two_staged_gemms_sim(ow, aow):
+    """precision = BF16X3_DECODE: kernels/ffn_fused.hpp (linear1 + GELU + linear2 + residual + LayerNorm in one launch, hidden
+    activation in LDS, pre-split weights) against the two staged GEMMs it replaces ("fused_ffn" = 0): same products, same K order,
+    same LayerNorm reduction order -> bit-identical on the simulator.  Decoder with ragged lengths (120 rows: one full 64-row tile,
+    one partial, padded-frame skipping on), the MldVae encoder (S = T + 2 rows per sample) and the ActorVae decoder."""
+    ops, _, bv = ow
+    e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2, precision=1)
+    e.set_option("gemm_small_m", 0)
+    z = syn._rng(7, "g8").standard_normal((3, 1, 256)).astype(np.float32)
+    g = syn._rng(3, "enc")
+    feats_in = g.standard_normal((3, 40, 263)).astype(np.float32)
+    for i, n in enumerate([40, 23, 7]):
+        feats_in[i, n:] = 0
+    eps = g.standard_normal((3, 1, 256)).astype(np.float32)
+    outs = []
+    for ff in (1, 0):
+        e.set_option("fused_ffn", ff)
+        feats = np.zeros((3, 40, 263), np.float32)
+        e.vae_decode(z, [40, 23, 7], feats)
+        lat, mu, lv = (np.zeros((3, 1, 256), np.float32) for _ in range(3))
+        e.vae_encode(feats_in, [40, 23, 7], 40, eps, lat, mu, lv)
+        outs.append((feats, mu.copy(), lv.copy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.abs(a).max() > 1e-3 and np.array_equal(a, b)
+    err = np.abs(outs[0][0] - O.vae_decode(ops, bv, z, [40, 23, 7])).max()
+    assert 1e-7 < err < 2e-4
+    e.close()
+    aops, _, abv = aow
+    e = simlib.sim_action_engine(max_batch=4, max_frames=24, num_inference_steps=2, precision=1)
+    e.set_option("gemm_small_m", 0)
+    za = syn._rng(9, "adec").standard_normal((3, 1, 256)).astype(np.float32)
+    outs = []
+    for ff in (1, 0):
+        e.set_option("fused_ffn", ff)
+        f = np.zeros((3, 24, 150), np.float32)
+        e.vae_decode(za, [24, 11, 17], f)
+        outs.append(f)
+    assert np.abs(outs[0]).max() > 1e-3 and np.array_equal(outs[0], outs[1])
+    e.close()

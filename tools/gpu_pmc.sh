@@ -32,11 +32,11 @@ for C in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
     agg[C] = {k: (n, v / n) for k, (n, v) in a.items()}
 kern = {}
 coalesce = int(os.environ.get("PMC_COALESCE", "5"))
-for name, (prefix, _) in bench.kernel_table(bench.BATCH * coalesce).items():
+for name, (prefix, _) in bench.kernel_table(bench.BATCH * coalesce, os.environ.get("PMC_PRECISION", "bf16x3_decode")).items():
     ent = {}
     for C, table in agg.items():
         hits = [(k, v) for k, v in table.items() if k.startswith(prefix)]
-        if name.startswith("dec_") and name != "dec_attn":
+        if name.startswith("dec_") and name not in ("dec_attn", "dec_ffn"):
             kcs = ", 32, false>" if name == "dec_ffn2_ln" else ", 8, false>"
             hits = [(k, v) for k, v in hits if kcs in k]
         if hits:
