@@ -158,11 +158,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* __res
 // product runs as x = hi + lo in bf16 on v_mfma_f32_16x16x32_bf16 (3 MFMAs per 32-wide contraction chunk: lo*hi, hi*lo,
 // hi*hi; fp32 accumulate) -- 6 + 6.5 MFMAs of 16 cycles per 16 x 16 score / 16 x 64 output tile pair instead of 16 + 16 fp32
 // ones of 32 cycles.  Softmax, the 1/sqrt(d) scaling and the normalisation stay fp32.
-//   K   in LDS as two bf16 planes [key][64 dims] (row stride 36 words): lane (r, g) reads dims 32c + 8g .. + 7 of key r.
+//   K   in LDS as two bf16 planes [key][64 dims] (row stride 40 words): lane (r, g) reads dims 32c + 8g .. + 7 of key r.
 //   V^T in LDS as two bf16 planes [dim][keys]: the P.V contraction runs over 32 KEYS per MFMA; a lane's 8 k-slots are the
 //        keys it already holds scores for -- 16kt + 4g + {0..3} of the two key tiles (2kb, 2kb + 1) -- so P needs no shuffle,
 //        and the matching V operand is two 8-byte reads of 4 consecutive keys each from the transposed planes.
-constexpr int kAttnX3KStride = 36;   // words per K row: 64 bf16 = 32 words + 4 pad
+constexpr int kAttnX3KStride = 40;   // words per K row: 64 bf16 = 32 words + 8 pad (conflict-free ds_read_b128 at word 16c + 4g of key r, gemm.hpp kGemmLdsStride)
 template <int NKT>
 constexpr int attn_x3_vt_stride() { return ((NKT + 1) / 2) * 16 + 4; }   // words per V^T row: an even number of key tiles of 16 bf16 (= 8 words) + pad
 template <int NKT>

@@ -6,8 +6,8 @@
 // Here a workgroup keeps its 64 rows of X resident in LDS (split-bf16 image), walks the hidden dimension in 8 blocks of 128, and
 // for each block computes H = gelu(X W1_blk^T + b1) into LDS (split image again) and accumulates Y += H W2_blk^T in registers:
 // the hidden activation never leaves the CU, and the only streamed operand is the weights, 2 MB per workgroup, as ONE uniform
-// sequence of 128-row x 32-wide items (8 of W1 then 8 of W2 per hidden block) through the same 4-deep register ring + double
-// LDS buffer the staged GEMM uses -- the prefetch never drains at a phase change.
+// sequence of 128-row x 32-wide items (8 of W1 then 8 of W2 per hidden block) through an 8-deep register ring + the double
+// LDS buffer of the staged GEMM -- the prefetch never drains at a phase change.
 //
 // Weights come from the split-bf16 image of the arena (elementwise.hpp split_bf16_weights_kernel): 16-byte pieces go to LDS
 // untouched.  Same products, same K order (linear2's K chunks 0..31 in sequence), same column-to-wave assignment and reduction
@@ -35,10 +35,10 @@ struct FfnArgs {
   int skip_rpg = 1;
 };
 
-constexpr int kFfnXStride = 260;   // words per X row image: 8 K chunks x 32 words + 4 pad
-constexpr int kFfnHStride = 132;   // words per H row image: 4 K chunks x 32 words + 4 pad
-constexpr int kFfnWStride = 36;    // words per staged weight row: one K chunk + 4 pad
-constexpr int kFfnLdsBytes = (64 * kFfnXStride + 64 * kFfnHStride + 2 * 128 * kFfnWStride) * 4;   // 137 216 B: one workgroup per CU
+constexpr int kFfnXStride = 264;   // words per X row image: 8 K chunks x 32 words + 8 pad (strides = 8 mod 16: conflict-free ds_read_b128
+constexpr int kFfnHStride = 136;   // words per H row image: 4 K chunks x 32 words + 8 pad    fragment reads, see kGemmLdsStride)
+constexpr int kFfnWStride = 40;    // words per staged weight row: one K chunk + 8 pad
+constexpr int kFfnLdsBytes = (64 * kFfnXStride + 64 * kFfnHStride + 2 * 128 * kFfnWStride) * 4;   // 143 360 B: one workgroup per CU
 
 // grid = ceil(M / 64); block = 512 (8 waves: wm = wave >> 2 owns rows 32 wm .. + 31, wn = wave & 3).
 __global__ __launch_bounds__(512) void ffn_x3_kernel(FfnArgs p) {
@@ -72,7 +72,9 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(FfnArgs p) {
   //      s >= 8: hsel = (s - 8) >> 2, kc = (s - 8) & 3: for every wave column wn the 32 output rows 64 wn + 32 hsel .. + 31 of W2
   //      (so a wave keeps the columns gemm_kernel<2,4,2,4> gives it), K chunk 4 hb + kc.  Thread t stages rows (t >> 3) + 64 j.
   const int wrow = tid >> 3, c4 = tid & 7;
-  F4 ring[4][2];
+  constexpr int RD = 8;              // register prefetch ring depth in items: RD x 16 KB in flight per workgroup = per CU (4 and 8 measured
+                                     // the same, 294 / 296 us, while the kernel was bound by conflicted LDS reads; 8 kept)
+  F4 ring[RD][2];
   auto gload = [&](int slot, int hb, int s) {          // slot and s are constants after unrolling
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -104,10 +106,8 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(FfnArgs p) {
       m = m < p.M ? m : p.M - 1;
       xv[j] = ld4(p.X + (long long)m * D + c * 4);
     }
-    gload(0, 0, 0);
-    gload(1, 0, 1);
-    gload(2, 0, 2);
-    gload(3, 0, 3);
+#pragma unroll
+    for (int i = 0; i < RD; ++i) gload(i, 0, i);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int idx = tid + j * 512, row = idx >> 6, c = idx & 63;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(FfnArgs p) {
       *reinterpret_cast<uint2_t*>(rowp + 16) = uint2_t{l0, l1};
     }
     lstore(0, 0);
-    gload(0, 0, 4);
+    gload(0, RD >> 4, RD & 15);
   }
   __syncthreads();
 
@@ -192,14 +192,13 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(FfnArgs p) {
               hp[32 + b * 16 + r] = (unsigned short)lo;
             }
       }
-      // item it + 1 -> the other LDS buffer, item it + 5 -> the ring slot that just became free (hidden blocks past the end are
-      // clamped: redundant loads, never stored)
-      const int s5 = (s + 5) & 15;
-      if (s < 15 || hb < 7) lstore((s + 1) & 1, (s + 1) & 3);
+      // item it + 1 -> the other LDS buffer, item it + 1 + RD -> the ring slot that just became free (hidden blocks past the end
+      // are clamped: redundant loads, never stored)
+      if (s < 15 || hb < 7) lstore((s + 1) & 1, (s + 1) % RD);
       {
-        int hb5 = hb + (s + 5 >= 16 ? 1 : 0);
-        hb5 = hb5 < 8 ? hb5 : 7;
-        gload((s + 5) & 3, hb5, s5);
+        int hbn = hb + ((s + 1 + RD) >> 4);
+        hbn = hbn < 8 ? hbn : 7;
+        gload((s + 1) % RD, hbn, (s + 1 + RD) & 15);
       }
       __syncthreads();
     }
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(FfnArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) vals[a][n][i] = (vals[a][n][i] - mean[a][i]) * rstd[a][i] * gm[n] + bt[n];
   }
-  float* Cs = reinterpret_cast<float*>(Xs);            // [64][260]
+  float* Cs = reinterpret_cast<float*>(Xs);            // [64][260] (fits the 64 x 264 words of Xs)
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll

@@ -225,14 +225,15 @@ __global__ __launch_bounds__(NW * 64) void attn_seq_kernel(const float* __restri
 // 3 bf16 MFMAs (lo*hi, hi*lo, hi*hi) per 32-wide contraction chunk, fp32 accumulate; softmax and scaling in fp32.
 template <int NKT, int HD>
 constexpr int attn_seq_x3_lds_bytes() {
-  constexpr int kwords = 2 * NKT * 16 * (HD / 2 + 4), vwords = 2 * HD * (((NKT + 1) / 2) * 16 + 4);
+  constexpr int kwords = 2 * NKT * 16 * (HD / 2 + (NKT <= 13 ? 8 : 4)), vwords = 2 * HD * (((NKT + 1) / 2) * 16 + 4);
   return (kwords > vwords ? kwords : vwords) * 4;
 }
 
 template <int NKT, int HD, int NW = 8>
 __global__ __launch_bounds__(NW * 64) void attn_seq_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                           const int* __restrict__ lens, int T, int H) {
-  constexpr int C4 = HD / 4, KST = HD / 2 + 4, NKB = (NKT + 1) / 2, VST = NKB * 16 + 4, NCH = HD / 32;
+  // K row stride = 8 mod 16 words: conflict-free ds_read_b128 fragment reads (gemm.hpp kGemmLdsStride); 288 keys only fit with + 4
+  constexpr int C4 = HD / 4, KST = HD / 2 + (NKT <= 13 ? 8 : 4), NKB = (NKT + 1) / 2, VST = NKB * 16 + 4, NCH = HD / 32;
 #if defined(MLDHIP_SIM)
   unsigned* KV = reinterpret_cast<unsigned*>(hipsim::blk().dyn_smem.data());
 #else
