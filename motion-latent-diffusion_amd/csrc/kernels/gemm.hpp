@@ -91,8 +91,9 @@ __device__ __forceinline__ void load_frags(Frag (&f)[REP], const float* base, in
 // floats per staged row: one 32-wide K chunk + 8 pad.  The packed operand images (bf16 hi | lo) are read as ds_read_b128 at word
 // 4g of row r: that instruction is served in four 16-lane groups over 64 banks (MI355X_MICROARCH.md, LDS), and with a row stride
 // of 36 words rows r and r + 9 (mod 16) of one group land on the same banks -- 2-way conflicts, half the LDS rate, on kernels
-// whose split-bf16 MFMAs (16 cycles) make them LDS bound.  Strides = 8 mod 16 words are conflict free for that pattern.  (The fp32
-// fragments -- two ds_read_b128 at words 8g and 8g + 4 -- are 2-way at every stride; those kernels are not LDS bound.)
+// whose split-bf16 MFMAs (16 cycles) make them LDS bound.  Strides = 8 mod 16 words are conflict free for that pattern.  The fp32
+// fragments used to be two ds_read_b128 at words 8g and 8g + 4 -- 2-way at EVERY stride; they are now read at words 4g and 16 + 4g
+// (lfrags below, strip.hpp, tile32.hpp), the same conflict-free pattern.
 constexpr int kGemmLdsStride = 40;
 template <int WM, int WN, int MREP, int NREP>
 constexpr int gemm_lds_bytes() {    // the chunk double buffer, or the output tile parked for the 16-byte stores, whichever is larger
@@ -255,17 +256,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
       }
     };
     auto lfrags = [&](int buf) {
-      const float* as = smem + buf * ROWS * kGemmLdsStride + (wm * MREP * 16 + r) * kGemmLdsStride + g * 8;
-      const float* ws = smem + buf * ROWS * kGemmLdsStride + (BM + wn * NREP * 16 + r) * kGemmLdsStride + g * 8;
+      // fp32 fragments: words 4g .. 4g + 3 and 16 + 4g .. 16 + 4g + 3 of the chunk (conflict-free ds_read_b128, see kGemmLdsStride;
+      // the k-slot pairing is free as long as A and W agree)
+      const float* as = smem + buf * ROWS * kGemmLdsStride + (wm * MREP * 16 + r) * kGemmLdsStride + g * 4;
+      const float* ws = smem + buf * ROWS * kGemmLdsStride + (BM + wn * NREP * 16 + r) * kGemmLdsStride + g * 4;
 #pragma unroll
       for (int t = 0; t < MREP; ++t) {
-        const F4 a = ld4(as + t * 16 * kGemmLdsStride), b = ld4(as + t * 16 * kGemmLdsStride + 4);
+        const F4 a = ld4(as + t * 16 * kGemmLdsStride), b = ld4(as + t * 16 * kGemmLdsStride + 16);
         fa0[t].v[0] = a.x; fa0[t].v[1] = a.y; fa0[t].v[2] = a.z; fa0[t].v[3] = a.w;
         fa0[t].v[4] = b.x; fa0[t].v[5] = b.y; fa0[t].v[6] = b.z; fa0[t].v[7] = b.w;
       }
 #pragma unroll
       for (int t = 0; t < NREP; ++t) {
-        const F4 a = ld4(ws + t * 16 * kGemmLdsStride), b = ld4(ws + t * 16 * kGemmLdsStride + 4);
+        const F4 a = ld4(ws + t * 16 * kGemmLdsStride), b = ld4(ws + t * 16 * kGemmLdsStride + 16);
         fb0[t].v[0] = a.x; fb0[t].v[1] = a.y; fb0[t].v[2] = a.z; fb0[t].v[3] = a.w;
         fb0[t].v[4] = b.x; fb0[t].v[5] = b.y; fb0[t].v[6] = b.z; fb0[t].v[7] = b.w;
       }

@@ -19,9 +19,12 @@
 
 namespace mld {
 
-constexpr int kStripWStride = 36;                        // floats per staged W row: one 32-wide K chunk + 4 pad
+// LDS row strides = 8 (mod 16) words and fp32 fragments read as words 4g .. 4g + 3 and 16 + 4g .. 16 + 4g + 3 of the chunk (k-slot
+// pairing is free as long as A and W agree): a ds_read_b128 is served in four 16-lane groups over 64 banks, and "row r, word 4g" is
+// conflict free at these strides while the former "row r, words 8g / 8g + 4" is 2-way at every stride (gemm.hpp kGemmLdsStride).
+constexpr int kStripWStride = 40;                        // floats per staged W row: one 32-wide K chunk + 8 pad
 template <int NSRC, int CT = 1>
-constexpr int strip_lds_bytes() { return (32 * (256 * NSRC + 4) + 2 * 64 * CT * kStripWStride + 32) * 4; }   // CT=1: 51 840 / 84 608 B; CT=2: 70 272 B
+constexpr int strip_lds_bytes() { return (32 * (256 * NSRC + 8) + 2 * 64 * CT * kStripWStride + 32) * 4; }   // CT=1: 54 400 / 87 168 B; CT=2: 74 880 B (two workgroups per CU)
 
 // one 32-wide K chunk: RT 16-row tiles of the A strip against CT 16-column weight tiles (operand formats: tile32.hpp).
 // All fragments are read first, then the MFMAs run interleaved over the RT x CT independent accumulators, so consecutive
@@ -32,9 +35,9 @@ __device__ __forceinline__ void strip_mma(const float* a, int ast, const float* 
   if constexpr (PREC == PREC_F32) {
     F4 x[RT][2], y[CT][2];
 #pragma unroll
-    for (int t = 0; t < RT; ++t) { x[t][0] = ld4(a + t * 16 * ast + kc * 32 + g * 8); x[t][1] = ld4(a + t * 16 * ast + kc * 32 + g * 8 + 4); }
+    for (int t = 0; t < RT; ++t) { x[t][0] = ld4(a + t * 16 * ast + kc * 32 + g * 4); x[t][1] = ld4(a + t * 16 * ast + kc * 32 + 16 + g * 4); }
 #pragma unroll
-    for (int c = 0; c < CT; ++c) { y[c][0] = ld4(w + c * 64 * wst + g * 8); y[c][1] = ld4(w + c * 64 * wst + g * 8 + 4); }
+    for (int c = 0; c < CT; ++c) { y[c][0] = ld4(w + c * 64 * wst + g * 4); y[c][1] = ld4(w + c * 64 * wst + 16 + g * 4); }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
   constexpr int BN = 64 * CT, RT = NW == 8 ? 1 : 2, WJ = BN / (NW * 8);
   static_assert(NSRC == 1 || NSRC == 2, "one or two 256-wide K segments");
   static_assert(!(ATTN && (NS0 != 0 || NSRC != 1)), "the attention prologue feeds the out-projection only");
-  constexpr int K = 256 * NSRC, ST = K + 4, KCS = K / 32, RPW = 32 / NW;
+  constexpr int K = 256 * NSRC, ST = K + 8, KCS = K / 32, RPW = 32 / NW;
   constexpr int RD = 4;   // register prefetch ring depth in chunks (8 = the whole K = 256 panel up front was measured 1 % slower end to end)
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());

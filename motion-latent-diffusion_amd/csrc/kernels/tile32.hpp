@@ -50,13 +50,14 @@ struct Tile32Args {
   unsigned long long* trace = nullptr;   // measurement only: 8 timestamps per wave (see mldhip_profile_trace)
 };
 
-constexpr int kT32Stride = 260;                         // LDS row stride (floats): 256 + 4 pad
+constexpr int kT32Stride = 264;                         // LDS row stride (floats): 256 + 8 pad (= 8 mod 16: conflict-free ds_read_b128, gemm.hpp kGemmLdsStride)
 constexpr int kT32LdsFloats = (32 + 64) * kT32Stride + 32;   // A tile + W tile + per-row operand scales (PREC_FP8)
-constexpr int kT32LdsBytes = kT32LdsFloats * 4;              // 99,968 B -> one workgroup per CU
+constexpr int kT32LdsBytes = kT32LdsFloats * 4;              // 101,504 B -> one workgroup per CU
 
 // ---- operand formats shared by the loop kernels (tile32 / strip): an LDS row holds 256 K-values of one A or W row as
 // fp32 (256 words), bf16 (128 words) or e4m3 (64 words); lane l of the storing wave owns k = 4l..4l+3; a fragment of the
-// 32-wide K chunk kc is lane (r, g)'s 8 values k = 32kc + 8g .. +7 in every format (rt.hpp MFMA operand layouts).
+// 32-wide K chunk kc is lane (r, g)'s 8 values -- k = 32kc + 8g .. + 7 in the packed formats (rt.hpp MFMA operand layouts),
+// k = 32kc + 4g .. + 3 and 32kc + 16 + 4g .. + 3 in fp32 (any pairing is legal when A and W agree; this one is LDS-conflict free).
 template <int PREC>
 __device__ __forceinline__ void st_operand(float* row, int lane, F4 v, float scale) {
   if constexpr (PREC == PREC_F32) {
@@ -72,8 +73,8 @@ __device__ __forceinline__ void st_operand(float* row, int lane, F4 v, float sca
 template <int PREC>
 __device__ __forceinline__ void mma_chunk(const float* arow, const float* wrow, int kc, int g, f32x4& acc0, f32x4& acc1) {
   if constexpr (PREC == PREC_F32) {
-    const F4 a0 = ld4(arow + kc * 32 + g * 8), a1 = ld4(arow + kc * 32 + g * 8 + 4);
-    const F4 b0 = ld4(wrow + kc * 32 + g * 8), b1 = ld4(wrow + kc * 32 + g * 8 + 4);
+    const F4 a0 = ld4(arow + kc * 32 + g * 4), a1 = ld4(arow + kc * 32 + 16 + g * 4);   // k-slots 4g .. + 3 and 16 + 4g .. + 3 (A and W alike)
+    const F4 b0 = ld4(wrow + kc * 32 + g * 4), b1 = ld4(wrow + kc * 32 + 16 + g * 4);
     acc0 = mfma_f32_16x16x4(a0.x, b0.x, acc0);
     acc1 = mfma_f32_16x16x4(a0.y, b0.y, acc1);
     acc0 = mfma_f32_16x16x4(a0.z, b0.z, acc0);
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
   static_assert(MT == 16 || MT == 32, "row tile");
   static_assert(PREC == PREC_F32 || PREC == PREC_BF16 || PREC == PREC_FP8, "operand format");
   constexpr int RPW = MT / 8;                 // A rows assembled per wave
-  constexpr int KW = 256, ST = KW + 4;        // K columns resident in LDS, LDS row stride (floats)
+  constexpr int KW = 256, ST = kT32Stride;    // K columns resident in LDS, LDS row stride (floats)
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
 #else
