@@ -137,6 +137,9 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "strip_wide"      throughput kernels: 32 x 128 tiles for the wide GEMMs: 0 = auto (N >= 512), 1 = never, 2 = whenever N % 128 == 0
  *   "strip_waves"     throughput kernels: waves per workgroup of the 32 x 128 tiles, 4 or 8 (default 8)
  *   "strip_ffn2_split" throughput kernels: K slices (raw slabs) of the FFN2 GEMM, 1 or 2 (default 2)
+ *   "flash_attn"      split-bf16 modes, frame-level self-attention of the decoder / encoder: key-blocked online-softmax kernel with
+ *                     two workgroups per CU (kernels/attention.hpp attn_flash_x3_kernel): 0 = never, 1 = auto (default: calls
+ *                     with >= 512 (sample, head) pairs), 2 = always
  *   "fused_ffn"       split-bf16 modes: 1 (default) = linear1 + GELU + linear2 + residual + LayerNorm of a decoder / encoder layer as
  *                     ONE launch (kernels/ffn_fused.hpp; the hidden activation stays in LDS), 0 = the two staged GEMMs (A/B knob)
  *   "split_weights"   precision modes whose staged GEMMs run on split-bf16 MFMAs: 1 (default) = read the weights from the bf16

@@ -108,6 +108,7 @@ struct mldhip_engine {
   int strip_min_rows = 768;  // "strip_min_rows": auto switches to the throughput kernels at 6B >= this many token rows
   int strip_wide = 0;        // "strip_wide": 32 x 128 strip tiles for the wide GEMMs: 0 auto (N >= 512), 1 never, 2 whenever N % 128 == 0
   int strip_waves = 8;       // "strip_waves": waves per workgroup of the 32 x 128 strip tiles: 4 (two row tiles per wave) or 8 (one)
+  int flash_attn = 1;        // "flash_attn": split-bf16 frame-level self-attention key-blocked (attention.hpp attn_flash_x3_kernel): 0 never, 1 auto (>= 512 (sample, head) pairs), 2 always
   int fused_ffn = 1;         // "fused_ffn": split-bf16 decoder / encoder layers run linear1 + GELU + linear2 + residual + LayerNorm as one launch (kernels/ffn_fused.hpp)
   int split_weights = 1;     // "split_weights": split-bf16 staged GEMMs read the weights pre-split at finalize (0: split them in every workgroup)
   int strip_ffn2_split = 2;  // "strip_ffn2_split": K slices (= raw slabs) of FFN2 on the throughput kernels: 1 or 2

@@ -330,4 +330,206 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Key-blocked (online-softmax) form of attn_decode_x3_kernel for head dim 64: the same split-bf16 products and operand layouts,
+// but K and V pass through LDS in blocks of 32 keys (20 KB per stage, double buffered = 40 KB instead of 126 KB for a whole
+// (sample, head)), so two workgroups share a CU and one's staging, softmax and store drain run under the other's MFMAs; inside a
+// workgroup the next block's global loads are in flight while the current one is multiplied.  A wave works on BOTH of its query
+// tiles (wave w: tiles w and w + 8) per key block, so every K / V fragment it reads from LDS feeds two tiles.  One kernel for every
+// T (the block count is a run-time loop bound, uniform per workgroup).
+//   running max m, running sum l and the unnormalised output O per query; per block: S = Q K_blk^T, m' = max(m, max S),
+//   O *= exp(m - m'), P = exp(S - m'), l = l exp(m - m') + sum P, O += P V_blk; at the end O /= l.
+// Scores of query r live in lanes (r, g = 0..3) (swapped QK^T, as above) while the accumulator rows of lane (r, g) are queries
+// 4g + i: the per-query rescale factors are fetched with one lane shuffle per row (wave_bcast from lane 4g + i).
+constexpr int kFlashKStride = 40;    // words per K row of a block: 64 bf16 = 32 words + 8 pad (conflict-free ds_read_b128, gemm.hpp)
+constexpr int kFlashVStride = 20;    // words per V^T row of a block: 32 keys = 16 words + 4 pad (conflict-free ds_read_b64 at word 2g of row r)
+constexpr int kFlashStageWords = 2 * 32 * kFlashKStride + 2 * 64 * kFlashVStride;
+constexpr int kFlashLdsBytes = 2 * kFlashStageWords * 4;   // 40 960 B
+
+__global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                            const int* __restrict__ lens, int T, int H) {
+  constexpr int HD = 64, KST = kFlashKStride, VST = kFlashVStride, NW = 8;
+#if defined(MLDHIP_SIM)
+  unsigned* smem = reinterpret_cast<unsigned*>(hipsim::blk().dyn_smem.data());
+#else
+  extern __shared__ __attribute__((aligned(16))) unsigned smem_flash[];
+  unsigned* smem = smem_flash;
+#endif
+  const int D = H * HD;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int len = lens[b] < T ? lens[b] : T;
+  const int nkt = (len + 15) >> 4, nkb = (nkt + 1) >> 1, nqt = nkt;
+  const float* base = qkv + (long long)b * T * 3 * D + h * HD;
+
+  // ---- staging: thread t owns key (t >> 4) of the block, dims 4 (t & 15) .. + 3 of K and of V
+  const int skey = tid >> 4, c4 = tid & 15;
+  F4 kreg, vreg;
+  auto kvload = [&](int kb) {
+    const int key = kb * 32 + skey;
+    const int kc = key < len ? key : len - 1;
+    const float* p = base + (long long)kc * 3 * D + c4 * 4;
+    kreg = ld4(p + D);
+    vreg = ld4(p + 2 * D);
+  };
+  auto kvstore = [&](int kb) {
+    unsigned* Kh = smem + (kb & 1) * kFlashStageWords;
+    unsigned* Kl = Kh + 32 * KST;
+    unsigned* Vh = Kl + 32 * KST;
+    unsigned* Vl = Vh + 64 * VST;
+    const float m = kb * 32 + skey < len ? 1.f : 0.f;     // keys past the length: zero operands (their scores are masked as well)
+    unsigned h0, l0, h1, l1;
+    split_bf16_pair(kreg.x * m, kreg.y * m, h0, l0);
+    split_bf16_pair(kreg.z * m, kreg.w * m, h1, l1);
+    *reinterpret_cast<U2*>(Kh + skey * KST + c4 * 2) = U2{h0, h1};
+    *reinterpret_cast<U2*>(Kl + skey * KST + c4 * 2) = U2{l0, l1};
+    split_bf16_pair(vreg.x * m, vreg.y * m, h0, l0);
+    split_bf16_pair(vreg.z * m, vreg.w * m, h1, l1);
+    unsigned short* vh = reinterpret_cast<unsigned short*>(Vh) + skey;
+    unsigned short* vl = reinterpret_cast<unsigned short*>(Vl) + skey;
+    const int d0 = c4 * 4;
+    vh[(d0 + 0) * VST * 2] = (unsigned short)(h0 & 0xFFFFu); vh[(d0 + 1) * VST * 2] = (unsigned short)(h0 >> 16);
+    vh[(d0 + 2) * VST * 2] = (unsigned short)(h1 & 0xFFFFu); vh[(d0 + 3) * VST * 2] = (unsigned short)(h1 >> 16);
+    vl[(d0 + 0) * VST * 2] = (unsigned short)(l0 & 0xFFFFu); vl[(d0 + 1) * VST * 2] = (unsigned short)(l0 >> 16);
+    vl[(d0 + 2) * VST * 2] = (unsigned short)(l1 & 0xFFFFu); vl[(d0 + 3) * VST * 2] = (unsigned short)(l1 >> 16);
+  };
+  kvload(0);
+
+  // ---- this wave's query tiles: fragments of Q (pre-scaled by 1/sqrt(64), split hi / lo), running statistics, output accumulators
+  bool live[2];
+  U4 qh[2][2], ql[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int qt = wave + NW * t;
+    live[t] = qt < nqt;
+    int qrow = qt * 16 + r;
+    qrow = qrow < T ? qrow : T - 1;
+    const float* qp = base + (long long)qrow * 3 * D + g * 8;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const F4 t0 = ld4(qp + c * 32), t1 = ld4(qp + c * 32 + 4);
+      const float x[8] = {t0.x * 0.125f, t0.y * 0.125f, t0.z * 0.125f, t0.w * 0.125f, t1.x * 0.125f, t1.y * 0.125f, t1.z * 0.125f, t1.w * 0.125f};
+      split_hi_lo_x8(x, qh[t][c], ql[t][c]);
+    }
+  }
+  const int nt = live[1] ? 2 : 1;                  // waves 13 - 8 .. 7 of a 13-tile sequence have one tile: no MFMAs for a dead second one
+  float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+  f32x4 oacc[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  kvstore(0);
+  if (nkb > 1) kvload(1);
+  __syncthreads();
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    const unsigned* Kh = smem + (kb & 1) * kFlashStageWords;
+    const unsigned* Kl = Kh + 32 * KST;
+    const unsigned* Vh = Kl + 32 * KST;
+    const unsigned* Vl = Vh + 64 * VST;
+    if (live[0]) {                                // waves without a query tile only stage (wave-uniform branch)
+      // S = K_blk Q^T for the two 16-key tiles of the block, both query tiles
+      f32x4 s[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) s[t][k2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const U4 kh = *reinterpret_cast<const U4*>(Kh + (k2 * 16 + r) * KST + c * 16 + g * 4);
+          const U4 kl = *reinterpret_cast<const U4*>(Kl + (k2 * 16 + r) * KST + c * 16 + g * 4);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            if (t < nt) {
+              s[t][k2] = mfma_bf16_16x16x32(kl, qh[t][c], s[t][k2]);
+              s[t][k2] = mfma_bf16_16x16x32(kh, ql[t][c], s[t][k2]);
+              s[t][k2] = mfma_bf16_16x16x32(kh, qh[t][c], s[t][k2]);
+            }
+          }
+        }
+      U4 ph[2], pl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t >= nt) continue;
+        // online softmax of query r over this block's keys 32 kb + 16 k2 + 4 g + i
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool valid = kb * 32 + k2 * 16 + g * 4 + i < len;
+            s[t][k2][i] = valid ? s[t][k2][i] : -INFINITY;
+            mx = fmaxf(mx, s[t][k2][i]);
+          }
+        mx = max_groups(mx);
+        const float mnew = fmaxf(mrun[t], mx);     // finite: key 32 kb < len
+        const float alpha = expf(mrun[t] - mnew);  // exp(-inf) = 0 on the first block
+        float psum = 0.f;
+        float pf[8];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float e = expf(s[t][k2][i] - mnew);   // exp(-inf) = 0 for masked keys
+            pf[k2 * 4 + i] = e;
+            psum += e;
+          }
+        psum = sum_groups(psum);
+        lrun[t] = lrun[t] * alpha + psum;
+        mrun[t] = mnew;
+        split_hi_lo_x8(pf, ph[t], pl[t]);
+        // accumulator row i of this lane is query 4 g + i: its rescale factor sits in lane 4 g + i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float a = wave_bcast(alpha, g * 4 + i);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) oacc[t][dt][i] *= a;
+        }
+      }
+      // O += P V_blk: k-slot 8 g + j <-> key (j >> 2) * 16 + 4 g + (j & 3) of the block
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const unsigned* vh = Vh + (dt * 16 + r) * VST + g * 2;
+        const unsigned* vl = Vl + (dt * 16 + r) * VST + g * 2;
+        const U2 a0 = *reinterpret_cast<const U2*>(vh), a1 = *reinterpret_cast<const U2*>(vh + 8);
+        const U2 b0 = *reinterpret_cast<const U2*>(vl), b1 = *reinterpret_cast<const U2*>(vl + 8);
+        const U4 vhh = U4{a0.x, a0.y, a1.x, a1.y}, vll = U4{b0.x, b0.y, b1.x, b1.y};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if (t < nt) {
+            oacc[t][dt] = mfma_bf16_16x16x32(pl[t], vhh, oacc[t][dt]);
+            oacc[t][dt] = mfma_bf16_16x16x32(ph[t], vll, oacc[t][dt]);
+            oacc[t][dt] = mfma_bf16_16x16x32(ph[t], vhh, oacc[t][dt]);
+          }
+        }
+      }
+    }
+    if (kb + 1 < nkb) {
+      kvstore(kb + 1);
+      if (kb + 2 < nkb) kvload(kb + 2);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (!live[t]) continue;
+    const int qt = wave + NW * t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float inv = 1.0f / wave_bcast(lrun[t], g * 4 + i);
+      const int q = qt * 16 + g * 4 + i;
+      if (q < T) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[(long long)(b * T + q) * D + h * HD + dt * 16 + r] = oacc[t][dt][i] * inv;
+      }
+    }
+  }
+}
+
 }  // namespace mld

@@ -35,6 +35,15 @@ __device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
 #endif
 }
 
+// a value that is the same in every lane of the wave (e.g. threadIdx.x >> 6), moved to an SGPR so that branches on it are scalar
+__device__ __forceinline__ int wave_uniform(int v) {
+#if defined(MLDHIP_SIM)
+  return v;
+#else
+  return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
 __device__ __forceinline__ float wave_xor(float v, int mask) {
 #if defined(MLDHIP_SIM)
   return hipsim::shfl_xor(v, mask);

@@ -292,6 +292,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "strip_waves") {
     if (value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "strip_waves must be 4 or 8");
     e->strip_waves = (int)value;
+  } else if (n == "flash_attn") {
+    if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "flash_attn must be 0 (never), 1 (auto) or 2 (always)");
+    e->flash_attn = (int)value;
   } else if (n == "fused_ffn") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "fused_ffn must be 0 or 1");
     e->fused_ffn = (int)value;

@@ -650,3 +650,28 @@ def test_fused_ffn_block_equals_the_two_staged_gemms_sim(ow, aow):
         outs.append(f)
     assert np.abs(outs[0]).max() > 1e-3 and np.array_equal(outs[0], outs[1])
     e.close()
+
+
+def test_key_blocked_attention_matches_whole_kv_attention_sim(ow):
+    """attn_flash_x3_kernel ("flash_attn" = 2: online softmax over 32-key blocks, both query tiles of a wave per block) against
+    attn_decode_x3_kernel (= 0: all of K / V of a (sample, head) in LDS) inside the split-bf16 decoder: ragged lengths, an odd number
+    of key tiles (T = 100 -> 7), a length that is not a multiple of 16, more query tiles than waves (150 of 196 frames -> 10).  Different
+    summation order and an unnormalised P operand: features within 5e-5 of each other and both within 2e-4 of the fp32 oracle."""
+    ops, _, bv = ow
+    for B, T, lens in ((2, 100, [100, 37]), (1, 196, [150])):
+        e = simlib.sim_engine(max_batch=B, max_frames=T, num_inference_steps=2, precision=1)
+        e.set_option("gemm_small_m", 0)
+        z = syn._rng(8, "x3attn").standard_normal((B, 1, 256)).astype(np.float32)
+        ref = np.asarray(O.vae_decode(ops, bv, z, lens))
+        outs = []
+        for fl in (2, 0):
+            e.set_option("flash_attn", fl)
+            feats = np.zeros((B, T, 263), np.float32)
+            e.vae_decode(z, lens, feats)
+            assert 1e-7 < np.abs(feats - ref).max() < 2e-4
+            for i, n in enumerate(lens):
+                assert np.all(feats[i, n:] == 0)
+            outs.append(feats)
+        d = np.abs(outs[0] - outs[1]).max()
+        assert 0 < d < 5e-5, d
+        e.close()
