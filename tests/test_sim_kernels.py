@@ -668,7 +668,7 @@ def test_key_blocked_attention_matches_whole_kv_attention_sim(ow):
             e.set_option("flash_attn", fl)
             feats = np.zeros((B, T, 263), np.float32)
             e.vae_decode(z, lens, feats)
-            assert 1e-7 < np.abs(feats - ref).max() < 2e-4
+            assert 1e-7 < np.abs(feats[:, :max(lens)] - ref).max() < 2e-4
             for i, n in enumerate(lens):
                 assert np.all(feats[i, n:] == 0)
             outs.append(feats)
