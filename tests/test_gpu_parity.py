@@ -888,6 +888,32 @@ def test_fused_ffn_block_matches_the_two_staged_gemms_on_gpu(dev, golden_dir):
     e.close()
 
 
+def test_key_blocked_attention_matches_whole_kv_attention_on_gpu(dev, golden_dir):
+    """precision = BF16X3_DECODE: attn_flash_x3_kernel ("flash_attn" = 2; auto picks it from 512 (sample, head) pairs up) vs
+    attn_decode_x3_kernel (= 0) on the benchmarked shape, full-length and ragged: joints within 5e-5 of each other (summation
+    order, unnormalised P operand), and the key-blocked path inside the joints contract on the reference fixture."""
+    g = _gold(golden_dir, "pipeline_b64.npz")
+    e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=1)
+    _load(e)
+    outs = {}
+    for name, b in (("full", syn.make_batch(64)), ("ragged", syn.make_batch(64, "ragged", seed=5))):
+        for fl in (2, 0):
+            e.set_option("flash_attn", fl)
+            lat, feats, joints, _ = _run_sample(e, dev, b)
+            assert torch.isfinite(joints).all()
+            outs[name, fl] = (feats.clone(), joints.clone())
+        df = float((outs[name, 2][0] - outs[name, 0][0]).abs().max())
+        dj = float((outs[name, 2][1] - outs[name, 0][1]).abs().max())
+        print("%s: key-blocked vs whole-K/V attention: feats %.2e joints %.2e" % (name, df, dj))
+        assert 0 < df < 5e-5 and dj < 1e-4
+        for i, n in enumerate(b.lengths):
+            assert torch.all(outs[name, 2][0][i, n:] == 0)
+    err = float(np.abs(outs["full", 2][1].cpu().numpy()[:, ::4] - g["joints_every4"]).max())
+    print("key-blocked attention, joints vs reference golden: %.2e" % err)
+    assert err < 1e-3
+    e.close()
+
+
 def test_config3_shape_512_prompts_through_the_dp_sampler(dev):
     """BASELINE config 3 on the ranks this box has (1): 512 synthetic prompts, bs 64, sharded by DataParallelSampler -- every
     prompt exactly once and in order, and the coalesced + overlapped serving shape (4 chunks per engine call, 2 calls in flight)
