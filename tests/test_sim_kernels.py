@@ -655,10 +655,10 @@ def test_fused_ffn_block_equals_the_two_staged_gemms_sim(ow, aow):
 def test_key_blocked_attention_matches_whole_kv_attention_sim(ow):
     """attn_flash_x3_kernel ("flash_attn" = 2: online softmax over 32-key blocks, both query tiles of a wave per block) against
     attn_decode_x3_kernel (= 0: all of K / V of a (sample, head) in LDS) inside the split-bf16 decoder: ragged lengths, an odd number
-    of key tiles (T = 100 -> 7), a length that is not a multiple of 16, more query tiles than waves (150 of 196 frames -> 10).  Different
+    of key tiles (T = 68 -> 5), lengths that are not multiples of 16, more query tiles than waves (130 frames -> 9).  Different
     summation order and an unnormalised P operand: features within 5e-5 of each other and both within 2e-4 of the fp32 oracle."""
     ops, _, bv = ow
-    for B, T, lens in ((2, 100, [100, 37]), (1, 196, [150])):
+    for B, T, lens in ((2, 68, [68, 37]), (1, 144, [130])):
         e = simlib.sim_engine(max_batch=B, max_frames=T, num_inference_steps=2, precision=1)
         e.set_option("gemm_small_m", 0)
         z = syn._rng(8, "x3attn").standard_normal((B, 1, 256)).astype(np.float32)
