@@ -220,6 +220,85 @@ void denoiser_body(Ctx& c, const DenView& v) {
   }
 }
 
+// ---- sample-major persistent loop (kernels/loop_fused.hpp): built for the configurations the released checkpoints use
+bool fused_built(const E* e) {
+  return !is_novae(e) && e->cfg.latent_dim == 256 && e->cfg.ff_size == 1024 && e->cfg.num_heads == 4 && loop_prec(e) == PREC_F32;
+}
+bool use_fused(const E* e, int B) {
+  return e->loop_ips > 0 && (e->loop_kernel == 3 || (e->loop_kernel == 0 && B >= e->fused_min_batch));
+}
+
+// finalize-time: the denoiser's GEMM weights as the item stream the loop kernel consumes, its small parameters packed, the
+// DDIM coefficients of the scheduler's steps.  Item order = the kernel's phase order (loop_fused.hpp).
+int build_loop_stream(Ctx& c) {
+  E* e = c.e;
+  e->loop_ips = 0;
+  if (!fused_built(e) || !e->group_ready[0]) return 0;
+  const int L = e->cfg.num_layers, nb = (L - 1) / 2, n = e->cfg.num_inference_steps, F = e->cfg.ff_size;
+  std::vector<LoopItem> items;
+  auto push = [&](const float* w, int ld, int row0, int k0) { items.push_back(LoopItem{(long long)(w - e->arena) + (long long)row0 * ld + k0, ld, 0}); };
+  for (int l = 0; l < L; ++l) {
+    const EncLayerP& P_ = e->den[l];
+    for (int hp = 0; hp < 2; ++hp)
+      for (int part = 0; part < 3; ++part)
+        for (int kc = 0; kc < 8; ++kc) push(P_.in_w, 256, part * 256 + hp * 128, kc * 32);
+    for (int cb = 0; cb < 2; ++cb)
+      for (int kc = 0; kc < 8; ++kc) push(P_.out_w, 256, cb * 128, kc * 32);
+    for (int hb = 0; hb < 8; ++hb) {
+      for (int kc = 0; kc < 8; ++kc) push(P_.l1_w, 256, hb * 128, kc * 32);
+      for (int cb = 0; cb < 2; ++cb)
+        for (int kc = 0; kc < 4; ++kc) push(P_.l2_w, F, cb * 128, hb * 128 + kc * 32);
+    }
+    if (l >= nb && l + 1 < L) {
+      const float* w = P(e, "denoiser.encoder.linear_blocks." + std::to_string(l - nb) + ".weight");
+      for (int half = 0; half < 2; ++half)
+        for (int cb = 0; cb < 2; ++cb)
+          for (int kc = 0; kc < 8; ++kc) push(w, 512, cb * 128, half * 256 + kc * 32);
+    }
+  }
+  const size_t ips = items.size(), small_floats = (size_t)L * kLsLayer + (size_t)nb * 256 + 768, tail = (size_t)n * 4;
+  if (e->loop_stream) { (void)hipFree(e->loop_stream); e->loop_stream = nullptr; }
+  if (e->loop_small) { (void)hipFree(e->loop_small); e->loop_small = nullptr; }
+  LoopItem* items_dev = nullptr;
+  if (hipMalloc((void**)&e->loop_stream, ips * kLoopItemFloats * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&e->loop_small, (small_floats + tail) * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&items_dev, ips * sizeof(LoopItem)) != hipSuccess)
+    return e->fail(MLDHIP_EHIP, "hipMalloc(sample-major loop tables)");
+  e->loop_ddim = e->loop_small + small_floats;
+  hipError_t st = hipMemcpy(items_dev, items.data(), ips * sizeof(LoopItem), hipMemcpyHostToDevice);
+  if (st == hipSuccess) {
+    MLD_LAUNCH(pack_loop_stream_kernel, dim3((unsigned)ips), dim3(256), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->loop_stream);
+    check_launch(c, "pack_loop_stream");
+    st = hipStreamSynchronize(c.stream);
+  }
+  (void)hipFree(items_dev);
+  if (st != hipSuccess) return e->fail(MLDHIP_EHIP, "sample-major loop tables: %s", hipGetErrorString(st));
+  if (c.rc) return c.rc;
+  auto put = [&](size_t off, const float* src, size_t nfl) {
+    if (st == hipSuccess) st = hipMemcpy(e->loop_small + off, src, nfl * sizeof(float), hipMemcpyDeviceToDevice);
+  };
+  for (int l = 0; l < L; ++l) {
+    const EncLayerP& P_ = e->den[l];
+    const size_t o = (size_t)l * kLsLayer;
+    put(o + kLsInB, P_.in_b, 768); put(o + kLsOutB, P_.out_b, 256); put(o + kLsN1W, P_.n1_w, 256); put(o + kLsN1B, P_.n1_b, 256);
+    put(o + kLsL1B, P_.l1_b, 1024); put(o + kLsL2B, P_.l2_b, 256); put(o + kLsN2W, P_.n2_w, 256); put(o + kLsN2B, P_.n2_b, 256);
+  }
+  size_t o = (size_t)L * kLsLayer;
+  for (int i = 0; i < nb; ++i, o += 256) put(o, P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".bias"), 256);
+  put(o, P(e, "denoiser.encoder.norm.weight"), 256);
+  put(o + 256, P(e, "denoiser.encoder.norm.bias"), 256);
+  put(o + 512, P(e, "denoiser.query_pos.pe"), 256);
+  std::vector<float> coef((size_t)n * 4);
+  for (int s = 0; s < n; ++s) {
+    const DdimCoef k = ddim_coef(e, e->timesteps[s]);
+    coef[4 * s] = k.sqrt_at; coef[4 * s + 1] = k.sqrt_1mat; coef[4 * s + 2] = k.sqrt_ap; coef[4 * s + 3] = k.sqrt_1map;
+  }
+  if (st == hipSuccess) st = hipMemcpy(e->loop_ddim, coef.data(), coef.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (st != hipSuccess) return e->fail(MLDHIP_EHIP, "sample-major loop tables: %s", hipGetErrorString(st));
+  e->loop_ips = (int)ips;
+  return 0;
+}
+
 FinalArgs den_final_args(E* e, const DenView& v) {
   const EncLayerP& L = e->den.back();
   FinalArgs f;
@@ -505,7 +584,16 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
   e->phase = 0;
   if (text) text_projection(c, text, 2 * B, e->TP);
   else action_rows(c, 2 * B, B, e->TP);
-  {
+  if (use_fused(e, B)) {
+    // the whole reverse loop as one persistent launch: a workgroup per 8 motions (kernels/loop_fused.hpp)
+    LoopArgs a;
+    a.stream = e->loop_stream; a.ips = e->loop_ips; a.small = e->loop_small; a.T1 = e->T1; a.TP = e->TP; a.init_lat = init_lat;
+    a.lat = e->lat; a.skip = e->FS; a.ddim = e->loop_ddim; a.B = B; a.L = e->cfg.num_layers; a.n = n;
+    a.guidance = guidance; a.init_sigma = 1.0f;
+    MLD_LAUNCH(den_loop_kernel, dim3((B + 7) / 8), dim3(512), kLoopLdsBytes, stream, a);
+    count(c);
+    check_launch(c, "den_loop");
+  } else {
     const DenView v = den_view(e, 2 * B);
     MLD_LAUNCH(init_chain_kernel, dim3(B), dim3(256), 0, stream, init_lat, v.lat, v.X0, P(e, "denoiser.query_pos.pe"),
                (const float*)e->T1, (const float*)e->TP, B, 0, B, 1.0f /* init_noise_sigma */);

@@ -65,6 +65,10 @@ struct mldhip_engine {
   std::vector<Param> params;
   std::map<std::string, int> index;
   float* arena = nullptr;
+  float* loop_stream = nullptr;   // sample-major loop (kernels/loop_fused.hpp): GEMM weights of the denoiser re-packed in consumption order
+  float* loop_small = nullptr;    // ... its biases / LayerNorm parameters, packed; then the DDIM coefficients [n][4]
+  float* loop_ddim = nullptr;
+  int loop_ips = 0;               // weight items per reverse step (0: the variant is not built for this configuration)
   float* arena_x3 = nullptr;  // split-bf16 image of the arena (precision modes with split-bf16 staged GEMMs; built by finalize)
   size_t arena_floats = 0;
   std::vector<EncLayerP> den;      // execution order
@@ -93,6 +97,7 @@ struct mldhip_engine {
   float *X0, *Ha, *Hb, *H1, *S[8], *QKV, *AO, *FF, *lat, *T1, *temb0, *tmid, *text_bias, *t1_one, *temb0_one, *time_b2pe;
   // decode
   float *cv1, *cvec, *LNO, *feats_int, *joints_int, *zbuf;
+  float* FS = nullptr;   // sample-major loop: parked skip activations [ceil(max_batch / 8)][nb][48][256]
   float *Po, *Pf, *Ps;   // denoiser split-K slabs: out-proj [1], FFN2 [4], skip-linear [2], each [6*max_batch][256]
   unsigned long long* trace_buf = nullptr;   // measurement only (mldhip_profile_trace)
   unsigned long long* trace_on = nullptr;    // non-null while a traced launch is being built
@@ -104,7 +109,8 @@ struct mldhip_engine {
   float* TP;             // text projection rows [2*max_batch][256] (+pe[2]), gathered per chain
   // per-handle options (mldhip_set_option)
   int small_m = 256;         // "gemm_small_m": row count up to which the register-direct tiny-GEMM shape is used
-  int loop_kernel = 0;       // "loop_kernel": 0 auto (by rows), 1 latency kernels (tile32.hpp), 2 throughput kernels (strip.hpp)
+  int loop_kernel = 0;       // "loop_kernel": 0 auto (by rows / motions), 1 latency kernels (tile32.hpp), 2 throughput kernels (strip.hpp), 3 sample-major persistent loop (loop_fused.hpp)
+  int fused_min_batch = 1024;// "fused_min_batch": auto picks the sample-major loop from this many motions per call up
   int strip_min_rows = 768;  // "strip_min_rows": auto switches to the throughput kernels at 6B >= this many token rows
   int strip_wide = 0;        // "strip_wide": 32 x 128 strip tiles for the wide GEMMs: 0 auto (N >= 512), 1 never, 2 whenever N % 128 == 0
   int strip_waves = 8;       // "strip_waves": waves per workgroup of the 32 x 128 strip tiles: 4 (two row tiles per wave) or 8 (one)

@@ -1,0 +1,438 @@
+// The whole reverse-diffusion loop of the latent models as ONE persistent launch ("sample-major" loop).
+//
+// Why it exists.  In the denoiser (mld_denoiser.py:135-228) a motion only ever meets its own three tokens [latent, time, text]
+// (the 3-token self-attention of cross_attention.py:259-272), its own unconditional / conditional pair (classifier-free guidance,
+// mld.py:339-342) and its own latent (the DDIM step, mld.py:345-346): motions never interact.  The launch-per-GEMM families
+// (tile32.hpp, strip.hpp) nevertheless send every activation through HBM / L2 41 times per step and pay 2 050 dependent launches
+// per call, because they split each GEMM over the CUs by output COLUMNS.  Here the work is split by MOTIONS instead: a workgroup
+// owns 8 motions = 16 rows of the CFG batch x 3 tokens = 48 token rows for the whole call, keeps them in LDS, and streams the
+// weights: 1 launch, no inter-workgroup traffic, no activation ever leaves the CU (except the four skip activations, parked in a
+// workgroup-private slice of HBM), and the matrix pipe is the only thing left to wait for:
+//   per reverse step and workgroup  48 rows x 7.6 M weights x 2 = 730 MFLOP  against  30.4 MB of weights streamed from L2 / MALL
+//   = 24 FLOP per byte: at the CU's fp32-MFMA rate (256 FLOP/clk) the stream needs 10.7 B/clk/CU, well under the ~25 B/clk/CU
+//   the register-ring + ds_write staging of the other kernels sustains, so the kernel is MFMA bound by construction.
+// It wins once a call carries enough motions to give most CUs a workgroup (B >= ~1 000; 2 048 motions = 256 workgroups = one
+// per CU); below that the column-split families finish sooner (path_latent.hpp use_fused).
+//
+// Row order inside the workgroup: row = 16 t + c, t = token, c = row of the CFG batch (c < 8: unconditional half of the 8
+// motions, c >= 8: conditional half).  A 16-row MFMA tile is then ONE token of all 16 CFG rows, so the accumulator registers of
+// lane (r, g) for the three row tiles hold the three tokens of the SAME (CFG row 4g + i, column r): the 3-token attention, the
+// softmax and P.V are in-lane arithmetic on accumulators (only the 64-column dot products cross lanes: 4 DPP adds + one LDS
+// exchange among the four waves of a head), and q, k, v never exist in memory.
+//
+// Weight stream: `finalize` re-packs the denoiser's GEMM weights into the order this kernel consumes them, as "items" of
+// 128 output columns x 32 k (16 KB, rows contiguous): every thread fetches 2 x 16 bytes per item into a 4-deep register ring,
+// stores them to a double-buffered LDS stage, one barrier per item; each wave multiplies its 16 of the 128 columns against the
+// three row tiles (24 MFMAs per item and wave = 1 536 cycles per SIMD with two waves).  The sequence is uniform over phases,
+// layers and steps (it wraps at the end of a step), so the prefetch never drains.
+//
+// Replaces, per step: mld_denoiser.py:143-228 (token assembly, SkipTransformerEncoder, final norm), mld.py:325-346 (CFG + DDIM).
+#pragma once
+#include "tile32.hpp"
+
+namespace mld {
+
+// packed biases / LayerNorm parameters (floats): per layer [in_b 768 | out_b 256 | n1_w 256 | n1_b 256 | l1_b 1024 | l2_b 256 | n2_w 256 | n2_b 256],
+// then skip-linear biases [nb][256], encoder.norm weight / bias, query_pos.pe[0]
+constexpr int kLsInB = 0, kLsOutB = 768, kLsN1W = 1024, kLsN1B = 1280, kLsL1B = 1536, kLsL2B = 2560, kLsN2W = 2816, kLsN2B = 3072, kLsLayer = 3328;
+
+// items of one layer: QKV 48, out-proj 16, feed-forward 128; a skip linear: 32
+constexpr int kLoopItemsLayer = 192, kLoopItemsSkip = 32, kLoopItemFloats = 128 * 32;
+
+struct LoopItem { long long src; int ld; int pad; };   // element [row0][k0] of a weight (floats into the arena), row stride
+
+struct LoopArgs {
+  const float* stream;     // [ips][128][32] weight items in consumption order
+  int ips;                 // items per reverse step
+  const float* small;      // packed small parameters (layout above)
+  const float* T1;         // [n][256] time-token rows (time MLP + pe[1]) of the scheduler's timesteps
+  const float* TP;         // [2B][256] condition-token rows (+ pe[2]), unconditional half first
+  const float* init_lat;   // [B][256]
+  float* lat;              // [B][256] latents after the last step
+  float* skip;             // [gridDim.x][nb][48][256] workgroup-private skip activations
+  const float* ddim;       // [n][4] DdimCoef per step
+  int B, L, n;
+  float guidance, init_sigma;
+};
+
+constexpr int kLfXs = 264, kLfHs = 136, kLfWs = 40;      // LDS row strides (words), all = 8 mod 16: conflict-free fragment reads (strip.hpp)
+constexpr int kLfXFloats = 48 * kLfXs, kLfWBuf = 128 * kLfWs, kLfScFloats = 8 * 144, kLfRedFloats = 2 * 8 * 48, kLfLatFloats = 8 * 256;
+constexpr int kLoopLdsBytes = (2 * kLfXFloats + 2 * kLfWBuf + kLfScFloats + kLfRedFloats + kLfLatFloats) * 4;   // 158 208 B: one workgroup per CU
+
+// finalize-time: gathers the weight items into consumption order.  grid = items, block = 256.
+__global__ __launch_bounds__(256) void pack_loop_stream_kernel(const float* __restrict__ arena, const LoopItem* __restrict__ items,
+                                                               float* __restrict__ out) {
+  const LoopItem it = items[blockIdx.x];
+  for (int q = threadIdx.x; q < 1024; q += 256) {
+    const int row = q >> 3, c4 = q & 7;
+    st4(out + (long long)blockIdx.x * kLoopItemFloats + row * 32 + c4 * 4, ld4(arena + it.src + (long long)row * it.ld + c4 * 4));
+  }
+}
+
+// grid = ceil(B / 8), block = 512 (8 waves, two per SIMD).
+__global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
+#if defined(MLDHIP_SIM)
+  float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
+#else
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+#endif
+  float* Xs = smem;                       // [48][264] layer input / norm1 output (A operand, residual)
+  float* As = Xs + kLfXFloats;            // [48][264] attention output, or [48][136] one 128-wide block of the hidden activation
+  float* Ws = As + kLfXFloats;            // [2][128][40] weight item stage
+  float* sc = Ws + 2 * kLfWBuf;           // [8][9][16] per-wave partial attention scores
+  float* red = sc + kLfScFloats;          // [2][8][48] per-wave LayerNorm partial sums
+  float* lats = red + kLfRedFloats;       // [8][256] the workgroup's latents
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int s0 = blockIdx.x * 8, nb = (p.L - 1) / 2;
+  const float* sm_skip = p.small + (long long)p.L * kLsLayer;
+  const float* sm_fin = sm_skip + nb * 256;
+
+  // ---- weight ring: thread t holds 16 bytes of rows (t >> 3) and (t >> 3) + 64 of the items in flight
+  const int wrow = tid >> 3, wc4 = tid & 7;
+  const float* gsrc = p.stream + wrow * 32 + wc4 * 4;
+  float* wdst = Ws + wrow * kLfWs + wc4 * 4;
+  int gitem = 0;
+  F4 ring[4][2];
+  auto gload = [&](int slot) __attribute__((always_inline)) {
+    const float* s = gsrc + (long long)gitem * kLoopItemFloats;
+    ring[slot][0] = ld4(s);
+    ring[slot][1] = ld4(s + 64 * 32);
+    gitem = gitem + 1 == p.ips ? 0 : gitem + 1;
+  };
+  auto lstore = [&](int slot, int buf) __attribute__((always_inline)) {
+    st4(wdst + buf * kLfWBuf, ring[slot][0]);
+    st4(wdst + buf * kLfWBuf + 64 * kLfWs, ring[slot][1]);
+  };
+  // Items are numbered j = 0..7 inside a group of eight (every phase is a whole number of groups).  Before item j, LDS buffer
+  // j & 1 holds it and ring slots (j + 1) & 3 .. (j + 4) & 3 hold the next four.  stage(j) runs after item j's MFMAs.
+  auto stage = [&](int j) __attribute__((always_inline)) {
+    lstore((j + 1) & 3, (j + 1) & 1);
+    gload((j + 1) & 3);
+    __syncthreads();
+  };
+  // one item: this wave's 16 weight rows (= output columns) x 32 k against the three row tiles; `a` = row r of tile 0 at the
+  // chunk's first word + 4g, next tile `ts` words on.  3 independent accumulators x 8 k-steps: no MFMA waits for its predecessor.
+  const float* wfrag = Ws + (wave * 16 + r) * kLfWs + g * 4;
+  auto mma_item = [&](int j, const float* a, int ts, f32x4 (&acc)[3]) __attribute__((always_inline)) {
+    const float* w = wfrag + (j & 1) * kLfWBuf;
+    const F4 y0 = ld4(w), y1 = ld4(w + 16);
+    F4 x[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { x[t][0] = ld4(a + t * ts); x[t][1] = ld4(a + t * ts + 16); }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].x, y0.x, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].y, y0.y, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].z, y0.z, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].w, y0.w, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].x, y1.x, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].y, y1.y, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].z, y1.z, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].w, y1.w, acc[t]);
+  };
+  // items j0 .. j0 + n - 1 of the current group against consecutive 32-wide chunks of A starting at a0; the last item's
+  // stage() is left to the caller when it has something to publish before that barrier (stage_last = false)
+  auto run = [&](int j0, int n, const float* a0, int ts, f32x4 (&acc)[3], bool stage_last) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < n; ++c) {
+      mma_item(j0 + c, a0 + 32 * c, ts, acc);
+      if (c + 1 < n || stage_last) stage(j0 + c);
+    }
+  };
+  auto zero3 = [](f32x4 (&a)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // LayerNorm over the 256 columns of the 48 rows; v[cb][t][i] = this lane's element (row 16t + 4g + i, column 128cb + 16wave + r).
+  // Part 1 publishes the per-wave row sums (the caller then passes a barrier: stage() or __syncthreads()); part 2 finishes.
+  auto ln_part1 = [&](const float (&v)[2][3][4], int nt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (t < nt) {
+        F4 s;
+        s.x = sum16(v[0][t][0] + v[1][t][0]); s.y = sum16(v[0][t][1] + v[1][t][1]);
+        s.z = sum16(v[0][t][2] + v[1][t][2]); s.w = sum16(v[0][t][3] + v[1][t][3]);
+        if (r == 0) st4(red + wave * 48 + t * 16 + g * 4, s);
+      }
+    }
+  };
+  auto ln_part2 = [&](float (&v)[2][3][4], int nt, const float* gamma, const float* beta) __attribute__((always_inline)) {
+    const float g0 = gamma[wave * 16 + r], g1 = gamma[128 + wave * 16 + r], b0 = beta[wave * 16 + r], b1 = beta[128 + wave * 16 + r];
+    float sq[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (t < nt) {
+        F4 m = ld4(red + t * 16 + g * 4);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = f4add(m, ld4(red + w * 48 + t * 16 + g * 4));
+        const float mean[4] = {m.x * (1.0f / 256.0f), m.y * (1.0f / 256.0f), m.z * (1.0f / 256.0f), m.w * (1.0f / 256.0f)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[0][t][i] -= mean[i];
+          v[1][t][i] -= mean[i];
+          sq[t][i] = sum16(v[0][t][i] * v[0][t][i] + v[1][t][i] * v[1][t][i]);
+        }
+        if (r == 0) st4(red + 384 + wave * 48 + t * 16 + g * 4, F4{sq[t][0], sq[t][1], sq[t][2], sq[t][3]});
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (t < nt) {
+        F4 q = ld4(red + 384 + t * 16 + g * 4);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) q = f4add(q, ld4(red + 384 + w * 48 + t * 16 + g * 4));
+        const float rs[4] = {rsqrtf(q.x * (1.0f / 256.0f) + kLnEps), rsqrtf(q.y * (1.0f / 256.0f) + kLnEps),
+                             rsqrtf(q.z * (1.0f / 256.0f) + kLnEps), rsqrtf(q.w * (1.0f / 256.0f) + kLnEps)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[0][t][i] = v[0][t][i] * rs[i] * g0 + b0;
+          v[1][t][i] = v[1][t][i] * rs[i] * g1 + b1;
+        }
+      }
+    }
+  };
+
+  // token rows of one reverse step from the latents: row 16t + c; t = 0: latent + pe[0] (both CFG halves), 1: the step's time
+  // row, 2: the condition rows (mld_denoiser.py:143-196; rows beyond B repeat motion B - 1 and are never written back)
+  auto assemble = [&](int step) __attribute__((always_inline)) {
+    const float* pe0 = sm_fin + 512;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int q = tid + 512 * j, row = q >> 6, c4 = q & 63, c = row & 15;
+      F4 v;
+      if (row < 16) {
+        v = f4add(ld4(lats + (c & 7) * 256 + c4 * 4), ld4(pe0 + c4 * 4));
+      } else if (row < 32) {
+        v = ld4(p.T1 + (long long)step * 256 + c4 * 4);
+      } else {
+        int s = s0 + (c & 7);
+        s = s < p.B ? s : p.B - 1;
+        v = ld4(p.TP + (long long)((c < 8 ? 0 : p.B) + s) * 256 + c4 * 4);
+      }
+      st4(Xs + row * kLfXs + c4 * 4, v);
+    }
+  };
+
+  // ---- prologue: item 0 -> LDS buffer 0, items 1..4 -> ring slots 1, 2, 3, 0; latents; first step's token rows
+  gload(0);
+  lstore(0, 0);
+  gload(1); gload(2); gload(3); gload(0);
+  {
+    const int c = tid >> 6, c4 = tid & 63;
+    int s = s0 + c;
+    s = s < p.B ? s : p.B - 1;
+    F4 v = ld4(p.init_lat + (long long)s * 256 + c4 * 4);
+    st4(lats + c * 256 + c4 * 4, F4{v.x * p.init_sigma, v.y * p.init_sigma, v.z * p.init_sigma, v.w * p.init_sigma});
+  }
+  __syncthreads();
+  assemble(0);
+  __syncthreads();
+
+  const float* xa = Xs + r * kLfXs + g * 4;        // A fragments of the layer input
+  const float* aa = As + r * kLfXs + g * 4;        // ... of the attention output
+  const float* ha = As + r * kLfHs + g * 4;        // ... of a hidden-activation block
+  const int col0 = wave * 16 + r;                  // this lane's column inside a 128-column block
+
+  for (int step = 0; step < p.n; ++step) {
+    float v[2][3][4];                              // norm2 output of the current layer (row 16t + 4g + i, column 128cb + col0)
+    for (int l = 0; l < p.L; ++l) {
+      const float* sm = p.small + (long long)l * kLsLayer;
+      // ================= self-attention: two heads at a time (cross_attention.py:265-266; nn.MultiheadAttention, 4 heads of 64)
+      for (int hp = 0; hp < 2; ++hp) {
+        const float bq = sm[kLsInB + hp * 128 + col0], bk = sm[kLsInB + 256 + hp * 128 + col0], bv = sm[kLsInB + 512 + hp * 128 + col0];
+        f32x4 q[3], k[3], vv[3];
+        zero3(q); zero3(k); zero3(vv);
+        run(0, 8, xa, 16 * kLfXs, q, true);
+        run(0, 8, xa, 16 * kLfXs, k, true);
+        run(0, 8, xa, 16 * kLfXs, vv, false);
+        // partial scores over this wave's 16 columns of the head: s[t][t'] for the CFG rows 4g .. 4g + 3
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            F4 s;
+            s.x = sum16((q[t][0] + bq) * (k[u][0] + bk)); s.y = sum16((q[t][1] + bq) * (k[u][1] + bk));
+            s.z = sum16((q[t][2] + bq) * (k[u][2] + bk)); s.w = sum16((q[t][3] + bq) * (k[u][3] + bk));
+            if (r == 0) st4(sc + wave * 144 + (t * 3 + u) * 16 + g * 4, s);
+          }
+        stage(7);
+        const float* sb = sc + (wave & 4) * 144 + g * 4;   // the four waves of this head
+        float o[3][4];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          F4 s[3];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const float* e = sb + (t * 3 + u) * 16;
+            s[u] = f4add(f4add(ld4(e), ld4(e + 144)), f4add(ld4(e + 288), ld4(e + 432)));
+          }
+          const float s0v[4] = {s[0].x, s[0].y, s[0].z, s[0].w}, s1v[4] = {s[1].x, s[1].y, s[1].z, s[1].w}, s2v[4] = {s[2].x, s[2].y, s[2].z, s[2].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float a0 = s0v[i] * 0.125f, a1 = s1v[i] * 0.125f, a2 = s2v[i] * 0.125f;
+            const float m = fmaxf(a0, fmaxf(a1, a2));
+            const float e0 = expf(a0 - m), e1 = expf(a1 - m), e2 = expf(a2 - m);
+            const float inv = 1.0f / (e0 + e1 + e2);
+            o[t][i] = (e0 * inv) * (vv[0][i] + bv) + (e1 * inv) * (vv[1][i] + bv) + (e2 * inv) * (vv[2][i] + bv);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) As[(t * 16 + g * 4 + i) * kLfXs + hp * 128 + col0] = o[t][i];
+      }
+      __syncthreads();                                 // the attention output is complete before anybody multiplies it
+      // ================= out-projection + residual + norm1 -> Xs (in place)
+      {
+        const float ob0 = sm[kLsOutB + col0], ob1 = sm[kLsOutB + 128 + col0];
+        f32x4 o0[3], o1[3];
+        zero3(o0); zero3(o1);
+        run(0, 8, aa, 16 * kLfXs, o0, true);
+        run(0, 8, aa, 16 * kLfXs, o1, false);
+        float u[2][3][4];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float* xr = Xs + (t * 16 + g * 4 + i) * kLfXs + col0;
+            u[0][t][i] = o0[t][i] + ob0 + xr[0];
+            u[1][t][i] = o1[t][i] + ob1 + xr[128];
+          }
+        ln_part1(u, 3);
+        stage(7);
+        ln_part2(u, 3, sm + kLsN1W, sm + kLsN1B);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float* xr = Xs + (t * 16 + g * 4 + i) * kLfXs + col0;
+            xr[0] = u[0][t][i];
+            xr[128] = u[1][t][i];
+          }
+        __syncthreads();
+      }
+      // ================= feed-forward: hidden activation in blocks of 128 columns, linear2 accumulated in registers
+      {
+        f32x4 y0[3], y1[3];
+        zero3(y0); zero3(y1);
+        for (int hb = 0; hb < 8; ++hb) {
+          const float b1 = sm[kLsL1B + hb * 128 + col0];
+          f32x4 h[3];
+          zero3(h);
+          run(0, 8, xa, 16 * kLfXs, h, false);
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) As[(t * 16 + g * 4 + i) * kLfHs + col0] = gelu_erf(h[t][i] + b1);
+          stage(7);
+          run(0, 4, ha, 16 * kLfHs, y0, true);
+          run(4, 4, ha, 16 * kLfHs, y1, false);
+          if (hb < 7) stage(7);
+        }
+        const float lb0 = sm[kLsL2B + col0], lb1 = sm[kLsL2B + 128 + col0];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float* xr = Xs + (t * 16 + g * 4 + i) * kLfXs + col0;
+            v[0][t][i] = y0[t][i] + lb0 + xr[0];
+            v[1][t][i] = y1[t][i] + lb1 + xr[128];
+          }
+        ln_part1(v, 3);
+        stage(7);
+        ln_part2(v, 3, sm + kLsN2W, sm + kLsN2B);
+      }
+      if (l + 1 < p.L) {
+        // layer output -> Xs; first half of the stack: also parked for the skip connection (cross_attention.py:48-52)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float* xr = Xs + (t * 16 + g * 4 + i) * kLfXs + col0;
+            xr[0] = v[0][t][i];
+            xr[128] = v[1][t][i];
+          }
+        if (l < nb) {
+          float* sk = p.skip + ((long long)(blockIdx.x * nb + l) * 48) * 256;
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float* o = sk + (t * 16 + g * 4 + i) * 256 + col0;
+              o[0] = v[0][t][i];
+              o[128] = v[1][t][i];
+            }
+        }
+        __syncthreads();
+        if (l >= nb) {
+          // x = Linear(cat[x, skip]) (cross_attention.py:56-58): the x half of K from Xs, then the parked activation takes
+          // its place in Xs for the second half
+          const int si = l - nb;
+          const float sb0 = sm_skip[si * 256 + col0], sb1 = sm_skip[si * 256 + 128 + col0];
+          f32x4 z0[3], z1[3];
+          zero3(z0); zero3(z1);
+          run(0, 8, xa, 16 * kLfXs, z0, true);
+          run(0, 8, xa, 16 * kLfXs, z1, true);           // its last barrier: everybody is done reading x
+          const float* sk = p.skip + ((long long)(blockIdx.x * nb + (nb - 1 - si)) * 48) * 256;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            const int q = tid + 512 * j, row = q >> 6, c4 = q & 63;
+            st4(Xs + row * kLfXs + c4 * 4, ld4(sk + row * 256 + c4 * 4));
+          }
+          __syncthreads();
+          run(0, 8, xa, 16 * kLfXs, z0, true);
+          run(0, 8, xa, 16 * kLfXs, z1, true);
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float* xr = Xs + (t * 16 + g * 4 + i) * kLfXs + col0;
+              xr[0] = z0[t][i] + sb0;
+              xr[128] = z1[t][i] + sb1;
+            }
+          __syncthreads();
+        }
+      }
+    }
+    // ================= end of the step: encoder.norm on the latent token (mld_denoiser.py:206), CFG (mld.py:339-342), DDIM eta = 0
+    {
+      ln_part1(v, 1);
+      __syncthreads();
+      ln_part2(v, 1, sm_fin, sm_fin + 256);
+      const float sat = p.ddim[step * 4], s1mat = p.ddim[step * 4 + 1], sap = p.ddim[step * 4 + 2], s1map = p.ddim[step * 4 + 3];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float eu = v[cb][0][i], ec = wave_xor(eu, 32);     // CFG row c + 8 lives in lane + 32
+          if (g < 2) {
+            float* lp = lats + (g * 4 + i) * 256 + cb * 128 + col0;
+            const float eps = eu + p.guidance * (ec - eu);
+            const float x = lp[0];
+            const float x0 = (x - s1mat * eps) / sat;
+            lp[0] = sap * x0 + s1map * eps;
+          }
+        }
+      __syncthreads();
+      if (step + 1 < p.n) {
+        assemble(step + 1);
+        __syncthreads();
+      }
+    }
+  }
+  {
+    const int c = tid >> 6, c4 = tid & 63;
+    if (s0 + c < p.B) st4(p.lat + (long long)(s0 + c) * 256 + c4 * 4, ld4(lats + c * 256 + c4 * 4));
+  }
+}
+
+}  // namespace mld

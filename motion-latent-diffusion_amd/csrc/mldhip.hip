@@ -36,6 +36,7 @@
 #include "kernels/tile32.hpp"
 #include "kernels/strip.hpp"
 #include "kernels/ffn_fused.hpp"
+#include "kernels/loop_fused.hpp"
 
 using namespace mld;
 
@@ -152,6 +153,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   for (int i = 0; i < 8; ++i) want(&e->S[i], (i < (int)(L - 1) / 2) ? rows * D : 0);
   want(&e->QKV, rows * 3 * D); want(&e->AO, rows * D); want(&e->FF, rows * F);
   want(&e->lat, Bm * D); want(&e->zbuf, Bm * D);
+  want(&e->FS, (Bm + 7) / 8 * ((L - 1) / 2) * 48 * D);
   want(&e->Po, 6 * Bm * D); want(&e->Pf, 8 * 6 * Bm * D); want(&e->Ps, 2 * 6 * Bm * D); want(&e->TP, 2 * Bm * D);
   want(&e->T1, n * D); want(&e->temb0, n * TD); want(&e->tmid, n * D);
   want(&e->text_bias, D); want(&e->time_b2pe, D); want(&e->t1_one, D); want(&e->temb0_one, TD + D);
@@ -191,6 +193,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<13, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<13, 128>()));
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<18, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<18, 128>()));
   (void)hipFuncSetAttribute((const void*)ffn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_loop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
 #define MLD_T32_ATTR1(MT, NS, ...) \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<MT, NS, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
 #define MLD_T32_ATTR(NS)                                                                                                    \
@@ -241,6 +244,8 @@ void mldhip_destroy(mldhip_handle* e) {
 #endif
   if (e->arena) (void)hipFree(e->arena);
   if (e->arena_x3) (void)hipFree(e->arena_x3);
+  if (e->loop_stream) (void)hipFree(e->loop_stream);
+  if (e->loop_small) (void)hipFree(e->loop_small);
   for (auto& x : e->ctxs) {
     if (x.ws) (void)hipFree(x.ws);
     if (x.lens) (void)hipFree(x.lens);
@@ -281,8 +286,12 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   if (!e || !name) return MLDHIP_EINVAL;
   const std::string n = name;
   if (n == "loop_kernel") {
-    if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "loop_kernel must be 0 (auto), 1 (latency) or 2 (throughput)");
+    if (value < 0 || value > 3) return e->fail(MLDHIP_EINVAL, "loop_kernel must be 0 (auto), 1 (latency), 2 (throughput) or 3 (sample-major persistent loop)");
+    if (value == 3 && e->finalized && !e->loop_ips) return e->fail(MLDHIP_EINVAL, "loop_kernel 3: the sample-major loop is built for fp32 loop arithmetic, ff_size 1024, 4 heads");
     e->loop_kernel = (int)value;
+  } else if (n == "fused_min_batch") {
+    if (value < 1) return e->fail(MLDHIP_EINVAL, "fused_min_batch must be >= 1");
+    e->fused_min_batch = (int)std::min<int64_t>(value, 1 << 30);
   } else if (n == "strip_min_rows") {
     if (value < 1) return e->fail(MLDHIP_EINVAL, "strip_min_rows must be >= 1");
     e->strip_min_rows = (int)std::min<int64_t>(value, 1 << 30);
@@ -386,6 +395,7 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
     MLD_LAUNCH(split_bf16_weights_kernel, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, stream, e->arena, e->arena_x3, groups);
     if (check_launch(c, "split_bf16_weights")) return c.rc;
   }
+  if (int rc = build_loop_stream(c)) return rc;
   for (int k = 0; k < (int)e->ctxs.size(); ++k) {       // the derived tables live in each context's workspace
   bind_context(e, k);
   if (e->group_ready[0]) {
