@@ -69,7 +69,10 @@ int loop_prec(const E* e) {
 
 // split-bf16 mode: read W from the pre-split image of the weight arena when it lives there (derived tables in a workspace do not)
 void use_split_weights(const E* e, GemmArgs& a, int prec) {
-  if (prec == PREC_BF16X3 && e->split_weights && e->arena_x3 && a.W >= e->arena && a.W < e->arena + e->arena_floats) {
+  // the image holds one (hi | lo) record per ALIGNED group of 32 floats of the arena: a weight view that does not start on a
+  // group boundary, or whose rows / K slices do not, keeps the in-kernel split
+  if (prec == PREC_BF16X3 && e->split_weights && e->arena_x3 && a.W >= e->arena && a.W < e->arena + e->arena_floats &&
+      (a.W - e->arena) % 32 == 0 && a.ldw % 32 == 0 && a.sW % 32 == 0) {
     a.W = e->arena_x3 + (a.W - e->arena);
     a.w_split = 1;
   }

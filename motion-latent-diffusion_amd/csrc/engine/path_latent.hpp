@@ -128,7 +128,8 @@ DenView den_view(E* e, int R) {
   v.lat = e->lat;
   v.R = R;
   v.strip = use_strip(e, 3 * R);
-  v.ffn_slabs = v.strip ? e->strip_ffn2_split : e->cfg.ff_size / 256;
+  // throughput kernels: K slices of FFN2 no narrower than 256 (the staged GEMM takes K in {256, 512, 1024})
+  v.ffn_slabs = v.strip ? std::min(e->strip_ffn2_split, e->cfg.ff_size / 256) : e->cfg.ff_size / 256;
   v.skip_slabs = v.strip ? 1 : 2;
   return v;
 }
@@ -259,15 +260,19 @@ int build_loop_stream(Ctx& c) {
   const size_t ips = items.size(), small_floats = (size_t)L * kLsLayer + (size_t)nb * 256 + 768, tail = (size_t)n * 4;
   if (e->loop_stream) { (void)hipFree(e->loop_stream); e->loop_stream = nullptr; }
   if (e->loop_small) { (void)hipFree(e->loop_small); e->loop_small = nullptr; }
+  if (e->loop_stream_x3) { (void)hipFree(e->loop_stream_x3); e->loop_stream_x3 = nullptr; }
+  const bool want_x3 = e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE;      // the split mode: a second image of the stream
   LoopItem* items_dev = nullptr;
   if (hipMalloc((void**)&e->loop_stream, ips * kLoopItemFloats * sizeof(float)) != hipSuccess ||
+      (want_x3 && hipMalloc((void**)&e->loop_stream_x3, ips * kLoopItemFloats * sizeof(float)) != hipSuccess) ||
       hipMalloc((void**)&e->loop_small, (small_floats + tail) * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&items_dev, ips * sizeof(LoopItem)) != hipSuccess)
     return e->fail(MLDHIP_EHIP, "hipMalloc(sample-major loop tables)");
   e->loop_ddim = e->loop_small + small_floats;
   hipError_t st = hipMemcpy(items_dev, items.data(), ips * sizeof(LoopItem), hipMemcpyHostToDevice);
   if (st == hipSuccess) {
-    MLD_LAUNCH(pack_loop_stream_kernel, dim3((unsigned)ips), dim3(256), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->loop_stream);
+    MLD_LAUNCH(pack_loop_stream_kernel<false>, dim3((unsigned)ips), dim3(256), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->loop_stream);
+    if (want_x3) MLD_LAUNCH(pack_loop_stream_kernel<true>, dim3((unsigned)ips), dim3(256), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->loop_stream_x3);
     check_launch(c, "pack_loop_stream");
     st = hipStreamSynchronize(c.stream);
   }
@@ -342,7 +347,8 @@ void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr) {
     // the modes that run the decoder GEMMs on bf16 MFMAs run its attention split-bf16 as well (attention.hpp)
     // key-blocked form (40 KB of LDS, two workgroups per CU, any T): pays once there is more than one workgroup per CU to overlap
     // (B H >= 512: 108 vs 133 us at 1 280 workgroups); with one per CU the whole-K/V kernel below is 5 % faster (28.9 vs 30.3 us)
-    if (e->flash_attn == 2 || (e->flash_attn == 1 && B * H >= 512)) {
+    // (it covers 16 query tiles = 256 frames per (sample, head); longer sequences take the whole-K/V kernel)
+    if (T <= 256 && (e->flash_attn == 2 || (e->flash_attn == 1 && B * H >= 512))) {
       MLD_LAUNCH(attn_flash_x3_kernel, grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H);
       count(c);
       check_launch(c, "attn_flash_x3");
@@ -375,7 +381,8 @@ void ffn_block(Ctx& c, const float* x, float* y, int M, const float* w1, const f
                const float* gamma, const float* beta, int ragged_T) {
   E* e = c.e;
   const int D = e->cfg.latent_dim, F = e->cfg.ff_size;
-  auto in_arena = [&](const float* w) { return w >= e->arena && w < e->arena + e->arena_floats; };
+  // in the arena AND on a 32-float group boundary of it: the split image is built per aligned group (mldhip_finalize_weights)
+  auto in_arena = [&](const float* w) { return w >= e->arena && w < e->arena + e->arena_floats && (w - e->arena) % 32 == 0; };
   if (staged_prec(e) == PREC_BF16X3 && e->fused_ffn && e->split_weights && e->arena_x3 && D == 256 && F == 1024 && M > e->small_m &&
       !e->trace_on && in_arena(w1) && in_arena(w2)) {
     FfnArgs a;
@@ -587,10 +594,12 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
   if (use_fused(e, B)) {
     // the whole reverse loop as one persistent launch: a workgroup per 8 motions (kernels/loop_fused.hpp)
     LoopArgs a;
-    a.stream = e->loop_stream; a.ips = e->loop_ips; a.small = e->loop_small; a.T1 = e->T1; a.TP = e->TP; a.init_lat = init_lat;
+    const bool x3 = e->loop_stream_x3 && e->fused_x3;
+    a.stream = x3 ? e->loop_stream_x3 : e->loop_stream; a.ips = e->loop_ips; a.small = e->loop_small; a.T1 = e->T1; a.TP = e->TP; a.init_lat = init_lat;
     a.lat = e->lat; a.skip = e->FS; a.ddim = e->loop_ddim; a.B = B; a.L = e->cfg.num_layers; a.n = n;
     a.guidance = guidance; a.init_sigma = 1.0f;
-    MLD_LAUNCH(den_loop_kernel, dim3((B + 7) / 8), dim3(512), kLoopLdsBytes, stream, a);
+    if (x3) MLD_LAUNCH(den_loop_kernel<true>, dim3((B + 7) / 8), dim3(512), kLoopLdsBytes, stream, a);
+    else MLD_LAUNCH(den_loop_kernel<false>, dim3((B + 7) / 8), dim3(512), kLoopLdsBytes, stream, a);
     count(c);
     check_launch(c, "den_loop");
   } else {

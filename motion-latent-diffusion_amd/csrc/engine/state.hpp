@@ -66,6 +66,7 @@ struct mldhip_engine {
   std::map<std::string, int> index;
   float* arena = nullptr;
   float* loop_stream = nullptr;   // sample-major loop (kernels/loop_fused.hpp): GEMM weights of the denoiser re-packed in consumption order
+  float* loop_stream_x3 = nullptr;   // ... the same items as split-f16 images (the precision mode with split arithmetic)
   float* loop_small = nullptr;    // ... its biases / LayerNorm parameters, packed; then the DDIM coefficients [n][4]
   float* loop_ddim = nullptr;
   int loop_ips = 0;               // weight items per reverse step (0: the variant is not built for this configuration)
@@ -110,6 +111,7 @@ struct mldhip_engine {
   // per-handle options (mldhip_set_option)
   int small_m = 256;         // "gemm_small_m": row count up to which the register-direct tiny-GEMM shape is used
   int loop_kernel = 0;       // "loop_kernel": 0 auto (by rows / motions), 1 latency kernels (tile32.hpp), 2 throughput kernels (strip.hpp), 3 sample-major persistent loop (loop_fused.hpp)
+  int fused_x3 = 1;          // "fused_x3": in the split precision mode the sample-major loop multiplies on split-f16 MFMAs (0: exact fp32 MFMAs)
   int fused_min_batch = 1024;// "fused_min_batch": auto picks the sample-major loop from this many motions per call up
   int strip_min_rows = 768;  // "strip_min_rows": auto switches to the throughput kernels at 6B >= this many token rows
   int strip_wide = 0;        // "strip_wide": 32 x 128 strip tiles for the wide GEMMs: 0 auto (N >= 512), 1 never, 2 whenever N % 128 == 0

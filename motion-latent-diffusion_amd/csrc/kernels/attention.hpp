@@ -169,10 +169,10 @@ template <int NKT>
 constexpr int attn_x3_lds_bytes() { return (2 * NKT * 16 * kAttnX3KStride + 2 * 64 * attn_x3_vt_stride<NKT>()) * 4; }
 
 __device__ __forceinline__ void split_hi_lo_x8(const float (&x)[8], U4& hi, U4& lo) {
-  split_bf16_pair(x[0], x[1], hi.x, lo.x);
-  split_bf16_pair(x[2], x[3], hi.y, lo.y);
-  split_bf16_pair(x[4], x[5], hi.z, lo.z);
-  split_bf16_pair(x[6], x[7], hi.w, lo.w);
+  split16_pair(x[0], x[1], hi.x, lo.x);
+  split16_pair(x[2], x[3], hi.y, lo.y);
+  split16_pair(x[4], x[5], hi.z, lo.z);
+  split16_pair(x[6], x[7], hi.w, lo.w);
 }
 
 template <int NKT, int NW = 8>
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __
       const float m = key < len ? 1.f : 0.f;
       if (key < nkt * 16) {
         unsigned h0, l0, h1, l1;
-        split_bf16_pair(v[j].x * m, v[j].y * m, h0, l0);
-        split_bf16_pair(v[j].z * m, v[j].w * m, h1, l1);
+        split16_pair(v[j].x * m, v[j].y * m, h0, l0);
+        split16_pair(v[j].z * m, v[j].w * m, h1, l1);
         *reinterpret_cast<U2*>(Kh + key * KST + c4 * 2) = U2{h0, h1};
         *reinterpret_cast<U2*>(Kl + key * KST + c4 * 2) = U2{l0, l1};
       }
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __
       const float m = key < len ? 1.f : 0.f;
       if (key < nkb * 32) {                  // keys of the (possibly half-empty) last 32-key block are zero
         unsigned h0, l0, h1, l1;
-        split_bf16_pair(v[j].x * m, v[j].y * m, h0, l0);
-        split_bf16_pair(v[j].z * m, v[j].w * m, h1, l1);
+        split16_pair(v[j].x * m, v[j].y * m, h0, l0);
+        split16_pair(v[j].z * m, v[j].w * m, h1, l1);
         unsigned short* vh = reinterpret_cast<unsigned short*>(Vh) + key;
         unsigned short* vl = reinterpret_cast<unsigned short*>(Vl) + key;
         const int d0 = c4 * 4;
@@ -268,9 +268,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __
         for (int c = 0; c < 2; ++c) {
           const U4 kh = *reinterpret_cast<const U4*>(Kh + (kt * 16 + r) * KST + c * 16 + g * 4);
           const U4 kl = *reinterpret_cast<const U4*>(Kl + (kt * 16 + r) * KST + c * 16 + g * 4);
-          s[kt] = mfma_bf16_16x16x32(kl, qh[c], s[kt]);
-          s[kt] = mfma_bf16_16x16x32(kh, ql[c], s[kt]);
-          s[kt] = mfma_bf16_16x16x32(kh, qh[c], s[kt]);
+          s[kt] = mfma_x3_16x16x32(kl, qh[c], s[kt]);
+          s[kt] = mfma_x3_16x16x32(kh, ql[c], s[kt]);
+          s[kt] = mfma_x3_16x16x32(kh, qh[c], s[kt]);
         }
       }
     }
@@ -314,9 +314,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __
           const U2 a0 = *reinterpret_cast<const U2*>(vh), a1 = *reinterpret_cast<const U2*>(vh + 8);
           const U2 b0 = *reinterpret_cast<const U2*>(vl), b1 = *reinterpret_cast<const U2*>(vl + 8);
           const U4 vhh = U4{a0.x, a0.y, a1.x, a1.y}, vll = U4{b0.x, b0.y, b1.x, b1.y};
-          oacc[dt] = mfma_bf16_16x16x32(pl, vhh, oacc[dt]);
-          oacc[dt] = mfma_bf16_16x16x32(ph, vll, oacc[dt]);
-          oacc[dt] = mfma_bf16_16x16x32(ph, vhh, oacc[dt]);
+          oacc[dt] = mfma_x3_16x16x32(pl, vhh, oacc[dt]);
+          oacc[dt] = mfma_x3_16x16x32(ph, vll, oacc[dt]);
+          oacc[dt] = mfma_x3_16x16x32(ph, vhh, oacc[dt]);
         }
       }
     }
@@ -380,12 +380,12 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
     unsigned* Vl = Vh + 64 * VST;
     const float m = kb * 32 + skey < len ? 1.f : 0.f;     // keys past the length: zero operands (their scores are masked as well)
     unsigned h0, l0, h1, l1;
-    split_bf16_pair(kreg.x * m, kreg.y * m, h0, l0);
-    split_bf16_pair(kreg.z * m, kreg.w * m, h1, l1);
+    split16_pair(kreg.x * m, kreg.y * m, h0, l0);
+    split16_pair(kreg.z * m, kreg.w * m, h1, l1);
     *reinterpret_cast<U2*>(Kh + skey * KST + c4 * 2) = U2{h0, h1};
     *reinterpret_cast<U2*>(Kl + skey * KST + c4 * 2) = U2{l0, l1};
-    split_bf16_pair(vreg.x * m, vreg.y * m, h0, l0);
-    split_bf16_pair(vreg.z * m, vreg.w * m, h1, l1);
+    split16_pair(vreg.x * m, vreg.y * m, h0, l0);
+    split16_pair(vreg.z * m, vreg.w * m, h1, l1);
     unsigned short* vh = reinterpret_cast<unsigned short*>(Vh) + skey;
     unsigned short* vl = reinterpret_cast<unsigned short*>(Vl) + skey;
     const int d0 = c4 * 4;
@@ -446,9 +446,9 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             if (t < nt) {
-              s[t][k2] = mfma_bf16_16x16x32(kl, qh[t][c], s[t][k2]);
-              s[t][k2] = mfma_bf16_16x16x32(kh, ql[t][c], s[t][k2]);
-              s[t][k2] = mfma_bf16_16x16x32(kh, qh[t][c], s[t][k2]);
+              s[t][k2] = mfma_x3_16x16x32(kl, qh[t][c], s[t][k2]);
+              s[t][k2] = mfma_x3_16x16x32(kh, ql[t][c], s[t][k2]);
+              s[t][k2] = mfma_x3_16x16x32(kh, qh[t][c], s[t][k2]);
             }
           }
         }
@@ -502,9 +502,9 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           if (t < nt) {
-            oacc[t][dt] = mfma_bf16_16x16x32(pl[t], vhh, oacc[t][dt]);
-            oacc[t][dt] = mfma_bf16_16x16x32(ph[t], vll, oacc[t][dt]);
-            oacc[t][dt] = mfma_bf16_16x16x32(ph[t], vhh, oacc[t][dt]);
+            oacc[t][dt] = mfma_x3_16x16x32(pl[t], vhh, oacc[t][dt]);
+            oacc[t][dt] = mfma_x3_16x16x32(ph[t], vll, oacc[t][dt]);
+            oacc[t][dt] = mfma_x3_16x16x32(ph[t], vhh, oacc[t][dt]);
           }
         }
       }

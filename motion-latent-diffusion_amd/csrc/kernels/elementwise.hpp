@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void split_bf16_weights_kernel(const float* __
   if (grp >= groups) return;
   const float a = w[grp * 32 + 2 * pr], b = w[grp * 32 + 2 * pr + 1];
   unsigned hi, lo;
-  split_bf16_pair(a, b, hi, lo);
+  split16_pair(a, b, hi, lo);
   unsigned* o = reinterpret_cast<unsigned*>(out) + grp * 32;
   o[pr] = hi;
   o[16 + pr] = lo;

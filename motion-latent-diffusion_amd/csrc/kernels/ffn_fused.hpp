@@ -112,8 +112,8 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(FfnArgs p) {
     for (int j = 0; j < 8; ++j) {
       const int idx = tid + j * 512, row = idx >> 6, c = idx & 63;
       unsigned h0, l0, h1, l1;
-      split_bf16_pair(xv[j].x, xv[j].y, h0, l0);
-      split_bf16_pair(xv[j].z, xv[j].w, h1, l1);
+      split16_pair(xv[j].x, xv[j].y, h0, l0);
+      split16_pair(xv[j].z, xv[j].w, h1, l1);
       unsigned* rowp = Xs + row * XS + (c >> 3) * 32 + (c & 7) * 2;
       *reinterpret_cast<uint2_t*>(rowp) = uint2_t{h0, h1};
       *reinterpret_cast<uint2_t*>(rowp + 16) = uint2_t{l0, l1};
@@ -165,14 +165,14 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(FfnArgs p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           if (s < 8) {
-            acc1[a][b] = mfma_bf16_16x16x32(alo[a], bhi[b], acc1[a][b]);
-            acc1[a][b] = mfma_bf16_16x16x32(ahi[a], blo[b], acc1[a][b]);
-            acc1[a][b] = mfma_bf16_16x16x32(ahi[a], bhi[b], acc1[a][b]);
+            acc1[a][b] = mfma_x3_16x16x32(alo[a], bhi[b], acc1[a][b]);
+            acc1[a][b] = mfma_x3_16x16x32(ahi[a], blo[b], acc1[a][b]);
+            acc1[a][b] = mfma_x3_16x16x32(ahi[a], bhi[b], acc1[a][b]);
           } else {
             f32x4& acc = acc2[(s >> 2) & 1][a][b];       // hsel = (s - 8) >> 2
-            acc = mfma_bf16_16x16x32(alo[a], bhi[b], acc);
-            acc = mfma_bf16_16x16x32(ahi[a], blo[b], acc);
-            acc = mfma_bf16_16x16x32(ahi[a], bhi[b], acc);
+            acc = mfma_x3_16x16x32(alo[a], bhi[b], acc);
+            acc = mfma_x3_16x16x32(ahi[a], blo[b], acc);
+            acc = mfma_x3_16x16x32(ahi[a], bhi[b], acc);
           }
         }
       if (s == 7) {

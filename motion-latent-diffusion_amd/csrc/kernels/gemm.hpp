@@ -247,8 +247,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
           // row image: [32 x bf16 hi | 32 x bf16 lo | pad]; this thread owns k = 4*c4 .. 4*c4+3
           if (p.w_split && j >= NLA) { st4(dst + row * kGemmLdsStride + c4 * 4, v); continue; }   // W was split at finalize (split_bf16_weights_kernel): already the row image
           unsigned h0, l0, h1, l1;
-          split_bf16_pair(v.x, v.y, h0, l0);
-          split_bf16_pair(v.z, v.w, h1, l1);
+          split16_pair(v.x, v.y, h0, l0);
+          split16_pair(v.z, v.w, h1, l1);
           unsigned* rowp = reinterpret_cast<unsigned*>(dst + row * kGemmLdsStride);
           *reinterpret_cast<uint2_t*>(rowp + c4 * 2) = uint2_t{h0, h1};
           *reinterpret_cast<uint2_t*>(rowp + 16 + c4 * 2) = uint2_t{l0, l1};
@@ -319,9 +319,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
       for (int a = 0; a < MREP; ++a)
 #pragma unroll
         for (int b = 0; b < NREP; ++b) {
-          acc[a][b] = mfma_bf16_16x16x32(alo[a], bhi[b], acc[a][b]);
-          acc[a][b] = mfma_bf16_16x16x32(ahi[a], blo[b], acc[a][b]);
-          acc[a][b] = mfma_bf16_16x16x32(ahi[a], bhi[b], acc[a][b]);
+          acc[a][b] = mfma_x3_16x16x32(alo[a], bhi[b], acc[a][b]);
+          acc[a][b] = mfma_x3_16x16x32(ahi[a], blo[b], acc[a][b]);
+          acc[a][b] = mfma_x3_16x16x32(ahi[a], bhi[b], acc[a][b]);
         }
     };
     auto mma = [&](int buf) {

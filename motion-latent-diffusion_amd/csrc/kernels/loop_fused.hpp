@@ -7,24 +7,28 @@
 // per call, because they split each GEMM over the CUs by output COLUMNS.  Here the work is split by MOTIONS instead: a workgroup
 // owns 8 motions = 16 rows of the CFG batch x 3 tokens = 48 token rows for the whole call, keeps them in LDS, and streams the
 // weights: 1 launch, no inter-workgroup traffic, no activation ever leaves the CU (except the four skip activations, parked in a
-// workgroup-private slice of HBM), and the matrix pipe is the only thing left to wait for:
+// workgroup-private slice of HBM):
 //   per reverse step and workgroup  48 rows x 7.6 M weights x 2 = 730 MFLOP  against  30.4 MB of weights streamed from L2 / MALL
-//   = 24 FLOP per byte: at the CU's fp32-MFMA rate (256 FLOP/clk) the stream needs 10.7 B/clk/CU, well under the ~25 B/clk/CU
-//   the register-ring + ds_write staging of the other kernels sustains, so the kernel is MFMA bound by construction.
-// It wins once a call carries enough motions to give most CUs a workgroup (B >= ~1 000; 2 048 motions = 256 workgroups = one
-// per CU); below that the column-split families finish sooner (path_latent.hpp use_fused).
+//   = 24 FLOP per byte.  On exact-fp32 MFMAs (256 FLOP/clk/CU) the stream needs 10.7 B/clk/CU, well under what the register-ring
+//   + ds_write staging sustains: MFMA bound (measured r03: 85 ms for 50 steps at ANY batch up to 2 048 motions = 0.70 of the fp32
+//   MFMA peak).  On split-f16 MFMAs (rt.hpp: 3 instead of 8 matrix instructions per chunk, each twice as fast) the matrix work
+//   shrinks 5x and the weight stream becomes the bound.
+// It wins once a call carries enough motions to give most CUs a workgroup (2 048 motions = 256 workgroups = one per CU); below
+// ~1 000 motions the column-split families finish sooner (path_latent.hpp use_fused).
 //
 // Row order inside the workgroup: row = 16 t + c, t = token, c = row of the CFG batch (c < 8: unconditional half of the 8
 // motions, c >= 8: conditional half).  A 16-row MFMA tile is then ONE token of all 16 CFG rows, so the accumulator registers of
 // lane (r, g) for the three row tiles hold the three tokens of the SAME (CFG row 4g + i, column r): the 3-token attention, the
 // softmax and P.V are in-lane arithmetic on accumulators (only the 64-column dot products cross lanes: 4 DPP adds + one LDS
-// exchange among the four waves of a head), and q, k, v never exist in memory.
+// exchange among the four waves of a head), and q, k, v never exist in memory.  For the same reason every residual stays in
+// registers: the lane that produces element (row, column) of a LayerNorm output is the lane that needs it as the residual of
+// the next one.
 //
 // Weight stream: `finalize` re-packs the denoiser's GEMM weights into the order this kernel consumes them, as "items" of
-// 128 output columns x 32 k (16 KB, rows contiguous): every thread fetches 2 x 16 bytes per item into a 4-deep register ring,
-// stores them to a double-buffered LDS stage, one barrier per item; each wave multiplies its 16 of the 128 columns against the
-// three row tiles (24 MFMAs per item and wave = 1 536 cycles per SIMD with two waves).  The sequence is uniform over phases,
-// layers and steps (it wraps at the end of a step), so the prefetch never drains.
+// 128 output columns x 32 k (16 KB, rows contiguous; split mode: 16 words of high halves + 16 words of low halves per row):
+// every thread fetches 2 x 16 bytes per item into a 4-deep register ring, stores them to a double-buffered LDS stage, one
+// barrier per item; each wave multiplies its 16 of the 128 columns against the three row tiles.  The sequence is uniform over
+// phases, layers and steps (it wraps at the end of a step), so the prefetch never drains.
 //
 // Replaces, per step: mld_denoiser.py:143-228 (token assembly, SkipTransformerEncoder, final norm), mld.py:325-346 (CFG + DDIM).
 #pragma once
@@ -42,7 +46,7 @@ constexpr int kLoopItemsLayer = 192, kLoopItemsSkip = 32, kLoopItemFloats = 128 
 struct LoopItem { long long src; int ld; int pad; };   // element [row0][k0] of a weight (floats into the arena), row stride
 
 struct LoopArgs {
-  const float* stream;     // [ips][128][32] weight items in consumption order
+  const float* stream;     // [ips][128][32] weight items in consumption order (fp32, or the split image)
   int ips;                 // items per reverse step
   const float* small;      // packed small parameters (layout above)
   const float* T1;         // [n][256] time-token rows (time MLP + pe[1]) of the scheduler's timesteps
@@ -59,24 +63,40 @@ constexpr int kLfXs = 264, kLfHs = 136, kLfWs = 40;      // LDS row strides (wor
 constexpr int kLfXFloats = 48 * kLfXs, kLfWBuf = 128 * kLfWs, kLfScFloats = 8 * 144, kLfRedFloats = 2 * 8 * 48, kLfLatFloats = 8 * 256;
 constexpr int kLoopLdsBytes = (2 * kLfXFloats + 2 * kLfWBuf + kLfScFloats + kLfRedFloats + kLfLatFloats) * 4;   // 158 208 B: one workgroup per CU
 
-// finalize-time: gathers the weight items into consumption order.  grid = items, block = 256.
+// finalize-time: gathers the weight items into consumption order.  X3: every row of 32 floats becomes 16 words of packed high
+// halves + 16 words of packed low halves (the image a staged split GEMM keeps in LDS, elementwise.hpp).  grid = items, block = 256.
+template <bool X3>
 __global__ __launch_bounds__(256) void pack_loop_stream_kernel(const float* __restrict__ arena, const LoopItem* __restrict__ items,
                                                                float* __restrict__ out) {
   const LoopItem it = items[blockIdx.x];
-  for (int q = threadIdx.x; q < 1024; q += 256) {
-    const int row = q >> 3, c4 = q & 7;
-    st4(out + (long long)blockIdx.x * kLoopItemFloats + row * 32 + c4 * 4, ld4(arena + it.src + (long long)row * it.ld + c4 * 4));
+  float* dst = out + (long long)blockIdx.x * kLoopItemFloats;
+  if constexpr (!X3) {
+    for (int q = threadIdx.x; q < 1024; q += 256) {
+      const int row = q >> 3, c4 = q & 7;
+      st4(dst + row * 32 + c4 * 4, ld4(arena + it.src + (long long)row * it.ld + c4 * 4));
+    }
+  } else {
+    for (int q = threadIdx.x; q < 2048; q += 256) {
+      const int row = q >> 4, pr = q & 15;
+      const float* s = arena + it.src + (long long)row * it.ld + 2 * pr;
+      unsigned hi, lo;
+      split16_pair(s[0], s[1], hi, lo);
+      unsigned* o = reinterpret_cast<unsigned*>(dst) + row * 32;
+      o[pr] = hi;
+      o[16 + pr] = lo;
+    }
   }
 }
 
-// grid = ceil(B / 8), block = 512 (8 waves, two per SIMD).
+// grid = ceil(B / 8), block = 512 (8 waves, two per SIMD).  X3 = false: exact-fp32 MFMAs; true: split-f16 MFMAs.
+template <bool X3>
 __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
 #else
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #endif
-  float* Xs = smem;                       // [48][264] layer input / norm1 output (A operand, residual)
+  float* Xs = smem;                       // [48][264] layer input / norm1 output (the A operand; fp32, or the split image)
   float* As = Xs + kLfXFloats;            // [48][264] attention output, or [48][136] one 128-wide block of the hidden activation
   float* Ws = As + kLfXFloats;            // [2][128][40] weight item stage
   float* sc = Ws + 2 * kLfWBuf;           // [8][9][16] per-wave partial attention scores
@@ -87,6 +107,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   const int s0 = blockIdx.x * 8, nb = (p.L - 1) / 2;
   const float* sm_skip = p.small + (long long)p.L * kLsLayer;
   const float* sm_fin = sm_skip + nb * 256;
+  const int col0 = wave * 16 + r;                  // this lane's column inside a 128-column block
 
   // ---- weight ring: thread t holds 16 bytes of rows (t >> 3) and (t >> 3) + 64 of the items in flight
   const int wrow = tid >> 3, wc4 = tid & 7;
@@ -112,30 +133,44 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     __syncthreads();
   };
   // one item: this wave's 16 weight rows (= output columns) x 32 k against the three row tiles; `a` = row r of tile 0 at the
-  // chunk's first word + 4g, next tile `ts` words on.  3 independent accumulators x 8 k-steps: no MFMA waits for its predecessor.
+  // chunk's first word + 4g, next tile `ts` words on.  Both formats keep a chunk of a row as 32 words read as words 4g .. 4g + 3
+  // and 16 + 4g .. + 3: fp32 k-slots (any pairing is legal when A and W agree), or the high / low halves of k = 8g .. 8g + 7.
   const float* wfrag = Ws + (wave * 16 + r) * kLfWs + g * 4;
   auto mma_item = [&](int j, const float* a, int ts, f32x4 (&acc)[3]) __attribute__((always_inline)) {
     const float* w = wfrag + (j & 1) * kLfWBuf;
-    const F4 y0 = ld4(w), y1 = ld4(w + 16);
-    F4 x[3][2];
+    if constexpr (X3) {
+      const U4 wh = *reinterpret_cast<const U4*>(w), wl = *reinterpret_cast<const U4*>(w + 16);
+      U4 xh[3], xl[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) { x[t][0] = ld4(a + t * ts); x[t][1] = ld4(a + t * ts + 16); }
+      for (int t = 0; t < 3; ++t) { xh[t] = *reinterpret_cast<const U4*>(a + t * ts); xl[t] = *reinterpret_cast<const U4*>(a + t * ts + 16); }
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].x, y0.x, acc[t]);
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(xl[t], wh, acc[t]);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].y, y0.y, acc[t]);
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(xh[t], wl, acc[t]);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].z, y0.z, acc[t]);
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(xh[t], wh, acc[t]);
+    } else {
+      const F4 y0 = ld4(w), y1 = ld4(w + 16);
+      F4 x[3][2];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].w, y0.w, acc[t]);
+      for (int t = 0; t < 3; ++t) { x[t][0] = ld4(a + t * ts); x[t][1] = ld4(a + t * ts + 16); }
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].x, y1.x, acc[t]);
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].x, y0.x, acc[t]);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].y, y1.y, acc[t]);
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].y, y0.y, acc[t]);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].z, y1.z, acc[t]);
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].z, y0.z, acc[t]);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].w, y1.w, acc[t]);
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].w, y0.w, acc[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].x, y1.x, acc[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].y, y1.y, acc[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].z, y1.z, acc[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].w, y1.w, acc[t]);
+    }
   };
   // items j0 .. j0 + n - 1 of the current group against consecutive 32-wide chunks of A starting at a0; the last item's
   // stage() is left to the caller when it has something to publish before that barrier (stage_last = false)
@@ -151,8 +186,30 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     for (int t = 0; t < 3; ++t) a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  // LayerNorm over the 256 columns of the 48 rows; v[cb][t][i] = this lane's element (row 16t + 4g + i, column 128cb + 16wave + r).
-  // Part 1 publishes the per-wave row sums (the caller then passes a barrier: stage() or __syncthreads()); part 2 finishes.
+  // ---- this lane's elements (row 16t + 4g + i, column 128cb + col0) of an operand buffer with row stride `st` words:
+  // fp32: one word; split: one half-word in the chunk's high words and one in its low words (chunk = 32 words per 32 columns).
+  // `cw` = the block's first word in the row (128 cb for a 256-wide buffer, 0 for the hidden block).
+  const int hw0 = ((wave >> 1) * 32 + (wave & 1) * 8 + (r >> 1)) * 2 + (r & 1);     // half-word offset of column col0 in its row
+  auto put = [&](float* buf, int st, int cw, const float (&val)[3][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float* row = buf + (t * 16 + g * 4 + i) * st + cw;
+        if constexpr (X3) {
+          unsigned short hi, lo;
+          split16_one(val[t][i], hi, lo);
+          unsigned short* h = reinterpret_cast<unsigned short*>(row) + hw0;
+          h[0] = hi;
+          h[32] = lo;
+        } else {
+          row[col0] = val[t][i];
+        }
+      }
+  };
+
+  // LayerNorm over the 256 columns of rows 16t + 4g + i, t < nt; v[cb][t][i] = this lane's element.  Part 1 publishes the per-wave
+  // row sums (the caller then passes a barrier: stage() or __syncthreads()); part 2 finishes (one more barrier inside).
   auto ln_part1 = [&](const float (&v)[2][3][4], int nt) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -165,8 +222,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     }
   };
   auto ln_part2 = [&](float (&v)[2][3][4], int nt, const float* gamma, const float* beta) __attribute__((always_inline)) {
-    const float g0 = gamma[wave * 16 + r], g1 = gamma[128 + wave * 16 + r], b0 = beta[wave * 16 + r], b1 = beta[128 + wave * 16 + r];
-    float sq[3][4];
+    const float g0 = gamma[col0], g1 = gamma[128 + col0], b0 = beta[col0], b1 = beta[128 + col0];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       if (t < nt) {
@@ -174,13 +230,14 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
 #pragma unroll
         for (int w = 1; w < 8; ++w) m = f4add(m, ld4(red + w * 48 + t * 16 + g * 4));
         const float mean[4] = {m.x * (1.0f / 256.0f), m.y * (1.0f / 256.0f), m.z * (1.0f / 256.0f), m.w * (1.0f / 256.0f)};
+        float sq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           v[0][t][i] -= mean[i];
           v[1][t][i] -= mean[i];
-          sq[t][i] = sum16(v[0][t][i] * v[0][t][i] + v[1][t][i] * v[1][t][i]);
+          sq[i] = sum16(v[0][t][i] * v[0][t][i] + v[1][t][i] * v[1][t][i]);
         }
-        if (r == 0) st4(red + 384 + wave * 48 + t * 16 + g * 4, F4{sq[t][0], sq[t][1], sq[t][2], sq[t][3]});
+        if (r == 0) st4(red + 384 + wave * 48 + t * 16 + g * 4, F4{sq[0], sq[1], sq[2], sq[3]});
       }
     }
     __syncthreads();
@@ -201,25 +258,27 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     }
   };
 
-  // token rows of one reverse step from the latents: row 16t + c; t = 0: latent + pe[0] (both CFG halves), 1: the step's time
-  // row, 2: the condition rows (mld_denoiser.py:143-196; rows beyond B repeat motion B - 1 and are never written back)
+  // token rows of one reverse step, each lane its own elements: row 16t + c; t = 0: latent + pe[0] (both CFG halves), 1: the
+  // step's time row, 2: the condition rows (mld_denoiser.py:143-196; rows beyond B repeat motion B - 1, never written back)
+  float x[2][3][4];                                // the layer input at this lane's positions (operand image in Xs, residual here)
   auto assemble = [&](int step) __attribute__((always_inline)) {
     const float* pe0 = sm_fin + 512;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int q = tid + 512 * j, row = q >> 6, c4 = q & 63, c = row & 15;
-      F4 v;
-      if (row < 16) {
-        v = f4add(ld4(lats + (c & 7) * 256 + c4 * 4), ld4(pe0 + c4 * 4));
-      } else if (row < 32) {
-        v = ld4(p.T1 + (long long)step * 256 + c4 * 4);
-      } else {
+    for (int cb = 0; cb < 2; ++cb) {
+      const int col = cb * 128 + col0;
+      const float pe = pe0[col], tt = p.T1[(long long)step * 256 + col];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = g * 4 + i;
         int s = s0 + (c & 7);
         s = s < p.B ? s : p.B - 1;
-        v = ld4(p.TP + (long long)((c < 8 ? 0 : p.B) + s) * 256 + c4 * 4);
+        x[cb][0][i] = lats[(c & 7) * 256 + col] + pe;
+        x[cb][1][i] = tt;
+        x[cb][2][i] = p.TP[(long long)((c < 8 ? 0 : p.B) + s) * 256 + col];
       }
-      st4(Xs + row * kLfXs + c4 * 4, v);
     }
+    put(Xs, kLfXs, 0, x[0]);
+    put(Xs, kLfXs, 128, x[1]);
   };
 
   // ---- prologue: item 0 -> LDS buffer 0, items 1..4 -> ring slots 1, 2, 3, 0; latents; first step's token rows
@@ -230,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     const int c = tid >> 6, c4 = tid & 63;
     int s = s0 + c;
     s = s < p.B ? s : p.B - 1;
-    F4 v = ld4(p.init_lat + (long long)s * 256 + c4 * 4);
+    const F4 v = ld4(p.init_lat + (long long)s * 256 + c4 * 4);
     st4(lats + c * 256 + c4 * 4, F4{v.x * p.init_sigma, v.y * p.init_sigma, v.z * p.init_sigma, v.w * p.init_sigma});
   }
   __syncthreads();
@@ -240,10 +299,8 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   const float* xa = Xs + r * kLfXs + g * 4;        // A fragments of the layer input
   const float* aa = As + r * kLfXs + g * 4;        // ... of the attention output
   const float* ha = As + r * kLfHs + g * 4;        // ... of a hidden-activation block
-  const int col0 = wave * 16 + r;                  // this lane's column inside a 128-column block
 
   for (int step = 0; step < p.n; ++step) {
-    float v[2][3][4];                              // norm2 output of the current layer (row 16t + 4g + i, column 128cb + col0)
     for (int l = 0; l < p.L; ++l) {
       const float* sm = p.small + (long long)l * kLsLayer;
       // ================= self-attention: two heads at a time (cross_attention.py:265-266; nn.MultiheadAttention, 4 heads of 64)
@@ -254,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         run(0, 8, xa, 16 * kLfXs, q, true);
         run(0, 8, xa, 16 * kLfXs, k, true);
         run(0, 8, xa, 16 * kLfXs, vv, false);
-        // partial scores over this wave's 16 columns of the head: s[t][t'] for the CFG rows 4g .. 4g + 3
+        // partial scores over this wave's 16 columns of the head: s[t][u] for the CFG rows 4g .. 4g + 3
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -285,39 +342,29 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
             o[t][i] = (e0 * inv) * (vv[0][i] + bv) + (e1 * inv) * (vv[1][i] + bv) + (e2 * inv) * (vv[2][i] + bv);
           }
         }
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) As[(t * 16 + g * 4 + i) * kLfXs + hp * 128 + col0] = o[t][i];
+        put(As, kLfXs, hp * 128, o);
       }
       __syncthreads();                                 // the attention output is complete before anybody multiplies it
-      // ================= out-projection + residual + norm1 -> Xs (in place)
+      // ================= out-projection + residual + norm1 -> Xs
+      float u[2][3][4];
       {
         const float ob0 = sm[kLsOutB + col0], ob1 = sm[kLsOutB + 128 + col0];
         f32x4 o0[3], o1[3];
         zero3(o0); zero3(o1);
         run(0, 8, aa, 16 * kLfXs, o0, true);
         run(0, 8, aa, 16 * kLfXs, o1, false);
-        float u[2][3][4];
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float* xr = Xs + (t * 16 + g * 4 + i) * kLfXs + col0;
-            u[0][t][i] = o0[t][i] + ob0 + xr[0];
-            u[1][t][i] = o1[t][i] + ob1 + xr[128];
+            u[0][t][i] = o0[t][i] + ob0 + x[0][t][i];
+            u[1][t][i] = o1[t][i] + ob1 + x[1][t][i];
           }
         ln_part1(u, 3);
         stage(7);
         ln_part2(u, 3, sm + kLsN1W, sm + kLsN1B);
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float* xr = Xs + (t * 16 + g * 4 + i) * kLfXs + col0;
-            xr[0] = u[0][t][i];
-            xr[128] = u[1][t][i];
-          }
+        put(Xs, kLfXs, 0, u[0]);
+        put(Xs, kLfXs, 128, u[1]);
         __syncthreads();
       }
       // ================= feed-forward: hidden activation in blocks of 128 columns, linear2 accumulated in registers
@@ -329,10 +376,12 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
           f32x4 h[3];
           zero3(h);
           run(0, 8, xa, 16 * kLfXs, h, false);
+          float hv[3][4];
 #pragma unroll
           for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) As[(t * 16 + g * 4 + i) * kLfHs + col0] = gelu_erf(h[t][i] + b1);
+            for (int i = 0; i < 4; ++i) hv[t][i] = gelu_erf(h[t][i] + b1);
+          put(As, kLfHs, 0, hv);
           stage(7);
           run(0, 4, ha, 16 * kLfHs, y0, true);
           run(4, 4, ha, 16 * kLfHs, y1, false);
@@ -343,24 +392,17 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         for (int t = 0; t < 3; ++t)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float* xr = Xs + (t * 16 + g * 4 + i) * kLfXs + col0;
-            v[0][t][i] = y0[t][i] + lb0 + xr[0];
-            v[1][t][i] = y1[t][i] + lb1 + xr[128];
+            x[0][t][i] = y0[t][i] + lb0 + u[0][t][i];
+            x[1][t][i] = y1[t][i] + lb1 + u[1][t][i];
           }
-        ln_part1(v, 3);
+        ln_part1(x, 3);
         stage(7);
-        ln_part2(v, 3, sm + kLsN2W, sm + kLsN2B);
+        ln_part2(x, 3, sm + kLsN2W, sm + kLsN2B);
       }
       if (l + 1 < p.L) {
         // layer output -> Xs; first half of the stack: also parked for the skip connection (cross_attention.py:48-52)
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float* xr = Xs + (t * 16 + g * 4 + i) * kLfXs + col0;
-            xr[0] = v[0][t][i];
-            xr[128] = v[1][t][i];
-          }
+        put(Xs, kLfXs, 0, x[0]);
+        put(Xs, kLfXs, 128, x[1]);
         if (l < nb) {
           float* sk = p.skip + ((long long)(blockIdx.x * nb + l) * 48) * 256;
 #pragma unroll
@@ -368,8 +410,8 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               float* o = sk + (t * 16 + g * 4 + i) * 256 + col0;
-              o[0] = v[0][t][i];
-              o[128] = v[1][t][i];
+              o[0] = x[0][t][i];
+              o[128] = x[1][t][i];
             }
         }
         __syncthreads();
@@ -385,8 +427,18 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
           const float* sk = p.skip + ((long long)(blockIdx.x * nb + (nb - 1 - si)) * 48) * 256;
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
-            const int q = tid + 512 * j, row = q >> 6, c4 = q & 63;
-            st4(Xs + row * kLfXs + c4 * 4, ld4(sk + row * 256 + c4 * 4));
+            const int qd = tid + 512 * j, row = qd >> 6, c4 = qd & 63;
+            const F4 sv = ld4(sk + row * 256 + c4 * 4);
+            if constexpr (X3) {
+              unsigned h0, l0, h1, l1;
+              split16_pair(sv.x, sv.y, h0, l0);
+              split16_pair(sv.z, sv.w, h1, l1);
+              unsigned* d = reinterpret_cast<unsigned*>(Xs) + row * kLfXs + (c4 >> 3) * 32 + (c4 & 7) * 2;
+              *reinterpret_cast<U2*>(d) = U2{h0, h1};
+              *reinterpret_cast<U2*>(d + 16) = U2{l0, l1};
+            } else {
+              st4(Xs + row * kLfXs + c4 * 4, sv);
+            }
           }
           __syncthreads();
           run(0, 8, xa, 16 * kLfXs, z0, true);
@@ -395,30 +447,31 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
           for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              float* xr = Xs + (t * 16 + g * 4 + i) * kLfXs + col0;
-              xr[0] = z0[t][i] + sb0;
-              xr[128] = z1[t][i] + sb1;
+              x[0][t][i] = z0[t][i] + sb0;
+              x[1][t][i] = z1[t][i] + sb1;
             }
+          put(Xs, kLfXs, 0, x[0]);
+          put(Xs, kLfXs, 128, x[1]);
           __syncthreads();
         }
       }
     }
     // ================= end of the step: encoder.norm on the latent token (mld_denoiser.py:206), CFG (mld.py:339-342), DDIM eta = 0
     {
-      ln_part1(v, 1);
+      ln_part1(x, 1);
       __syncthreads();
-      ln_part2(v, 1, sm_fin, sm_fin + 256);
+      ln_part2(x, 1, sm_fin, sm_fin + 256);
       const float sat = p.ddim[step * 4], s1mat = p.ddim[step * 4 + 1], sap = p.ddim[step * 4 + 2], s1map = p.ddim[step * 4 + 3];
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float eu = v[cb][0][i], ec = wave_xor(eu, 32);     // CFG row c + 8 lives in lane + 32
+          const float eu = x[cb][0][i], ec = wave_xor(eu, 32);     // CFG row c + 8 lives in lane + 32
           if (g < 2) {
             float* lp = lats + (g * 4 + i) * 256 + cb * 128 + col0;
             const float eps = eu + p.guidance * (ec - eu);
-            const float x = lp[0];
-            const float x0 = (x - s1mat * eps) / sat;
+            const float xt = lp[0];
+            const float x0 = (xt - s1mat * eps) / sat;
             lp[0] = sap * x0 + s1map * eps;
           }
         }

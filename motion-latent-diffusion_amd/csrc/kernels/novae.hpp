@@ -275,8 +275,8 @@ __global__ __launch_bounds__(NW * 64) void attn_seq_x3_kernel(const float* __res
         const float m = key < len ? 1.f : 0.f;
         if (j0 + u < NIT) {
           unsigned h0, l0, h1, l1;
-          split_bf16_pair(v[u].x * m, v[u].y * m, h0, l0);
-          split_bf16_pair(v[u].z * m, v[u].w * m, h1, l1);
+          split16_pair(v[u].x * m, v[u].y * m, h0, l0);
+          split16_pair(v[u].z * m, v[u].w * m, h1, l1);
           if (!vphase) {
             if (key < nkt * 16) {
               *reinterpret_cast<U2*>(Kh + key * KST + c4 * 2) = U2{h0, h1};
@@ -320,9 +320,9 @@ __global__ __launch_bounds__(NW * 64) void attn_seq_x3_kernel(const float* __res
         for (int c = 0; c < NCH; ++c) {
           const U4 kh = *reinterpret_cast<const U4*>(Kh + (kt * 16 + r) * KST + c * 16 + g * 4);
           const U4 kl = *reinterpret_cast<const U4*>(Kl + (kt * 16 + r) * KST + c * 16 + g * 4);
-          s[kt] = mfma_bf16_16x16x32(kl, qh[c], s[kt]);
-          s[kt] = mfma_bf16_16x16x32(kh, ql[c], s[kt]);
-          s[kt] = mfma_bf16_16x16x32(kh, qh[c], s[kt]);
+          s[kt] = mfma_x3_16x16x32(kl, qh[c], s[kt]);
+          s[kt] = mfma_x3_16x16x32(kh, ql[c], s[kt]);
+          s[kt] = mfma_x3_16x16x32(kh, qh[c], s[kt]);
         }
       }
     }
@@ -369,9 +369,9 @@ __global__ __launch_bounds__(NW * 64) void attn_seq_x3_kernel(const float* __res
         const U2 a0 = *reinterpret_cast<const U2*>(vh), a1 = *reinterpret_cast<const U2*>(vh + 8);
         const U2 b0 = *reinterpret_cast<const U2*>(vl), b1 = *reinterpret_cast<const U2*>(vl + 8);
         const U4 vhh = U4{a0.x, a0.y, a1.x, a1.y}, vll = U4{b0.x, b0.y, b1.x, b1.y};
-        oacc[dt] = mfma_bf16_16x16x32(pl, vhh, oacc[dt]);
-        oacc[dt] = mfma_bf16_16x16x32(ph, vll, oacc[dt]);
-        oacc[dt] = mfma_bf16_16x16x32(ph, vhh, oacc[dt]);
+        oacc[dt] = mfma_x3_16x16x32(pl, vhh, oacc[dt]);
+        oacc[dt] = mfma_x3_16x16x32(ph, vll, oacc[dt]);
+        oacc[dt] = mfma_x3_16x16x32(ph, vhh, oacc[dt]);
       }
     }
   }

@@ -152,22 +152,42 @@ __device__ __forceinline__ void st4(float* p, F4 v) { *reinterpret_cast<F4*>(p) 
 
 constexpr float kLnEps = 1e-5f;
 
-// ---- split-bf16 arithmetic ("bf16x3"): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) keeps 16 mantissa
-// bits; x*y ~ hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulate) costs 3 matrix
-// instructions per 32-wide K chunk instead of 8 fp32 ones at 1/16 the rate: ~5x the fp32 MFMA throughput
-// at ~1e-5 relative error per product (vs 6e-8 for fp32, 4e-3 for plain bf16).
+// ---- split 16-bit arithmetic ("x3"): x = hi + lo with hi = f16(x), lo = f16(x - hi) keeps 22 mantissa bits;
+// x*y ~ lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_f16 (fp32 accumulate) costs 3 matrix instructions per 32-wide K chunk
+// instead of 8 fp32 ones at 1/16 the rate: ~5x the fp32 MFMA throughput at ~5e-7 relative error per product (fp32: 6e-8, plain
+// bf16: 4e-3).  Rounds 1-2 split into bf16 halves (16 mantissa bits, 1.5e-5 per product): same instruction count and rate,
+// 30x the error -- 50 guided steps amplified that to 1.1e-3 on the joints and ruled the reverse loop out; IEEE half does not
+// (oracle-side emulation: latents 1.5e-4 from fp64 against 8e-5 for fp32 and 2.4e-3 for the bf16 split).  What half gives up
+// is range: hi saturates at +-65 504 (activations here are post-LayerNorm / post-GELU / attention outputs, |x| < ~100; weights
+// < 10) and low parts of |x| < 0.125 fall into f16 subnormals (absolute error <= 3e-8, kept: hipcc's default mode preserves
+// f16 denormals on the conversions and on MFMA inputs).
 struct alignas(16) U4 { unsigned x, y, z, w; };
 __device__ __forceinline__ unsigned bf16_rne_bits(float x) {      // round-to-nearest-even, result in bits 0..15
   unsigned u = __builtin_bit_cast(unsigned, x);
   u += 0x7FFFu + ((u >> 16) & 1u);
   return u >> 16;
 }
-// two floats -> packed bf16 pair of the high parts and of the low parts (element 0 in the low half)
-__device__ __forceinline__ void split_bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
-  const unsigned ha = bf16_rne_bits(a), hb = bf16_rne_bits(b);
-  const float ra = a - __builtin_bit_cast(float, ha << 16), rb = b - __builtin_bit_cast(float, hb << 16);
+__device__ __forceinline__ unsigned f16_rne_bits(float x) {       // IEEE half, round-to-nearest-even, in bits 0..15
+  const _Float16 h = (_Float16)x;
+  return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float f16_bits_value(unsigned b) {
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(b & 0xFFFFu));
+}
+// two floats -> packed half pair of the high parts and of the low parts (element 0 in the low half of the word)
+__device__ __forceinline__ void split16_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  const float ca = fminf(fmaxf(a, -65504.f), 65504.f), cb = fminf(fmaxf(b, -65504.f), 65504.f);
+  const unsigned ha = f16_rne_bits(ca), hb = f16_rne_bits(cb);
+  const float ra = ca - f16_bits_value(ha), rb = cb - f16_bits_value(hb);
   hi = ha | (hb << 16);
-  lo = bf16_rne_bits(ra) | (bf16_rne_bits(rb) << 16);
+  lo = f16_rne_bits(ra) | (f16_rne_bits(rb) << 16);
+}
+// one float -> (high, low) half bits (kernels that write 16-bit elements of a split image one at a time)
+__device__ __forceinline__ void split16_one(float a, unsigned short& hi, unsigned short& lo) {
+  const float ca = fminf(fmaxf(a, -65504.f), 65504.f);
+  const unsigned h = f16_rne_bits(ca);
+  hi = (unsigned short)h;
+  lo = (unsigned short)f16_rne_bits(ca - f16_bits_value(h));
 }
 // v_mfma_f32_16x16x32_bf16: lane l supplies A[row = l&15][k = 8*(l>>4) + j] and B[k = 8*(l>>4) + j][col = l&15],
 // j = 0..7 packed little-endian in 4 dwords; C/D as for the fp32 form.
@@ -178,6 +198,17 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(U4 a, U4 b, f32x4 c) {
 #else
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
+
+// v_mfma_f32_16x16x32_f16: the same operand layout with IEEE half elements (the split arithmetic above)
+__device__ __forceinline__ f32x4 mfma_x3_16x16x32(U4 a, U4 b, f32x4 c) {
+#if defined(MLDHIP_SIM)
+  const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+  return hipsim::mfma_f16_16x16x32(av, bv, c);
+#else
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 #endif
 }
 

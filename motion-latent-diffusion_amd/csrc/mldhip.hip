@@ -193,7 +193,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<13, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<13, 128>()));
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<18, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<18, 128>()));
   (void)hipFuncSetAttribute((const void*)ffn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLdsBytes);
-  (void)hipFuncSetAttribute((const void*)den_loop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_loop_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_loop_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
 #define MLD_T32_ATTR1(MT, NS, ...) \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<MT, NS, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
 #define MLD_T32_ATTR(NS)                                                                                                    \
@@ -245,6 +246,7 @@ void mldhip_destroy(mldhip_handle* e) {
   if (e->arena) (void)hipFree(e->arena);
   if (e->arena_x3) (void)hipFree(e->arena_x3);
   if (e->loop_stream) (void)hipFree(e->loop_stream);
+  if (e->loop_stream_x3) (void)hipFree(e->loop_stream_x3);
   if (e->loop_small) (void)hipFree(e->loop_small);
   for (auto& x : e->ctxs) {
     if (x.ws) (void)hipFree(x.ws);
@@ -289,6 +291,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value < 0 || value > 3) return e->fail(MLDHIP_EINVAL, "loop_kernel must be 0 (auto), 1 (latency), 2 (throughput) or 3 (sample-major persistent loop)");
     if (value == 3 && e->finalized && !e->loop_ips) return e->fail(MLDHIP_EINVAL, "loop_kernel 3: the sample-major loop is built for fp32 loop arithmetic, ff_size 1024, 4 heads");
     e->loop_kernel = (int)value;
+  } else if (n == "fused_x3") {
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "fused_x3 must be 0 or 1");
+    e->fused_x3 = (int)value;
   } else if (n == "fused_min_batch") {
     if (value < 1) return e->fail(MLDHIP_EINVAL, "fused_min_batch must be >= 1");
     e->fused_min_batch = (int)std::min<int64_t>(value, 1 << 30);
@@ -391,7 +396,7 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
   if (e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE || e->cfg.precision == MLDHIP_PREC_FP8_DENOISER) {
     // the staged GEMMs of these modes run on split-bf16 MFMAs: split the weights once, here, not in every workgroup
     if (!e->arena_x3 && hipMalloc((void**)&e->arena_x3, e->arena_floats * sizeof(float)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(split weights)");
-    const long long groups = (long long)(e->arena_floats / 32);
+    const long long groups = (long long)((e->arena_floats + 31) / 32);   // arena_floats is a multiple of kAlign = 64
     MLD_LAUNCH(split_bf16_weights_kernel, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, stream, e->arena, e->arena_x3, groups);
     if (check_launch(c, "split_bf16_weights")) return c.rc;
   }

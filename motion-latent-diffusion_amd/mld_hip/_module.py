@@ -65,11 +65,16 @@ class HipModule(nn.Module):
         eng = self.engine
         _engine.check_arch(eng, type(self).__name__, **self._arch)
         sig = (id(eng), self._signature())
-        if sig != self._synced_sig:
+        # One engine serves every module of the same (device, variant, architecture): a second model with the same
+        # hyper-parameters overwrites this module's tensors in the shared arena, so "unchanged since MY last upload" is not
+        # enough -- the engine remembers who uploaded each prefix last.
+        owners = eng.__dict__.setdefault("_owner", {})
+        if sig != self._synced_sig or owners.get(self._prefix) != (id(self), sig):
             for name, p in self.named_parameters():
                 eng.load_tensor(self._prefix + name, p.data)
             eng._dirty = True
             self._synced_sig = sig
+            owners[self._prefix] = (id(self), sig)
         _engine.finalize_if_dirty(eng, self._stream())
         return eng
 

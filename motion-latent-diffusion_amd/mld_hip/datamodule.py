@@ -47,11 +47,13 @@ class HipDataModule:
     def _engine(self, device):
         eng = _engine.get_engine(self._engine_key if self._engine_key is not None else device, self.variant or "text",
                                  want=self._shared_arch)
-        if self._loaded_on is not eng:
+        owners = eng.__dict__.setdefault("_owner", {})           # see HipModule.sync_weights: engines are shared per architecture
+        if self._loaded_on is not eng or owners.get("mean/std") != id(self):
             eng.load_tensor("mean", self.mean)
             eng.load_tensor("std", self.std)
             eng._dirty = True
             self._loaded_on = eng
+            owners["mean/std"] = id(self)
         return eng
 
     def feats2joints(self, features: torch.Tensor, mask=None) -> torch.Tensor:

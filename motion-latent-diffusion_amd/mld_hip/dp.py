@@ -54,17 +54,23 @@ def gather_lengths_order(n: int, world: int) -> List[Tuple[int, int]]:
 
 
 class DataParallelSampler:
-    """Shard a list of prompts over the ranks of the default process group; each rank runs the model on its block in
-    chunks of `batch_size` and returns (global_indices, joints_list) for its block.
+    """Shard a list of prompts (or action labels) over the ranks of the default process group; each rank runs the model on its
+    block in chunks of `batch_size` and returns (global_indices, motions) for its block -- joints [len, 22, 3] per prompt for the
+    text models (``MLD.forward``, mld.py:216-265; also the diffusion-only variant), features [len, nfeats] per label for the
+    action model (``MLD.a2m_eval``, mld.py:710-735: its joints need SMPL).
 
-    in_flight > 1 (text-to-motion models on the fused engine path): consecutive chunks are issued on `in_flight` rotating
+    `init_latents` (optional, indexed like the prompts: [N, 1, D] latents, or [N, Tmax, nfeats] raw-motion noise for the
+    diffusion-only variant) pins the starting noise per PROMPT, so a motion does not depend on the world size or on which rank /
+    chunk it lands in -- what the multi-process tests compare.  Without it every chunk draws from torch's generator.
+
+    in_flight > 1 (latent text-to-motion models on the fused engine path): consecutive chunks are issued on `in_flight` rotating
     HIP streams, so several batches overlap on the GPU (configure the engine with ``mld_hip.engine.configure("text", max_in_flight=in_flight)`` before
     its first use; with fewer workspaces the engine orders the calls behind each other on the device -- a workspace is
     never shared by two calls at once).  Results are identical either way.
 
     coalesce > 1: `coalesce` consecutive chunks go into ONE engine call (``MLD.sample_many`` -> ``mldhip_sample_many``: one chain over
-    coalesce x batch_size motions on the throughput kernels); combined with in_flight = 4 this is the serving shape bench.py's
-    headline measures (configure ``max_batch >= coalesce * batch_size``).  Set GPU_MAX_HW_QUEUES=8 before HIP initialises."""
+    coalesce x batch_size motions; from ~1 000 motions per call the engine runs the reverse loop as one persistent launch, a
+    workgroup per 8 motions -- configure ``max_batch >= coalesce * batch_size``)."""
 
     def __init__(self, model, batch_size: int = 64, in_flight: int = 1, coalesce: int = 1):
         self.model = model
@@ -72,19 +78,47 @@ class DataParallelSampler:
         self.in_flight = max(1, int(in_flight))
         self.coalesce = max(1, int(coalesce))
 
-    def __call__(self, texts: Sequence[str], lengths: Sequence[int]):
+    def __call__(self, texts: Sequence[str] = None, lengths: Sequence[int] = None, actions: Sequence[int] = None, init_latents=None,
+                 step_noise=None):
+        """step_noise (diffusion-only variant, optional): the DDPM scheduler's per-step draws [steps, N, Tmax, nfeats], indexed
+        like the prompts -- with `init_latents` it makes a motion independent of how the prompts are sharded and chunked."""
         import torch.distributed as dist
+        m = self.model
+        action = getattr(m, "condition", None) == "action"
+        items = actions if action else texts
+        if items is None or lengths is None or len(items) != len(lengths):
+            raise ValueError("DataParallelSampler needs %s and lengths of equal size" % ("actions" if action else "texts"))
         rank = dist.get_rank() if dist.is_initialized() else 0
         world = dist.get_world_size() if dist.is_initialized() else 1
-        lo, hi = shard_range(len(texts), rank, world)
+        lo, hi = shard_range(len(items), rank, world)
         chunks = [(s, min(hi, s + self.batch_size)) for s in range(lo, hi, self.batch_size)]
-        m = self.model
+        dev = next(m.parameters()).device
+        novae = getattr(m, "vae_type", "") == "no"
+
+        def noise(s, e, ln):
+            if init_latents is None:
+                return None
+            z = init_latents[s:e]
+            if novae:
+                z = z[:, :max(ln)]                   # the chunk's own Tmax (mld.py:296-301)
+            return z.to(dev).float().contiguous()
+
         overlap = ((self.in_flight > 1 or self.coalesce > 1) and torch.cuda.is_available() and getattr(m, "fused", False)
-                   and getattr(m, "condition", None) == "text" and getattr(m, "vae_type", "") != "no")   # plain text-to-motion only
+                   and getattr(m, "condition", None) == "text" and not novae)              # latent text-to-motion only
         out = []
         if not overlap:
             for s, e in chunks:
-                out.extend(m({"text": list(texts[s:e]), "length": list(lengths[s:e])}))
+                ln = [int(x) for x in lengths[s:e]]
+                if action:
+                    acts = [int(a) for a in actions[s:e]]
+                    rs = m.a2m_eval({"action": torch.tensor(acts, device=dev).reshape(-1, 1), "length": ln}, init_latents=noise(s, e, ln))
+                    feats = rs["m_rst"].cpu()
+                    out.extend(feats[k, :n] for k, n in enumerate(ln))
+                elif novae and step_noise is not None:
+                    sn = step_noise[:, s:e, :max(ln)].to(dev).float().contiguous()
+                    out.extend(m({"text": list(texts[s:e]), "length": ln}, init_latents=noise(s, e, ln), step_noise=sn))
+                else:
+                    out.extend(m({"text": list(texts[s:e]), "length": ln}, init_latents=noise(s, e, ln)))
             return list(range(lo, hi)), out
         streams = [torch.cuda.Stream() for _ in range(self.in_flight)]
         for st in streams:
@@ -93,15 +127,16 @@ class DataParallelSampler:
         groups = [chunks[g:g + self.coalesce] for g in range(0, len(chunks), self.coalesce)]
         for i, grp in enumerate(groups):
             with torch.cuda.stream(streams[i % self.in_flight]):
-                reqs = []
+                reqs, lats = [], []
                 for s, e in grp:
                     tx, ln = list(texts[s:e]), [int(x) for x in lengths[s:e]]
                     reqs.append((m.text_encoder([""] * len(tx) + tx), ln))      # mld.py:224-231: unconditional half first
+                    lats.append(noise(s, e, ln))
                 if len(reqs) == 1:
-                    joints, _, _ = m.sample(*reqs[0])
+                    joints, _, _ = m.sample(*reqs[0], init_latents=lats[0])
                     pending.append((joints, reqs[0][1]))
                 else:
-                    for (joints, _, _), (_, ln) in zip(m.sample_many(reqs), reqs):
+                    for (joints, _, _), (_, ln) in zip(m.sample_many(reqs, init_latents=lats if init_latents is not None else None), reqs):
                         pending.append((joints, ln))
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)

@@ -72,9 +72,14 @@ class HipDDIMScheduler:
         sa, sb = float(a_t ** 0.5), float((1 - a_t) ** 0.5)
         pa, pb = float(a_p ** 0.5), float((1 - a_p) ** 0.5)
         x0 = (sample - sb * model_output) / sa
-        if sample.is_cuda and sample.dtype == torch.float32 and model_output.dtype == torch.float32:
-            from . import engine as _engine          # device tensors: the step runs in libmldhip (mldhip_ddim_step)
-            eng = _engine.get_engine(sample.device, self._variant, want=self._shared_arch or self.engine_config(self.num_inference_steps))
+        # device tensors: the step runs in libmldhip (mldhip_ddim_step) -- but only on the engine of the model this scheduler
+        # belongs to, and only while set_timesteps() agrees with that engine's grid: mldhip_ddim_step derives t_prev from the
+        # ENGINE's num_inference_steps.  A stand-alone scheduler, or one re-gridded with another step count, uses the torch
+        # arithmetic below (same formula) instead of instantiating an engine for an elementwise update.
+        if (sample.is_cuda and sample.dtype == torch.float32 and model_output.dtype == torch.float32 and self._shared_arch
+                and self._shared_arch.get("num_inference_steps") == self.num_inference_steps):
+            from . import engine as _engine
+            eng = _engine.get_engine(sample.device, self._variant, want=self._shared_arch)
             out = torch.empty_like(sample, memory_format=torch.contiguous_format)
             eng.ddim_step(model_output.contiguous(), t, sample.contiguous(), out, out.numel(), _engine.current_stream_handle(sample))
             return SchedulerOutput(prev_sample=out, pred_original_sample=x0)

@@ -16,9 +16,33 @@ import simlib  # noqa: E402
 from mld_hip import dp, synthetic as syn  # noqa: E402
 
 
+def sampler_job(mode, out_path, n):
+    """mode 'action' / 'novae': this rank's shard through mld_hip.MLD + DataParallelSampler (the drop-in surface), the
+    weights from ONE packed broadcast, starting noise pinned per prompt; rank 0 saves what every rank produced."""
+    import dp_models
+    rank, world = dist.get_rank(), dist.get_world_size()
+    template = dp_models.state_template(mode)
+    src = template if rank == 0 else {k: np.full_like(v, np.nan) for k, v in template.items()}
+    state = dp.broadcast_state(src, template, torch.device("cpu"), src=0)
+    model, close = dp_models.build(mode, {k: v.clone() for k, v in state.items()}, key=f"inject:dp_{mode}_{rank}")
+    try:
+        kw = dp_models.job(mode, n)
+        idx, motions = dp.DataParallelSampler(model, batch_size=2)(**kw)
+    finally:
+        close()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (idx, [np.asarray(m) for m in motions]))
+    if rank == 0:
+        np.savez(out_path, **{f"m_{i}": m for ids, ms in gathered for i, m in zip(ids, ms)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     out_path, nprompts = sys.argv[1], int(sys.argv[2])
     dist.init_process_group("gloo")
+    if len(sys.argv) > 3:
+        return sampler_job(sys.argv[3], out_path, nprompts)
     rank, world = dist.get_rank(), dist.get_world_size()
     template = {**{"denoiser." + k: v for k, v in syn.make_denoiser_state_dict().items()},
                 **{"vae." + k: v for k, v in syn.make_vae_state_dict().items()}}

@@ -85,14 +85,21 @@ static float bf16_to_float(unsigned short h) {
   return f;
 }
 
-static void compute_mfma_bf16(WaveState& w, int slot) {
+static float f16_to_float(unsigned short h) {
+  _Float16 v;
+  std::memcpy(&v, &h, 2);
+  return (float)v;
+}
+
+template <float (*CVT)(unsigned short)>
+static void compute_mfma_16bit(WaveState& w, int slot) {
   float A[16][32], B[32][16];
   for (int l = 0; l < 64; ++l) {
     const unsigned* p = reinterpret_cast<const unsigned*>(w.buf[slot][l]);
     for (int j = 0; j < 8; ++j) {
       const unsigned short ah = (p[j >> 1] >> (16 * (j & 1))) & 0xFFFFu, bh = (p[4 + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
-      A[l & 15][(l >> 4) * 8 + j] = bf16_to_float(ah);
-      B[(l >> 4) * 8 + j][l & 15] = bf16_to_float(bh);
+      A[l & 15][(l >> 4) * 8 + j] = CVT(ah);
+      B[(l >> 4) * 8 + j][l & 15] = CVT(bh);
     }
   }
   for (int l = 0; l < 64; ++l) {
@@ -101,7 +108,7 @@ static void compute_mfma_bf16(WaveState& w, int slot) {
     for (int r = 0; r < 4; ++r) {
       const int row = (l >> 4) * 4 + r;
       float d = cp[r];
-      for (int k = 0; k < 32; ++k) d = fmaf(A[row][k], B[k][col], d);   // products of bf16 are exact in fp32
+      for (int k = 0; k < 32; ++k) d = fmaf(A[row][k], B[k][col], d);   // products of bf16 / f16 values are exact in fp32 (f16 subnormal x subnormal aside: below 4e-15)
       w.res[slot][l][r] = d;
     }
   }
@@ -139,7 +146,8 @@ int wave_arrive(const void* payload, int nbytes, int is_mfma) {
     if (is_mfma) {
       if (w.alive != 64) { std::fprintf(stderr, "hipsim: MFMA issued by a partial wave\n"); std::abort(); }
       if (is_mfma == 1) compute_mfma(w, slot);
-      else if (is_mfma == 2) compute_mfma_bf16(w, slot);
+      else if (is_mfma == 2) compute_mfma_16bit<bf16_to_float>(w, slot);
+      else if (is_mfma == 4) compute_mfma_16bit<f16_to_float>(w, slot);
       else compute_mfma_fp8(w, slot);
     }
     w.count = 0;

@@ -62,7 +62,7 @@ void sync_threads();
 
 // ---- wave-level rendezvous: every live lane of the wave must call the same op ----
 // Deposits `nbytes` of payload, waits for the whole wave, returns the slot index used.
-int wave_arrive(const void* payload, int nbytes, int mfma_kind /*0 none, 1 f32 16x16x4, 2 bf16 16x16x32*/);
+int wave_arrive(const void* payload, int nbytes, int mfma_kind /*0 none, 1 f32 16x16x4, 2 bf16 16x16x32, 3 fp8 16x16x32, 4 f16 16x16x32*/);
 
 inline float shfl_xor(float v, int mask) {
   BlockState& b = blk();
@@ -101,6 +101,20 @@ inline f32x4 mfma_bf16_16x16x32(const unsigned (&a)[4], const unsigned (&bq)[4],
   float cf[4] = {c[0], c[1], c[2], c[3]};
   std::memcpy(&payload[8], cf, 16);
   int slot = wave_arrive(payload, 48, 2);
+  WaveState& w = b.waves[b.cur->wave];
+  const float* r = w.res[slot][b.cur->lane];
+  f32x4 d = {r[0], r[1], r[2], r[3]};
+  return d;
+}
+
+// v_mfma_f32_16x16x32_f16: same operand layout with IEEE half elements
+inline f32x4 mfma_f16_16x16x32(const unsigned (&a)[4], const unsigned (&bq)[4], f32x4 c) {
+  BlockState& b = blk();
+  unsigned payload[12];
+  for (int i = 0; i < 4; ++i) { payload[i] = a[i]; payload[4 + i] = bq[i]; }
+  float cf[4] = {c[0], c[1], c[2], c[3]};
+  std::memcpy(&payload[8], cf, 16);
+  int slot = wave_arrive(payload, 48, 4);
   WaveState& w = b.waves[b.cur->wave];
   const float* r = w.res[slot][b.cur->lane];
   f32x4 d = {r[0], r[1], r[2], r[3]};

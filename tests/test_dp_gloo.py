@@ -58,3 +58,29 @@ def test_two_rank_job_matches_single_process(tmp_path, world):
             seen += 1
     assert seen == nprompts
     eng.close()
+
+
+@pytest.mark.parametrize("mode,n", [("action", 3), ("novae", 3)])
+def test_two_rank_sampler_job_other_variants_match_single_process(tmp_path, mode, n):
+    """BASELINE config 5 (action-to-motion, quoted on 2 GPUs) and config 4 through the drop-in surface: mld_hip.MLD +
+    DataParallelSampler on two gloo ranks (each with its own engine, weights from the one broadcast, noise pinned per prompt)
+    must give the motions of a single-process run of the same prompts -- a motion may not depend on the rank it lands on."""
+    import dp_models
+    out = str(tmp_path / f"dp_{mode}.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519" if mode == "action" else "29521", os.path.join(HERE, "dp_worker.py"), out, str(n), mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    model, close = dp_models.build(mode, dp_models.state_template(mode), key=f"inject:dp_{mode}_single")
+    try:
+        kw = dp_models.job(mode, n)
+        idx, ref = dp.DataParallelSampler(model, batch_size=4)(**kw)            # one process, one chunk
+    finally:
+        close()
+    assert idx == list(range(n)) and sorted(got.files) == [f"m_{i}" for i in range(n)]
+    for i in range(n):
+        want = np.asarray(ref[i])
+        assert got[f"m_{i}"].shape == want.shape == (kw["lengths"][i], 150) if mode == "action" else (kw["lengths"][i], 22, 3)
+        assert np.abs(got[f"m_{i}"] - want).max() < 2e-5

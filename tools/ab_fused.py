@@ -49,8 +49,10 @@ def timed(fn, reps=3):
 
 # ---- parity of request 0 (reference fixture) per family and call size
 par = {}
-for fam in (1, 2, 3):
+FAMS = [(1, 0, "fam1"), (2, 0, "fam2"), (3, 0, "fam3"), (3, 1, "fam3x3")] if PREC == 1 else [(1, 0, "fam1"), (2, 0, "fam2"), (3, 0, "fam3")]
+for fam, x3, tag in FAMS:
     eng.set_option("loop_kernel", fam)
+    eng.set_option("fused_x3", x3)
     for n in SIZES:
         if n > NMAX or (fam == 1 and n > 320):
             continue
@@ -58,13 +60,14 @@ for fam in (1, 2, 3):
             q["joints_out"].zero_(); q["latents_out"].zero_()
         eng.sample_many(reqs[:n // 64]); torch.cuda.synchronize()
         q = reqs[0]
-        par[f"fam{fam}_B{n}"] = dict(latents=float(np.abs(q["latents_out"].cpu().numpy() - g["latents"]).max()),
-                                     joints=float(np.abs(q["joints_out"].cpu().numpy()[:, ::4] - g["joints_every4"]).max()))
-        print("parity", fam, n, par[f"fam{fam}_B{n}"], flush=True)
+        par[f"{tag}_B{n}"] = dict(latents=float(np.abs(q["latents_out"].cpu().numpy() - g["latents"]).max()),
+                                  joints=float(np.abs(q["joints_out"].cpu().numpy()[:, ::4] - g["joints_every4"]).max()))
+        print("parity", tag, n, par[f"{tag}_B{n}"], flush=True)
 out["parity_request0_vs_reference_fixture"] = par
 
 # ---- every request of the biggest fused call vs the same request alone on the latency kernels
 eng.set_option("loop_kernel", 3)
+eng.set_option("fused_x3", 1 if PREC == 1 else 0)
 eng.sample_many(reqs); torch.cuda.synchronize()
 fused_j = [q["joints_out"].clone() for q in reqs]
 fused_l = [q["latents_out"].clone() for q in reqs]
@@ -81,22 +84,24 @@ print("fused vs latency kernels, all requests:", worst, flush=True)
 
 # ---- timing, one call at a time
 tim = {}
-for fam in (2, 3):
+for fam, x3, tag in FAMS[1:]:
     eng.set_option("loop_kernel", fam)
+    eng.set_option("fused_x3", x3)
     for n in SIZES:
         if n > NMAX:
             continue
         k = n // 64
         t_loop = timed(lambda: eng.sample_many(lat_only[:k]))
         t_all = timed(lambda: eng.sample_many(reqs[:k]))
-        tim[f"fam{fam}_B{n}"] = dict(loop_ms=round(t_loop * 1e3, 2), all_ms=round(t_all * 1e3, 2), motions_per_s=round(n / t_all, 1),
+        tim[f"{tag}_B{n}"] = dict(loop_ms=round(t_loop * 1e3, 2), all_ms=round(t_all * 1e3, 2), motions_per_s=round(n / t_all, 1),
                                      loop_motions_per_s=round(n / t_loop, 1))
-        print("time", fam, n, tim[f"fam{fam}_B{n}"], flush=True)
+        print("time", tag, n, tim[f"{tag}_B{n}"], flush=True)
 out["one_call_at_a_time"] = tim
 
 # ---- calls in flight (4 streams), 320 motions per call for the column-split family; fused: 2 x 1024
-def in_flight(fam, per_call, nfl, ncalls):
+def in_flight(fam, per_call, nfl, ncalls, x3=0):
     eng.set_option("loop_kernel", fam)
+    eng.set_option("fused_x3", x3)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
     k = per_call // 64
     groups = [reqs[(i * k) % nreq:(i * k) % nreq + k] for i in range(nfl)]
@@ -114,9 +119,10 @@ def in_flight(fam, per_call, nfl, ncalls):
 fl = {}
 fl["fam2_320x4"] = in_flight(2, 320, 4, 8)
 if NMAX >= 2048:
-    fl["fam3_1024x2"] = in_flight(3, 1024, 2, 4)
-    fl["fam3_2048x1"] = in_flight(3, 2048, 1, 2)
-    fl["fam3_2048x2"] = in_flight(3, 2048, 2, 4)
+    x3 = 1 if PREC == 1 else 0
+    fl["fam3_1024x2"] = in_flight(3, 1024, 2, 4, x3)
+    fl["fam3_2048x1"] = in_flight(3, 2048, 1, 2, x3)
+    fl["fam3_2048x2"] = in_flight(3, 2048, 2, 4, x3)
 print("in flight:", fl, flush=True)
 out["in_flight_motions_per_s"] = fl
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
