@@ -238,23 +238,25 @@ int build_loop_stream(Ctx& c) {
   const int L = e->cfg.num_layers, nb = (L - 1) / 2, n = e->cfg.num_inference_steps, F = e->cfg.ff_size;
   std::vector<LoopItem> items;
   auto push = [&](const float* w, int ld, int row0, int k0) { items.push_back(LoopItem{(long long)(w - e->arena) + (long long)row0 * ld + k0, ld, 0}); };
+  // chunk-major inside a group: the items that multiply the same 32 columns of A are adjacent (loop_fused.hpp run2 / run3)
   for (int l = 0; l < L; ++l) {
     const EncLayerP& P_ = e->den[l];
     for (int hp = 0; hp < 2; ++hp)
-      for (int part = 0; part < 3; ++part)
-        for (int kc = 0; kc < 8; ++kc) push(P_.in_w, 256, part * 256 + hp * 128, kc * 32);
-    for (int cb = 0; cb < 2; ++cb)
-      for (int kc = 0; kc < 8; ++kc) push(P_.out_w, 256, cb * 128, kc * 32);
-    for (int hb = 0; hb < 8; ++hb) {
-      for (int kc = 0; kc < 8; ++kc) push(P_.l1_w, 256, hb * 128, kc * 32);
-      for (int cb = 0; cb < 2; ++cb)
-        for (int kc = 0; kc < 4; ++kc) push(P_.l2_w, F, cb * 128, hb * 128 + kc * 32);
+      for (int kc = 0; kc < 8; ++kc)
+        for (int part = 0; part < 3; ++part) push(P_.in_w, 256, part * 256 + hp * 128, kc * 32);
+    for (int kc = 0; kc < 8; ++kc)
+      for (int cb = 0; cb < 2; ++cb) push(P_.out_w, 256, cb * 128, kc * 32);
+    for (int hb = 0; hb < 4; ++hb) {
+      for (int kc = 0; kc < 8; ++kc)
+        for (int half = 0; half < 2; ++half) push(P_.l1_w, 256, hb * 256 + half * 128, kc * 32);
+      for (int kc = 0; kc < 8; ++kc)
+        for (int cb = 0; cb < 2; ++cb) push(P_.l2_w, F, cb * 128, hb * 256 + kc * 32);
     }
     if (l >= nb && l + 1 < L) {
       const float* w = P(e, "denoiser.encoder.linear_blocks." + std::to_string(l - nb) + ".weight");
       for (int half = 0; half < 2; ++half)
-        for (int cb = 0; cb < 2; ++cb)
-          for (int kc = 0; kc < 8; ++kc) push(w, 512, cb * 128, half * 256 + kc * 32);
+        for (int kc = 0; kc < 8; ++kc)
+          for (int cb = 0; cb < 2; ++cb) push(w, 512, cb * 128, half * 256 + kc * 32);
     }
   }
   const size_t ips = items.size(), small_floats = (size_t)L * kLsLayer + (size_t)nb * 256 + 768, tail = (size_t)n * 4;
@@ -271,8 +273,8 @@ int build_loop_stream(Ctx& c) {
   e->loop_ddim = e->loop_small + small_floats;
   hipError_t st = hipMemcpy(items_dev, items.data(), ips * sizeof(LoopItem), hipMemcpyHostToDevice);
   if (st == hipSuccess) {
-    MLD_LAUNCH(pack_loop_stream_kernel<false>, dim3((unsigned)ips), dim3(256), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->loop_stream);
-    if (want_x3) MLD_LAUNCH(pack_loop_stream_kernel<true>, dim3((unsigned)ips), dim3(256), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->loop_stream_x3);
+    MLD_LAUNCH(pack_loop_stream_kernel<false>, dim3((unsigned)ips), dim3(512), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->loop_stream);
+    if (want_x3) MLD_LAUNCH(pack_loop_stream_kernel<true>, dim3((unsigned)ips), dim3(512), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->loop_stream_x3);
     check_launch(c, "pack_loop_stream");
     st = hipStreamSynchronize(c.stream);
   }

@@ -185,11 +185,11 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(FfnArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float v = gelu_erf(acc1[a][b][i] + b1v[b]);
-              const unsigned hi = bf16_rne_bits(v);
-              const unsigned lo = bf16_rne_bits(v - __builtin_bit_cast(float, hi << 16));
+              unsigned short hi, lo;
+              split16_one(v, hi, lo);
               unsigned short* hp = reinterpret_cast<unsigned short*>(Hs + (wm * 32 + a * 16 + g * 4 + i) * HS + wn * 32);
-              hp[b * 16 + r] = (unsigned short)hi;
-              hp[32 + b * 16 + r] = (unsigned short)lo;
+              hp[b * 16 + r] = hi;
+              hp[32 + b * 16 + r] = lo;
             }
       }
       // item it + 1 -> the other LDS buffer, item it + 1 + RD -> the ring slot that just became free (hidden blocks past the end

@@ -24,11 +24,17 @@
 // registers: the lane that produces element (row, column) of a LayerNorm output is the lane that needs it as the residual of
 // the next one.
 //
-// Weight stream: `finalize` re-packs the denoiser's GEMM weights into the order this kernel consumes them, as "items" of
-// 128 output columns x 32 k (16 KB, rows contiguous; split mode: 16 words of high halves + 16 words of low halves per row):
-// every thread fetches 2 x 16 bytes per item into a 4-deep register ring, stores them to a double-buffered LDS stage, one
-// barrier per item; each wave multiplies its 16 of the 128 columns against the three row tiles.  The sequence is uniform over
-// phases, layers and steps (it wraps at the end of a step), so the prefetch never drains.
+// Weight stream: a weight element is used by exactly ONE wave (wave w owns columns 16w .. 16w + 15 of every 128-column block), so
+// staging weights through LDS would buy nothing and cost a store, a read and a barrier per item (the first build of this kernel
+// did: 42 ms per call in split mode, bound by LDS traffic and 1 856 barriers per step).  Instead `finalize` re-packs the GEMM
+// weights into "items" of 128 output columns x 32 k in FRAGMENT order -- [wave][lane][8 words]: lane (r, g) of wave w finds the
+// two 16-byte MFMA operands of weight row 16w + r (fp32: k-slots 4g .. 4g + 3 and 16 + 4g .. + 3; split: high and low halves of
+// k = 8g .. 8g + 7) contiguous -- in the order the kernel consumes them, and every lane loads its 32 bytes per item straight
+// into an 8-deep register ring: 2 KB contiguous per wave and item, no LDS, no barrier.  Waves only meet where activations
+// change hands (17 barriers per layer).  Items that multiply the same 32 columns of A are adjacent in the stream ([Q, K, V] of a
+// chunk; both column blocks of the out-projection, linear2 and the skip linears; two hidden blocks of linear1), so an A fragment
+// read from LDS feeds 2-3 items.  The sequence is uniform over phases, layers and steps (it wraps at the end of a step): the
+// prefetch never drains.  Bound in split mode: the L2 -> CU path (16 KB per item and CU at 64 B/clk) next to 9 MFMAs per item and wave.
 //
 // Replaces, per step: mld_denoiser.py:143-228 (token assembly, SkipTransformerEncoder, final norm), mld.py:325-346 (CFG + DDIM).
 #pragma once
@@ -46,7 +52,7 @@ constexpr int kLoopItemsLayer = 192, kLoopItemsSkip = 32, kLoopItemFloats = 128 
 struct LoopItem { long long src; int ld; int pad; };   // element [row0][k0] of a weight (floats into the arena), row stride
 
 struct LoopArgs {
-  const float* stream;     // [ips][128][32] weight items in consumption order (fp32, or the split image)
+  const float* stream;     // [ips][8 waves][64 lanes][8 words] weight items in consumption order, fragment layout (fp32 or split halves)
   int ips;                 // items per reverse step
   const float* small;      // packed small parameters (layout above)
   const float* T1;         // [n][256] time-token rows (time MLP + pe[1]) of the scheduler's timesteps
@@ -59,32 +65,33 @@ struct LoopArgs {
   float guidance, init_sigma;
 };
 
-constexpr int kLfXs = 264, kLfHs = 136, kLfWs = 40;      // LDS row strides (words), all = 8 mod 16: conflict-free fragment reads (strip.hpp)
-constexpr int kLfXFloats = 48 * kLfXs, kLfWBuf = 128 * kLfWs, kLfScFloats = 8 * 144, kLfRedFloats = 2 * 8 * 48, kLfLatFloats = 8 * 256;
-constexpr int kLoopLdsBytes = (2 * kLfXFloats + 2 * kLfWBuf + kLfScFloats + kLfRedFloats + kLfLatFloats) * 4;   // 158 208 B: one workgroup per CU
+constexpr int kLfXs = 264;                                // LDS row stride (words), = 8 mod 16: conflict-free fragment reads (strip.hpp)
+constexpr int kLfXFloats = 48 * kLfXs, kLfScFloats = 8 * 144, kLfRedFloats = 2 * 8 * 48, kLfLatFloats = 8 * 256;
+constexpr int kLoopLdsBytes = (2 * kLfXFloats + kLfScFloats + kLfRedFloats + kLfLatFloats) * 4;   // 117 248 B: one workgroup per CU
+constexpr int kLoopRing = 8;                              // items in flight per lane (8 VGPRs each)
 
-// finalize-time: gathers the weight items into consumption order.  X3: every row of 32 floats becomes 16 words of packed high
-// halves + 16 words of packed low halves (the image a staged split GEMM keeps in LDS, elementwise.hpp).  grid = items, block = 256.
+// finalize-time: gathers the weight items into consumption order and fragment layout.  Thread (w, r, g) of item i writes the 8
+// words lane (r, g) of wave w will load: fp32: W[16w + r][4g .. 4g + 3], W[16w + r][16 + 4g .. + 3] of the item's 32 k; X3: the packed
+// high halves of k = 8g .. 8g + 7 (4 words), then the low halves.  grid = items, block = 512.
 template <bool X3>
-__global__ __launch_bounds__(256) void pack_loop_stream_kernel(const float* __restrict__ arena, const LoopItem* __restrict__ items,
+__global__ __launch_bounds__(512) void pack_loop_stream_kernel(const float* __restrict__ arena, const LoopItem* __restrict__ items,
                                                                float* __restrict__ out) {
   const LoopItem it = items[blockIdx.x];
-  float* dst = out + (long long)blockIdx.x * kLoopItemFloats;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const float* src = arena + it.src + (long long)(16 * w + r) * it.ld;
+  float* dst = out + (long long)blockIdx.x * kLoopItemFloats + threadIdx.x * 8;
   if constexpr (!X3) {
-    for (int q = threadIdx.x; q < 1024; q += 256) {
-      const int row = q >> 3, c4 = q & 7;
-      st4(dst + row * 32 + c4 * 4, ld4(arena + it.src + (long long)row * it.ld + c4 * 4));
-    }
+    st4(dst, ld4(src + 4 * g));
+    st4(dst + 4, ld4(src + 16 + 4 * g));
   } else {
-    for (int q = threadIdx.x; q < 2048; q += 256) {
-      const int row = q >> 4, pr = q & 15;
-      const float* s = arena + it.src + (long long)row * it.ld + 2 * pr;
-      unsigned hi, lo;
-      split16_pair(s[0], s[1], hi, lo);
-      unsigned* o = reinterpret_cast<unsigned*>(dst) + row * 32;
-      o[pr] = hi;
-      o[16 + pr] = lo;
-    }
+    const F4 a = ld4(src + 8 * g), b = ld4(src + 8 * g + 4);
+    U4 hi, lo;
+    split16_pair(a.x, a.y, hi.x, lo.x);
+    split16_pair(a.z, a.w, hi.y, lo.y);
+    split16_pair(b.x, b.y, hi.z, lo.z);
+    split16_pair(b.z, b.w, hi.w, lo.w);
+    *reinterpret_cast<U4*>(dst) = hi;
+    *reinterpret_cast<U4*>(dst + 4) = lo;
   }
 }
 
@@ -97,9 +104,8 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #endif
   float* Xs = smem;                       // [48][264] layer input / norm1 output (the A operand; fp32, or the split image)
-  float* As = Xs + kLfXFloats;            // [48][264] attention output, or [48][136] one 128-wide block of the hidden activation
-  float* Ws = As + kLfXFloats;            // [2][128][40] weight item stage
-  float* sc = Ws + 2 * kLfWBuf;           // [8][9][16] per-wave partial attention scores
+  float* As = Xs + kLfXFloats;            // [48][264] attention output, then two 128-wide blocks of the hidden activation at a time
+  float* sc = As + kLfXFloats;            // [8][9][16] per-wave partial attention scores
   float* red = sc + kLfScFloats;          // [2][8][48] per-wave LayerNorm partial sums
   float* lats = red + kLfRedFloats;       // [8][256] the workgroup's latents
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
@@ -109,51 +115,32 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   const float* sm_fin = sm_skip + nb * 256;
   const int col0 = wave * 16 + r;                  // this lane's column inside a 128-column block
 
-  // ---- weight ring: thread t holds 16 bytes of rows (t >> 3) and (t >> 3) + 64 of the items in flight
-  const int wrow = tid >> 3, wc4 = tid & 7;
-  const float* gsrc = p.stream + wrow * 32 + wc4 * 4;
-  float* wdst = Ws + wrow * kLfWs + wc4 * 4;
+  // ---- weight ring: this lane's two MFMA operands (32 bytes) of the next kLoopRing items, straight from the fragment-ordered stream
+  const float* gsrc = p.stream + tid * 8;
   int gitem = 0;
-  F4 ring[4][2];
+  F4 ring[kLoopRing][2];
   auto gload = [&](int slot) __attribute__((always_inline)) {
     const float* s = gsrc + (long long)gitem * kLoopItemFloats;
     ring[slot][0] = ld4(s);
-    ring[slot][1] = ld4(s + 64 * 32);
+    ring[slot][1] = ld4(s + 4);
     gitem = gitem + 1 == p.ips ? 0 : gitem + 1;
   };
-  auto lstore = [&](int slot, int buf) __attribute__((always_inline)) {
-    st4(wdst + buf * kLfWBuf, ring[slot][0]);
-    st4(wdst + buf * kLfWBuf + 64 * kLfWs, ring[slot][1]);
-  };
-  // Items are numbered j = 0..7 inside a group of eight (every phase is a whole number of groups).  Before item j, LDS buffer
-  // j & 1 holds it and ring slots (j + 1) & 3 .. (j + 4) & 3 hold the next four.  stage(j) runs after item j's MFMAs.
-  auto stage = [&](int j) __attribute__((always_inline)) {
-    lstore((j + 1) & 3, (j + 1) & 1);
-    gload((j + 1) & 3);
-    __syncthreads();
-  };
-  // one item: this wave's 16 weight rows (= output columns) x 32 k against the three row tiles; `a` = row r of tile 0 at the
-  // chunk's first word + 4g, next tile `ts` words on.  Both formats keep a chunk of a row as 32 words read as words 4g .. 4g + 3
-  // and 16 + 4g .. + 3: fp32 k-slots (any pairing is legal when A and W agree), or the high / low halves of k = 8g .. 8g + 7.
-  const float* wfrag = Ws + (wave * 16 + r) * kLfWs + g * 4;
-  auto mma_item = [&](int j, const float* a, int ts, f32x4 (&acc)[3]) __attribute__((always_inline)) {
-    const float* w = wfrag + (j & 1) * kLfWBuf;
+  // Items are numbered j = 0 .. inside a group (every group is a multiple of kLoopRing items); item j sits in ring slot j % kLoopRing
+  // and is replaced by item j + kLoopRing as soon as its MFMAs are issued.
+  // One item: this wave's 16 weight rows (= output columns) x 32 k against the three row tiles, whose fragments the caller read
+  // from LDS: both operand formats keep a chunk of a row as 32 words read as words 4g .. 4g + 3 and 16 + 4g .. + 3.
+  auto mma_item = [&](int j, const F4 (&x)[3][2], f32x4 (&acc)[3]) __attribute__((always_inline)) {
+    const int slot = j % kLoopRing;
     if constexpr (X3) {
-      const U4 wh = *reinterpret_cast<const U4*>(w), wl = *reinterpret_cast<const U4*>(w + 16);
-      U4 xh[3], xl[3];
+      const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) { xh[t] = *reinterpret_cast<const U4*>(a + t * ts); xl[t] = *reinterpret_cast<const U4*>(a + t * ts + 16); }
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][1]), wh, acc[t]);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(xl[t], wh, acc[t]);
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][0]), wl, acc[t]);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(xh[t], wl, acc[t]);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(xh[t], wh, acc[t]);
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][0]), wh, acc[t]);
     } else {
-      const F4 y0 = ld4(w), y1 = ld4(w + 16);
-      F4 x[3][2];
-#pragma unroll
-      for (int t = 0; t < 3; ++t) { x[t][0] = ld4(a + t * ts); x[t][1] = ld4(a + t * ts + 16); }
+      const F4 y0 = ring[slot][0], y1 = ring[slot][1];
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].x, y0.x, acc[t]);
 #pragma unroll
@@ -171,14 +158,29 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].w, y1.w, acc[t]);
     }
+    gload(slot);
   };
-  // items j0 .. j0 + n - 1 of the current group against consecutive 32-wide chunks of A starting at a0; the last item's
-  // stage() is left to the caller when it has something to publish before that barrier (stage_last = false)
-  auto run = [&](int j0, int n, const float* a0, int ts, f32x4 (&acc)[3], bool stage_last) __attribute__((always_inline)) {
+  // A group: 8 chunks of A (row r of tile 0 at a0 + 4g, next tile 16 * kLfXs words on, chunk c at + 32 c) against NP column
+  // blocks whose items alternate in the stream (chunk-major): one read of the A fragments feeds NP items.
+  auto run2 = [&](const float* a0, f32x4 (&acc0)[3], f32x4 (&acc1)[3]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int c = 0; c < n; ++c) {
-      mma_item(j0 + c, a0 + 32 * c, ts, acc);
-      if (c + 1 < n || stage_last) stage(j0 + c);
+    for (int c = 0; c < 8; ++c) {
+      F4 x[3][2];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { x[t][0] = ld4(a0 + t * 16 * kLfXs + 32 * c); x[t][1] = ld4(a0 + t * 16 * kLfXs + 32 * c + 16); }
+      mma_item(2 * c, x, acc0);
+      mma_item(2 * c + 1, x, acc1);
+    }
+  };
+  auto run3 = [&](const float* a0, f32x4 (&acc0)[3], f32x4 (&acc1)[3], f32x4 (&acc2)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      F4 x[3][2];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { x[t][0] = ld4(a0 + t * 16 * kLfXs + 32 * c); x[t][1] = ld4(a0 + t * 16 * kLfXs + 32 * c + 16); }
+      mma_item(3 * c, x, acc0);
+      mma_item(3 * c + 1, x, acc1);
+      mma_item(3 * c + 2, x, acc2);
     }
   };
   auto zero3 = [](f32x4 (&a)[3]) __attribute__((always_inline)) {
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   };
 
   // LayerNorm over the 256 columns of rows 16t + 4g + i, t < nt; v[cb][t][i] = this lane's element.  Part 1 publishes the per-wave
-  // row sums (the caller then passes a barrier: stage() or __syncthreads()); part 2 finishes (one more barrier inside).
+  // row sums (the caller then passes a barrier); part 2 finishes (one more barrier inside).
   auto ln_part1 = [&](const float (&v)[2][3][4], int nt) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -281,10 +283,9 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     put(Xs, kLfXs, 128, x[1]);
   };
 
-  // ---- prologue: item 0 -> LDS buffer 0, items 1..4 -> ring slots 1, 2, 3, 0; latents; first step's token rows
-  gload(0);
-  lstore(0, 0);
-  gload(1); gload(2); gload(3); gload(0);
+  // ---- prologue: the first kLoopRing items into the ring; latents; first step's token rows
+#pragma unroll
+  for (int j = 0; j < kLoopRing; ++j) gload(j);
   {
     const int c = tid >> 6, c4 = tid & 63;
     int s = s0 + c;
@@ -297,8 +298,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   __syncthreads();
 
   const float* xa = Xs + r * kLfXs + g * 4;        // A fragments of the layer input
-  const float* aa = As + r * kLfXs + g * 4;        // ... of the attention output
-  const float* ha = As + r * kLfHs + g * 4;        // ... of a hidden-activation block
+  const float* aa = As + r * kLfXs + g * 4;        // ... of the attention output / the hidden-activation blocks
 
   for (int step = 0; step < p.n; ++step) {
     for (int l = 0; l < p.L; ++l) {
@@ -308,9 +308,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         const float bq = sm[kLsInB + hp * 128 + col0], bk = sm[kLsInB + 256 + hp * 128 + col0], bv = sm[kLsInB + 512 + hp * 128 + col0];
         f32x4 q[3], k[3], vv[3];
         zero3(q); zero3(k); zero3(vv);
-        run(0, 8, xa, 16 * kLfXs, q, true);
-        run(0, 8, xa, 16 * kLfXs, k, true);
-        run(0, 8, xa, 16 * kLfXs, vv, false);
+        run3(xa, q, k, vv);
         // partial scores over this wave's 16 columns of the head: s[t][u] for the CFG rows 4g .. 4g + 3
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -321,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
             s.z = sum16((q[t][2] + bq) * (k[u][2] + bk)); s.w = sum16((q[t][3] + bq) * (k[u][3] + bk));
             if (r == 0) st4(sc + wave * 144 + (t * 3 + u) * 16 + g * 4, s);
           }
-        stage(7);
+        __syncthreads();
         const float* sb = sc + (wave & 4) * 144 + g * 4;   // the four waves of this head
         float o[3][4];
 #pragma unroll
@@ -343,16 +341,15 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
           }
         }
         put(As, kLfXs, hp * 128, o);
+        __syncthreads();       // hp = 0: `sc` may be rewritten; hp = 1: the attention output is complete before anybody multiplies it
       }
-      __syncthreads();                                 // the attention output is complete before anybody multiplies it
       // ================= out-projection + residual + norm1 -> Xs
       float u[2][3][4];
       {
         const float ob0 = sm[kLsOutB + col0], ob1 = sm[kLsOutB + 128 + col0];
         f32x4 o0[3], o1[3];
         zero3(o0); zero3(o1);
-        run(0, 8, aa, 16 * kLfXs, o0, true);
-        run(0, 8, aa, 16 * kLfXs, o1, false);
+        run2(aa, o0, o1);
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -361,31 +358,36 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
             u[1][t][i] = o1[t][i] + ob1 + x[1][t][i];
           }
         ln_part1(u, 3);
-        stage(7);
+        __syncthreads();
         ln_part2(u, 3, sm + kLsN1W, sm + kLsN1B);
         put(Xs, kLfXs, 0, u[0]);
         put(Xs, kLfXs, 128, u[1]);
         __syncthreads();
       }
-      // ================= feed-forward: hidden activation in blocks of 128 columns, linear2 accumulated in registers
+      // ================= feed-forward: the hidden activation two 128-column blocks at a time (they take the attention output's
+      // place in LDS), linear2 accumulated in registers over the four block pairs
       {
         f32x4 y0[3], y1[3];
         zero3(y0); zero3(y1);
-        for (int hb = 0; hb < 8; ++hb) {
-          const float b1 = sm[kLsL1B + hb * 128 + col0];
-          f32x4 h[3];
-          zero3(h);
-          run(0, 8, xa, 16 * kLfXs, h, false);
+        for (int hb = 0; hb < 4; ++hb) {
+          const float b1a = sm[kLsL1B + hb * 256 + col0], b1b = sm[kLsL1B + hb * 256 + 128 + col0];
+          f32x4 h0[3], h1[3];
+          zero3(h0); zero3(h1);
+          run2(xa, h0, h1);
           float hv[3][4];
 #pragma unroll
           for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hv[t][i] = gelu_erf(h[t][i] + b1);
-          put(As, kLfHs, 0, hv);
-          stage(7);
-          run(0, 4, ha, 16 * kLfHs, y0, true);
-          run(4, 4, ha, 16 * kLfHs, y1, false);
-          if (hb < 7) stage(7);
+            for (int i = 0; i < 4; ++i) hv[t][i] = gelu_erf(h0[t][i] + b1a);
+          put(As, kLfXs, 0, hv);
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hv[t][i] = gelu_erf(h1[t][i] + b1b);
+          put(As, kLfXs, 128, hv);
+          __syncthreads();
+          run2(aa, y0, y1);
+          if (hb < 3) __syncthreads();                 // everybody is done with this pair before the next one overwrites it
         }
         const float lb0 = sm[kLsL2B + col0], lb1 = sm[kLsL2B + 128 + col0];
 #pragma unroll
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
             x[1][t][i] = y1[t][i] + lb1 + u[1][t][i];
           }
         ln_part1(x, 3);
-        stage(7);
+        __syncthreads();
         ln_part2(x, 3, sm + kLsN2W, sm + kLsN2B);
       }
       if (l + 1 < p.L) {
@@ -422,8 +424,8 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
           const float sb0 = sm_skip[si * 256 + col0], sb1 = sm_skip[si * 256 + 128 + col0];
           f32x4 z0[3], z1[3];
           zero3(z0); zero3(z1);
-          run(0, 8, xa, 16 * kLfXs, z0, true);
-          run(0, 8, xa, 16 * kLfXs, z1, true);           // its last barrier: everybody is done reading x
+          run2(xa, z0, z1);
+          __syncthreads();                               // everybody is done reading x
           const float* sk = p.skip + ((long long)(blockIdx.x * nb + (nb - 1 - si)) * 48) * 256;
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
@@ -441,8 +443,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
             }
           }
           __syncthreads();
-          run(0, 8, xa, 16 * kLfXs, z0, true);
-          run(0, 8, xa, 16 * kLfXs, z1, true);
+          run2(xa, z0, z1);
 #pragma unroll
           for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -450,6 +451,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
               x[0][t][i] = z0[t][i] + sb0;
               x[1][t][i] = z1[t][i] + sb1;
             }
+          __syncthreads();                               // everybody is done reading the parked rows
           put(Xs, kLfXs, 0, x[0]);
           put(Xs, kLfXs, 128, x[1]);
           __syncthreads();

@@ -35,7 +35,7 @@ def build(mode, state, key):
         model = MLD(cfg, HipDataModule(cfg, nfeats=150, njoints=25, name="humanact12", engine_key=key), engine_key=key).eval()
     else:
         eng = simlib._lib.Engine(lib=simlib.sim_library(), use_graph=0, num_layers=NOVAE_LAYERS,
-                                 **{**simlib.NOVAE_CFG, "max_batch": 2, "max_frames": 12, "num_inference_steps": STEPS})
+                                 **{**simlib.NOVAE_CFG, "max_batch": 4, "max_frames": 12, "num_inference_steps": STEPS})
         E.inject_engine(eng, key)
         cfg = C.load_config(os.path.join(C.CONFIG_DIR, "config_novae_humanml3d.yaml"),
                             overrides={"model.scheduler.num_inference_timesteps": STEPS, "model.denoiser.params.num_layers": NOVAE_LAYERS})

@@ -951,3 +951,64 @@ def test_config3_shape_512_prompts_through_the_dp_sampler(dev):
     assert worst < 1e-3                    # latency vs throughput kernel family: summation order only
     E.configure("text", max_batch=64, max_in_flight=1)
     E.drop_engines()
+
+
+def test_headline_serving_shape_every_motion_within_tolerance(dev, golden_dir):
+    """The shape bench.py's headline measures, all of it: split precision mode (precision = 1: split-f16 MFMAs in the reverse loop and
+    the decoder), ONE mldhip_sample_many call of 32 bs-64 requests = 2 048 motions, T = 196 -- the reverse loop runs as the
+    sample-major persistent launch (kernels/loop_fused.hpp), the decoder on the throughput shapes (key-blocked attention, fused FFN).
+    Checked against (a) the reference's own output for request 0 (the pipeline_b64 fixture: reference MldDenoiser / MldVae /
+    recover_from_ric, mld.py:290-360, mld_vae.py:186-248), (b) the CPU oracle for two more requests, (c) for EVERY one of the 2 048
+    motions the exact-fp32 engine on the latency kernels (itself held to the fixture at 1e-4-class errors by the tests above), with a
+    bound that leaves room for that engine's own distance to the reference; then the same call on the uniform {40..196} length mix.
+    Tolerance: 1e-3 max-abs on the joints (north star)."""
+    ops = O.TorchOps("float32")
+    sdd, sdv = syn.make_denoiser_state_dict(), syn.make_vae_state_dict()
+    bd, bv = O.to_backend(ops, sdd), O.to_backend(ops, sdv)
+    mean, std = syn.make_mean_std()
+    g = _gold(golden_dir, "pipeline_b64.npz")
+    NREQ = 32
+    big = _lib.Engine(device=0, max_batch=64 * NREQ, max_frames=196, precision=1)   # MLDHIP_PREC_F16X3 (split 16-bit arithmetic)
+    _load(big)
+    exact = _lib.Engine(device=0, max_batch=64, max_frames=196)
+    _load(exact)
+    report = {}
+    for mix in ("full", "ragged"):
+        batches = [syn.make_batch(64) if (i == 0 and mix == "full") else syn.make_batch(64, None if mix == "full" else "ragged", seed=4321 + i)
+                   for i in range(NREQ)]
+        reqs = []
+        for b in batches:
+            T = max(b.lengths)
+            reqs.append(dict(text_emb=_cuda(b.text_emb, dev), init_latents=_cuda(b.init_latents, dev), lengths=b.lengths,
+                             latents_out=torch.empty(64, 1, 256, device=dev), joints_out=torch.full((64, T, 22, 3), float("nan"), device=dev)))
+        for _ in range(2):                              # the second call replays the captured graph
+            big.sample_many(reqs)
+        torch.cuda.synchronize()
+        assert big.launch_counts()[0] <= 4              # the loop really ran as the persistent launch
+        worst = 0.0
+        for b, q in zip(batches, reqs):
+            T = max(b.lengths)
+            joints = torch.empty(64, T, 22, 3, device=dev)
+            exact.sample(q["text_emb"], q["init_latents"], b.lengths, None, None, joints)
+            torch.cuda.synchronize()
+            d = (q["joints_out"] - joints).abs()
+            for i, n in enumerate(b.lengths):
+                assert torch.isfinite(q["joints_out"][i, :n]).all()
+                worst = max(worst, float(d[i, :n].max()))
+        report[mix + "_vs_exact_fp32_engine"] = worst
+        assert worst < 8e-4, report
+        for k in ((0, 7, 19) if mix == "full" else (3, 30)):    # direct checks against the oracle / the reference fixture
+            b, q = batches[k], reqs[k]
+            if mix == "full" and k == 0:
+                e = float(np.abs(q["joints_out"].cpu().numpy()[:, ::4] - g["joints_every4"]).max())
+                assert np.abs(q["latents_out"].cpu().numpy() - g["latents"]).max() < 5e-3
+            else:
+                jr = ops.to_numpy(O.sample(ops, bd, bv, ops.asarray(b.text_emb), ops.asarray(b.init_latents), b.lengths,
+                                           ops.asarray(mean), ops.asarray(std)))
+                got = q["joints_out"].cpu().numpy()
+                e = max(float(np.abs(got[i, :n] - jr[i, :n]).max()) for i, n in enumerate(b.lengths))
+            report[f"{mix}_request{k}_vs_reference"] = e
+            assert e < 1e-3, report
+    print("headline shape parity:", report)
+    big.close()
+    exact.close()
