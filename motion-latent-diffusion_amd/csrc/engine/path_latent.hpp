@@ -600,8 +600,13 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
     a.stream = x3 ? e->loop_stream_x3 : e->loop_stream; a.ips = e->loop_ips; a.small = e->loop_small; a.T1 = e->T1; a.TP = e->TP; a.init_lat = init_lat;
     a.lat = e->lat; a.skip = e->FS; a.ddim = e->loop_ddim; a.B = B; a.L = e->cfg.num_layers; a.n = n;
     a.guidance = guidance; a.init_sigma = 1.0f;
-    if (x3) MLD_LAUNCH(den_loop_kernel<true>, dim3((B + 7) / 8), dim3(512), kLoopLdsBytes, stream, a);
-    else MLD_LAUNCH(den_loop_kernel<false>, dim3((B + 7) / 8), dim3(512), kLoopLdsBytes, stream, a);
+    const dim3 grid((B + 7) / 8);
+    if (x3 && e->fused_dbg == 1) MLD_LAUNCH((den_loop_kernel<true, 4, 1>), grid, dim3(512), kLoopLdsBytes, stream, a);
+    else if (x3 && e->fused_dbg == 2) MLD_LAUNCH((den_loop_kernel<true, 4, 2>), grid, dim3(512), kLoopLdsBytes, stream, a);
+    else if (x3 && e->fused_ring == 8) MLD_LAUNCH((den_loop_kernel<true, 8>), grid, dim3(512), kLoopLdsBytes, stream, a);
+    else if (x3) MLD_LAUNCH((den_loop_kernel<true, 4>), grid, dim3(512), kLoopLdsBytes, stream, a);
+    else if (e->fused_ring == 8) MLD_LAUNCH((den_loop_kernel<false, 8>), grid, dim3(512), kLoopLdsBytes, stream, a);
+    else MLD_LAUNCH((den_loop_kernel<false, 4>), grid, dim3(512), kLoopLdsBytes, stream, a);
     count(c);
     check_launch(c, "den_loop");
   } else {

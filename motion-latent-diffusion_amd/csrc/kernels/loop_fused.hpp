@@ -68,7 +68,7 @@ struct LoopArgs {
 constexpr int kLfXs = 264;                                // LDS row stride (words), = 8 mod 16: conflict-free fragment reads (strip.hpp)
 constexpr int kLfXFloats = 48 * kLfXs, kLfScFloats = 8 * 144, kLfRedFloats = 2 * 8 * 48, kLfLatFloats = 8 * 256;
 constexpr int kLoopLdsBytes = (2 * kLfXFloats + kLfScFloats + kLfRedFloats + kLfLatFloats) * 4;   // 117 248 B: one workgroup per CU
-constexpr int kLoopRing = 8;                              // items in flight per lane (8 VGPRs each)
+
 
 // finalize-time: gathers the weight items into consumption order and fragment layout.  Thread (w, r, g) of item i writes the 8
 // words lane (r, g) of wave w will load: fp32: W[16w + r][4g .. 4g + 3], W[16w + r][16 + 4g .. + 3] of the item's 32 k; X3: the packed
@@ -96,8 +96,12 @@ __global__ __launch_bounds__(512) void pack_loop_stream_kernel(const float* __re
 }
 
 // grid = ceil(B / 8), block = 512 (8 waves, two per SIMD).  X3 = false: exact-fp32 MFMAs; true: split-f16 MFMAs.
-template <bool X3>
+// kLoopRing = items in flight per lane (8 VGPRs each; 4 or 8: every group of items is a multiple of 8 long).
+// DBG (measurement builds, mldhip_set_option "fused_dbg"): 1 = the weight ring is loaded once and never refreshed (matrix +
+// LDS + epilogue time without the stream), 2 = the stream is loaded but not multiplied (one VALU add per item keeps the loads live).
+template <bool X3, int kLoopRing, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
+  static_assert(kLoopRing == 4 || kLoopRing == 8, "ring depth");
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
 #else
@@ -131,7 +135,9 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   // from LDS: both operand formats keep a chunk of a row as 32 words read as words 4g .. 4g + 3 and 16 + 4g .. + 3.
   auto mma_item = [&](int j, const F4 (&x)[3][2], f32x4 (&acc)[3]) __attribute__((always_inline)) {
     const int slot = j % kLoopRing;
-    if constexpr (X3) {
+    if constexpr (DBG == 2) {
+      acc[0][0] += ring[slot][0].x + ring[slot][1].w + x[0][0].x;
+    } else if constexpr (X3) {
       const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][1]), wh, acc[t]);
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].w, y1.w, acc[t]);
     }
-    gload(slot);
+    if constexpr (DBG != 1) gload(slot);
   };
   // A group: 8 chunks of A (row r of tile 0 at a0 + 4g, next tile 16 * kLfXs words on, chunk c at + 32 c) against NP column
   // blocks whose items alternate in the stream (chunk-major): one read of the A fragments feeds NP items.
@@ -183,6 +189,14 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
       mma_item(3 * c + 2, x, acc2);
     }
   };
+  // a copy of a lane-dependent index the optimiser cannot see through: address arithmetic built on it stays where it is written
+  // instead of being hoisted out of the step / layer loops and held (or spilled) across the GEMM phases
+  auto opaque = [](int v) __attribute__((always_inline)) {
+#if !defined(MLDHIP_SIM)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+  };
   auto zero3 = [](f32x4 (&a)[3]) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -206,6 +220,22 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
           h[32] = lo;
         } else {
           row[col0] = val[t][i];
+        }
+      }
+  };
+  // ... and back: the residual of a LayerNorm is read from the operand buffer it was multiplied from (split mode: high + low
+  // half, the value the GEMMs saw, 2^-22 from the fp32 one), so no activation stays in registers across a GEMM phase
+  auto get = [&](const float* buf, int st, int cw, float (&val)[3][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* row = buf + (t * 16 + g * 4 + i) * st + cw;
+        if constexpr (X3) {
+          const unsigned short* h = reinterpret_cast<const unsigned short*>(row) + hw0;
+          val[t][i] = f16_bits_value(h[0]) + f16_bits_value(h[32]);
+        } else {
+          val[t][i] = row[col0];
         }
       }
   };
@@ -262,30 +292,28 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
 
   // token rows of one reverse step, each lane its own elements: row 16t + c; t = 0: latent + pe[0] (both CFG halves), 1: the
   // step's time row, 2: the condition rows (mld_denoiser.py:143-196; rows beyond B repeat motion B - 1, never written back)
-  float x[2][3][4];                                // the layer input at this lane's positions (operand image in Xs, residual here)
   auto assemble = [&](int step) __attribute__((always_inline)) {
     const float* pe0 = sm_fin + 512;
+    const int gq = opaque(g), cq = opaque(col0);
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-      const int col = cb * 128 + col0;
-      const float pe = pe0[col], tt = p.T1[(long long)step * 256 + col];
+      const unsigned col = cb * 128 + cq;
+      const float pe = pe0[col], tt = p.T1[(unsigned)step * 256u + col];
+      float xv[3][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int c = g * 4 + i;
-        int s = s0 + (c & 7);
-        s = s < p.B ? s : p.B - 1;
-        x[cb][0][i] = lats[(c & 7) * 256 + col] + pe;
-        x[cb][1][i] = tt;
-        x[cb][2][i] = p.TP[(long long)((c < 8 ? 0 : p.B) + s) * 256 + col];
+        const int c = gq * 4 + i;
+        int sidx = s0 + (c & 7);
+        sidx = sidx < p.B ? sidx : p.B - 1;
+        xv[0][i] = lats[(c & 7) * 256 + col] + pe;
+        xv[1][i] = tt;
+        xv[2][i] = p.TP[(unsigned)((c < 8 ? 0 : p.B) + sidx) * 256u + col];
       }
+      put(Xs, kLfXs, cb * 128, xv);
     }
-    put(Xs, kLfXs, 0, x[0]);
-    put(Xs, kLfXs, 128, x[1]);
   };
 
-  // ---- prologue: the first kLoopRing items into the ring; latents; first step's token rows
-#pragma unroll
-  for (int j = 0; j < kLoopRing; ++j) gload(j);
+  // ---- prologue: latents; first step's token rows; the first kLoopRing items into the ring
   {
     const int c = tid >> 6, c4 = tid & 63;
     int s = s0 + c;
@@ -296,13 +324,16 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   __syncthreads();
   assemble(0);
   __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kLoopRing; ++j) gload(j);
 
   const float* xa = Xs + r * kLfXs + g * 4;        // A fragments of the layer input
   const float* aa = As + r * kLfXs + g * 4;        // ... of the attention output / the hidden-activation blocks
 
   for (int step = 0; step < p.n; ++step) {
+    float x[2][3][4];                              // norm2 output of the current layer at this lane's positions
     for (int l = 0; l < p.L; ++l) {
-      const float* sm = p.small + (long long)l * kLsLayer;
+      const float* sm = p.small + (unsigned)l * (unsigned)kLsLayer;
       // ================= self-attention: two heads at a time (cross_attention.py:265-266; nn.MultiheadAttention, 4 heads of 64)
       for (int hp = 0; hp < 2; ++hp) {
         const float bq = sm[kLsInB + hp * 128 + col0], bk = sm[kLsInB + 256 + hp * 128 + col0], bv = sm[kLsInB + 512 + hp * 128 + col0];
@@ -335,8 +366,8 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
           for (int i = 0; i < 4; ++i) {
             const float a0 = s0v[i] * 0.125f, a1 = s1v[i] * 0.125f, a2 = s2v[i] * 0.125f;
             const float m = fmaxf(a0, fmaxf(a1, a2));
-            const float e0 = expf(a0 - m), e1 = expf(a1 - m), e2 = expf(a2 - m);
-            const float inv = 1.0f / (e0 + e1 + e2);
+            const float e0 = fast_exp(a0 - m), e1 = fast_exp(a1 - m), e2 = fast_exp(a2 - m);
+            const float inv = fast_rcp(e0 + e1 + e2);
             o[t][i] = (e0 * inv) * (vv[0][i] + bv) + (e1 * inv) * (vv[1][i] + bv) + (e2 * inv) * (vv[2][i] + bv);
           }
         }
@@ -344,18 +375,20 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         __syncthreads();       // hp = 0: `sc` may be rewritten; hp = 1: the attention output is complete before anybody multiplies it
       }
       // ================= out-projection + residual + norm1 -> Xs
-      float u[2][3][4];
       {
         const float ob0 = sm[kLsOutB + col0], ob1 = sm[kLsOutB + 128 + col0];
         f32x4 o0[3], o1[3];
         zero3(o0); zero3(o1);
         run2(aa, o0, o1);
+        float u[2][3][4];
+        get(Xs, kLfXs, 0, u[0]);
+        get(Xs, kLfXs, 128, u[1]);
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            u[0][t][i] = o0[t][i] + ob0 + x[0][t][i];
-            u[1][t][i] = o1[t][i] + ob1 + x[1][t][i];
+            u[0][t][i] += o0[t][i] + ob0;
+            u[1][t][i] += o1[t][i] + ob1;
           }
         ln_part1(u, 3);
         __syncthreads();
@@ -390,12 +423,14 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
           if (hb < 3) __syncthreads();                 // everybody is done with this pair before the next one overwrites it
         }
         const float lb0 = sm[kLsL2B + col0], lb1 = sm[kLsL2B + 128 + col0];
+        get(Xs, kLfXs, 0, x[0]);
+        get(Xs, kLfXs, 128, x[1]);
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            x[0][t][i] = y0[t][i] + lb0 + u[0][t][i];
-            x[1][t][i] = y1[t][i] + lb1 + u[1][t][i];
+            x[0][t][i] += y0[t][i] + lb0;
+            x[1][t][i] += y1[t][i] + lb1;
           }
         ln_part1(x, 3);
         __syncthreads();
@@ -406,12 +441,13 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         put(Xs, kLfXs, 0, x[0]);
         put(Xs, kLfXs, 128, x[1]);
         if (l < nb) {
-          float* sk = p.skip + ((long long)(blockIdx.x * nb + l) * 48) * 256;
+          float* sk = p.skip + (size_t)(blockIdx.x * nb + l) * (48 * 256);
+          const int gq = opaque(g), cq = opaque(col0);
 #pragma unroll
           for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              float* o = sk + (t * 16 + g * 4 + i) * 256 + col0;
+              float* o = sk + (unsigned)((t * 16 + gq * 4 + i) * 256 + cq);
               o[0] = x[0][t][i];
               o[128] = x[1][t][i];
             }
@@ -426,11 +462,12 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
           zero3(z0); zero3(z1);
           run2(xa, z0, z1);
           __syncthreads();                               // everybody is done reading x
-          const float* sk = p.skip + ((long long)(blockIdx.x * nb + (nb - 1 - si)) * 48) * 256;
+          const float* sk = p.skip + (size_t)(blockIdx.x * nb + (nb - 1 - si)) * (48 * 256);
+          const int tq = opaque(tid);
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
-            const int qd = tid + 512 * j, row = qd >> 6, c4 = qd & 63;
-            const F4 sv = ld4(sk + row * 256 + c4 * 4);
+            const int qd = tq + 512 * j, row = qd >> 6, c4 = qd & 63;
+            const F4 sv = ld4(sk + (unsigned)(row * 256 + c4 * 4));
             if constexpr (X3) {
               unsigned h0, l0, h1, l1;
               split16_pair(sv.x, sv.y, h0, l0);

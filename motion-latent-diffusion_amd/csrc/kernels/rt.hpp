@@ -130,16 +130,35 @@ __device__ __forceinline__ float max64(float v) {
 #endif
 }
 
+// 1 / x and e^x on the hardware's 1-ulp transcendental units (v_rcp_f32, v_exp_f32): libm's expf and IEEE division expand to
+// 6-10 instructions each (range handling, Newton step, div_fixup), which is what the epilogues of the sample-major loop and of the
+// decoder's feed-forward kernels were spending their VALU time on (r03: the split-mode loop ran 27.9 of its 35 ms WITHOUT any weight
+// traffic).  Arguments here are finite and the results feed fp32 arithmetic with >= 1e-7 of its own rounding.
+__device__ __forceinline__ float fast_rcp(float x) {
+#if defined(MLDHIP_SIM)
+  return 1.0f / x;
+#else
+  return __builtin_amdgcn_rcpf(x);
+#endif
+}
+__device__ __forceinline__ float fast_exp(float x) {
+#if defined(MLDHIP_SIM)
+  return expf(x);
+#else
+  return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+#endif
+}
+
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26), branch free: the epilogue of the FFN1 GEMMs
 // evaluates it 4-32 times per lane and libm's erff is a divergent multi-branch routine.
 __device__ __forceinline__ float erf_as(float x) {
   const float ax = fabsf(x);
-  const float t = 1.0f / fmaf(0.3275911f, ax, 1.0f);
+  const float t = fast_rcp(fmaf(0.3275911f, ax, 1.0f));
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
   p = fmaf(p, t, 0.254829592f);
-  const float y = 1.0f - p * t * expf(-ax * ax);
+  const float y = 1.0f - p * t * fast_exp(-ax * ax);
   return copysignf(y, x);
 }
 

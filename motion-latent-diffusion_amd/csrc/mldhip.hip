@@ -193,8 +193,12 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<13, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<13, 128>()));
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<18, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<18, 128>()));
   (void)hipFuncSetAttribute((const void*)ffn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLdsBytes);
-  (void)hipFuncSetAttribute((const void*)den_loop_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
-  (void)hipFuncSetAttribute((const void*)den_loop_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_loop_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_loop_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
 #define MLD_T32_ATTR1(MT, NS, ...) \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<MT, NS, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
 #define MLD_T32_ATTR(NS)                                                                                                    \
@@ -294,6 +298,12 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "fused_x3") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "fused_x3 must be 0 or 1");
     e->fused_x3 = (int)value;
+  } else if (n == "fused_dbg") {
+    if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "fused_dbg must be 0, 1 or 2");
+    e->fused_dbg = (int)value;
+  } else if (n == "fused_ring") {
+    if (value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "fused_ring must be 4 or 8");
+    e->fused_ring = (int)value;
   } else if (n == "fused_min_batch") {
     if (value < 1) return e->fail(MLDHIP_EINVAL, "fused_min_batch must be >= 1");
     e->fused_min_batch = (int)std::min<int64_t>(value, 1 << 30);

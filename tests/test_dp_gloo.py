@@ -43,9 +43,16 @@ def test_two_rank_job_matches_single_process(tmp_path, world):
     assert r.returncode == 0, r.stderr[-2000:]
     got = np.load(out)
     # single process, whole batch
-    eng = simlib.sim_engine(max_batch=8, max_frames=24, num_inference_steps=2)
-    b = syn.make_batch(nprompts, [20, 13, 7, 16, 9], seed=77)
-    ref = np.zeros((nprompts, 20, 22, 3), np.float32)
+    dims = syn.ModelDims(num_layers=3)
+    eng = simlib._lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=8, max_frames=16, num_inference_steps=2, num_layers=3)
+    eng.load_state_dict(syn.make_denoiser_state_dict(dims=dims), "denoiser.")
+    eng.load_state_dict(syn.make_vae_state_dict(dims=dims), "vae.")
+    mean, std = syn.make_mean_std()
+    eng.load_tensor("mean", mean)
+    eng.load_tensor("std", std)
+    eng.finalize()
+    b = syn.make_batch(nprompts, [16, 13, 7, 16, 9], seed=77)
+    ref = np.zeros((nprompts, 16, 22, 3), np.float32)
     eng.sample(b.text_emb, b.init_latents, b.lengths, None, None, ref)
     seen = 0
     for key in got.files:

@@ -390,7 +390,7 @@ def test_strip_family_sample_is_exact_sim(ow):
     assert np.abs(lat - lr).max() < 5e-4 and np.abs(joints - jr).max() < 1e-4
     assert e.launch_counts()[0] == 1 + 1 + 2 * (9 * 4 + 4 + 1)
     with pytest.raises(_lib.MldHipError):
-        e.set_option("loop_kernel", 3)
+        e.set_option("loop_kernel", 4)
     with pytest.raises(_lib.MldHipError):
         e.set_option("no_such_option", 1)
     e.close()
@@ -675,3 +675,45 @@ def test_key_blocked_attention_matches_whole_kv_attention_sim(ow):
         d = np.abs(outs[0] - outs[1]).max()
         assert 0 < d < 5e-5, d
         e.close()
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_sample_major_persistent_loop_sim(prec):
+    """loop_kernel = 3 (kernels/loop_fused.hpp): the whole reverse loop as ONE launch, a workgroup per 8 motions -- B = 11 (two
+    workgroups, the second one with 3 live motions and 5 clamped duplicates), a 3-layer skip stack (one skip linear), 2 steps,
+    against the oracle and against the latency family; exact-fp32 MFMAs (precision 0, and precision 1 with fused_x3 = 0) and the
+    split-f16 MFMAs of precision 1; both ring depths.  Launch count: condition rows + the loop."""
+    dims = syn.ModelDims(num_layers=3)
+    sdd, sdv = syn.make_denoiser_state_dict(dims=dims), syn.make_vae_state_dict(dims=dims)
+    e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=12, max_frames=8, num_inference_steps=2, num_layers=3, precision=prec)
+    e.load_state_dict(sdd, "denoiser.")
+    e.load_state_dict(sdv, "vae.")
+    e.finalize()
+    b = syn.make_batch(11, [8, 5, 3, 8, 1, 7, 2, 6, 8, 4, 8], seed=9)
+    ops = O.NumpyOps(np.float32)
+    ref = np.asarray(O.diffusion_reverse(ops, O.to_backend(ops, sdd), b.text_emb, b.init_latents, 7.5, 2, 4))
+    e.set_option("loop_kernel", 1)
+    lat1 = np.zeros((11, 1, 256), np.float32)
+    e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat1)
+    e.set_option("loop_kernel", 3)
+    for x3, ring in ((0, 4), (0, 8), (1, 4), (1, 8)):
+        e.set_option("fused_x3", x3)
+        e.set_option("fused_ring", ring)
+        lat = np.full((11, 1, 256), np.nan, np.float32)
+        e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
+        assert e.launch_counts()[0] == 2
+        assert np.abs(lat - ref).max() < 2e-4 and np.abs(lat - lat1).max() < 2e-4, (prec, x3, ring)
+    with pytest.raises(_lib.MldHipError):
+        e.set_option("fused_ring", 6)
+    e.close()
+
+
+def test_sample_major_loop_is_refused_where_it_is_not_built_sim():
+    """ff_size 512 has no sample-major build: loop_kernel = 3 is refused after finalize, auto never picks it."""
+    dims = syn.ModelDims(num_layers=3, ff_size=512)
+    e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=4, max_frames=8, num_inference_steps=2, num_layers=3, ff_size=512)
+    e.load_state_dict(syn.make_denoiser_state_dict(dims=dims), "denoiser.")
+    e.finalize()
+    with pytest.raises(_lib.MldHipError):
+        e.set_option("loop_kernel", 3)
+    e.close()
