@@ -8,23 +8,26 @@
 One "step" = one pass of the hot path over one batch: 50-step DDIM latent sampling with classifier-free guidance ->
 motion-VAE decode -> (T,22,3) joints for B=64 synthetic HumanML3D-shaped prompts (config_mld_humanml3d.yaml, T=196),
 inputs resident in HBM, text embeddings precomputed (the frozen CLIP encoder is outside this path).  The K steps are K
-independent bs-64 requests that are all available at t = 0; the serving front end (mldhip_sample_many) coalesces
---coalesce of them into ONE reverse-diffusion chain + ONE decode (default: ceil(K / in-flight), at most 8), and
---in-flight (default 4) such calls overlap on the chip on separate HIP streams / engine workspaces.
-`value_single_batch` is the same K steps issued strictly one bs-64 batch after another (per-batch latency view); the
-"one call per request, four in flight" figure of round 1 is reported as `per_request_in_flight`.  Ranks are pure data parallel: weights
-are broadcast once from rank 0 (one RCCL broadcast of the packed blob), every rank samples its own prompts, no data-path
-collective.  Rank 0 prints ONE JSON line.
+independent bs-64 requests that are all available at t = 0; the serving entry (mldhip_sample_many) takes up to --coalesce of
+them (default 32 = 2 048 motions) per call: ONE persistent launch runs the whole reverse loop of the call (a workgroup per 8
+motions, kernels/loop_fused.hpp), then one decode.  Calls are issued one after another on ONE stream: no calls in flight, no
+stream / hardware-queue placement to get right (round 2's headline needed both).  The timed region (exactly K steps between
+barrier + synchronize pairs) is repeated --repeats times; `value` is the median repetition, min / max are carried.
+`single_batch` is the same K steps issued strictly one bs-64 batch after another on the latency kernels (the configuration
+BASELINE.json's metric names literally), with its own roofline.  Ranks are pure data parallel: weights are broadcast once
+from rank 0 (one RCCL broadcast of the packed blob), every rank samples its own prompts, no data-path collective.  Rank 0
+prints ONE JSON line.
 
-Arithmetic: the headline runs `--precision bf16x3_decode` (reverse loop, attention, norms: exact-fp32 MFMA; decoder GEMMs:
-split-bf16, 3 bf16 MFMAs with fp32 accumulate) -- the fastest mode that meets the <= 1e-3 joint tolerance against the
-reference (asserted by tests/test_gpu_parity.py; its measured error is in `parity`).  All-fp32 and plain bf16 are reported
-as `alt_modes`, each with its measured error.
+Arithmetic: the headline runs `--precision f16x3` (split-f16: every GEMM operand x = hi + lo in IEEE half, three
+v_mfma_f32_16x16x32_f16 per product with fp32 accumulation, 22 mantissa bits; attention scores / softmax / LayerNorm /
+residuals / scheduler in fp32) -- it meets the <= 1e-3 joint tolerance with a 5x margin (tests/test_gpu_parity.py asserts
+every motion of this call shape; the measured error is in `parity`).  Exact-fp32 MFMA and plain bf16 are reported as
+`alt_modes`, each with its measured error.
 
-The roofline block is the dominant kernel's algorithmic FLOPs / its duration inside the DEPENDENT chain: bench.py runs a
-short rocprofv3 --kernel-trace --stats child of the same workload and reads the dispatch average (`clock: rocprofv3`);
-without rocprofv3 it falls back to HIP events around the real layer chain with and without that kernel (`clock:
-chain_events`).  The back-to-back launch interval (r01's number) is carried beside it, never used for `frac`.
+roofline: the dominant kernel of the headline call by rocprofv3 time -- algorithmic FLOPs per launch / its average dispatch
+duration from a rocprofv3 --kernel-trace --stats child run of the same call shape (HIP events around loop-only calls on the
+launch stream are carried beside it).  The peak is the one that binds the kernel's arithmetic: split-f16 kernels issue
+three f16 MFMAs per algorithmic product, so their roof is the dense f16 MFMA peak / 3; exact-fp32 kernels: the fp32 MFMA peak.
 """
 import argparse
 import csv
@@ -40,10 +43,9 @@ import time
 
 import numpy as np
 
-# The steps in flight run on separate HIP streams; ROCm multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues
-# by reference count, and with the default the bench's four streams regularly end up sharing queues with each other or with
-# the engine's capture stream (measured: 6.2 k vs 7.4 k motions/s for the same code, tools/dbg_inflight.py).  Eight queues
-# give every stream of this process its own.  Must be set before the HIP runtime initialises (i.e. before `import torch`).
+# Only the secondary legs (round-2 serving shape, config 4 / 5) put calls in flight on several HIP streams; ROCm multiplexes
+# streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, eight give each of those streams its own (DESIGN.md §3 point 15).
+# The headline runs on ONE stream and does not depend on this.  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -58,13 +60,16 @@ from mld_hip import synthetic as syn  # noqa: E402
 
 METRIC = "motions/sec (50-step DDIM + VAE decode), HumanML3D bs64, 1/2/4/8 GPU"      # BASELINE.json "metric", verbatim
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
-BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA dense peak (no sparsity)
+BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 / f16 MFMA dense peak (no sparsity)
+X3_PEAK_TF = BF16_MFMA_PEAK_TF / 3.0   # split-f16 kernels: three 16-bit MFMAs per algorithmic product
 BATCH, FRAMES, STEPS_DDIM = 64, 196, 50
-PRECISIONS = {"f32": 0, "bf16x3_decode": 1, "bf16": 2, "fp8_denoiser": 3}
+PRECISIONS = {"f32": 0, "f16x3": 1, "bf16": 2, "fp8_denoiser": 3}
+PEAK_TF = {"f32": FP32_MFMA_PEAK_TF, "f16x3": X3_PEAK_TF, "bf16": BF16_MFMA_PEAK_TF, "fp8_denoiser": X3_PEAK_TF}
 DTYPE = {"f32": "f32 (exact-fp32 MFMA everywhere)",
-         "bf16x3_decode": "f32 (reverse loop, attention, norms, accumulation) + split-bf16 x3 MFMA, fp32 accumulate (decoder GEMMs)",
+         "f16x3": "split-f16: GEMM operands as hi + lo IEEE half, 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate (22 mantissa bits); "
+                  "softmax / LayerNorm / residuals / scheduler fp32",
          "bf16": "bf16 MFMA operands in every GEMM, fp32 accumulate / attention / norms / residual stream",
-         "fp8_denoiser": "fp8 e4m3 MFMA operands in the reverse-loop GEMMs, split-bf16 decoder GEMMs, fp32 elsewhere"}
+         "fp8_denoiser": "fp8 e4m3 MFMA operands in the reverse-loop GEMMs, split-f16 decoder GEMMs, fp32 elsewhere"}
 # profile-hook name -> (rocprofv3 kernel-name prefix, launches per sample()) at the two shapes the bench runs the loop at:
 # one bs-64 request (6B = 384 rows: latency kernels, tile32.hpp) and coalesced requests (>= 768 rows: throughput kernels, strip.hpp)
 KERNEL_LATENCY = {
@@ -90,8 +95,8 @@ KERNEL_DECODE_X3 = {   # split-bf16 modes: the feed-forward block is ONE launch 
     "dec_ffn": ("mld::ffn_x3_kernel", 9)}
 
 
-def kernel_table(batch, precision="bf16x3_decode"):
-    dec = KERNEL_DECODE_X3 if precision in ("bf16x3_decode", "fp8_denoiser") else KERNEL_DECODE
+def kernel_table(batch, precision="f16x3"):
+    dec = KERNEL_DECODE_X3 if precision in ("f16x3", "fp8_denoiser") else KERNEL_DECODE
     if dec is KERNEL_DECODE_X3 and batch * 4 >= 512:     # >= 512 (sample, head) pairs: the key-blocked attention kernel (mldhip.h "flash_attn")
         dec = {**dec, "dec_attn": ("mld::attn_flash_x3_kernel", 9)}
     return {**(KERNEL_THROUGHPUT if 6 * batch >= 768 else KERNEL_LATENCY), **dec}
@@ -185,37 +190,37 @@ def chain_marginal_us(eng, name, B, T, iters, stream):
     return max(0.0, run(full) - run([k for k in full if k != name]))
 
 
-def rocprof_child_stats(precision, coalesce, timeout=240):
-    """rocprofv3 --kernel-trace --stats over a short single-stream run of THIS workload in a child process -> {kernel: (avg ns, calls)}."""
+def rocprof_child_stats(precision, coalesce, extra=(), keep_env="MLD_BENCH_KEEP_ROCPROF", timeout=240):
+    """rocprofv3 --kernel-trace --stats over a short single-stream run of THIS workload in a child process -> {kernel: (avg ns, calls, total ns)}."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     out = tempfile.mkdtemp(prefix="mld_rocprof_")
     cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable,
-           os.path.abspath(__file__), "--profile-child", "--precision", precision, "--coalesce", str(coalesce)]
+           os.path.abspath(__file__), "--profile-child", "--precision", precision, "--coalesce", str(coalesce)] + list(extra)
     try:
         subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
         files = glob.glob(os.path.join(out, "**", "*kernel_stats.csv"), recursive=True)
         if not files:
             return None, "no kernel_stats.csv produced"
         rows = list(csv.DictReader(open(files[0])))
-        keep = os.environ.get("MLD_BENCH_KEEP_ROCPROF")     # tools/gpu_check.sh: keep the very summary the JSON line was computed from
+        keep = os.environ.get(keep_env)     # tools/gpu_check.sh: keep the very summary the JSON line was computed from
         if keep:
             shutil.copy(files[0], keep)
-        return {r["Name"]: (float(r["AverageNs"]), int(r["Calls"])) for r in rows}, \
-            "child run: bench.py --profile-child --coalesce %d (3 calls, one at a time)" % coalesce
+        return {r["Name"]: (float(r["AverageNs"]), int(r["Calls"]), float(r["TotalDurationNs"])) for r in rows}, \
+            "child run: bench.py --profile-child --coalesce %d %s(3 calls, one at a time)" % (coalesce, " ".join(extra) + " " if extra else "")
     except Exception as ex:  # never let the profiler take the bench down
         return None, repr(ex)[:200]
     finally:
         shutil.rmtree(out, ignore_errors=True)
 
 
-def cpu_baseline(seed, threads, lengths_file=None, timeout=300):
+def cpu_baseline(seed, threads, lengths_file=None, timeout=300, device="cpu", repeat=1):
     """The oracle ("port" of the reference path, torch-CPU backend) on the host cores: one full batch (64 motions, T=196,
     50 steps) in a child process with a bounded runtime.  Returns (info, joints)."""
     out_npy = "/tmp/mld_cpu_baseline_joints_%d.npy" % os.getpid()
     cmd = [sys.executable, os.path.join(REPO, "oracle", "cpu_baseline.py"), "--batch", str(BATCH), "--frames", str(FRAMES),
-           "--seed", str(seed), "--threads", str(threads), "--out", out_npy]
+           "--seed", str(seed), "--threads", str(threads), "--out", out_npy, "--device", device, "--repeat", str(repeat)]
     if lengths_file:
         cmd += ["--lengths", lengths_file]
     try:
@@ -249,7 +254,7 @@ def bench_a2m(local, dev, warmup, steps, streams, B=256, T=60):
     gflop = den15 * STEPS_DDIM + dec6 - (6 - 1) / 2 * 2.0 * B * T * 512 * 256 / 1e9   # ActorVae has no skip linears
     modes = {}
     nfl = len(streams)          # the caller's streams: their hardware-queue placement is already known to be good (DESIGN.md §3 point 15)
-    for prec in ("f32", "bf16x3_decode", "bf16", "fp8_denoiser"):
+    for prec in ("f32", "f16x3", "bf16", "fp8_denoiser"):
         eng = _lib.Engine(device=local, max_batch=B, max_frames=T, condition=_lib.COND_ACTION, nclasses=12, vae_arch=_lib.VAE_ACTOR,
                           vae_num_layers=6, num_layers=15, nfeats=150, max_in_flight=nfl, precision=PRECISIONS[prec])
         eng.load_state_dict(sdd, "denoiser.")
@@ -267,6 +272,9 @@ def bench_a2m(local, dev, warmup, steps, streams, B=256, T=60):
         dt1 = run_steps(call, n1, streams, single=streams[0]) / n1
         modes[prec] = {"value": round(B * steps / dt, 1), "value_single_batch": round(B / dt1, 1), "ms_per_step_single": round(dt1 * 1e3, 3),
                        "achieved_tflops": round(gflop / 1e3 / (dt / steps), 1), "max_abs_latents_vs_reference": err}
+        modes[prec]["frac_of_mfma_peak"] = round(modes[prec]["achieved_tflops"] / (FP32_MFMA_PEAK_TF if prec in ("f32", "f16x3") else PEAK_TF[prec]), 4)
+        modes[prec]["peak_note"] = "fp32 MFMA peak (the reverse loop, 90 % of this workload's FLOPs, runs exact fp32 on the column-split kernels at this batch)" \
+            if prec in ("f32", "f16x3") else "dense 16-bit / fp8-at-bf16-rate MFMA peak of the loop GEMMs' operand format"
         eng.close()
     return {"workload": "config_mld_humanact12.yaml (action-to-motion), bs=256, T=60, 50-step DDIM, CFG 7.5, ActorVae decode -> feats; "
                         "%d steps in flight; reverse loop at 6B = 1536 rows on the throughput kernels (kernels/strip.hpp)" % nfl,
@@ -317,7 +325,7 @@ def bench_novae(local, dev, full, streams, B=64, T=196):
     gf_step = (9 * (lin(m, 512, 1536) + 3 * lin(m, 512, 512) + 2 * lin(m, 512, 1024) + 4.0 * m * T * 512 + 4.0 * m * 2 * 512)
                + lin(m, 263, 512) + lin(m, 512, 263)) / 1e9
     modes = {}
-    for prec in ("f32", "bf16x3_decode", "bf16"):
+    for prec in ("f32", "f16x3", "bf16"):
         engs, x0, joints = [], [], []
         for i in range(nfl):
             eng = _lib.Engine(device=local, max_batch=B, max_frames=T, latent_dim=512, vae_arch=_lib.VAE_NONE, denoiser_arch=_lib.ARCH_TRANS_DEC,
@@ -347,7 +355,7 @@ def bench_novae(local, dev, full, streams, B=64, T=196):
         dt = run(1234)
         ms_step = dt * 1e3 / (steps * nfl)
         modes[prec] = {"ms_per_ddpm_step": round(ms_step, 3), "achieved_tflops": round(gf_step / ms_step, 1),
-                       "frac_of_fp32_mfma_peak": round(gf_step / ms_step / FP32_MFMA_PEAK_TF, 4),
+                       "frac_of_mfma_peak": round(gf_step / ms_step / PEAK_TF[prec], 4), "peak_tflops_of_this_mode": round(PEAK_TF[prec], 1),
                        "value": round(B / ms_step, 3), "finite": bool(all(torch.isfinite(j).all().item() for j in joints))}
         for eng in engs:
             eng.close()
@@ -356,7 +364,21 @@ def bench_novae(local, dev, full, streams, B=64, T=196):
             "unit": "motions/s of the 1000-step sampler (= 64 / (1000 x ms_per_ddpm_step))", "extrapolated_from_steps": None if full else steps,
             "algorithmic_gflop_per_ddpm_step": round(gf_step, 1), "kernel_launches_per_ddpm_step": 114, "modes": modes,
             "error_vs_reference": "f32: tests/test_gpu_parity.py::test_novae_full_length_1000_steps_vs_reference_golden; every mode: "
-                                  "tools/ab_precision.py -> profiles/r02_precision_ab.json"}
+                                  "tools/ab_precision.py -> profiles/r03_precision_ab.json",
+            "peaks": "f32: fp32 MFMA 157.3 TF; f16x3: dense 16-bit MFMA peak / 3 (three MFMAs per product) = 833 TF; bf16: 2500 TF"}
+
+
+def make_requests(dev, n, rank, with_lat=False):
+    """n bs-64 requests, each with its own prompts / noise (seeded per rank and slot) and output buffers, all resident in HBM"""
+    reqs = []
+    for sl in range(n):
+        bt = syn.make_batch(BATCH, None, seed=1234 + rank + 1000 * sl, max_len=FRAMES)
+        r = dict(text_emb=torch.from_numpy(bt.text_emb).to(dev), init_latents=torch.from_numpy(bt.init_latents).to(dev), lengths=bt.lengths,
+                 joints_out=torch.empty(BATCH, FRAMES, 22, 3, device=dev))
+        if with_lat:
+            r["latents_out"] = torch.empty(BATCH, 1, 256, device=dev)
+        reqs.append(r)
+    return reqs
 
 
 def profile_child(a):
@@ -366,12 +388,8 @@ def profile_child(a):
     torch.cuda.set_device(0)
     c = max(1, a.coalesce)
     eng = make_engine(0, synthetic_state(), a.precision, max_batch=BATCH * c)
-    reqs = []
-    for i in range(c):
-        bt = syn.make_batch(BATCH, None, seed=1234 + 1000 * i, max_len=FRAMES)
-        reqs.append(dict(text_emb=torch.from_numpy(bt.text_emb).to(dev), init_latents=torch.from_numpy(bt.init_latents).to(dev), lengths=bt.lengths,
-                         joints_out=torch.empty(BATCH, FRAMES, 22, 3, device=dev)))
-    for _ in range(max(1, a.steps if a.steps < 20 else 4)):
+    reqs = make_requests(dev, c, 0)
+    for _ in range(max(1, a.steps if a.steps < 20 else 3)):
         if c == 1:
             eng.sample(reqs[0]["text_emb"], reqs[0]["init_latents"], reqs[0]["lengths"], None, None, reqs[0]["joints_out"])
         else:
@@ -379,23 +397,26 @@ def profile_child(a):
     torch.cuda.synchronize()
 
 
+def spread(ts):
+    ts = sorted(ts)
+    return {"median": ts[len(ts) // 2], "min": ts[0], "max": ts[-1], "n": len(ts)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", choices=list(PRECISIONS)[:3], default=os.environ.get("MLD_BENCH_PRECISION", "bf16x3_decode"),
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--precision", choices=list(PRECISIONS)[:3], default=os.environ.get("MLD_BENCH_PRECISION", "f16x3"),
                     help="arithmetic mode of the headline (see the module docstring); the others are reported as alt_modes")
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("MLD_BENCH_IN_FLIGHT", "4")),
-                    help="engine calls in flight per GPU: consecutive calls rotate over this many HIP streams / engine workspaces")
-    ap.add_argument("--coalesce", type=int, default=int(os.environ.get("MLD_BENCH_COALESCE", "0")),
-                    help="bs-64 requests coalesced into one engine call (mldhip_sample_many); 0 = ceil(steps / in-flight), at most 8; "
-                         "1 = one call per request (round 1's setting)")
+    ap.add_argument("--coalesce", type=int, default=int(os.environ.get("MLD_BENCH_COALESCE", "32")),
+                    help="bs-64 requests per engine call (mldhip_sample_many), at most 32; 1 = one call per request")
+    ap.add_argument("--repeats", type=int, default=5, help="repetitions of the K-step timed region (median reported, min / max carried)")
     ap.add_argument("--eager", action="store_true", help="disable hipGraph replay (debug)")
     ap.add_argument("--full", action="store_true", help="run the config-4 leg at its real length (1000 DDPM steps; ~1 min)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 child (roofline falls back to chain events)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the alternate arithmetic modes and the coalesced-request measurement")
+    ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 children (rooflines fall back to HIP events)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the alternate arithmetic modes and serving shapes")
     ap.add_argument("--no-a2m", action="store_true", help="skip the secondary action-to-motion (config 5) measurement")
     ap.add_argument("--no-clip", action="store_true", help="skip timing a random-init CLIP text tower on PyTorch-ROCm")
     ap.add_argument("--no-novae", action="store_true", help="skip the secondary diffusion-only (config 4) measurement")
@@ -432,53 +453,31 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    nfl = max(1, min(8, a.in_flight))
-    coalesce = a.coalesce if a.coalesce > 0 else max(1, min(8, -(-a.steps // nfl)))
+    K = a.steps
+    coalesce = max(1, min(32, a.coalesce, K))
     weights, weight_bytes, bcast_s = pack_and_broadcast_weights(rank, dev)
-    eng = make_engine(local, weights, a.precision, max_batch=BATCH * coalesce, nfl=nfl, graph=not a.eager)
+    eng = make_engine(local, weights, a.precision, max_batch=BATCH * coalesce, graph=not a.eager)
     ident = (rank, local) + device_identity(local)
     ranks_seen = [ident]
     if dist:
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, ident)
-
-    # nfl x coalesce request slots, each with its own prompts (seeded per rank and slot) and buffers; call g of the timed
-    # region serves the `coalesce` requests of group g % nfl on stream g % nfl.  Every request is one full pass of the hot
-    # path over one bs-64 batch; the last call may hold fewer requests so that exactly K steps are timed.
     stream = torch.cuda.current_stream()
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
-    slots = []
-    for sl in range(nfl * coalesce):
-        bt = syn.make_batch(BATCH, None, seed=1234 + rank + 1000 * sl, max_len=FRAMES)
-        slots.append({"batch": bt, "text": torch.from_numpy(bt.text_emb).to(dev), "lat0": torch.from_numpy(bt.init_latents).to(dev),
-                      "lat": torch.empty(BATCH, 1, 256, device=dev), "feats": torch.empty(BATCH, FRAMES, 263, device=dev),
-                      "joints": torch.empty(BATCH, FRAMES, 22, 3, device=dev)})
-    joints = slots[0]["joints"]
+    reqs = make_requests(dev, coalesce, rank, with_lat=True)
+    calls = [coalesce] * (K // coalesce) + ([K % coalesce] if K % coalesce else [])     # requests per call of one timed region: exactly K steps
 
-    def request(sl, lengths=None):
-        s = slots[sl]
-        return dict(text_emb=s["text"], init_latents=s["lat0"], lengths=lengths if lengths is not None else s["batch"].lengths,
-                    latents_out=s["lat"], feats_out=s["feats"], joints_out=s["joints"])
+    def issue(e_, lengths=None):
+        for n in calls:
+            if n == 1:
+                r = reqs[0]
+                e_.sample(r["text_emb"], r["init_latents"], lengths[0] if lengths else r["lengths"], r["latents_out"], None, r["joints_out"], stream.cuda_stream)
+            else:
+                e_.sample_many([dict(r, lengths=lengths[i]) if lengths else r for i, r in enumerate(reqs[:n])], stream.cuda_stream)
 
-    def call(e_, g, nreq, st, lengths=None):
-        """one engine call: the first `nreq` requests of group g % nfl on stream st"""
-        base = (g % nfl) * coalesce
-        if nreq == 1 and coalesce == 1:
-            s = slots[base]
-            e_.sample(s["text"], s["lat0"], lengths[base] if lengths else s["batch"].lengths, s["lat"], s["feats"], s["joints"], st.cuda_stream)
-        else:
-            e_.sample_many([request(base + k, lengths[base + k] if lengths else None) for k in range(nreq)], st.cuda_stream)
-
-    def issue(e_, nsteps, lengths=None):
-        g, left = 0, nsteps
-        while left > 0:
-            n = min(coalesce, left)
-            call(e_, g, n, streams[g % nfl], lengths)
-            g, left = g + 1, left - n
-
-    def step_single(e_, i, lengths=None):
-        s = slots[i % len(slots)]
-        e_.sample(s["text"], s["lat0"], lengths[i % len(slots)] if lengths else s["batch"].lengths, s["lat"], s["feats"], s["joints"], stream.cuda_stream)
+    def issue_single(e_, nsteps):
+        for i in range(nsteps):
+            r = reqs[i % len(reqs)]
+            e_.sample(r["text_emb"], r["init_latents"], r["lengths"], r["latents_out"], None, r["joints_out"], stream.cuda_stream)
 
     def timed(fn):
         torch.cuda.synchronize()
@@ -504,38 +503,42 @@ def main():
         return dt, per_rank
 
     torch.cuda.synchronize()                     # inputs were uploaded on the default stream
-    wsteps = max(a.warmup, 1) * coalesce * nfl   # W untimed rounds: every workspace captures every call shape of the timed region
-    issue(eng, wsteps)
-    if a.steps % coalesce:
-        for g in range(nfl):
-            call(eng, g, a.steps % coalesce, streams[g])
-    for i in range(2):
-        step_single(eng, i)
-    dt, per_rank_s = timed(lambda: issue(eng, a.steps))
-    ms_per_step = dt / a.steps * 1e3
-    value = world * BATCH * a.steps / dt
-    dt1 = timed(lambda: [step_single(eng, i) for i in range(a.steps)])[0]      # the same steps strictly one bs-64 batch after another
+    for _ in range(max(a.warmup, 1)):            # W untimed rounds of the K steps: every call shape of the timed region is captured
+        issue(eng)
+    launches_headline = eng.launch_counts()      # [reverse loop, decode, joints] launches of the last (headline-shaped) call
+    issue_single(eng, 2)
+    reps = [timed(lambda: issue(eng)) for _ in range(max(1, a.repeats))]
+    order = sorted(range(len(reps)), key=lambda i: reps[i][0])
+    dt, per_rank_s = reps[order[len(order) // 2]]            # the median repetition IS the reported K-step region
+    ms_per_step = dt / K * 1e3
+    value = world * BATCH * K / dt
+    K1 = min(K, 16)
+    reps1 = [timed(lambda: issue_single(eng, K1))[0] / K1 for _ in range(max(1, a.repeats))]     # strictly one bs-64 batch after another
+    ms1 = spread(reps1)
     gf_total, gf_den, gf_dec = algorithmic_gflop(BATCH, FRAMES)
     tf_job = gf_total / 1e3 / (ms_per_step * 1e-3)
+    PB = BATCH * coalesce
 
     out = {
-        "metric": METRIC, "value": round(value, 2), "unit": "motions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "metric": METRIC, "value": round(value, 2), "unit": "motions/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": DTYPE[a.precision], "data": "synthetic",
-        "value_single_batch": round(world * BATCH * a.steps / dt1, 2), "ms_per_step_single_batch": round(dt1 / a.steps * 1e3, 4),
+        "repeats": {"n": len(reps), "value_median": round(value, 2), "value_min": round(world * BATCH * K / max(r[0] for r in reps), 2),
+                    "value_max": round(world * BATCH * K / min(r[0] for r in reps), 2),
+                    "note": "the K-step timed region repeated n times, barrier + synchronize on both sides of each; `value` / `ms_per_step` are the median repetition"},
         "config": {"workload": "config_mld_humanml3d.yaml, bs=64 per step (request), T=196, 50-step DDIM, CFG 7.5, VAE decode + feats2joints; "
-                               "%d requests coalesced per engine call (mldhip_sample_many), %d calls in flight per GPU on %d HIP streams "
-                               "(value_single_batch: one bs-64 batch at a time)" % (coalesce, nfl, nfl),
-                   "requests_per_call": coalesce, "in_flight": nfl, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "global_batch": BATCH * world, "parallelism": f"dp{world}", "graph": not a.eager, "precision": a.precision,
+                               "%d requests (%d motions) per engine call (mldhip_sample_many: the reverse loop of a call is ONE persistent launch, "
+                               "a workgroup per 8 motions), calls one after another on one stream; `single_batch`: one bs-64 batch at a time" % (coalesce, PB),
+                   "requests_per_call": coalesce, "calls_per_timed_region": len(calls), "in_flight": 1, "global_batch": BATCH * world,
+                   "parallelism": f"dp{world}", "graph": not a.eager, "precision": a.precision,
                    "weights": "synthetic (seeded numpy), one broadcast of %.1f MB" % (weight_bytes / 1e6),
-                   "launches_per_step": eng.launch_counts()},
+                   "launches_per_call": launches_headline},
         "whole_job": {"algorithmic_gflop_per_batch": round(gf_total, 1), "denoise_gflop_per_step": round(gf_den, 3), "decode_gflop": round(gf_dec, 1),
                       "achieved_tflops": round(tf_job, 2), "frac_of_fp32_mfma_peak": round(tf_job / FP32_MFMA_PEAK_TF, 4),
-                      "frac_of_bf16_mfma_peak": round(tf_job / BF16_MFMA_PEAK_TF, 5),
-                      "note": "per GPU, amortised over the steps in flight; the reverse loop (58 % of the FLOPs) is exact fp32 in the parity modes, "
-                              "so the fp32 MFMA peak is the bound that applies to it"},
+                      "frac_of_mode_peak": round(tf_job / PEAK_TF[a.precision], 4), "mode_peak_tflops": round(PEAK_TF[a.precision], 1),
+                      "note": "per GPU; mode peak = the MFMA roof of the headline arithmetic (f16x3: dense f16 peak / 3 products)"},
     }
-    per_rank_v = [BATCH * a.steps / t for t in per_rank_s]
+    per_rank_v = [BATCH * K / t for t in per_rank_s]
     out["distributed"] = {"backend": "nccl (RCCL)" if dist else "none (single process)", "world_size": world,
                           "ranks_seen": [list(r) for r in ranks_seen], "distinct_devices": len({r[2] for r in ranks_seen}),
                           "weight_broadcast": {"bytes": weight_bytes, "seconds": round(bcast_s, 4), "collectives": 1 if dist else 0,
@@ -543,62 +546,81 @@ def main():
                           "per_rank_motions_per_s": {"min": round(min(per_rank_v), 2), "max": round(max(per_rank_v), 2)},
                           "data_path_collectives": 0}
     if rank == 0:
-        # ---- per-kernel table at the shape of one headline call (coalesce x 64 motions): back-to-back launch interval
-        #      (HIP events on the launch stream) ...
-        PB = BATCH * coalesce
-        table = kernel_table(PB, a.precision)
-        kern = {}
-        for name, (_, cnt) in table.items():
-            ms, fl = time_kernel(eng, name, PB, FRAMES, 100 if name.startswith("den") else max(6, 30 // coalesce), stream)
-            kern[name] = {"interval_us": round(ms * 1e3, 2), "gflop": round(fl / 1e9, 4), "launches_per_call": cnt}
-        # ---- ... and each kernel's duration inside the dependent chain: rocprofv3 dispatch averages of a child run of this call shape
+        solo = world == 1 and not a.eager
+        # ---- headline call shape under rocprofv3 (child process, same call shape, one call at a time): per-kernel table + the dominant kernel
         stats, where = (None, "disabled") if (a.no_rocprof or dist is not None or a.eager) else rocprof_child_stats(a.precision, coalesce)
-        for name, (prefix, cnt) in table.items():
-            k = kern[name]
-            if stats:
-                hits = [(n, v) for n, v in stats.items() if n.startswith(prefix)]
-                if name.startswith("dec_") and name not in ("dec_attn", "dec_ffn"):
-                    # decoder GEMMs share two templates: K = 256 vs K = 1024 differ in the KCS argument; QKV and FFN1 are one kernel (same tile, same K)
-                    kcs = ", 32, false>" if name == "dec_ffn2_ln" else ", 8, false>"
-                    hits = [(n, v) for n, v in hits if kcs in n]
-                if hits:
-                    n, (avg, calls) = max(hits, key=lambda kv: kv[1][1])
-                    k["rocprof_us"], k["rocprof_kernel"], k["rocprof_calls"] = round(avg / 1e3, 2), n[:90], calls
-            if name in ("den_qkv", "den_outproj", "den_ffn1", "den_ffn2"):
-                k["chain_us"] = round(chain_marginal_us(eng, name, PB, FRAMES, 60, stream), 2)
-            dur = k.get("rocprof_us") or k.get("chain_us") or k["interval_us"]
-            k["clock"] = "rocprofv3" if "rocprof_us" in k else "chain_events" if "chain_us" in k else "interval"
-            if name in ("dec_qkv", "dec_ffn1") and "dec_ffn1" in table and "rocprof_us" in k:
-                # one kernel serves both: split its average by their FLOP ratio is not measurable -- report the interval clock for these two
-                dur, k["clock"] = k["interval_us"], "interval (shares its rocprofv3 row with the other K = 256 decoder GEMM)"
-            k["tflops"] = round(k["gflop"] / (dur * 1e-6) / 1e3, 3) if dur else 0.0
-            k["share_ms"] = round(dur * cnt / 1e3, 3)
-        dom = max(kern, key=lambda n: kern[n]["share_ms"])
-        d = kern[dom]
-        traffic, traffic_note = None, "no PMC summary (profiles/r02_pmc_traffic.json)"
+        # HIP events on the launch stream around loop-only calls (latents out, no decode): the persistent loop kernel + the condition-row GEMM
+        lat_only = [dict(text_emb=r["text_emb"], init_latents=r["init_latents"], lengths=r["lengths"], latents_out=r["latents_out"]) for r in reqs]
+        if coalesce > 1:
+            eng.sample_many(lat_only, stream.cuda_stream)
+            loop_ms = min(events_ms(stream, lambda: eng.sample_many(lat_only, stream.cuda_stream))[0] for _ in range(3))
+        else:
+            loop_ms = None
+        fused = launches_headline[0] <= 4
+        x3 = a.precision == "f16x3"
+        flop_loop_call = gf_den * STEPS_DDIM * coalesce          # GFLOP of one call's reverse loop
+        kern = {}
+        if stats:
+            tot = sum(v[2] for v in stats.values()) or 1.0
+            for n, (avg, calls_, total) in sorted(stats.items(), key=lambda kv: -kv[1][2])[:12]:
+                kern[n[:110]] = {"avg_us": round(avg / 1e3, 2), "calls": calls_, "share_of_gpu_time": round(total / tot, 4)}
+        roof = {"bound": "mfma", "unit": "TFLOP/s", "source_hash": source_hash(),
+                "shape": "one headline call: %d motions, decoder at %d frame rows" % (PB, PB * FRAMES),
+                "rocprof": where if stats else "unavailable: %s" % where}
+        loop_rows = [(n, v) for n, v in (stats or {}).items() if "den_loop_kernel" in n]
+        if fused and (loop_rows or loop_ms):
+            avg_us = loop_rows[0][1][0] / 1e3 if loop_rows else None
+            use_us = avg_us or loop_ms * 1e3
+            peak = X3_PEAK_TF if x3 else FP32_MFMA_PEAK_TF
+            roof.update({"kernel": "den_loop_kernel (kernels/loop_fused.hpp): the whole 50-step reverse loop of the call, one launch",
+                         "achieved": round(flop_loop_call / use_us * 1e3, 2), "peak": round(peak, 1), "frac": round(flop_loop_call / use_us * 1e3 / peak, 4),
+                         "gflop_per_launch": round(flop_loop_call, 1), "avg_us_rocprof_dispatch": round(avg_us, 1) if avg_us else None,
+                         "avg_us_hip_events_loop_only_call": round(loop_ms * 1e3, 1) if loop_ms else None,
+                         "clock": "rocprofv3" if avg_us else "hip_events (includes the condition-row GEMM and the latent copies)",
+                         "dtype_of_kernel": "split-f16 x3 MFMA (roof = dense f16 MFMA peak / 3)" if x3 else "f32 MFMA",
+                         "share_of_gpu_time": kern.get(loop_rows[0][0][:110], {}).get("share_of_gpu_time") if loop_rows else None})
+        elif stats:
+            n, (avg, calls_, total) = max(stats.items(), key=lambda kv: kv[1][2])
+            roof.update({"kernel": n[:110], "achieved": None, "peak": PEAK_TF[a.precision], "frac": None, "avg_us_rocprof_dispatch": round(avg / 1e3, 2),
+                         "note": "column-split kernel families (small calls): see profiles/r02_* for their per-kernel FLOP table"})
+        traffic, traffic_note = None, "no PMC summary (profiles/r03_pmc_traffic.json)"
         try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r03_pmc_traffic.json")))
             if pmc.get("source_hash") == source_hash() and pmc.get("requests_per_call") == coalesce:
-                traffic = pmc["kernels"][dom]["traffic_bytes_per_launch"]
-                traffic_note = "profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on THIS source hash and call shape; L2<->fabric bytes per launch"
+                traffic = pmc["kernels"]["den_loop"]["traffic_bytes_per_launch"]
+                traffic_note = "profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on THIS source hash and call shape; L2<->fabric bytes per launch"
             else:
-                traffic_note = "profiles/r02_pmc_traffic.json was collected on source hash %s / %s requests per call, this run is %s / %d: refused as stale" % (
+                traffic_note = "profiles/r03_pmc_traffic.json was collected on source hash %s / %s requests per call, this run is %s / %d: refused as stale" % (
                     pmc.get("source_hash"), pmc.get("requests_per_call"), source_hash(), coalesce)
         except Exception:
             pass
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": d["tflops"], "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                           "frac": round(d["tflops"] / FP32_MFMA_PEAK_TF, 4), "traffic": traffic, "traffic_source": traffic_note,
-                           "clock": d["clock"], "avg_us": d.get("rocprof_us") or d.get("chain_us") or d["interval_us"],
-                           "avg_us_rocprof_dispatch": d.get("rocprof_us"), "avg_us_in_chain_events": d.get("chain_us"),
-                           "avg_us_back_to_back_interval": d["interval_us"], "gflop_per_launch": d["gflop"],
-                           "shape": "one headline call: %d motions, reverse loop at %d token rows, decoder at %d frame rows" % (PB, 6 * PB, PB * FRAMES),
-                           "dtype_of_kernel": "f32 MFMA" if dom.startswith("den") or a.precision == "f32" else "split-bf16 x3 MFMA",
-                           "rocprof": where if stats else "unavailable: %s" % where, "source_hash": source_hash()}
+        roof["traffic"], roof["traffic_source"] = traffic, traffic_note
+        roof["algorithmic_bytes_per_launch"] = int(STEPS_DDIM * 30.4e6 + PB * 3 * 1024 * 2)     # the weight stream once per step chip-wide + latents / condition rows
+        out["roofline"] = roof
         out["kernels"] = kern
+        # ---- the configuration BASELINE.json names literally: one bs-64 batch at a time (latency kernels), first-class with its own roofline
+        single = {"value": round(world * BATCH / ms1["median"], 2), "unit": "motions/s", "ms_per_batch": {k: (round(v * 1e3, 4) if k != "n" else v) for k, v in ms1.items()},
+                  "steps_per_repetition": K1, "shape": "mldhip_sample, B = 64, T = 196: 2 052 dependent launches (hipGraph replay), reverse loop at 384 token rows on the latency kernels (tile32.hpp)"}
+        if solo and not a.no_rocprof:
+            st1, where1 = rocprof_child_stats(a.precision, 1, keep_env="MLD_BENCH_KEEP_ROCPROF_SINGLE")
+            if st1:
+                pref = "void mld::gemm_tile32_kernel<32, 1, false"          # FFN1 of the loop: norm1 on load + linear1 + GELU
+                hits = [(n, v) for n, v in st1.items() if n.startswith(pref)]
+                if hits:
+                    n, (avg, calls_, total) = max(hits, key=lambda kv: kv[1][1])
+                    gf = 2.0 * 384 * 256 * 1024 / 1e9
+                    tot1 = sum(v[2] for v in st1.values()) or 1.0
+                    single["roofline"] = {"bound": "mfma", "kernel": "den_ffn1 = " + n[:80], "achieved": round(gf / (avg * 1e-9) / 1e3, 2), "peak": FP32_MFMA_PEAK_TF,
+                                          "unit": "TFLOP/s", "frac": round(gf / (avg * 1e-9) / 1e3 / FP32_MFMA_PEAK_TF, 4), "avg_us_rocprof_dispatch": round(avg / 1e3, 2),
+                                          "launches_per_batch": 9 * STEPS_DDIM, "gflop_per_launch": round(gf, 4),
+                                          "share_of_gpu_time": round(total / tot1, 4), "rocprof": where1,
+                                          "note": "one request is a chain of 2 052 dependent launches of ~5-8 us: launch-latency bound, not MFMA bound (DESIGN.md §3 point 3 / 17c)"}
+        out["single_batch"] = single
+        out["value_single_batch"], out["ms_per_step_single_batch"] = single["value"], round(ms1["median"] * 1e3, 4)
+
         cj = None
         if world == 1 and not a.no_cpu_baseline:
-            # MKL/OpenMP oversubscribes badly on a 256-thread host with these small GEMMs: use <= 32 threads
-            threads = min(32, os.cpu_count() or 1)
+            threads = min(32, os.cpu_count() or 1)          # MKL/OpenMP oversubscribes badly on a 256-thread host with these small GEMMs
             info, cj = cpu_baseline(1234 + rank, threads)
             if cj is not None:
                 out["cpu_baseline"] = {"value": round(info["motions_per_s"], 2), "unit": "motions/s", "cores": info["threads"],
@@ -608,86 +630,119 @@ def main():
                                            "value": 15.2, "unit": "motions/s", "cores": 8, "host": "survey sandbox, Xeon 2.1 GHz, MKL",
                                            "provenance": "SURVEY.md §8(d) probe: the reference's own MldDenoiser / MldVae modules + restated DDIM at B=64 "
                                                          "(4.2 s per batch); /root/reference cannot travel to the GPU box, so it is not re-timed here"}}
-                issue(eng, coalesce)              # the headline call shape again: slot 0's joints come from a coalesced call
-                torch.cuda.synchronize()
-                err_c = float(np.abs(joints.cpu().numpy() - cj).max())
-                step_single(eng, 0)
-                torch.cuda.synchronize()
-                out["parity"] = {"max_abs_joints_vs_oracle": max(err_c, float(np.abs(joints.cpu().numpy() - cj).max())), "tolerance": 1e-3,
-                                 "precision": a.precision, "max_abs_joints_vs_oracle_coalesced_call": err_c,
-                                 "max_abs_joints_vs_oracle_single_call": float(np.abs(joints.cpu().numpy() - cj).max())}
             else:
                 out["cpu_baseline"] = {"value": None, "unit": "motions/s", "cores": threads, "kind": "port", "sample": str(info)}
-        if world == 1 and not a.eager and not a.no_alt:
+            # the same array code on stock ATen kernels of the SAME GPU (SURVEY.md §7.2b "PyTorch-ROCm eager motions/s on the same GPU")
+            info_g, jg = cpu_baseline(1234 + rank, threads, device="cuda", repeat=3)
+            if jg is not None:
+                out["eager_same_gpu"] = {"value": round(info_g["motions_per_s"], 2), "unit": "motions/s", "kind": "oracle.mld_oracle.TorchOps on cuda: plain PyTorch-ROCm eager, fp32, "
+                                         "one bs-64 batch (T=196, 50 steps), best of 3; NOT the reference's nn.Modules (they cannot travel), the same arithmetic graph",
+                                         "seconds_per_batch": round(info_g["seconds"], 4),
+                                         "max_abs_joints_vs_cpu_oracle": float(np.abs(jg - cj).max()) if cj is not None else None}
+            else:
+                out["eager_same_gpu"] = {"value": None, "error": str(info_g)}
+        if solo:
+            # ---- parity of the headline call, ALL of it: every request against the exact-fp32 engine on the latency kernels (itself
+            #      within ~1e-4 of the reference fixture, tests/test_gpu_parity.py), request 0 against the CPU oracle run above
+            issue(eng)
+            torch.cuda.synchronize()
+            got = [r["joints_out"].clone() for r in reqs]
+            ex = make_engine(local, weights, "f32", max_batch=BATCH)
+            worst, per = 0.0, []
+            jbuf = torch.empty(BATCH, FRAMES, 22, 3, device=dev)
+            for r, g_ in zip(reqs, got):
+                ex.sample(r["text_emb"], r["init_latents"], r["lengths"], None, None, jbuf, stream.cuda_stream)
+                torch.cuda.synchronize()
+                per.append(round(float((g_ - jbuf).abs().max()), 7))
+            worst = max(per)
+            issue_single(eng, 1)                 # request 0 again, alone, on the latency kernels of the headline mode
+            ex.sample(reqs[0]["text_emb"], reqs[0]["init_latents"], reqs[0]["lengths"], None, None, jbuf, stream.cuda_stream)
+            torch.cuda.synchronize()
+            j_single, j_exact = reqs[0]["joints_out"].cpu().numpy(), jbuf.cpu().numpy()
+            par = {"tolerance": 1e-3, "precision": a.precision, "motions_checked": PB,
+                   "max_abs_joints_vs_exact_fp32_engine_all_requests": worst, "per_request": per,
+                   "max_abs_joints_vs_exact_fp32_engine_single_call": float(np.abs(j_single - j_exact).max())}
+            if cj is not None:
+                par["max_abs_joints_vs_oracle_request0_of_headline_call"] = float(np.abs(got[0].cpu().numpy() - cj).max())
+                par["max_abs_joints_vs_oracle_single_call"] = float(np.abs(j_single - cj).max())
+                par["max_abs_joints_vs_oracle"] = max(par["max_abs_joints_vs_oracle_request0_of_headline_call"], par["max_abs_joints_vs_oracle_single_call"])
+                par["exact_fp32_engine_vs_oracle_request0"] = float(np.abs(j_exact - cj).max())
+            out["parity"] = par
+            ex.close()
+        if solo and not a.no_alt:
             # ---- the other arithmetic modes on the same workload and timing rule, each with its measured error
             alts = {}
-            for prec in [p for p in ("f32", "bf16x3_decode", "bf16") if p != a.precision]:
-                e2 = make_engine(local, weights, prec, max_batch=BATCH * coalesce, nfl=nfl)
-                issue(e2, coalesce * nfl)
-                if a.steps % coalesce:
-                    for g in range(nfl):
-                        call(e2, g, a.steps % coalesce, streams[g])
-                for i in range(2):
-                    step_single(e2, i)
+            for prec in [p for p in ("f32", "f16x3", "bf16") if p != a.precision]:
+                e2 = make_engine(local, weights, prec, max_batch=PB)
+                issue(e2)
+                fused2 = e2.launch_counts()[0] <= 4
+                issue_single(e2, 2)
                 torch.cuda.synchronize()
-                t4 = run_steps(lambda i, st: issue(e2, a.steps), 1, [None])
-                n1 = max(4, a.steps // 2)
-                t1 = run_steps(lambda i, st: step_single(e2, i), n1, [None]) / n1
-                alt = {"value": round(BATCH * a.steps / t4, 2), "value_single_batch": round(BATCH / t1, 2), "dtype": DTYPE[prec]}
+                t4 = min(run_steps(lambda i, st: issue(e2), 1, [None]) for _ in range(3))
+                t1 = run_steps(lambda i, st: issue_single(e2, 1), 8, [None]) / 8
+                alt = {"value": round(BATCH * K / t4, 2), "value_single_batch": round(BATCH / t1, 2), "dtype": DTYPE[prec],
+                       "loop": "sample-major persistent launch" if fused2 else "column-split throughput kernels (strip.hpp): the persistent loop is built for fp32 / split-f16 operands"}
+                if fused2:
+                    e2.sample_many(lat_only, stream.cuda_stream)
+                    lm_ = min(events_ms(stream, lambda: e2.sample_many(lat_only, stream.cuda_stream))[0] for _ in range(3))
+                    pk = FP32_MFMA_PEAK_TF if prec == "f32" else X3_PEAK_TF
+                    alt["loop_kernel_roofline"] = {"avg_us_hip_events_loop_only_call": round(lm_ * 1e3, 1), "achieved_tflops": round(flop_loop_call / lm_, 2),
+                                                   "peak": round(pk, 1), "frac": round(flop_loop_call / lm_ / pk, 4)}
                 if cj is not None:
-                    step_single(e2, 0)
+                    issue(e2)
                     torch.cuda.synchronize()
-                    alt["max_abs_joints_vs_oracle"] = float(np.abs(joints.cpu().numpy() - cj).max())
+                    alt["max_abs_joints_vs_oracle"] = float(np.abs(reqs[0]["joints_out"].cpu().numpy() - cj).max())
                 alts[prec] = alt
                 e2.close()
             out["alt_modes"] = alts
-            # ---- round 1's serving shape: one engine call per request, `nfl` calls in flight (latency kernels, 384 rows per chain)
-            if coalesce > 1:
-                e1 = make_engine(local, weights, a.precision, max_batch=BATCH, nfl=nfl)
-                one = lambda i, st: e1.sample(slots[i % len(slots)]["text"], slots[i % len(slots)]["lat0"], slots[i % len(slots)]["batch"].lengths,
-                                              None, None, slots[i % len(slots)]["joints"], streams[i % nfl].cuda_stream)
-                run_steps(one, 2 * nfl, [None])
-                t = run_steps(one, max(a.steps, 4 * nfl), [None])
-                out["per_request_in_flight"] = {"value": round(BATCH * max(a.steps, 4 * nfl) / t, 2), "unit": "motions/s", "calls_in_flight": nfl,
-                                                "note": "mldhip_sample per bs-64 request, %d in flight: the headline shape of round 1" % nfl}
-                e1.close()
-            step_single(eng, 0)                  # slot 0 holds the headline engine's result again
-            torch.cuda.synchronize()
-        if world == 1 and not a.eager:
+            # ---- round 2's serving shape for continuity: 5 requests per call on the column-split throughput kernels, 4 calls in flight
+            nfl, c2 = 4, 5
+            e5 = make_engine(local, weights, a.precision, max_batch=BATCH * c2, nfl=nfl)
+            e5.set_option("loop_kernel", 2)
+            streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+            r5 = make_requests(dev, c2 * nfl, 7)
+            call5 = lambda i, st: e5.sample_many(r5[(i % nfl) * c2:(i % nfl) * c2 + c2], streams[i % nfl].cuda_stream)
+            run_steps(call5, 2 * nfl, [None])
+            t5 = run_steps(call5, 8, [None])
+            out["round2_shape"] = {"value": round(BATCH * c2 * 8 / t5, 2), "unit": "motions/s", "requests_per_call": c2, "calls_in_flight": nfl,
+                                   "note": "5 x 64 motions per call on the column-split throughput kernels (strip.hpp), 4 calls in flight on 4 streams: round 2's headline shape, this round's build"}
+            e5.close()
+        if solo:
             # also a realistic length mix -- uniform in {40, 44, ..., 196}, seed 1234 (same Tmax, ragged masks)
             rng = np.random.Generator(np.random.PCG64(1234))
-            mix = [[int(v) for v in rng.choice(np.arange(40, 197, 4), BATCH)] for _ in range(len(slots))]
+            mix = [[int(v) for v in rng.choice(np.arange(40, 197, 4), BATCH)] for _ in range(len(reqs))]
             for ln in mix:
                 ln[0] = FRAMES                                  # keep Tmax = 196 so buffers / graphs are the same
-            issue(eng, coalesce * nfl, mix)
-            dtm = run_steps(lambda i, st: issue(eng, a.steps, mix), 1, [None])
-            lm = {"value": round(BATCH * a.steps / dtm, 2), "unit": "motions/s", "ms_per_step": round(dtm / a.steps * 1e3, 4),
+            issue(eng, mix)
+            dtm = min(run_steps(lambda i, st: issue(eng, mix), 1, [None]) for _ in range(3))
+            lm = {"value": round(BATCH * K / dtm, 2), "unit": "motions/s", "ms_per_step": round(dtm / K * 1e3, 4),
                   "lengths": "uniform in {40..196 step 4}, seed 1234, Tmax 196; mean %.1f frames" % float(np.mean(mix))}
             if not a.no_cpu_baseline:
                 lf = "/tmp/mld_bench_lengths_%d.json" % os.getpid()
                 json.dump(mix[0], open(lf, "w"))
                 info, jm = cpu_baseline(1234 + rank, min(32, os.cpu_count() or 1), lengths_file=lf)
                 if jm is not None:
-                    issue(eng, coalesce, mix)
+                    issue(eng, mix)
                     torch.cuda.synchronize()
-                    j = joints.cpu().numpy()
+                    j = reqs[0]["joints_out"].cpu().numpy()
                     lm["max_abs_joints_vs_oracle"] = float(max(np.abs(j[i, :n] - jm[i, :n]).max() for i, n in enumerate(mix[0])))
                     lm["tolerance"] = 1e-3
             out["length_mix"] = lm
-        if world == 1 and not a.eager:
+        if solo:
             out["other_workloads"] = []
+            s2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
             if not a.no_a2m:
-                out["other_workloads"].append(bench_a2m(local, dev, 2, max(4, a.steps // 3), streams[:2]))
+                out["other_workloads"].append(bench_a2m(local, dev, 2, 8, s2))
             if not a.no_novae:
-                out["other_workloads"].append(bench_novae(local, dev, a.full, streams[:2]))
+                out["other_workloads"].append(bench_novae(local, dev, a.full, s2))
         if world == 1 and not a.no_clip:
             try:
                 te = bench_text_encoder(dev)
                 te["single_batch_motions_per_s_incl_text"] = round(BATCH / (out["ms_per_step_single_batch"] + te["ms_per_128_prompts"]) * 1e3, 1)
-                te["note"] = "text encoding of a batch can overlap the sampling of the batches already in flight; this is the strictly serial view"
+                te["note"] = "text encoding of a batch can overlap the sampling of the batches already queued; this is the strictly serial view"
                 out["text_encoder"] = te
-            except Exception as ex:  # transformers missing / API drift: report, never fail the bench
-                out["text_encoder"] = {"error": repr(ex)[:200]}
+            except Exception as ex_:  # transformers missing / API drift: report, never fail the bench
+                out["text_encoder"] = {"error": repr(ex_)[:200]}
         print(json.dumps(out))
     if dist:
         dist.barrier()

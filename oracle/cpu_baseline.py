@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--out", default="")
     ap.add_argument("--lengths", default="", help="JSON file with one length per motion (default: all --frames)")
+    ap.add_argument("--device", default="cpu", help="cpu (the baseline) or cuda (bench.py eager_same_gpu: the same code on stock ATen kernels)")
+    ap.add_argument("--repeat", type=int, default=1, help="timed repetitions (the minimum is reported)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -29,7 +31,8 @@ def main():
     from oracle import mld_oracle as O
     if a.threads > 0:
         torch.set_num_threads(a.threads)
-    ops = O.TorchOps()
+    ops = O.TorchOps(device=a.device)
+    sync = torch.cuda.synchronize if a.device != "cpu" else (lambda: None)
     bd = O.to_backend(ops, syn.make_denoiser_state_dict())
     bv = O.to_backend(ops, syn.make_vae_state_dict())
     b = syn.make_batch(a.batch, None, seed=a.seed, max_len=a.frames)
@@ -39,13 +42,17 @@ def main():
     args = (ops.asarray(b.text_emb), ops.asarray(b.init_latents), b.lengths, ops.asarray(mean), ops.asarray(std))
     with torch.no_grad():
         O.sample(ops, bd, bv, args[0][: 4], args[1][:2], b.lengths[:2], args[3], args[4], steps=2)   # warm the allocator
-        t0 = time.time()
-        joints = O.sample(ops, bd, bv, *args, steps=a.steps)
-        dt = time.time() - t0
+        sync()
+        dt = float("inf")
+        for _ in range(max(1, a.repeat)):
+            t0 = time.time()
+            joints = O.sample(ops, bd, bv, *args, steps=a.steps)
+            sync()
+            dt = min(dt, time.time() - t0)
     if a.out:
         np.save(a.out, ops.to_numpy(joints))
     print(json.dumps({"seconds": dt, "motions_per_s": a.batch / dt, "threads": torch.get_num_threads(),
-                      "cores": os.cpu_count(), "batch": a.batch, "frames": a.frames, "steps": a.steps}))
+                      "cores": os.cpu_count(), "batch": a.batch, "frames": a.frames, "steps": a.steps, "device": a.device}))
 
 
 if __name__ == "__main__":

@@ -129,16 +129,19 @@ class TorchOps:
     """torch-CPU backend: same arithmetic through ATen/MKL (multi-threaded)."""
     name = "torch"
 
-    def __init__(self, dtype="float32"):
+    def __init__(self, dtype="float32", device="cpu"):
+        """device = "cpu" (the cpu_baseline port) or "cuda" (bench.py's eager_same_gpu comparator: the same array code through
+        stock ATen on the GPU the engine runs on)."""
         import torch
         self.t = torch
         self.dtype = getattr(torch, dtype) if isinstance(dtype, str) else dtype
+        self.device = torch.device(device)
 
     def asarray(self, x):
         t = self.t
         if isinstance(x, t.Tensor):
-            return x.to(self.dtype)
-        return t.as_tensor(np.asarray(x)).to(self.dtype)
+            return x.to(device=self.device, dtype=self.dtype)
+        return t.as_tensor(np.asarray(x)).to(device=self.device, dtype=self.dtype)
 
     def to_numpy(self, x):
         return x.detach().cpu().numpy()
@@ -196,7 +199,7 @@ class TorchOps:
 
     def mask_from_lengths(self, lengths, tmax):
         t = self.t
-        return t.arange(tmax)[None, :] < t.as_tensor(list(lengths))[:, None]
+        return t.arange(tmax, device=self.device)[None, :] < t.as_tensor(list(lengths), device=self.device)[:, None]
 
 
 # ----------------------------------------------------------------------------- primitives

@@ -8,7 +8,7 @@ from mld_hip import _lib, synthetic as syn
 
 dev = torch.device("cuda:0")
 GOLD = os.path.join(ROOT, "tests", "golden")
-NAMES = {0: "f32", 1: "bf16x3_decode", 2: "bf16", 3: "fp8_denoiser"}
+NAMES = {0: "f32", 1: "f16x3", 2: "bf16", 3: "fp8_denoiser"}
 STEPS = int(os.environ.get("AB_STEPS", "12"))
 out = {}
 

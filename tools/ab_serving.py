@@ -15,7 +15,7 @@ for i in range(16):
     reqs.append(dict(text_emb=torch.from_numpy(b.text_emb).to(dev), init_latents=torch.from_numpy(b.init_latents).to(dev), lengths=b.lengths,
                      joints_out=torch.empty(64, 196, 22, 3, device=dev)))
 out = {}
-for prec, pname in ((0, "f32"), (1, "bf16x3_decode")):
+for prec, pname in ((0, "f32"), (1, "f16x3")):
     for nreq in (1, 2, 4, 8):
         for nfl in (1, 2, 3, 4):
             if nreq * nfl > 16: continue

@@ -11,7 +11,7 @@ TAG=${1:-r02}
 export GPU_MAX_HW_QUEUES=${PMC_HW_QUEUES:-4}
 for C in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES}; do
   cd /tmp && timeout ${PMC_TIMEOUT:-180} rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$C -o pmc -- \
-    python $GRAFT_REPO_ROOT/bench.py --profile-child --precision ${PMC_PRECISION:-bf16x3_decode} --coalesce ${PMC_COALESCE:-5} --steps ${PMC_CALLS:-1} > $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$C.log 2>&1
+    python $GRAFT_REPO_ROOT/bench.py --profile-child --precision ${PMC_PRECISION:-f16x3} --coalesce ${PMC_COALESCE:-5} --steps ${PMC_CALLS:-1} > $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$C.log 2>&1
   cd $GRAFT_REPO_ROOT
 done
 python - "$TAG" <<'PY'
@@ -32,7 +32,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
     agg[C] = {k: (n, v / n) for k, (n, v) in a.items()}
 kern = {}
 coalesce = int(os.environ.get("PMC_COALESCE", "5"))
-for name, (prefix, _) in bench.kernel_table(bench.BATCH * coalesce, os.environ.get("PMC_PRECISION", "bf16x3_decode")).items():
+for name, (prefix, _) in bench.kernel_table(bench.BATCH * coalesce, os.environ.get("PMC_PRECISION", "f16x3")).items():
     ent = {}
     for C, table in agg.items():
         hits = [(k, v) for k, v in table.items() if k.startswith(prefix)]

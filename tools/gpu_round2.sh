@@ -12,7 +12,7 @@ prof() {  # $1 = output csv name, rest = command
   local f=$(find $d -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/r02_kernel_stats_$name.csv
   find $d -name "*kernel_trace*.csv" -delete
 }
-prof single_request python $R/bench.py --profile-child --precision bf16x3_decode --coalesce 1
+prof single_request python $R/bench.py --profile-child --precision f16x3 --coalesce 1
 cat > /tmp/novae_run.py <<'PY'
 import sys, os, time, json
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"]); sys.path.insert(0, os.path.join(os.environ["GRAFT_REPO_ROOT"], "motion-latent-diffusion_amd"))
