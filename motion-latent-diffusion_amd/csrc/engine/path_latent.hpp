@@ -246,11 +246,13 @@ int build_loop_stream(Ctx& c) {
         for (int part = 0; part < 3; ++part) push(P_.in_w, 256, part * 256 + hp * 128, kc * 32);
     for (int kc = 0; kc < 8; ++kc)
       for (int cb = 0; cb < 2; ++cb) push(P_.out_w, 256, cb * 128, kc * 32);
-    for (int hb = 0; hb < 4; ++hb) {
-      for (int kc = 0; kc < 8; ++kc)
-        for (int half = 0; half < 2; ++half) push(P_.l1_w, 256, hb * 256 + half * 128, kc * 32);
-      for (int kc = 0; kc < 8; ++kc)
-        for (int cb = 0; cb < 2; ++cb) push(P_.l2_w, F, cb * 128, hb * 256 + kc * 32);
+    // feed-forward, in the order of the software pipeline: linear1 of block 0, then [linear1 of block hb + 1, linear2's share of block hb]
+    auto f1 = [&](int hb) { for (int kc = 0; kc < 8; ++kc) push(P_.l1_w, 256, hb * 128, kc * 32); };
+    auto f2 = [&](int hb) { for (int kc = 0; kc < 4; ++kc) for (int cb = 0; cb < 2; ++cb) push(P_.l2_w, F, cb * 128, hb * 128 + kc * 32); };
+    f1(0);
+    for (int hb = 0; hb < 8; ++hb) {
+      if (hb < 7) f1(hb + 1);
+      f2(hb);
     }
     if (l >= nb && l + 1 < L) {
       const float* w = P(e, "denoiser.encoder.linear_blocks." + std::to_string(l - nb) + ".weight");
@@ -304,6 +306,43 @@ int build_loop_stream(Ctx& c) {
   if (st != hipSuccess) return e->fail(MLDHIP_EHIP, "sample-major loop tables: %s", hipGetErrorString(st));
   e->loop_ips = (int)ips;
   return 0;
+}
+
+// finalize-time (split precision modes): linear1 / linear2 of every decoder / encoder layer in the item order of
+// kernels/ffn_strip.hpp -- run1(0), then [run1(hb), run2(hb - 1)] for hb = 1..7, then run2(7) -- as split-f16 fragment images
+int build_ffn_streams(Ctx& c) {
+  E* e = c.e;
+  e->ffn_stream_of.clear();
+  if (e->ffn_streams) { (void)hipFree(e->ffn_streams); e->ffn_streams = nullptr; }
+  const bool split = e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE || e->cfg.precision == MLDHIP_PREC_FP8_DENOISER;
+  if (!split || is_novae(e) || e->cfg.latent_dim != 256 || e->cfg.ff_size != 1024) return 0;
+  std::vector<std::pair<const float*, const float*>> layers;
+  if (e->group_ready[1]) for (auto& L : e->dec) layers.push_back({L.l1_w, L.l2_w});
+  if (e->group_ready[3]) for (auto& L : e->venc) layers.push_back({L.l1_w, L.l2_w});
+  if (layers.empty()) return 0;
+  std::vector<LoopItem> items;
+  auto push = [&](const float* w, int ld, int row0, int k0) { items.push_back(LoopItem{(long long)(w - e->arena) + (long long)row0 * ld + k0, ld, 0}); };
+  for (auto& lw : layers) {
+    auto f1 = [&](int hb) { for (int kc = 0; kc < 8; ++kc) push(lw.first, 256, hb * 128, kc * 32); };
+    auto f2 = [&](int hb) { for (int kc = 0; kc < 4; ++kc) for (int cb = 0; cb < 2; ++cb) push(lw.second, 1024, cb * 128, hb * 128 + kc * 32); };
+    f1(0);
+    for (int hb = 1; hb < 8; ++hb) { f1(hb); f2(hb - 1); }
+    f2(7);
+  }
+  LoopItem* items_dev = nullptr;
+  if (hipMalloc((void**)&e->ffn_streams, items.size() * kLoopItemFloats * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&items_dev, items.size() * sizeof(LoopItem)) != hipSuccess)
+    return e->fail(MLDHIP_EHIP, "hipMalloc(feed-forward weight streams)");
+  hipError_t st = hipMemcpy(items_dev, items.data(), items.size() * sizeof(LoopItem), hipMemcpyHostToDevice);
+  if (st == hipSuccess) {
+    MLD_LAUNCH(pack_loop_stream_kernel<true>, dim3((unsigned)items.size()), dim3(512), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->ffn_streams);
+    check_launch(c, "pack_ffn_streams");
+    st = hipStreamSynchronize(c.stream);
+  }
+  (void)hipFree(items_dev);
+  if (st != hipSuccess) return e->fail(MLDHIP_EHIP, "feed-forward weight streams: %s", hipGetErrorString(st));
+  for (size_t i = 0; i < layers.size(); ++i) e->ffn_stream_of[layers[i].first] = e->ffn_streams + i * (size_t)kFfnStripItems * kLoopItemFloats;
+  return c.rc;
 }
 
 FinalArgs den_final_args(E* e, const DenView& v) {
@@ -385,6 +424,17 @@ void ffn_block(Ctx& c, const float* x, float* y, int M, const float* w1, const f
   const int D = e->cfg.latent_dim, F = e->cfg.ff_size;
   // in the arena AND on a 32-float group boundary of it: the split image is built per aligned group (mldhip_finalize_weights)
   auto in_arena = [&](const float* w) { return w >= e->arena && w < e->arena + e->arena_floats && (w - e->arena) % 32 == 0; };
+  if (staged_prec(e) == PREC_BF16X3 && e->ffn_strip && D == 256 && F == 1024 && M > e->small_m && !e->trace_on && e->ffn_stream_of.count(w1)) {
+    // register-direct form (kernels/ffn_strip.hpp): weights from the layer's fragment-ordered stream, 96- or 64-row strips
+    FfnArgs a;
+    a.X = x; a.W1 = e->ffn_stream_of[w1]; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.Y = y; a.M = M;
+    if (ragged_T > 0) { a.skip_lens = e->lens_dev; a.skip_rpg = ragged_T; }
+    if (e->ffn_strip == 6) MLD_LAUNCH(ffn_strip_x3_kernel<6>, dim3((M + 95) / 96), dim3(512), (ffn_strip_lds_bytes<6>()), c.stream, a);
+    else MLD_LAUNCH(ffn_strip_x3_kernel<4>, dim3((M + 63) / 64), dim3(512), (ffn_strip_lds_bytes<4>()), c.stream, a);
+    count(c);
+    check_launch(c, "ffn_strip_x3");
+    return;
+  }
   if (staged_prec(e) == PREC_BF16X3 && e->fused_ffn && e->split_weights && e->arena_x3 && D == 256 && F == 1024 && M > e->small_m &&
       !e->trace_on && in_arena(w1) && in_arena(w2)) {
     FfnArgs a;

@@ -1,0 +1,248 @@
+// Post-norm feed-forward block of a decoder / encoder layer, split-f16 operands, second form (round 3):
+//   Y = LayerNorm(X + linear2(gelu(linear1(X))))        (cross_attention.py:340-343 decoder layer, :268-271 encoder layer)
+// for D = 256, FF = 1024 -- same contract as ffn_fused.hpp (FfnArgs), restructured with what the sample-major loop taught
+// (loop_fused.hpp): a weight element is used by exactly one wave (wave w owns columns 16w .. 16w + 15 of every 128-column block,
+// ALL row tiles of the strip), so weights never go through LDS: every lane loads its two 16-byte MFMA operands per item
+// straight from a fragment-ordered stream (`finalize` re-packs linear1 / linear2 per layer in consumption order) into a register
+// ring -- no weight staging, no barrier per item (ffn_fused.hpp: 128 barriers and 2 MB of LDS stores + 4 MB of LDS reads per
+// workgroup).  What is left in LDS is the strip itself -- RT x 16 rows of X as a split image -- and one 128-wide block of the
+// hidden activation at a time.  RT = 6 (96 rows): 2 MB of weights per 96 rows instead of per 64, i.e. 1.5x less L2 -> CU traffic,
+// which is what bounds the decoder.
+//
+// Pipeline over the eight hidden blocks:   run1(0); gelu(0)
+//   hb = 1..7:  W(hb-1) | run1(hb) | { run2(hb-1) || gelu(hb) }        W = barrier, write H block to LDS, barrier
+//   W(7) | run2(7) | bias + residual + LayerNorm -> Y
+// run1 = linear1 of a block (8 items), run2 = linear2's share of a block (8 items: 4 K chunks x 2 column blocks, A fragments
+// shared), gelu = bias + erf-GELU + hi/lo split of the block's accumulators into registers: pure VALU, issued between the
+// matrix instructions of run2, which do not depend on it.  The H block is single-buffered: it is rewritten only between the
+// two barriers of W, after every wave has left run2 of the previous block.
+//
+// Summation order differs from ffn_fused.hpp (K chunks in order, one accumulator per tile in both), so results agree to fp32
+// rounding, not bitwise.
+#pragma once
+#include "ffn_fused.hpp"
+#include "loop_fused.hpp"
+
+namespace mld {
+
+constexpr int kFsXs = 264, kFsHs = 136;      // row strides (words), = 8 mod 16 (conflict-free fragment reads)
+template <int RT>
+constexpr int ffn_strip_lds_bytes() { return (RT * 16 * kFsXs + RT * 16 * kFsHs + 2 * 8 * RT * 16) * 4; }   // RT = 6: 159 744 B; RT = 4: 106 496 B
+
+// items of one layer's stream: run1(0), then [run1(hb), run2(hb - 1)] for hb = 1..7, then run2(7); 128 items of 16 KB
+constexpr int kFfnStripItems = 128;
+
+// grid = ceil(M / (16 RT)); block = 512.  p.W1 = the layer's fragment-ordered stream (W2 unused).
+template <int RT>
+__global__ __launch_bounds__(512, 2) void ffn_strip_x3_kernel(FfnArgs p) {
+  constexpr int BM = RT * 16, XS = kFsXs, HS = kFsHs;
+#if defined(MLDHIP_SIM)
+  float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
+#else
+  extern __shared__ __attribute__((aligned(16))) float smem_fs[];
+  float* smem = smem_fs;
+#endif
+  float* Xs = smem;                    // [BM][264] split image of the strip (A operand of linear1, residual)
+  float* Hs = Xs + BM * XS;            // [BM][136] split image of one hidden block (A operand of linear2)
+  float* red = Hs + BM * HS;           // [2][8][BM] LayerNorm partial sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * BM;
+  const int col0 = wave * 16 + r;
+
+  if (p.skip_lens) {                   // uniform exit for strips of padded frames only (gemm.hpp)
+    const int t0 = m0, t1 = (t0 + BM < p.M ? t0 + BM : p.M) - 1;
+    bool all_padding = true;
+    for (int b = t0 / p.skip_rpg; b <= t1 / p.skip_rpg; ++b) {
+      const int first = (t0 > b * p.skip_rpg ? t0 : b * p.skip_rpg) - b * p.skip_rpg;
+      if (first < p.skip_lens[b]) { all_padding = false; break; }
+    }
+    if (all_padding) return;
+  }
+
+  // ---- weight ring (loop_fused.hpp): 4 items in flight per lane
+  constexpr int RING = 4;
+  const float* gsrc = p.W1 + tid * 8;
+  F4 ring[RING][2];
+  int gitem = 0;
+  auto gload = [&](int slot) __attribute__((always_inline)) {
+    const int it = gitem < kFfnStripItems ? gitem : kFfnStripItems - 1;     // past the end: a redundant load, never multiplied
+    const float* s = gsrc + (unsigned)it * (unsigned)kLoopItemFloats;
+    ring[slot][0] = ld4(s);
+    ring[slot][1] = ld4(s + 4);
+    ++gitem;
+  };
+  auto mma_item = [&](int j, const F4 (&x)[RT][2], f32x4 (&acc)[RT]) __attribute__((always_inline)) {
+    const int slot = j % RING;
+    const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][1]), wh, acc[t]);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][0]), wl, acc[t]);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][0]), wh, acc[t]);
+    gload(slot);
+    sched_fence();                     // keeps the ring's loads where they are written (rt.hpp)
+  };
+  auto frags = [&](const float* a0, int st, int c, F4 (&x)[RT][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) { x[t][0] = ld4(a0 + t * 16 * st + 32 * c); x[t][1] = ld4(a0 + t * 16 * st + 32 * c + 16); }
+  };
+
+  // ---- prologue: the strip -> split image; the first items of the stream are in flight meanwhile
+#pragma unroll
+  for (int j = 0; j < RING; ++j) gload(j);
+#pragma unroll
+  for (int j = 0; j < RT * 2; ++j) {
+    const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;
+    const F4 v = ld4(p.X + (size_t)m * 256 + c4 * 4);
+    unsigned h0, l0, h1, l1;
+    split16_pair(v.x, v.y, h0, l0);
+    split16_pair(v.z, v.w, h1, l1);
+    unsigned* d = reinterpret_cast<unsigned*>(Xs) + row * XS + (c4 >> 3) * 32 + (c4 & 7) * 2;
+    *reinterpret_cast<U2*>(d) = U2{h0, h1};
+    *reinterpret_cast<U2*>(d + 16) = U2{l0, l1};
+  }
+  __syncthreads();
+
+  const float* xa = Xs + r * XS + g * 4;
+  const float* ha = Hs + r * HS + g * 4;
+  const int hw0 = ((wave >> 1) * 32 + (wave & 1) * 8 + (r >> 1)) * 2 + (r & 1);     // half-word offset of column col0 in a row image
+
+  f32x4 h[RT], y0[RT], y1[RT];
+  unsigned hv[RT][4];                  // one hidden block after bias + GELU: packed (low half | high half << 16)
+#pragma unroll
+  for (int t = 0; t < RT; ++t) { y0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; y1[t] = y0[t]; }
+  auto run1 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) h[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // RT <= 4: the fragments of chunk c + 1 are requested before chunk c is multiplied (the fence in mma_item keeps that order);
+    // RT = 6 has no registers for a second fragment set: the SIMD's other wave covers the LDS latency
+    constexpr int NB = RT <= 4 ? 2 : 1;
+    F4 x[NB][RT][2];
+    if constexpr (NB == 2) frags(xa, XS, 0, x[0]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if constexpr (NB == 2) { if (c + 1 < 8) frags(xa, XS, c + 1, x[(c + 1) & 1]); }
+      else frags(xa, XS, c, x[0]);
+      mma_item(c, x[c & (NB - 1)], h);
+    }
+  };
+  constexpr int NB = RT <= 4 ? 2 : 1;
+  auto gelu_one = [&](int t, int i, float b1) __attribute__((always_inline)) {
+    unsigned short hi, lo;
+    split16_one(gelu_erf(h[t][i] + b1), hi, lo);
+    hv[t][i] = (unsigned)hi | ((unsigned)lo << 16);
+  };
+  auto write_block = [&]() __attribute__((always_inline)) {
+    __syncthreads();                   // every wave has left run2 of the previous block
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned short* q = reinterpret_cast<unsigned short*>(Hs + (t * 16 + g * 4 + i) * HS) + hw0;
+        q[0] = (unsigned short)(hv[t][i] & 0xFFFFu);
+        q[32] = (unsigned short)(hv[t][i] >> 16);
+      }
+    __syncthreads();
+  };
+
+  run1();
+  {
+    const float b1 = p.b1[col0];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gelu_one(t, i, b1);
+  }
+  for (int hb = 1; hb < 8; ++hb) {
+    write_block();                     // block hb - 1 -> LDS
+    const float b1 = p.b1[hb * 128 + col0];
+    run1();                            // linear1 of block hb
+    // linear2's share of block hb - 1 (8 items: 4 chunks x 2 column blocks) with the GELU of block hb spread between its items
+    constexpr int PER = (RT * 4 + 7) / 8;
+    F4 x[NB][RT][2];
+    if constexpr (NB == 2) frags(ha, HS, 0, x[0]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if constexpr (NB == 2) { if (c + 1 < 4) frags(ha, HS, c + 1, x[(c + 1) & 1]); }
+      else frags(ha, HS, c, x[0]);
+      mma_item(2 * c, x[c & (NB - 1)], y0);
+#pragma unroll
+      for (int e = (2 * c) * PER; e < (2 * c + 1) * PER; ++e)
+        if (e < RT * 4) gelu_one(e >> 2, e & 3, b1);
+      mma_item(2 * c + 1, x[c & (NB - 1)], y1);
+#pragma unroll
+      for (int e = (2 * c + 1) * PER; e < (2 * c + 2) * PER; ++e)
+        if (e < RT * 4) gelu_one(e >> 2, e & 3, b1);
+    }
+  }
+  write_block();
+  {
+    F4 x[NB][RT][2];
+    if constexpr (NB == 2) frags(ha, HS, 0, x[0]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if constexpr (NB == 2) { if (c + 1 < 4) frags(ha, HS, c + 1, x[(c + 1) & 1]); }
+      else frags(ha, HS, c, x[0]);
+      mma_item(2 * c, x[c & (NB - 1)], y0);
+      mma_item(2 * c + 1, x[c & (NB - 1)], y1);
+    }
+  }
+
+  // ---- bias + residual (the strip's own image: high + low half) + LayerNorm over the 256 columns, 8 waves x 2 column blocks
+  const float lb0 = p.b2[col0], lb1 = p.b2[128 + col0];
+  const float g0 = p.gamma[col0], g1 = p.gamma[128 + col0], e0 = p.beta[col0], e1 = p.beta[128 + col0];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    F4 s;
+    float* sp = &s.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned short* q = reinterpret_cast<const unsigned short*>(Xs + (t * 16 + g * 4 + i) * XS) + hw0;
+      y0[t][i] += lb0 + f16_bits_value(q[0]) + f16_bits_value(q[32]);
+      y1[t][i] += lb1 + f16_bits_value(q[256]) + f16_bits_value(q[288]);      // + 128 words: the second column block
+      sp[i] = sum16(y0[t][i] + y1[t][i]);
+    }
+    if (r == 0) st4(red + wave * BM + t * 16 + g * 4, s);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    F4 m = ld4(red + t * 16 + g * 4);
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = f4add(m, ld4(red + w * BM + t * 16 + g * 4));
+    const float mean[4] = {m.x * (1.0f / 256.0f), m.y * (1.0f / 256.0f), m.z * (1.0f / 256.0f), m.w * (1.0f / 256.0f)};
+    F4 s;
+    float* sp = &s.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      y0[t][i] -= mean[i];
+      y1[t][i] -= mean[i];
+      sp[i] = sum16(y0[t][i] * y0[t][i] + y1[t][i] * y1[t][i]);
+    }
+    if (r == 0) st4(red + 8 * BM + wave * BM + t * 16 + g * 4, s);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    F4 q = ld4(red + 8 * BM + t * 16 + g * 4);
+#pragma unroll
+    for (int w = 1; w < 8; ++w) q = f4add(q, ld4(red + 8 * BM + w * BM + t * 16 + g * 4));
+    const float rs[4] = {rsqrtf(q.x * (1.0f / 256.0f) + kLnEps), rsqrtf(q.y * (1.0f / 256.0f) + kLnEps),
+                         rsqrtf(q.z * (1.0f / 256.0f) + kLnEps), rsqrtf(q.w * (1.0f / 256.0f) + kLnEps)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + t * 16 + g * 4 + i;
+      if (m < p.M) {
+        float* o = p.Y + (size_t)m * 256 + col0;
+        o[0] = y0[t][i] * rs[i] * g0 + e0;
+        o[128] = y1[t][i] * rs[i] * g1 + e1;
+      }
+    }
+  }
+}
+
+}  // namespace mld

@@ -66,8 +66,11 @@ struct LoopArgs {
 };
 
 constexpr int kLfXs = 264;                                // LDS row stride (words), = 8 mod 16: conflict-free fragment reads (strip.hpp)
-constexpr int kLfXFloats = 48 * kLfXs, kLfScFloats = 8 * 144, kLfRedFloats = 2 * 8 * 48, kLfLatFloats = 8 * 256;
-constexpr int kLoopLdsBytes = (2 * kLfXFloats + kLfScFloats + kLfRedFloats + kLfLatFloats) * 4;   // 117 248 B: one workgroup per CU
+constexpr int kLfHs = 136;                                // ... of a 128-wide block of the hidden activation
+constexpr int kLfXFloats = 48 * kLfXs, kLfHFloats = 48 * kLfHs, kLfAFloats = 2 * kLfHFloats;     // As: the attention output [48][264], or two hidden blocks
+constexpr int kLfScFloats = 8 * 144, kLfRedFloats = 2 * 8 * 48, kLfLatFloats = 8 * 256;
+static_assert(kLfAFloats >= kLfXFloats, "the attention output and the two hidden-block buffers share one region");
+constexpr int kLoopLdsBytes = (kLfXFloats + kLfAFloats + kLfScFloats + kLfRedFloats + kLfLatFloats) * 4;   // 118 784 B: one workgroup per CU
 
 
 // finalize-time: gathers the weight items into consumption order and fragment layout.  Thread (w, r, g) of item i writes the 8
@@ -108,8 +111,8 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #endif
   float* Xs = smem;                       // [48][264] layer input / norm1 output (the A operand; fp32, or the split image)
-  float* As = Xs + kLfXFloats;            // [48][264] attention output, then two 128-wide blocks of the hidden activation at a time
-  float* sc = As + kLfXFloats;            // [8][9][16] per-wave partial attention scores
+  float* As = Xs + kLfXFloats;            // [48][264] attention output, then [2][48][136]: two 128-wide blocks of the hidden activation in turn
+  float* sc = As + kLfAFloats;            // [8][9][16] per-wave partial attention scores
   float* red = sc + kLfScFloats;          // [2][8][48] per-wave LayerNorm partial sums
   float* lats = red + kLfRedFloats;       // [8][256] the workgroup's latents
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
@@ -165,28 +168,55 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
       for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].w, y1.w, acc[t]);
     }
     if constexpr (DBG != 1) gload(slot);
+    sched_fence();
   };
   // A group: 8 chunks of A (row r of tile 0 at a0 + 4g, next tile 16 * kLfXs words on, chunk c at + 32 c) against NP column
   // blocks whose items alternate in the stream (chunk-major): one read of the A fragments feeds NP items.
+  // (the A fragments of chunk c + 1 are requested before chunk c is multiplied: the fence in mma_item keeps that order)
+  auto afrag = [&](const float* a0, int ts, int c, F4 (&x)[3][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { x[t][0] = ld4(a0 + t * ts + 32 * c); x[t][1] = ld4(a0 + t * ts + 32 * c + 16); }
+  };
   auto run2 = [&](const float* a0, f32x4 (&acc0)[3], f32x4 (&acc1)[3]) __attribute__((always_inline)) {
+    F4 x[2][3][2];
+    afrag(a0, 16 * kLfXs, 0, x[0]);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      F4 x[3][2];
-#pragma unroll
-      for (int t = 0; t < 3; ++t) { x[t][0] = ld4(a0 + t * 16 * kLfXs + 32 * c); x[t][1] = ld4(a0 + t * 16 * kLfXs + 32 * c + 16); }
-      mma_item(2 * c, x, acc0);
-      mma_item(2 * c + 1, x, acc1);
+      if (c + 1 < 8) afrag(a0, 16 * kLfXs, c + 1, x[(c + 1) & 1]);
+      mma_item(2 * c, x[c & 1], acc0);
+      mma_item(2 * c + 1, x[c & 1], acc1);
     }
   };
   auto run3 = [&](const float* a0, f32x4 (&acc0)[3], f32x4 (&acc1)[3], f32x4 (&acc2)[3]) __attribute__((always_inline)) {
+    F4 x[2][3][2];
+    afrag(a0, 16 * kLfXs, 0, x[0]);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      F4 x[3][2];
+      if (c + 1 < 8) afrag(a0, 16 * kLfXs, c + 1, x[(c + 1) & 1]);
+      mma_item(3 * c, x[c & 1], acc0);
+      mma_item(3 * c + 1, x[c & 1], acc1);
+      mma_item(3 * c + 2, x[c & 1], acc2);
+    }
+  };
+  // one column block against 8 chunks (linear1 of one 128-wide hidden block)
+  auto run1 = [&](const float* a0, f32x4 (&acc0)[3]) __attribute__((always_inline)) {
+    F4 x[2][3][2];
+    afrag(a0, 16 * kLfXs, 0, x[0]);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) { x[t][0] = ld4(a0 + t * 16 * kLfXs + 32 * c); x[t][1] = ld4(a0 + t * 16 * kLfXs + 32 * c + 16); }
-      mma_item(3 * c, x, acc0);
-      mma_item(3 * c + 1, x, acc1);
-      mma_item(3 * c + 2, x, acc2);
+    for (int c = 0; c < 8; ++c) {
+      if (c + 1 < 8) afrag(a0, 16 * kLfXs, c + 1, x[(c + 1) & 1]);
+      mma_item(c, x[c & 1], acc0);
+    }
+  };
+  // both column blocks of linear2 against the 4 chunks of one hidden block (row stride kLfHs)
+  auto run2h = [&](const float* a0, f32x4 (&acc0)[3], f32x4 (&acc1)[3]) __attribute__((always_inline)) {
+    F4 x[2][3][2];
+    afrag(a0, 16 * kLfHs, 0, x[0]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c + 1 < 4) afrag(a0, 16 * kLfHs, c + 1, x[(c + 1) & 1]);
+      mma_item(2 * c, x[c & 1], acc0);
+      mma_item(2 * c + 1, x[c & 1], acc1);
     }
   };
   // a copy of a lane-dependent index the optimiser cannot see through: address arithmetic built on it stays where it is written
@@ -206,22 +236,23 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   // fp32: one word; split: one half-word in the chunk's high words and one in its low words (chunk = 32 words per 32 columns).
   // `cw` = the block's first word in the row (128 cb for a 256-wide buffer, 0 for the hidden block).
   const int hw0 = ((wave >> 1) * 32 + (wave & 1) * 8 + (r >> 1)) * 2 + (r & 1);     // half-word offset of column col0 in its row
+  auto put_one = [&](float* buf, int st, int cw, int t, int i, float val) __attribute__((always_inline)) {
+    float* row = buf + (t * 16 + g * 4 + i) * st + cw;
+    if constexpr (X3) {
+      unsigned short hi, lo;
+      split16_one(val, hi, lo);
+      unsigned short* h = reinterpret_cast<unsigned short*>(row) + hw0;
+      h[0] = hi;
+      h[32] = lo;
+    } else {
+      row[col0] = val;
+    }
+  };
   auto put = [&](float* buf, int st, int cw, const float (&val)[3][4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float* row = buf + (t * 16 + g * 4 + i) * st + cw;
-        if constexpr (X3) {
-          unsigned short hi, lo;
-          split16_one(val[t][i], hi, lo);
-          unsigned short* h = reinterpret_cast<unsigned short*>(row) + hw0;
-          h[0] = hi;
-          h[32] = lo;
-        } else {
-          row[col0] = val[t][i];
-        }
-      }
+      for (int i = 0; i < 4; ++i) put_one(buf, st, cw, t, i, val[t][i]);
   };
   // ... and back: the residual of a LayerNorm is read from the operand buffer it was multiplied from (split mode: high + low
   // half, the value the GEMMs saw, 2^-22 from the fp32 one), so no activation stays in registers across a GEMM phase
@@ -397,31 +428,44 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         put(Xs, kLfXs, 128, u[1]);
         __syncthreads();
       }
-      // ================= feed-forward: the hidden activation two 128-column blocks at a time (they take the attention output's
-      // place in LDS), linear2 accumulated in registers over the four block pairs
+      // ================= feed-forward, software pipelined over the eight 128-wide blocks of the hidden activation: the GELU /
+      // split / store epilogue of block hb (VALU + LDS) is issued in the same region as linear1's MFMAs of block hb + 1 -- the two
+      // are independent and run on different pipes -- then one barrier, then linear2's share of block hb accumulates in registers.
+      // Two block buffers: block hb + 1 is written while a slower wave may still multiply block hb - 1 ... never the same buffer.
       {
-        f32x4 y0[3], y1[3];
-        zero3(y0); zero3(y1);
-        for (int hb = 0; hb < 4; ++hb) {
-          const float b1a = sm[kLsL1B + hb * 256 + col0], b1b = sm[kLsL1B + hb * 256 + 128 + col0];
-          f32x4 h0[3], h1[3];
-          zero3(h0); zero3(h1);
-          run2(xa, h0, h1);
-          float hv[3][4];
+        f32x4 y0[3], y1[3], hA[3], hB[3];
+        zero3(y0); zero3(y1); zero3(hA);
+        const float* ha = As + r * kLfHs + g * 4;
+        // block hb: epilogue of `cur` (its linear1 accumulators) next to linear1 of block hb + 1 into `nxt`, barrier, linear2's share
+        auto ffn_stage = [&](int hb, f32x4 (&cur)[3], f32x4 (&nxt)[3], bool more) __attribute__((always_inline)) {
+          const float b1 = sm[kLsL1B + hb * 128 + col0];
+          float* hbuf = As + (hb & 1) * kLfHFloats;
+          zero3(nxt);
+          // the epilogue's 12 elements are written out between the 8 items of the next block's linear1: two elements after each of
+          // the first six items, so the VALU / LDS work sits in the shadow of matrix instructions that do not depend on it
+          F4 x[2][3][2];
+          if (more) afrag(xa, 16 * kLfXs, 0, x[0]);
 #pragma unroll
-          for (int t = 0; t < 3; ++t)
+          for (int c = 0; c < 8; ++c) {
+            if (more) {
+              if (c + 1 < 8) afrag(xa, 16 * kLfXs, c + 1, x[(c + 1) & 1]);
+              mma_item(c, x[c & 1], nxt);
+            }
+            if (c < 6) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hv[t][i] = gelu_erf(h0[t][i] + b1a);
-          put(As, kLfXs, 0, hv);
-#pragma unroll
-          for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hv[t][i] = gelu_erf(h1[t][i] + b1b);
-          put(As, kLfXs, 128, hv);
+              for (int e = 2 * c; e < 2 * c + 2; ++e) put_one(hbuf, kLfHs, 0, e >> 2, e & 3, gelu_erf(cur[e >> 2][e & 3] + b1));
+            }
+          }
           __syncthreads();
-          run2(aa, y0, y1);
-          if (hb < 3) __syncthreads();                 // everybody is done with this pair before the next one overwrites it
+          run2h(ha + (hb & 1) * kLfHFloats, y0, y1);
+        };
+        run1(xa, hA);
+        for (int hq = 0; hq < 3; ++hq) {
+          ffn_stage(2 * hq, hA, hB, true);
+          ffn_stage(2 * hq + 1, hB, hA, true);
         }
+        ffn_stage(6, hA, hB, true);
+        ffn_stage(7, hB, hA, false);
         const float lb0 = sm[kLsL2B + col0], lb1 = sm[kLsL2B + 128 + col0];
         get(Xs, kLfXs, 0, x[0]);
         get(Xs, kLfXs, 128, x[1]);

@@ -277,6 +277,15 @@ __device__ __forceinline__ float fp8_pow2_scale(float amax) {
   return ldexpf(1.f, 8 - e);          // s * amax = m * 256 in [128, 256)
 }
 
+// scheduling fence: nothing moves across it.  The register-direct weight rings of loop_fused.hpp / ffn_strip.hpp depend on it -- without
+// a fence after every item, hipcc's scheduler sinks each `global_load` of the ring down to its first use (it trades the prefetch
+// distance for register pressure) and the kernels run one L2 round trip per item (r03: s_waitcnt vmcnt(0) behind every load).
+__device__ __forceinline__ void sched_fence() {
+#if !defined(MLDHIP_SIM)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // shader-clock timestamp pinned in program order (phase tracing of a kernel; measurement only)
 __device__ __forceinline__ unsigned long long clock_pinned() {
 #if defined(MLDHIP_SIM)

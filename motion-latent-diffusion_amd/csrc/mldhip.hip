@@ -37,6 +37,7 @@
 #include "kernels/strip.hpp"
 #include "kernels/ffn_fused.hpp"
 #include "kernels/loop_fused.hpp"
+#include "kernels/ffn_strip.hpp"
 
 using namespace mld;
 
@@ -193,6 +194,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<13, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<13, 128>()));
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<18, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<18, 128>()));
   (void)hipFuncSetAttribute((const void*)ffn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLdsBytes);
+  (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<6>());
+  (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<4>());
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
@@ -249,6 +252,7 @@ void mldhip_destroy(mldhip_handle* e) {
 #endif
   if (e->arena) (void)hipFree(e->arena);
   if (e->arena_x3) (void)hipFree(e->arena_x3);
+  if (e->ffn_streams) (void)hipFree(e->ffn_streams);
   if (e->loop_stream) (void)hipFree(e->loop_stream);
   if (e->loop_stream_x3) (void)hipFree(e->loop_stream_x3);
   if (e->loop_small) (void)hipFree(e->loop_small);
@@ -319,6 +323,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "flash_attn") {
     if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "flash_attn must be 0 (never), 1 (auto) or 2 (always)");
     e->flash_attn = (int)value;
+  } else if (n == "ffn_strip") {
+    if (value != 0 && value != 4 && value != 6) return e->fail(MLDHIP_EINVAL, "ffn_strip must be 0, 4 or 6");
+    e->ffn_strip = (int)value;
   } else if (n == "fused_ffn") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "fused_ffn must be 0 or 1");
     e->fused_ffn = (int)value;
@@ -411,6 +418,7 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
     if (check_launch(c, "split_bf16_weights")) return c.rc;
   }
   if (int rc = build_loop_stream(c)) return rc;
+  if (int rc = build_ffn_streams(c)) return rc;
   for (int k = 0; k < (int)e->ctxs.size(); ++k) {       // the derived tables live in each context's workspace
   bind_context(e, k);
   if (e->group_ready[0]) {
