@@ -27,6 +27,25 @@ def load_example_input(txt_path):
     return texts, lens
 
 
+def write_motions(model, texts, lengths, out_dir, replication=1, task="Example", log=print):
+    """Sample `replication` times and write the files the reference's demo writes (demo.py:166-194): per motion i
+    ``<task>_<length_i>_batch<id>_<i>.npy`` = joints (nframe, 22, 3) float32 and the prompt under the same name with ``.txt``.
+    The reference never advances ``id`` (demo.py:188), so its replications overwrite each other under ``batch0``; here replication
+    r > 0 is kept as ``batch<r>`` and replication 0 carries the reference's exact names.  Returns the list of .npy paths."""
+    os.makedirs(out_dir, exist_ok=True)
+    paths = []
+    for rep in range(replication):
+        joints = model({"length": list(lengths), "text": list(texts)})
+        for i, j in enumerate(joints):
+            path = os.path.join(out_dir, f"{task}_{lengths[i]}_batch{rep}_{i}.npy")
+            with open(path.replace(".npy", ".txt"), "w") as f:
+                f.write(texts[i])
+            np.save(path, j.detach().cpu().numpy())
+            paths.append(path)
+            log("  wrote", path, tuple(j.shape))
+    return paths
+
+
 def main(argv=None):
     from .config import load_config
     from .datamodule import HipDataModule
@@ -48,7 +67,7 @@ def main(argv=None):
     try:
         model = MLD(cfg, dm)
         note = "CLIP text encoder"
-    except FileNotFoundError:
+    except (FileNotFoundError, OSError):
         model = MLD(cfg, dm, text_encoder=SyntheticTextEncoder())
         note = "SYNTHETIC text encoder (no CLIP weights on disk)"
     ckpt = cfg.TEST.CHECKPOINTS
@@ -59,16 +78,8 @@ def main(argv=None):
         note += "; SYNTHETIC weights (checkpoint %s not found)" % ckpt
     model.to(dev).eval()
     torch.manual_seed(a.seed)
-    os.makedirs(a.out_dir, exist_ok=True)
     print("mld_hip demo:", note, "| stats:", dm.stats)
-    for rep in range(a.replication):
-        joints = model({"length": lengths, "text": texts})
-        for i, j in enumerate(joints):
-            path = os.path.join(a.out_dir, f"Example_{lengths[i]}_batch{rep}_{i}.npy")
-            np.save(path, j.numpy())
-            with open(path.replace(".npy", ".txt"), "w") as f:
-                f.write(texts[i])
-            print("  wrote", path, tuple(j.shape))
+    return write_motions(model, texts, lengths, a.out_dir, a.replication)
 
 
 if __name__ == "__main__":

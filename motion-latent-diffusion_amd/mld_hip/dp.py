@@ -62,6 +62,8 @@ class DataParallelSampler:
     `init_latents` (optional, indexed like the prompts: [N, 1, D] latents, or [N, Tmax, nfeats] raw-motion noise for the
     diffusion-only variant) pins the starting noise per PROMPT, so a motion does not depend on the world size or on which rank /
     chunk it lands in -- what the multi-process tests compare.  Without it every chunk draws from torch's generator.
+    (Diffusion-only variant: the reference's trans_dec denoiser attends over the padded batch, so there a motion also depends on the
+    Tmax of the chunk it is sampled in -- reference behaviour, reproduced; equal-Tmax chunks give shard-invariant motions.)
 
     in_flight > 1 (latent text-to-motion models on the fused engine path): consecutive chunks are issued on `in_flight` rotating
     HIP streams, so several batches overlap on the GPU (configure the engine with ``mld_hip.engine.configure("text", max_in_flight=in_flight)`` before

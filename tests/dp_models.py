@@ -28,10 +28,10 @@ def state_template(mode):
 def build(mode, state, key):
     """(model bound to a fresh simulator engine with `state` loaded through load_state_dict, closer)"""
     if mode == "action":
-        eng = simlib._lib.Engine(lib=simlib.sim_library(), use_graph=0, **{**simlib.ACTION_CFG, "max_batch": 4, "max_frames": 16,
+        eng = simlib._lib.Engine(lib=simlib.sim_library(), use_graph=0, **{**simlib.SIM_ACTION_CFG, "max_batch": 4, "max_frames": 16,
                                                                         "num_inference_steps": STEPS})
         E.inject_engine(eng, key)
-        cfg = C.load_config(os.path.join(C.CONFIG_DIR, "config_mld_humanact12.yaml"), overrides={"model.scheduler.num_inference_timesteps": STEPS})
+        cfg = C.load_config(os.path.join(C.CONFIG_DIR, "config_mld_humanact12.yaml"), overrides={"model.scheduler.num_inference_timesteps": STEPS, **simlib.ACTION_OVERRIDES})
         model = MLD(cfg, HipDataModule(cfg, nfeats=150, njoints=25, name="humanact12", engine_key=key), engine_key=key).eval()
     else:
         eng = simlib._lib.Engine(lib=simlib.sim_library(), use_graph=0, num_layers=NOVAE_LAYERS,
@@ -56,7 +56,10 @@ def job(mode, n):
         lengths = [16, 9, 12, 16, 5][:n]
         return dict(actions=[int(a) for a in g.integers(0, 12, n)], lengths=lengths,
                     init_latents=torch.from_numpy(g.standard_normal((n, 1, 256)).astype(np.float32)))
-    lengths = [12, 7, 9, 12, 5][:n]
+    # equal lengths: in the diffusion-only variant the denoiser attends over the PADDED batch (mld_denoiser.py:208-221 passes no key
+    # padding mask to the trans_dec stack), so -- in the reference as here -- a motion depends on the Tmax of the batch it is sampled
+    # in; with one Tmax the shard / chunk boundaries cannot matter
+    lengths = [12] * n
     return dict(texts=["prompt %d" % i for i in range(n)], lengths=lengths,
                 init_latents=torch.from_numpy(g.standard_normal((n, 12, 263)).astype(np.float32)),
                 step_noise=torch.from_numpy(g.standard_normal((STEPS, n, 12, 263)).astype(np.float32)))

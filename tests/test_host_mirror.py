@@ -19,6 +19,9 @@ from mld_hip.text_encoder import SyntheticTextEncoder
 from mld_hip.vae import HipActorVae, HipMldVae
 from oracle import mld_oracle as O
 
+# the simulator engines of this file run 3-layer skip stacks (tests/simlib.py): the YAML's layer counts are overridden to match
+TEXT_OVERRIDES = {"model.denoiser.params.num_layers": simlib.SIM_LAYERS, "model.motion_vae.params.num_layers": simlib.SIM_LAYERS}
+
 REF = "/root/reference"
 
 
@@ -114,7 +117,7 @@ def test_unsupported_configurations_fail_loudly():
 
 @pytest.fixture(scope="module")
 def sim_key():
-    eng = simlib._lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=4, max_frames=40, num_inference_steps=2)
+    eng = simlib._lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=4, max_frames=40, num_inference_steps=2, num_layers=simlib.SIM_LAYERS)
     key = E.inject_engine(eng, "inject:hostmirror")
     yield key
     E._engines.pop(key, None)
@@ -122,7 +125,7 @@ def sim_key():
 
 
 def _cfg2():
-    return C.load_config(overrides={"model.scheduler.num_inference_timesteps": 2})
+    return C.load_config(overrides={"model.scheduler.num_inference_timesteps": 2, **TEXT_OVERRIDES})
 
 
 def test_modules_forward_through_the_engine(sim_key):
@@ -134,11 +137,11 @@ def test_modules_forward_through_the_engine(sim_key):
     x = torch.from_numpy(np.concatenate([b.init_latents] * 2))
     out = den(sample=x, timestep=torch.tensor(981), encoder_hidden_states=torch.from_numpy(b.text_emb), lengths=[20, 13] * 2)
     assert isinstance(out, tuple) and out[0].shape == (4, 1, 256)
-    ref = O.denoiser_forward(ops, O.to_backend(ops, syn.make_denoiser_state_dict()), x.numpy(), 981, b.text_emb)
+    ref = O.denoiser_forward(ops, O.to_backend(ops, simlib.text_weights()[0]), x.numpy(), 981, b.text_emb)
     assert np.abs(out[0].numpy() - ref).max() < 5e-5
     z = torch.randn(1, 2, 256)
     feats = vae.decode(z, [20, 13])
-    fr = O.vae_decode(ops, O.to_backend(ops, syn.make_vae_state_dict()), z.permute(1, 0, 2).numpy(), [20, 13])
+    fr = O.vae_decode(ops, O.to_backend(ops, simlib.text_weights()[1]), z.permute(1, 0, 2).numpy(), [20, 13])
     assert feats.shape == (2, 20, 263) and np.abs(feats.numpy() - fr).max() < 5e-5
     # weights are re-uploaded after load_state_dict
     sd = den.state_dict()
@@ -151,7 +154,7 @@ def test_modules_forward_through_the_engine(sim_key):
     fe[1, 13:] = 0
     eps = torch.randn(2, 256)
     latent, dist = vae.encode(fe, [20, 13], eps=eps)
-    lr, mr, lvr = O.vae_encode(ops, O.to_backend(ops, syn.make_vae_state_dict()), fe.numpy(), [20, 13], eps.numpy()[:, None, :])
+    lr, mr, lvr = O.vae_encode(ops, O.to_backend(ops, simlib.text_weights()[1]), fe.numpy(), [20, 13], eps.numpy()[:, None, :])
     assert latent.shape == (1, 2, 256) and isinstance(dist, torch.distributions.Normal)
     assert np.abs(dist.loc[0].numpy() - mr[:, 0]).max() < 5e-5
     assert np.abs(dist.scale[0].numpy() - np.sqrt(np.exp(lvr[:, 0]))).max() < 5e-5
@@ -173,7 +176,7 @@ def test_mld_forward_fused_and_modular_agree_with_oracle(sim_key):
     emb = enc([""] * 2 + texts).numpy()
     assert (emb[0] == emb[1]).all()
     mean, std = syn.make_mean_std()
-    jr = O.sample(ops, O.to_backend(ops, syn.make_denoiser_state_dict()), O.to_backend(ops, syn.make_vae_state_dict()),
+    jr = O.sample(ops, O.to_backend(ops, simlib.text_weights()[0]), O.to_backend(ops, simlib.text_weights()[1]),
                   emb, lat0.numpy(), lengths, mean, std, steps=2)
     for i, n in enumerate(lengths):
         assert np.abs(joints[i].numpy() - jr[i, :n]).max() < 1e-4
@@ -184,7 +187,7 @@ def test_mld_forward_fused_and_modular_agree_with_oracle(sim_key):
     j2 = model.feats2joints(feats)
     assert np.abs(j2.numpy() - jr).max() < 1e-4
     # condition 'text_uncond' (mld.py:228-229): the same network, empty prompts on both CFG halves -> text-independent motions
-    cfg_u = C.load_config(overrides={"model.scheduler.num_inference_timesteps": 2, "model.condition": "text_uncond"})
+    cfg_u = C.load_config(overrides={"model.scheduler.num_inference_timesteps": 2, "model.condition": "text_uncond", **TEXT_OVERRIDES})
     mu = MLD(cfg_u, dm, text_encoder=enc, engine_key=sim_key).eval()
     ja = mu({"text": texts, "length": lengths}, init_latents=lat0)
     jb = mu({"text": ["something else entirely", "x"], "length": lengths}, init_latents=lat0)
@@ -240,7 +243,7 @@ def test_action_mld_fused_and_modular_agree_with_oracle():
     eng = simlib.sim_action_engine(max_batch=4, max_frames=24, num_inference_steps=2)
     key = E.inject_engine(eng, "inject:hostmirror_a2m")
     try:
-        cfg = C.load_config(A2M_CFG, overrides={"model.scheduler.num_inference_timesteps": 2})
+        cfg = C.load_config(A2M_CFG, overrides={"model.scheduler.num_inference_timesteps": 2, **simlib.ACTION_OVERRIDES})
         dm = HipDataModule(cfg, nfeats=150, njoints=25, name="humanact12", engine_key=key)
         model = MLD(cfg, dm, engine_key=key).eval()
         assert model.fused and model.text_encoder is None and model.vae_type == "actor"
@@ -365,6 +368,30 @@ def test_demo_example_parser(tmp_path):
     p.write_text("50 a man kicks with something or someone with his left leg.\n100 A person is skipping rope.\n")
     texts, lens = load_example_input(str(p))
     assert lens == [50, 100] and texts[1] == "A person is skipping rope."
+
+
+def test_demo_writer_file_contract(tmp_path, sim_key):
+    """The demo's output contract (reference demo.py:166-194): for a "<length> <prompt>" example file, one
+    ``Example_<length>_batch0_<i>.npy`` of shape (length_i, 22, 3) float32 per line plus the prompt as ``.txt`` beside it."""
+    from mld_hip.demo import load_example_input, write_motions
+    ex = tmp_path / "example.txt"
+    ex.write_text("20 a man kicks with his left leg.\n13 A person is skipping rope.\n\n")
+    texts, lengths = load_example_input(str(ex))
+    cfg = _cfg2()
+    model = MLD(cfg, HipDataModule(cfg, engine_key=sim_key), text_encoder=SyntheticTextEncoder(), engine_key=sim_key).eval()
+    sdd, sdv = simlib.text_weights()
+    model.denoiser.load_state_dict({k: torch.from_numpy(v) for k, v in sdd.items()}, strict=True)
+    model.vae.load_state_dict({k: torch.from_numpy(v) for k, v in sdv.items()}, strict=True)
+    out = tmp_path / "results"
+    paths = write_motions(model, texts, lengths, str(out), replication=2, log=lambda *a: None)
+    names = sorted(os.listdir(out))
+    assert names == sorted(f"Example_{n}_batch{r}_{i}.{ext}" for r in range(2) for i, n in enumerate(lengths) for ext in ("npy", "txt"))
+    assert [os.path.basename(p) for p in paths[:2]] == ["Example_20_batch0_0.npy", "Example_13_batch0_1.npy"]      # the reference's names
+    for i, n in enumerate(lengths):
+        j = np.load(out / f"Example_{n}_batch0_{i}.npy")
+        assert j.shape == (n, 22, 3) and j.dtype == np.float32 and np.isfinite(j).all()
+        assert (out / f"Example_{n}_batch0_{i}.txt").read_text() == texts[i]
+    assert not np.array_equal(np.load(out / "Example_20_batch0_0.npy"), np.load(out / "Example_20_batch1_0.npy"))   # a fresh draw per replication
 
 
 def test_lightning_checkpoint_is_readable_without_lightning(tmp_path):

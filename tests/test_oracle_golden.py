@@ -134,7 +134,7 @@ def test_action_variant_matches_reference(golden_dir):
     """EmbedAction denoiser (15 layers), ActorVae decode and encode vs the reference modules' outputs."""
     from simlib import action_weights
     ops = O.NumpyOps(np.float32)
-    sdd, sdv = action_weights()
+    sdd, sdv = action_weights(15, 6)          # the fixture's depth (config_mld_humanact12), not the simulator's
     bd, bv = O.to_backend(ops, sdd), O.to_backend(ops, sdv)
     g = _load(golden_dir, "action_ops_b4.npz")
     out = O.denoiser_forward_action(ops, bd, g["sample"], 981, g["cond"])

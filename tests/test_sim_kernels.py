@@ -24,7 +24,8 @@ def eng():
 @pytest.fixture(scope="module")
 def ow():
     ops = O.NumpyOps(np.float32)
-    return ops, O.to_backend(ops, syn.make_denoiser_state_dict()), O.to_backend(ops, syn.make_vae_state_dict())
+    sdd, sdv = simlib.text_weights()
+    return ops, O.to_backend(ops, sdd), O.to_backend(ops, sdv)
 
 
 def test_schedule_tables(eng):
@@ -126,8 +127,9 @@ def test_full_sample_sim(eng, ow):
     assert np.abs(feats - fr).max() < 1e-4
     assert np.abs(joints - jr).max() < 1e-4
     den, dec, jn = eng.launch_counts()
-    # text projection + per chain (default: one chain): init + steps * (9 layers * 4 + 4 skip + 1 final)
-    assert den == 1 + 1 * (1 + 2 * (9 * 4 + 4 + 1)) and dec == 2 + 1 + 9 * 5 + 4 + 2 and jn == 1
+    # text projection + per chain (default: one chain): init + steps * (L layers * 4 + (L - 1) / 2 skip + 1 final)
+    L, nb = simlib.SIM_LAYERS, (simlib.SIM_LAYERS - 1) // 2
+    assert den == 1 + 1 * (1 + 2 * (L * 4 + nb + 1)) and dec == 2 + 1 + L * 5 + nb + 2 and jn == 1
 
 
 def test_abi_errors_sim(eng):
@@ -214,7 +216,8 @@ def test_action_full_sample_sim(aeng, aow):
     assert np.abs(feats - fr).max() < 1e-4
     den, dec, _ = aeng.launch_counts()
     # label gather + init + steps * (15 layers * 4 + 7 skip + 1 final); decode: 2 cross-attn + queries + 6 * 5 + final
-    assert den == 1 + 1 + 2 * (15 * 4 + 7 + 1) and dec == 2 + 1 + 6 * 5 + 1
+    La, Lv = simlib.SIM_ACTION_LAYERS, simlib.SIM_ACTOR_VAE_LAYERS
+    assert den == 1 + 1 + 2 * (La * 4 + (La - 1) // 2 + 1) and dec == 2 + 1 + Lv * 5 + 1
 
 
 # ------------------------------------------------------------------ diffusion-only variant (BASELINE config 4)
@@ -388,7 +391,7 @@ def test_strip_family_sample_is_exact_sim(ow):
     e.sample(b.text_emb, b.init_latents, b.lengths, lat, None, joints)
     jr, _, lr = O.sample(ops, bd, bv, b.text_emb, b.init_latents, b.lengths, mean, std, steps=2, return_intermediates=True)
     assert np.abs(lat - lr).max() < 5e-4 and np.abs(joints - jr).max() < 1e-4
-    assert e.launch_counts()[0] == 1 + 1 + 2 * (9 * 4 + 4 + 1)
+    assert e.launch_counts()[0] == 1 + 1 + 2 * (simlib.SIM_LAYERS * 4 + (simlib.SIM_LAYERS - 1) // 2 + 1)
     with pytest.raises(_lib.MldHipError):
         e.set_option("loop_kernel", 4)
     with pytest.raises(_lib.MldHipError):
@@ -585,27 +588,28 @@ def test_split_bf16_weights_presplit_is_bit_identical_sim(ow, now):
     """precision = BF16X3_DECODE: finalize builds a split-bf16 image of the weight arena (elementwise.hpp split_bf16_weights_kernel)
     and the staged GEMMs copy its 16-byte pieces to LDS untouched; "split_weights" = 0 splits in every workgroup as before.
     Same split routine, same operand image -> the decoder features and the diffusion-only denoiser output are bit-identical."""
-    e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2, precision=1)
+    e = simlib.sim_engine(max_batch=2, max_frames=24, num_inference_steps=2, precision=1)
     e.set_option("gemm_small_m", 0)
-    z = syn._rng(7, "g8").standard_normal((3, 1, 256)).astype(np.float32)
+    e.set_option("ffn_strip", 0)                        # the staged-GEMM / ffn_fused path is the one that reads the split image
+    z = syn._rng(7, "g8").standard_normal((2, 1, 256)).astype(np.float32)
     outs = []
     for sw in (1, 0):
         e.set_option("split_weights", sw)
-        feats = np.zeros((3, 40, 263), np.float32)
-        e.vae_decode(z, [40, 23, 7], feats)
+        feats = np.zeros((2, 24, 263), np.float32)
+        e.vae_decode(z, [24, 7], feats)
         outs.append(feats)
     assert np.abs(outs[0]).max() > 0.1 and np.array_equal(outs[0], outs[1])
     e.close()
-    e = simlib.sim_novae_engine(num_layers=2, max_batch=2, max_frames=40, num_inference_steps=4, precision=1)
+    e = simlib.sim_novae_engine(num_layers=1, max_batch=2, max_frames=24, num_inference_steps=4, precision=1)
     e.set_option("gemm_small_m", 0)
     g = syn._rng(12, "nvx3")
-    x = g.standard_normal((2, 37, 263)).astype(np.float32)
+    x = g.standard_normal((2, 21, 263)).astype(np.float32)
     te = g.standard_normal((2, 1, 768)).astype(np.float32)
     outs = []
     for sw in (1, 0):
         e.set_option("split_weights", sw)
-        out = np.zeros((2, 37, 263), np.float32)
-        e.denoiser_forward_novae(x, 999, te, [37, 20], 37, out)
+        out = np.zeros((2, 21, 263), np.float32)
+        e.denoiser_forward_novae(x, 999, te, [21, 12], 21, out)
         outs.append(out)
     assert np.abs(outs[0]).max() > 0.1 and np.array_equal(outs[0], outs[1])
     e.close()
@@ -614,39 +618,41 @@ def test_split_bf16_weights_presplit_is_bit_identical_sim(ow, now):
 def test_fused_ffn_block_equals_the_two_staged_gemms_sim(ow, aow):
     """precision = BF16X3_DECODE: kernels/ffn_fused.hpp (linear1 + GELU + linear2 + residual + LayerNorm in one launch, hidden
     activation in LDS, pre-split weights) against the two staged GEMMs it replaces ("fused_ffn" = 0): same products, same K order,
-    same LayerNorm reduction order -> bit-identical on the simulator.  Decoder with ragged lengths (120 rows: one full 64-row tile,
+    same LayerNorm reduction order -> bit-identical on the simulator.  Decoder with ragged lengths (80 rows: one full 64-row tile,
     one partial, padded-frame skipping on), the MldVae encoder (S = T + 2 rows per sample) and the ActorVae decoder."""
     ops, _, bv = ow
     e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2, precision=1)
     e.set_option("gemm_small_m", 0)
-    z = syn._rng(7, "g8").standard_normal((3, 1, 256)).astype(np.float32)
+    e.set_option("ffn_strip", 0)                        # (the register-direct form has its own test below)
+    z = syn._rng(7, "g8").standard_normal((2, 1, 256)).astype(np.float32)
     g = syn._rng(3, "enc")
-    feats_in = g.standard_normal((3, 40, 263)).astype(np.float32)
-    for i, n in enumerate([40, 23, 7]):
+    feats_in = g.standard_normal((2, 40, 263)).astype(np.float32)
+    for i, n in enumerate([40, 23]):
         feats_in[i, n:] = 0
-    eps = g.standard_normal((3, 1, 256)).astype(np.float32)
+    eps = g.standard_normal((2, 1, 256)).astype(np.float32)
     outs = []
     for ff in (1, 0):
         e.set_option("fused_ffn", ff)
-        feats = np.zeros((3, 40, 263), np.float32)
-        e.vae_decode(z, [40, 23, 7], feats)
-        lat, mu, lv = (np.zeros((3, 1, 256), np.float32) for _ in range(3))
-        e.vae_encode(feats_in, [40, 23, 7], 40, eps, lat, mu, lv)
+        feats = np.zeros((2, 40, 263), np.float32)
+        e.vae_decode(z, [40, 23], feats)
+        lat, mu, lv = (np.zeros((2, 1, 256), np.float32) for _ in range(3))
+        e.vae_encode(feats_in, [40, 23], 40, eps, lat, mu, lv)
         outs.append((feats, mu.copy(), lv.copy()))
     for a, b in zip(outs[0], outs[1]):
         assert np.abs(a).max() > 1e-3 and np.array_equal(a, b)
-    err = np.abs(outs[0][0] - O.vae_decode(ops, bv, z, [40, 23, 7])).max()
+    err = np.abs(outs[0][0] - O.vae_decode(ops, bv, z, [40, 23])).max()
     assert 1e-7 < err < 2e-4
     e.close()
     aops, _, abv = aow
     e = simlib.sim_action_engine(max_batch=4, max_frames=24, num_inference_steps=2, precision=1)
     e.set_option("gemm_small_m", 0)
-    za = syn._rng(9, "adec").standard_normal((3, 1, 256)).astype(np.float32)
+    e.set_option("ffn_strip", 0)
+    za = syn._rng(9, "adec").standard_normal((2, 1, 256)).astype(np.float32)
     outs = []
     for ff in (1, 0):
         e.set_option("fused_ffn", ff)
-        f = np.zeros((3, 24, 150), np.float32)
-        e.vae_decode(za, [24, 11, 17], f)
+        f = np.zeros((2, 24, 150), np.float32)
+        e.vae_decode(za, [24, 11], f)
         outs.append(f)
     assert np.abs(outs[0]).max() > 1e-3 and np.array_equal(outs[0], outs[1])
     e.close()
@@ -658,7 +664,7 @@ def test_key_blocked_attention_matches_whole_kv_attention_sim(ow):
     of key tiles (T = 68 -> 5), lengths that are not multiples of 16, more query tiles than waves (130 frames -> 9).  Different
     summation order and an unnormalised P operand: features within 5e-5 of each other and both within 2e-4 of the fp32 oracle."""
     ops, _, bv = ow
-    for B, T, lens in ((2, 68, [68, 37]), (1, 144, [130])):
+    for B, T, lens in ((1, 68, [37]), (1, 132, [130])):
         e = simlib.sim_engine(max_batch=B, max_frames=T, num_inference_steps=2, precision=1)
         e.set_option("gemm_small_m", 0)
         z = syn._rng(8, "x3attn").standard_normal((B, 1, 256)).astype(np.float32)
@@ -689,14 +695,14 @@ def test_sample_major_persistent_loop_sim(prec):
     e.load_state_dict(sdd, "denoiser.")
     e.load_state_dict(sdv, "vae.")
     e.finalize()
-    b = syn.make_batch(11, [8, 5, 3, 8, 1, 7, 2, 6, 8, 4, 8], seed=9)
+    b = syn.make_batch(11, [8, 5, 3, 8, 1, 7, 2, 6, 8, 4, 8], seed=9)      # lengths do not matter to the loop (latents only)
     ops = O.NumpyOps(np.float32)
     ref = np.asarray(O.diffusion_reverse(ops, O.to_backend(ops, sdd), b.text_emb, b.init_latents, 7.5, 2, 4))
     e.set_option("loop_kernel", 1)
     lat1 = np.zeros((11, 1, 256), np.float32)
     e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat1)
     e.set_option("loop_kernel", 3)
-    for x3, ring in ((0, 4), (0, 8), (1, 4), (1, 8)):
+    for x3, ring in (((0, 4), (0, 8)) if prec == 0 else ((1, 4), (1, 8))):
         e.set_option("fused_x3", x3)
         e.set_option("fused_ring", ring)
         lat = np.full((11, 1, 256), np.nan, np.float32)
@@ -716,4 +722,38 @@ def test_sample_major_loop_is_refused_where_it_is_not_built_sim():
     e.finalize()
     with pytest.raises(_lib.MldHipError):
         e.set_option("loop_kernel", 3)
+    e.close()
+
+
+def test_register_direct_ffn_kernel_sim(ow):
+    """kernels/ffn_strip.hpp ("ffn_strip" = 6 / 4: 96- / 64-row strips, weights register-direct from the layer's fragment-ordered
+    stream, GELU of block hb + 1 between the matrix instructions of linear2's share of block hb) against ffn_fused.hpp (= 0) and the
+    oracle: decoder with ragged lengths (M = 120 frame rows: a full strip and a partial one, strips of padding skipped) and the MldVae
+    encoder (S = T + 2 token rows per sample, no skipping).  Same products, another summation order: fp32 rounding apart."""
+    ops, _, bv = ow
+    e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2, precision=1)
+    e.set_option("gemm_small_m", 0)
+    z = syn._rng(7, "g8").standard_normal((3, 1, 256)).astype(np.float32)
+    g = syn._rng(3, "enc")
+    lens = [40, 23, 7]
+    feats_in = g.standard_normal((3, 40, 263)).astype(np.float32)
+    for i, n in enumerate(lens):
+        feats_in[i, n:] = 0
+    eps = g.standard_normal((3, 1, 256)).astype(np.float32)
+    ref = np.asarray(O.vae_decode(ops, bv, z, lens))
+    outs = {}
+    for opt in (0, 6, 4):
+        e.set_option("ffn_strip", opt)
+        feats = np.full((3, 40, 263), np.nan, np.float32)
+        e.vae_decode(z, lens, feats)
+        mu, lv, lat = (np.zeros((3, 1, 256), np.float32) for _ in range(3))
+        e.vae_encode(feats_in, lens, 40, eps, lat, mu, lv)
+        assert np.isfinite(feats).all() and 1e-7 < np.abs(feats - ref).max() < 2e-4
+        for i, n in enumerate(lens):
+            assert np.all(feats[i, n:] == 0)
+        outs[opt] = (feats, mu.copy())
+    for opt in (6, 4):
+        assert 0 < np.abs(outs[opt][0] - outs[0][0]).max() < 5e-5 and 0 < np.abs(outs[opt][1] - outs[0][1]).max() < 5e-5
+    with pytest.raises(_lib.MldHipError):
+        e.set_option("ffn_strip", 5)
     e.close()

@@ -95,10 +95,10 @@ def test_mld_forward_through_clip_adapter_on_the_simulator(clip_dir):
     from mld_hip.mld import MLD
     from oracle import mld_oracle as O
 
-    eng = simlib._lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=2, max_frames=16, num_inference_steps=2)
+    eng = simlib._lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=2, max_frames=16, num_inference_steps=2, num_layers=simlib.SIM_LAYERS)
     key = E.inject_engine(eng, "inject:clip")
-    cfg = C.load_config()
-    cfg.model.scheduler.num_inference_timesteps = 2
+    cfg = C.load_config(overrides={"model.scheduler.num_inference_timesteps": 2, "model.denoiser.params.num_layers": simlib.SIM_LAYERS,
+                                   "model.motion_vae.params.num_layers": simlib.SIM_LAYERS})
     enc = MldTextEncoder(clip_dir[0])
     model = MLD(cfg, HipDataModule(cfg, engine_key=key), text_encoder=enc, engine_key=key).eval()
     texts, lengths = ["a man walks.", "a person runs."], [12, 9]
@@ -108,8 +108,49 @@ def test_mld_forward_through_clip_adapter_on_the_simulator(clip_dir):
     emb = enc([""] * 2 + texts).numpy()
     ops = O.NumpyOps(np.float32)
     mean, std = syn.make_mean_std()
-    jr = O.sample(ops, O.to_backend(ops, syn.make_denoiser_state_dict()), O.to_backend(ops, syn.make_vae_state_dict()), emb,
+    sdd, sdv = simlib.text_weights()
+    jr = O.sample(ops, O.to_backend(ops, sdd), O.to_backend(ops, sdv), emb,
                   lat0.numpy(), lengths, mean, std, steps=2)
     for i, n in enumerate(lengths):
         assert np.abs(joints[i].numpy() - jr[i, :n]).max() < 1e-3
     eng.close()
+
+
+def test_checkpoint_load_reinjects_the_clip_weights(clip_dir):
+    """MLD.load_state_dict as the demo uses it (demo.py:129-150 -> base.py:117-127): released checkpoints carry no usable CLIP tensors,
+    so the model's OWN text-encoder tensors are put back under ``text_encoder.*`` before a STRICT load; evaluator nets (``t2m_*``) are
+    dropped; whatever ``text_encoder.*`` a checkpoint does carry is ignored.  Run with the real adapter class (random-init CLIP)."""
+    import simlib
+    from mld_hip import config as C
+    from mld_hip import engine as E
+    from mld_hip.datamodule import HipDataModule
+    from mld_hip.mld import MLD
+
+    eng = simlib._lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=2, max_frames=16, num_inference_steps=2, num_layers=simlib.SIM_LAYERS)
+    key = E.inject_engine(eng, "inject:clip_ckpt")
+    try:
+        cfg = C.load_config(overrides={"model.scheduler.num_inference_timesteps": 2, "model.denoiser.params.num_layers": simlib.SIM_LAYERS,
+                                       "model.motion_vae.params.num_layers": simlib.SIM_LAYERS})
+        enc = MldTextEncoder(clip_dir[0])
+        model = MLD(cfg, HipDataModule(cfg, engine_key=key), text_encoder=enc, engine_key=key).eval()
+        clip_before = {k: v.clone() for k, v in enc.state_dict().items()}
+        assert len(clip_before) > 10
+        sdd, sdv = simlib.text_weights()
+        ckpt = {**{"denoiser." + k: torch.from_numpy(v) for k, v in sdd.items()}, **{"vae." + k: torch.from_numpy(v) for k, v in sdv.items()}}
+        bogus = next(iter(clip_before))
+        ckpt["text_encoder." + bogus] = torch.full_like(clip_before[bogus], 7.0)         # stale CLIP tensor in the file: must not be loaded
+        ckpt["t2m_moveencoder.main.0.weight"] = torch.zeros(3, 3)                          # evaluator net: must not make the strict load fail
+        res = model.load_state_dict(ckpt, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        after = enc.state_dict()
+        assert all(torch.equal(after[k], clip_before[k]) for k in clip_before)             # CLIP untouched, stale tensor ignored
+        k0 = "encoder.norm.weight"
+        assert torch.equal(model.denoiser.state_dict()[k0], torch.from_numpy(sdd[k0]))
+        ckpt.pop("denoiser." + k0)
+        with pytest.raises(RuntimeError):                                                  # strict: a missing network tensor is an error
+            model.load_state_dict(ckpt, strict=True)
+        joints = model({"text": ["a man walks."], "length": [9]})                          # and the loaded model samples
+        assert tuple(joints[0].shape) == (9, 22, 3) and torch.isfinite(joints[0]).all()
+    finally:
+        E._engines.pop(key, None)
+        eng.close()
