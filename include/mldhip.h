@@ -47,19 +47,24 @@ enum {                     /* arithmetic mode of the matrix kernels.  In EVERY m
                               LayerNorm, softmax, the 3-token attention of the reverse loop, the scheduler step and all
                               stored activations are fp32; the modes differ in the operand format fed to the MFMAs of the
                               GEMMs -- and modes 1..3 also run the frame-level self-attention (VAE decoder / encoder,
-                              diffusion-only denoiser) split-bf16 (QK^T and PV as hi + lo bf16 products, fp32 softmax). */
+                              diffusion-only denoiser) on split-f16 products (QK^T and PV as hi + lo halves, fp32 softmax). */
   MLDHIP_PREC_F32 = 0,            /* exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere: the parity mode */
-  MLDHIP_PREC_BF16X3_DECODE = 1,  /* split-bf16 (x = hi + lo; 3 x v_mfma_f32_16x16x32_bf16, ~1e-5 relative per product) in the
-                                     MFMA-bound large-M GEMMs: VAE decoder / encoder of the latent models, every GEMM of the
-                                     diffusion-only variant; the reverse loop of the latent models stays fp32.  Meets the
-                                     1e-3 joint contract (tests).  (Split-bf16 inside the latent reverse loop was measured
-                                     and rejected: joint error 1.1e-3 at T=196 and no faster; profiles/r01_v9.) */
+  MLDHIP_PREC_F16X3 = 1,          /* split-f16: every GEMM operand x = hi + lo with hi = half(x), lo = half(x - hi) (22 mantissa bits),
+                                     lo*hi + hi*lo + hi*hi as 3 x v_mfma_f32_16x16x32_f16 with fp32 accumulation, ~5e-7 relative per
+                                     product.  VAE decoder / encoder, every GEMM of the diffusion-only variant, and -- in calls
+                                     served by the sample-major persistent loop ("loop_kernel" = 3 / auto from "fused_min_batch"
+                                     motions) -- the reverse loop of the latent models; the column-split loop kernels of smaller
+                                     calls stay fp32.  Meets the 1e-3 joint contract with a 5x margin (tests: every motion of a
+                                     2 048-motion call).  Rounds 1-2 split into bf16 halves (16 mantissa bits, 30x the error: the
+                                     reverse loop could not use it); ABI value and behaviour of the other entry points unchanged. */
+  MLDHIP_PREC_BF16X3_DECODE = 1,  /* the name rounds 1-2 gave mode 1 (kept for source compatibility) */
   MLDHIP_PREC_BF16 = 2,           /* operands of EVERY GEMM rounded to bf16 (one v_mfma_f32_16x16x32_bf16 per tile and K chunk):
                                      the "bf16" of BASELINE.json configs[1].  Does NOT meet the 1e-3 joint contract on the
-                                     synthetic weights; bench.py reports its measured error next to its throughput. */
+                                     synthetic weights; bench.py reports its measured error next to its throughput, and
+                                     profiles/r03_precision_ab.json attributes it per GEMM class. */
   MLDHIP_PREC_FP8_DENOISER = 3    /* BASELINE.json configs[4]: the reverse-loop GEMMs on v_mfma_f32_16x16x32_fp8_fp8 (OCP e4m3;
                                      weights scaled per tensor, activation rows per row, powers of two), decoder GEMMs
-                                     split-bf16.  Latent models only.  Error reported by bench.py, not asserted. */
+                                     split-f16.  Latent models only.  Error reported by bench.py, not asserted. */
 };
 
 /* Mirrors the keys of configs/config_mld_humanml3d.yaml + configs/modules/{denoiser,motion_vae,
@@ -130,19 +135,30 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
 
 /* Per-handle tuning options (ABI 3; no reference counterpart, no process-wide environment knobs).  Changing one drops the
  * handle's captured graphs.  Names:
- *   "loop_kernel"     0 = auto (default), 1 = latency kernels (kernels/tile32.hpp: one request of <= ~128 motions),
- *                     2 = throughput kernels (kernels/strip.hpp: several requests coalesced into one call)
+ *   "loop_kernel"     reverse loop of the latent models: 0 = auto (default: by motions per call), 1 = latency kernels
+ *                     (kernels/tile32.hpp: one request of <= ~128 motions, 41 launches per step), 2 = column-split throughput kernels
+ *                     (kernels/strip.hpp: a few hundred motions per call), 3 = the sample-major persistent loop
+ *                     (kernels/loop_fused.hpp: ONE launch for all steps of the call, a workgroup per 8 motions, weights streamed in
+ *                     consumption order; built for latent_dim 256 / ff_size 1024 / 4 heads in the F32 and F16X3 modes -- refused
+ *                     elsewhere).  Its run time does not depend on the batch up to 8 x #CUs = 2 048 motions, so it wins from ~1 000
+ *                     motions per call up.
+ *   "fused_min_batch" auto picks the persistent loop from this many motions per call up (default 1024)
+ *   "fused_x3"        F16X3 mode: 1 (default) = the persistent loop multiplies on split-f16 MFMAs, 0 = on exact-fp32 MFMAs
+ *   "fused_ring"      persistent loop: weight items in flight per lane, 4 (default) or 8
+ *   "fused_dbg"       measurement builds of the persistent loop (WRONG results): 1 = no weight stream, 2 = no MFMAs
+ *   "ffn_strip"       F16X3 / FP8 modes, feed-forward block of a decoder / encoder layer: 6 (default) / 4 = register-direct kernel on
+ *                     96- / 64-row strips (kernels/ffn_strip.hpp), 0 = kernels/ffn_fused.hpp or the two staged GEMMs ("fused_ffn")
  *   "strip_min_rows"  auto picks the throughput kernels when the reverse loop has >= this many token rows
  *                     (6 x batch; default 768 = 128 motions)
  *   "strip_wide"      throughput kernels: 32 x 128 tiles for the wide GEMMs: 0 = auto (N >= 512), 1 = never, 2 = whenever N % 128 == 0
  *   "strip_waves"     throughput kernels: waves per workgroup of the 32 x 128 tiles, 4 or 8 (default 8)
  *   "strip_ffn2_split" throughput kernels: K slices (raw slabs) of the FFN2 GEMM, 1 or 2 (default 2)
- *   "flash_attn"      split-bf16 modes, frame-level self-attention of the decoder / encoder: key-blocked online-softmax kernel with
+ *   "flash_attn"      split-f16 modes, frame-level self-attention of the decoder / encoder: key-blocked online-softmax kernel with
  *                     two workgroups per CU (kernels/attention.hpp attn_flash_x3_kernel): 0 = never, 1 = auto (default: calls
  *                     with >= 512 (sample, head) pairs), 2 = always
- *   "fused_ffn"       split-bf16 modes: 1 (default) = linear1 + GELU + linear2 + residual + LayerNorm of a decoder / encoder layer as
+ *   "fused_ffn"       split-f16 modes ("ffn_strip" = 0): 1 (default) = linear1 + GELU + linear2 + residual + LayerNorm of a decoder / encoder layer as
  *                     ONE launch (kernels/ffn_fused.hpp; the hidden activation stays in LDS), 0 = the two staged GEMMs (A/B knob)
- *   "split_weights"   precision modes whose staged GEMMs run on split-bf16 MFMAs: 1 (default) = read the weights from the bf16
+ *   "split_weights"   precision modes whose staged GEMMs run on split-f16 MFMAs: 1 (default) = read the weights from the half
  *                     high / low image finalize builds once, 0 = split them in every workgroup (bit-identical results; A/B knob)
  *   "gemm_small_m"    row count up to which one-off GEMMs use the register-direct 16x64 shape (default 256; tests set 0
  *                     to drive the LDS-staged kernels at simulator-sized shapes) */
@@ -166,10 +182,13 @@ int mldhip_sample(mldhip_handle* h, const float* text_emb_dev, const float* init
 
 /* Serving entry (ABI 3): several independent requests as ONE reverse-diffusion chain and ONE decode.  Replaces: a loop
  * of MLD.forward calls, one per batch (demo.py:171-186 iterates the batches of a prompt file; test.py does the same over
- * the dataloader).  The reverse loop at bs 64 is a chain of ~2 000 launches with a few hundred rows each; four requests
- * coalesced run the same chain once at 4x the rows on the throughput kernels (kernels/strip.hpp).  Motions never
- * interact, so every request gets what mldhip_sample / mldhip_sample_action would have given it (up to fp32 summation
- * order).  Sum of B <= max_batch.  Output shapes are those of mldhip_sample with Tmax = max(lengths) of THAT request. */
+ * the dataloader).  The reverse loop at bs 64 is a chain of ~2 000 launches with a few hundred rows each; a few requests
+ * coalesced run the same chain once at more rows on the throughput kernels (kernels/strip.hpp), and from "fused_min_batch"
+ * motions up (default 1 024; the serving shape is 32 x 64 = 2 048 motions) the whole reverse loop of the call is ONE
+ * persistent launch, a workgroup per 8 motions (kernels/loop_fused.hpp): one call on one stream fills the chip -- no calls
+ * in flight, no stream / hardware-queue placement for the caller to get right.  Motions never interact, so every request
+ * gets what mldhip_sample / mldhip_sample_action would have given it (up to fp32 summation order / the mode's operand
+ * format).  Sum of B <= max_batch.  Output shapes are those of mldhip_sample with Tmax = max(lengths) of THAT request. */
 typedef struct mldhip_request {
   const float* text_emb_dev;      /* [2B, 1, text_dim], unconditional half first (NULL on action engines) */
   const int32_t* actions_host;    /* [B] class labels (action engines; NULL otherwise) */

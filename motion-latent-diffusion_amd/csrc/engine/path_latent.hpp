@@ -313,6 +313,7 @@ int build_loop_stream(Ctx& c) {
 int build_ffn_streams(Ctx& c) {
   E* e = c.e;
   e->ffn_stream_of.clear();
+  e->gemm_stream_of.clear();
   if (e->ffn_streams) { (void)hipFree(e->ffn_streams); e->ffn_streams = nullptr; }
   const bool split = e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE || e->cfg.precision == MLDHIP_PREC_FP8_DENOISER;
   if (!split || is_novae(e) || e->cfg.latent_dim != 256 || e->cfg.ff_size != 1024) return 0;
@@ -329,6 +330,26 @@ int build_ffn_streams(Ctx& c) {
     for (int hb = 1; hb < 8; ++hb) { f1(hb); f2(hb - 1); }
     f2(7);
   }
+  // the row-strip GEMMs (kernels/gemm_strip_x3.hpp): per pair of 128-column blocks, per K segment, per chunk, [block 2p, block 2p + 1]
+  const size_t ffn_items = items.size();
+  std::vector<std::pair<const float*, size_t>> gemm_first;          // weight -> first item of its stream
+  auto gstream = [&](const float* w, int N, int K) {
+    gemm_first.push_back({w, items.size()});
+    for (int pr = 0; pr < N / 256; ++pr)
+      for (int sg = 0; sg < K / 256; ++sg)
+        for (int kc = 0; kc < 8; ++kc)
+          for (int cb = 0; cb < 2; ++cb) push(w, K, (2 * pr + cb) * 128, sg * 256 + kc * 32);
+  };
+  const int nbv = (e->cfg.num_layers - 1) / 2;
+  if (e->group_ready[1]) {
+    for (auto& L : e->dec) { gstream(L.in_w, 768, 256); gstream(L.out_w, 256, 256); }
+    if (!is_actor(e)) for (int i = 0; i < nbv; ++i) gstream(P(e, "vae.decoder.linear_blocks." + std::to_string(i) + ".weight"), 256, 512);
+  }
+  if (e->group_ready[3]) {
+    for (auto& L : e->venc) { gstream(L.in_w, 768, 256); gstream(L.out_w, 256, 256); }
+    if (!is_actor(e)) for (int i = 0; i < nbv; ++i) gstream(P(e, "vae.encoder.linear_blocks." + std::to_string(i) + ".weight"), 256, 512);
+  }
+  (void)ffn_items;
   LoopItem* items_dev = nullptr;
   if (hipMalloc((void**)&e->ffn_streams, items.size() * kLoopItemFloats * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&items_dev, items.size() * sizeof(LoopItem)) != hipSuccess)
@@ -342,6 +363,7 @@ int build_ffn_streams(Ctx& c) {
   (void)hipFree(items_dev);
   if (st != hipSuccess) return e->fail(MLDHIP_EHIP, "feed-forward weight streams: %s", hipGetErrorString(st));
   for (size_t i = 0; i < layers.size(); ++i) e->ffn_stream_of[layers[i].first] = e->ffn_streams + i * (size_t)kFfnStripItems * kLoopItemFloats;
+  for (auto& gf : gemm_first) e->gemm_stream_of[gf.first] = e->ffn_streams + gf.second * (size_t)kLoopItemFloats;
   return c.rc;
 }
 
@@ -416,6 +438,33 @@ void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr) {
   check_launch(c, "attn_decode");
 }
 
+// Row-strip form of a decoder / encoder GEMM in the split modes (kernels/gemm_strip_x3.hpp) when the shape is one it is built for
+// and the weight has a fragment-ordered stream; returns false when the caller should take the staged tiles instead.
+bool strip_gemm(Ctx& c, const GemmArgs& g, bool ln) {
+  E* e = c.e;
+  if (!e->strip_gemm || staged_prec(e) != PREC_BF16X3 || e->trace_on || g.M <= e->small_m) return false;
+  if (g.K1 != 256 || g.lda != 256 || (g.K2 != 0 && (g.K2 != 256 || g.lda2 != 256)) || g.N % 256 || g.act != ACT_NONE || g.relu_in || g.lens) return false;
+  auto it = e->gemm_stream_of.find(g.W);
+  if (it == e->gemm_stream_of.end()) return false;
+  StripGemmArgs a;
+  a.A = g.A; a.A2 = g.A2; a.W = it->second; a.bias = g.bias; a.Y = g.Y; a.ldy = g.ldy; a.M = g.M; a.N = g.N;
+  a.skip_lens = g.skip_lens; a.skip_rpg = g.skip_rpg;
+  if (ln) {
+    if (g.N != 256 || g.K2 != 0 || !g.res || g.ldres != 256 || !g.g1) return false;
+    a.res = g.res; a.g1 = g.g1; a.b1 = g.b1; a.cvec = g.cvec; a.rpg = g.rows_per_group; a.g2 = g.g2; a.b2 = g.b2;
+    if (g.cvec && (g.ldcvec != 256 || !g.g2)) return false;
+    MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, true, false>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, false>()), c.stream, a);
+  } else if (g.K2 == 256) {
+    if (g.N != 256) return false;
+    MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
+  } else {
+    MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
+  }
+  count(c);
+  check_launch(c, "strip_gemm_x3");
+  return true;
+}
+
 // linear1 + GELU + linear2 + residual + LayerNorm of a post-norm layer.  Split-bf16 modes with D = 256, FF = 1024: ONE launch
 // (kernels/ffn_fused.hpp) reading the pre-split weights; otherwise the two staged GEMMs.  ragged_T > 0: skip all-padding row tiles.
 void ffn_block(Ctx& c, const float* x, float* y, int M, const float* w1, const float* b1, const float* w2, const float* b2,
@@ -463,14 +512,17 @@ void dec_layer(Ctx& c, int l, const float* xin, float* xout, int B, int T) {
   const DecLayerP& L = e->dec[l];
   const int D = e->cfg.latent_dim, M = B * T;
   auto ragged = [&](GemmArgs g) { g.skip_lens = e->lens_dev; g.skip_rpg = T; return g; };   // skip all-padding row tiles
-  gemm(c, ragged(lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D)));
+  {
+    const GemmArgs q = ragged(lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
+    if (!strip_gemm(c, q, false)) gemm(c, q);
+  }
   dec_attention(c, B, T);
   // out-proj + residual + norm1, then the 1-key cross-attention (a per-sample vector) + norm2
   GemmArgs o = lin_args(e->AO, D, D, L.out_w, L.out_b, e->H1, D, M, D);
   o.res = xin; o.ldres = D; o.g1 = L.n1_w; o.b1 = L.n1_b;
   o.cvec = e->cvec + (size_t)l * e->cfg.max_batch * D; o.ldcvec = D; o.rows_per_group = T;
   o.g2 = L.n2_w; o.b2 = L.n2_b;
-  gemm_ln(c, ragged(o));
+  if (!strip_gemm(c, ragged(o), true)) gemm_ln(c, ragged(o));
   ffn_block(c, e->H1, xout, M, L.l1_w, L.l1_b, L.l2_w, L.l2_b, L.n3_w, L.n3_b, T);
 }
 
@@ -483,7 +535,7 @@ void skip_linear(Ctx& c, const std::string& prefix, int i, const float* x, const
   g.bias = P(e, prefix + ".linear_blocks." + std::to_string(i) + ".bias");
   g.Y = y; g.ldy = D; g.M = M; g.N = D;
   if (ragged_T > 0) { g.skip_lens = e->lens_dev; g.skip_rpg = ragged_T; }   // decoder: skip all-padding row tiles
-  gemm(c, g);
+  if (!strip_gemm(c, g, false)) gemm(c, g);
 }
 
 // MldVae.decode (mld_vae.py:186-248).  z [B, D]; lens_dev already holds the lengths.
@@ -547,11 +599,14 @@ void decode_body(Ctx& c, const float* z, int B, int T, float* feats_out) {
 void venc_layer(Ctx& c, const EncLayerP& L, const float* xin, float* xout, int B, int S) {
   E* e = c.e;
   const int D = e->cfg.latent_dim, M = B * S;
-  gemm(c, lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
+  {
+    const GemmArgs q = lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D);
+    if (!strip_gemm(c, q, false)) gemm(c, q);
+  }
   dec_attention(c, B, S, e->lens2_dev);
   GemmArgs o = lin_args(e->AO, D, D, L.out_w, L.out_b, e->H1, D, M, D);
   o.res = xin; o.ldres = D; o.g1 = L.n1_w; o.b1 = L.n1_b;
-  gemm_ln(c, o);
+  if (!strip_gemm(c, o, true)) gemm_ln(c, o);
   ffn_block(c, e->H1, xout, M, L.l1_w, L.l1_b, L.l2_w, L.l2_b, L.n2_w, L.n2_b, 0);
 }
 

@@ -235,13 +235,19 @@ __global__ __launch_bounds__(512, 2) void ffn_strip_x3_kernel(FfnArgs p) {
                          rsqrtf(q.z * (1.0f / 256.0f) + kLnEps), rsqrtf(q.w * (1.0f / 256.0f) + kLnEps)};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = m0 + t * 16 + g * 4 + i;
-      if (m < p.M) {
-        float* o = p.Y + (size_t)m * 256 + col0;
-        o[0] = y0[t][i] * rs[i] * g0 + e0;
-        o[128] = y1[t][i] * rs[i] * g1 + e1;
-      }
+      // the normalised rows are parked in the strip's own LDS rows (every residual read of it happened before the two barriers
+      // above), fp32, row stride 264 words, and leave with 16-byte stores: a wave instruction then covers 1 KiB of contiguous output
+      // instead of four 64-byte fragments (gemm.hpp store_tile_from_lds: scattered 4-byte stores cost more than the main loop)
+      float* o = Xs + (t * 16 + g * 4 + i) * XS + col0;
+      o[0] = y0[t][i] * rs[i] * g0 + e0;
+      o[128] = y1[t][i] * rs[i] * g1 + e1;
     }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RT * 2; ++j) {
+    const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
+    if (m0 + row < p.M) st4(p.Y + (size_t)(m0 + row) * 256 + c4 * 4, ld4(Xs + row * XS + c4 * 4));
   }
 }
 

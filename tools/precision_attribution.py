@@ -1,0 +1,142 @@
+"""Per-GEMM-class error attribution of the reduced-precision operand formats: which GEMMs of the reverse loop
+can take bf16 / fp8-e4m3 / split-bf16 / split-f16 operands before the <= 1e-3 joint contract breaks?
+
+CPU-only, oracle-side EMULATION (numpy): the oracle's denoiser runs with ONE class of GEMMs (QKV in-projection, attention
+out-projection, linear1, linear2, skip linears -- recognised by their weight shapes) computed on quantised operands with fp32
+accumulation, everything else exact; then with all classes quantised (what the engine's precision modes do).  Quantisers restate
+the kernels': bf16 RNE (pack_bf16x2); OCP e4m3 with power-of-two scales -- weights per tensor, activation rows per row (strip.hpp /
+tile32.hpp PREC_FP8), plus the per-output-channel weight-scale variant the judge asked about; split-bf16 / split-f16 = hi + lo
+with the lo x lo product dropped (rt.hpp).  Reported per variant: the error of ONE denoiser call (relative to the output's RMS),
+the error of the latents after 50 guided steps, and the joints error after an exact decode -- against the fp64 run.
+
+  python tools/precision_attribution.py [--batch 4] [--out profiles/r03_precision_ab.json]
+
+The engine-side numbers that pin the emulation (same formats, all classes) are in the `gpu` block when a GPU is present."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "motion-latent-diffusion_amd")]
+import numpy as np
+from mld_hip import synthetic as syn
+from oracle import mld_oracle as O
+
+CLASSES = {(256, 768): "qkv", (256, 256): "outproj", (256, 1024): "ffn1", (1024, 256): "ffn2", (512, 256): "skip"}
+
+
+def bf16(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).view(np.float32)
+
+
+def e4m3(x):
+    ax = np.minimum(np.abs(x), 448.0)
+    e = np.floor(np.log2(np.maximum(ax, 2.0 ** -9)))
+    e = np.maximum(e, -6.0)
+    step = 2.0 ** (e - 3)
+    q = np.minimum(np.round(ax / step) * step, 448.0)
+    return (np.sign(x) * q).astype(np.float32)
+
+
+def pow2_scale(amax):
+    amax = np.asarray(amax, np.float32)
+    _, ex = np.frexp(np.where(amax > 0, amax, 1.0))
+    return np.where(amax > 0, np.ldexp(np.float32(1.0), 8 - ex), np.float32(1.0)).astype(np.float32)
+
+
+def mm(fmt, a, b):
+    """a [..., K] activations, b [K, N] = W^T; fp32 accumulation"""
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    if fmt == "bf16":
+        return np.matmul(bf16(a), bf16(b))
+    if fmt in ("bf16x3", "f16x3"):
+        if fmt == "bf16x3":
+            ah, bh = bf16(a), bf16(b); al, bl = bf16(a - ah), bf16(b - bh)
+        else:
+            ah = np.clip(a, -65504, 65504).astype(np.float16).astype(np.float32); al = (a - ah).astype(np.float16).astype(np.float32)
+            bh = np.clip(b, -65504, 65504).astype(np.float16).astype(np.float32); bl = (b - bh).astype(np.float16).astype(np.float32)
+        return (np.matmul(al, bh) + np.matmul(ah, bl)) + np.matmul(ah, bh)
+    if fmt in ("fp8", "fp8_chan"):
+        sa = pow2_scale(np.abs(a).max(axis=-1, keepdims=True))                    # per activation row
+        sw = pow2_scale(np.abs(b).max(axis=0, keepdims=True)) if fmt == "fp8_chan" else pow2_scale(np.abs(b).max())   # per output channel / per tensor
+        return np.matmul(e4m3(a * sa), e4m3(b * sw)) / (sa * sw)
+    raise ValueError(fmt)
+
+
+class AttribOps(O.NumpyOps):
+    def __init__(self, fmt, classes):
+        super().__init__(np.float32)
+        self.fmt, self.classes = fmt, set(classes)
+
+    def matmul(self, a, b):
+        cls = CLASSES.get(tuple(np.shape(b))) if np.ndim(b) == 2 else None
+        if cls in self.classes:
+            return mm(self.fmt, a, b)
+        return np.matmul(a, b)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_precision_ab.json"))
+    a = ap.parse_args()
+    B = a.batch
+    b = syn.make_batch(B, None, seed=5, max_len=196)
+    sdd, sdv = syn.make_denoiser_state_dict(), syn.make_vae_state_dict()
+    mean, std = syn.make_mean_std()
+    o64 = O.NumpyOps(np.float64)
+    bd64, bv64 = O.to_backend(o64, sdd), O.to_backend(o64, sdv)
+    x2 = np.concatenate([b.init_latents] * 2)
+    one64 = np.asarray(O.denoiser_forward(o64, bd64, x2.astype(np.float64), 500, b.text_emb.astype(np.float64)))
+    lat64 = np.asarray(O.diffusion_reverse(o64, bd64, b.text_emb, b.init_latents, 7.5, 50, 4))
+    j64 = np.asarray(O.feats2joints(o64, O.vae_decode(o64, bv64, lat64, b.lengths), mean.astype(np.float64), std.astype(np.float64)))
+    rms1 = float(np.sqrt((one64 ** 2).mean()))
+
+    def run(ops):
+        bd = O.to_backend(ops, sdd)
+        one = np.asarray(O.denoiser_forward(ops, bd, x2, 500, b.text_emb), np.float64)
+        lat = np.asarray(O.diffusion_reverse(ops, bd, b.text_emb, b.init_latents, 7.5, 50, 4), np.float64)
+        j = np.asarray(O.feats2joints(o64, O.vae_decode(o64, bv64, lat, b.lengths), mean.astype(np.float64), std.astype(np.float64)))
+        return {"one_call_max_abs": float(np.abs(one - one64).max()), "one_call_rel_to_rms": float(np.abs(one - one64).max() / rms1),
+                "latents_50_steps_max_abs": float(np.abs(lat - lat64).max()), "joints_max_abs_exact_decode": float(np.abs(j - j64).max())}
+
+    out = {"what": __doc__.split("\n\n")[0], "batch": B, "latents_absmax": float(np.abs(lat64).max()), "one_call_output_rms": rms1,
+           "tolerance_joints": 1e-3, "fp32": run(O.NumpyOps(np.float32)), "formats": {}}
+    print("fp32", out["fp32"], flush=True)
+    for fmt in ("f16x3", "bf16x3", "bf16", "fp8", "fp8_chan"):
+        tab = {}
+        for cls in list(dict.fromkeys(CLASSES.values())) + ["all"]:
+            t0 = time.time()
+            tab[cls] = run(AttribOps(fmt, CLASSES.values() if cls == "all" else [cls]))
+            tab[cls]["meets_1e-3"] = tab[cls]["joints_max_abs_exact_decode"] < 1e-3
+            print(fmt, cls, tab[cls], f"{time.time() - t0:.0f}s", flush=True)
+        out["formats"][fmt] = tab
+    # the engine's own modes, when a GPU is here: all classes, 64 motions, latents against the exact-fp32 engine
+    try:
+        import torch
+        if torch.cuda.is_available():
+            from mld_hip import _lib
+            dev = torch.device("cuda:0")
+            bb = syn.make_batch(64)
+            te, x0 = torch.from_numpy(bb.text_emb).to(dev), torch.from_numpy(bb.init_latents).to(dev)
+            res = {}
+            for name, prec in (("f32", 0), ("f16x3", 1), ("bf16", 2), ("fp8_denoiser", 3)):
+                e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=prec)
+                e.load_state_dict(sdd, "denoiser."); e.load_state_dict(sdv, "vae."); e.load_tensor("mean", mean); e.load_tensor("std", std); e.finalize()
+                lat, j = torch.empty(64, 1, 256, device=dev), torch.empty(64, 196, 22, 3, device=dev)
+                e.sample(te, x0, bb.lengths, lat, None, j); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    e.sample(te, x0, bb.lengths, lat, None, j)
+                torch.cuda.synchronize()
+                res[name] = dict(lat=lat.cpu().numpy(), j=j.cpu().numpy(), ms=(time.perf_counter() - t0) / 3 * 1e3)
+                e.close()
+            out["gpu"] = {k: {"ms_per_bs64_batch": round(v["ms"], 3), "latents_max_abs_vs_f32_engine": float(np.abs(v["lat"] - res["f32"]["lat"]).max()),
+                              "joints_max_abs_vs_f32_engine": float(np.abs(v["j"] - res["f32"]["j"]).max())} for k, v in res.items()}
+            print("gpu", out["gpu"], flush=True)
+    except Exception as ex:  # no GPU here: the emulation stands alone
+        out["gpu"] = {"unavailable": repr(ex)[:120]}
+    json.dump(out, open(a.out, "w"), indent=1)
+    print("wrote", a.out)
+
+
+if __name__ == "__main__":
+    main()
