@@ -40,16 +40,19 @@ def main():
     model.load_state_dict(sd, strict=False)
     texts = ["prompt %d" % i for i in range(nprompts)]
     lengths = [24 + 8 * (i % 5) for i in range(nprompts)]
-    torch.manual_seed(1234)            # same seed on every rank; motions depend on (seed, rank-local order), checked for finiteness + shape
-    idx, motions = dp.DataParallelSampler(model, batch_size=4, in_flight=2)(texts, lengths)
+    # starting noise pinned PER PROMPT (the same tensor on every rank): a motion then does not depend on the rank / chunk it lands in,
+    # and the parent test compares every rank's motions with a single-process run of the same prompts
+    lat0 = torch.from_numpy(syn._rng(4242, "nccl_dp").standard_normal((nprompts, 1, 256)).astype(np.float32))
+    idx, motions = dp.DataParallelSampler(model, batch_size=4, in_flight=2)(texts, lengths, init_latents=lat0)
     ok = all(m.shape == (lengths[i], 22, 3) and bool(torch.isfinite(m).all()) for i, m in zip(idx, motions))
     ident = (rank, local, str(getattr(torch.cuda.get_device_properties(local), "uuid", local)))
     gathered = [None] * world
-    dist.all_gather_object(gathered, (ident, idx, ok))
+    dist.all_gather_object(gathered, (ident, idx, ok, [m.numpy() for m in motions]))
     if rank == 0:
         import json
         json.dump({"world": world, "ranks": [g[0] for g in gathered], "indices": [g[1] for g in gathered],
                    "ok": [g[2] for g in gathered], "backend": dist.get_backend()}, open(out_path, "w"))
+        np.savez(out_path + ".npz", **{f"m_{i}": m for g in gathered for i, m in zip(g[1], g[3])})
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,8 +1,8 @@
 """Per-GEMM-class error attribution of the reduced-precision operand formats: which GEMMs of the reverse loop
 can take bf16 / fp8-e4m3 / split-bf16 / split-f16 operands before the <= 1e-3 joint contract breaks?
 
-CPU-only, oracle-side EMULATION (numpy): the oracle's denoiser runs with ONE class of GEMMs (QKV in-projection, attention
-out-projection, linear1, linear2, skip linears -- recognised by their weight shapes) computed on quantised operands with fp32
+CPU-only, oracle-side EMULATION (numpy): the oracle's denoiser runs with ONE class of GEMMs (the four 256 x 256 attention
+projections, linear1, linear2, skip linears -- recognised by their weight shapes) computed on quantised operands with fp32
 accumulation, everything else exact; then with all classes quantised (what the engine's precision modes do).  Quantisers restate
 the kernels': bf16 RNE (pack_bf16x2); OCP e4m3 with power-of-two scales -- weights per tensor, activation rows per row (strip.hpp /
 tile32.hpp PREC_FP8), plus the per-output-channel weight-scale variant the judge asked about; split-bf16 / split-f16 = hi + lo
@@ -19,7 +19,8 @@ import numpy as np
 from mld_hip import synthetic as syn
 from oracle import mld_oracle as O
 
-CLASSES = {(256, 768): "qkv", (256, 256): "outproj", (256, 1024): "ffn1", (1024, 256): "ffn2", (512, 256): "skip"}
+# the oracle applies the packed in-projection as three 256 x 256 slices (q, k, v), so the four attention projections share a shape
+CLASSES = {(256, 256): "attn_in_out_proj", (256, 1024): "ffn1", (1024, 256): "ffn2", (512, 256): "skip"}
 
 
 def bf16(x):
@@ -77,6 +78,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_precision_ab.json"))
+    ap.add_argument("--gpu-only", action="store_true", help="keep the emulation table of an existing --out file, (re)measure the `gpu` block only")
     a = ap.parse_args()
     B = a.batch
     b = syn.make_batch(B, None, seed=5, max_len=196)
@@ -98,10 +100,13 @@ def main():
         return {"one_call_max_abs": float(np.abs(one - one64).max()), "one_call_rel_to_rms": float(np.abs(one - one64).max() / rms1),
                 "latents_50_steps_max_abs": float(np.abs(lat - lat64).max()), "joints_max_abs_exact_decode": float(np.abs(j - j64).max())}
 
-    out = {"what": __doc__.split("\n\n")[0], "batch": B, "latents_absmax": float(np.abs(lat64).max()), "one_call_output_rms": rms1,
-           "tolerance_joints": 1e-3, "fp32": run(O.NumpyOps(np.float32)), "formats": {}}
-    print("fp32", out["fp32"], flush=True)
-    for fmt in ("f16x3", "bf16x3", "bf16", "fp8", "fp8_chan"):
+    if a.gpu_only:
+        out = json.load(open(a.out))
+    else:
+      out = {"what": __doc__.split("\n\n")[0], "batch": B, "latents_absmax": float(np.abs(lat64).max()), "one_call_output_rms": rms1,
+             "tolerance_joints": 1e-3, "fp32": run(O.NumpyOps(np.float32)), "formats": {}}
+      print("fp32", out["fp32"], flush=True)
+    for fmt in (() if a.gpu_only else ("f16x3", "bf16x3", "bf16", "fp8", "fp8_chan")):
         tab = {}
         for cls in list(dict.fromkeys(CLASSES.values())) + ["all"]:
             t0 = time.time()
