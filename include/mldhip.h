@@ -148,6 +148,9 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "fused_dbg"       measurement builds of the persistent loop (WRONG results): 1 = no weight stream, 2 = no MFMAs
  *   "ffn_strip"       F16X3 / FP8 modes, feed-forward block of a decoder / encoder layer: 6 (default) / 4 = register-direct kernel on
  *                     96- / 64-row strips (kernels/ffn_strip.hpp), 0 = kernels/ffn_fused.hpp or the two staged GEMMs ("fused_ffn")
+ *   "strip_gemm"      F16X3 / FP8 modes, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:
+ *                     1 (default) = row-strip kernels with register-direct weights (kernels/gemm_strip_x3.hpp), 0 = staged tiles
+ *   "strip_ring"      row-strip GEMMs: weight items in flight per lane, 8 (default) or 4 (measured equal: r03_decoder_ab.json)
  *   "strip_min_rows"  auto picks the throughput kernels when the reverse loop has >= this many token rows
  *                     (6 x batch; default 768 = 128 motions)
  *   "strip_wide"      throughput kernels: 32 x 128 tiles for the wide GEMMs: 0 = auto (N >= 512), 1 = never, 2 = whenever N % 128 == 0

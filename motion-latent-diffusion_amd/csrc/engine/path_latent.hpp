@@ -456,9 +456,11 @@ bool strip_gemm(Ctx& c, const GemmArgs& g, bool ln) {
     MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, true, false>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, false>()), c.stream, a);
   } else if (g.K2 == 256) {
     if (g.N != 256) return false;
-    MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
+    if (e->strip_ring == 8) MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 8>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
+    else MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 4>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
   } else {
-    MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
+    if (e->strip_ring == 8) MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true, 8>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
+    else MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true, 4>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
   }
   count(c);
   check_launch(c, "strip_gemm_x3");

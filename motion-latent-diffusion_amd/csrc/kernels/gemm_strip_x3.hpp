@@ -33,10 +33,11 @@ constexpr int strip_gemm_lds_bytes() { return (NSEG * RT * 16 * kFsXs + (STAGE ?
 
 // grid = ceil(M / (16 RT)); block = 512.  STAGE: a separate [rows][136] staging tile for the output (needed when A must survive
 // the first pair: N > 256); otherwise the output is parked in A's own rows once the last product is done.
-template <int RT, int NSEG, bool LN, bool STAGE>
+template <int RT, int NSEG, bool LN, bool STAGE, int RING = 4>
 __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) {
   static_assert(!(LN && (NSEG != 1 || STAGE)), "the LayerNorm form is the N = 256, K = 256 out-projection");
-  constexpr int BM = RT * 16, XS = kFsXs, HS = kFsHs, RING = 4;
+  static_assert(RING == 4 || RING == 8, "weight items in flight per lane");
+  constexpr int BM = RT * 16, XS = kFsXs, HS = kFsHs;
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
 #else

@@ -10,9 +10,10 @@
 // workgroup-private slice of HBM):
 //   per reverse step and workgroup  48 rows x 7.6 M weights x 2 = 730 MFLOP  against  30.4 MB of weights streamed from L2 / MALL
 //   = 24 FLOP per byte.  On exact-fp32 MFMAs (256 FLOP/clk/CU) the stream needs 10.7 B/clk/CU, well under what the register-ring
-//   + ds_write staging sustains: MFMA bound (measured r03: 85 ms for 50 steps at ANY batch up to 2 048 motions = 0.70 of the fp32
+//   + ds_write staging sustains: MFMA bound (measured r03: 77 ms for 50 steps at ANY batch up to 2 048 motions = 0.77 of the fp32
 //   MFMA peak).  On split-f16 MFMAs (rt.hpp: 3 instead of 8 matrix instructions per chunk, each twice as fast) the matrix work
-//   shrinks 5x and the weight stream becomes the bound.
+//   shrinks 5x: 30 ms, of which the matrix pipe is busy 42 % and the VALU (GELU, hi / lo splits, LayerNorm, the 3-token softmax)
+//   about as long -- the epilogues of a phase cannot overlap the next phase's products, which depend on them.
 // It wins once a call carries enough motions to give most CUs a workgroup (2 048 motions = 256 workgroups = one per CU); below
 // ~1 000 motions the column-split families finish sooner (path_latent.hpp use_fused).
 //

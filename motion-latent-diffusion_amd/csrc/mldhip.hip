@@ -195,8 +195,10 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<13, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<13, 128>()));
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<18, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<18, 128>()));
   (void)hipFuncSetAttribute((const void*)ffn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLdsBytes);
-  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<6, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<6, 1, true>()));
-  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 2, false>()));
+  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<6, 1, false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<6, 1, true>()));
+  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 2, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 2, false>()));
+  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<6, 1, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<6, 1, true>()));
+  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 2, false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 2, false>()));
   (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<6, 1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<6, 1, false>()));
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<6>());
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<4>());
@@ -327,6 +329,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "flash_attn") {
     if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "flash_attn must be 0 (never), 1 (auto) or 2 (always)");
     e->flash_attn = (int)value;
+  } else if (n == "strip_ring") {
+    if (value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "strip_ring must be 4 or 8");
+    e->strip_ring = (int)value;
   } else if (n == "strip_gemm") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "strip_gemm must be 0 or 1");
     e->strip_gemm = (int)value;
