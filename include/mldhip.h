@@ -142,7 +142,8 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     consumption order; built for latent_dim 256 / ff_size 1024 / 4 heads in the F32 and F16X3 modes -- refused
  *                     elsewhere).  Its run time does not depend on the batch up to 8 x #CUs = 2 048 motions, so it wins from ~1 000
  *                     motions per call up.
- *   "fused_min_batch" auto picks the persistent loop from this many motions per call up (default 1024)
+ *   "fused_min_batch" auto picks the persistent loop from this many motions per call up; 0 (default) = by operand format: 320 on
+ *                     split-f16 MFMAs (29 ms per call whatever the batch), 1 280 on exact-fp32 MFMAs (77 ms)
  *   "fused_x3"        F16X3 mode: 1 (default) = the persistent loop multiplies on split-f16 MFMAs, 0 = on exact-fp32 MFMAs
  *   "fused_ring"      persistent loop: weight items in flight per lane, 4 (default) or 8
  *   "fused_dbg"       measurement builds of the persistent loop (WRONG results): 1 = no weight stream, 2 = no MFMAs
@@ -187,7 +188,7 @@ int mldhip_sample(mldhip_handle* h, const float* text_emb_dev, const float* init
  * of MLD.forward calls, one per batch (demo.py:171-186 iterates the batches of a prompt file; test.py does the same over
  * the dataloader).  The reverse loop at bs 64 is a chain of ~2 000 launches with a few hundred rows each; a few requests
  * coalesced run the same chain once at more rows on the throughput kernels (kernels/strip.hpp), and from "fused_min_batch"
- * motions up (default 1 024; the serving shape is 32 x 64 = 2 048 motions) the whole reverse loop of the call is ONE
+ * motions up (default: 320 in the F16X3 mode; the serving shape is 32 x 64 = 2 048 motions) the whole reverse loop of the call is ONE
  * persistent launch, a workgroup per 8 motions (kernels/loop_fused.hpp): one call on one stream fills the chip -- no calls
  * in flight, no stream / hardware-queue placement for the caller to get right.  Motions never interact, so every request
  * gets what mldhip_sample / mldhip_sample_action would have given it (up to fp32 summation order / the mode's operand

@@ -226,7 +226,10 @@ bool fused_built(const E* e) {
   return !is_novae(e) && e->cfg.latent_dim == 256 && e->cfg.ff_size == 1024 && e->cfg.num_heads == 4 && loop_prec(e) == PREC_F32;
 }
 bool use_fused(const E* e, int B) {
-  return e->loop_ips > 0 && (e->loop_kernel == 3 || (e->loop_kernel == 0 && B >= e->fused_min_batch));
+  // auto: the persistent loop takes the same time for any batch up to 8 x #CUs motions -- 29 ms on split-f16 MFMAs, 77 ms on exact-fp32
+  // ones (r03) -- the column-split throughput kernels 30 ms at 320 motions, 65 ms at 1 024, 120 ms at 2 048: cross-over by operand format
+  const int auto_min = e->fused_min_batch > 0 ? e->fused_min_batch : ((e->loop_stream_x3 && e->fused_x3) ? 320 : 1280);
+  return e->loop_ips > 0 && (e->loop_kernel == 3 || (e->loop_kernel == 0 && B >= auto_min));
 }
 
 // finalize-time: the denoiser's GEMM weights as the item stream the loop kernel consumes, its small parameters packed, the

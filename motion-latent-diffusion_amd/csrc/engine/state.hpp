@@ -117,7 +117,7 @@ struct mldhip_engine {
   int fused_x3 = 1;          // "fused_x3": in the split precision mode the sample-major loop multiplies on split-f16 MFMAs (0: exact fp32 MFMAs)
   int fused_ring = 4;        // "fused_ring": weight items in flight per lane in the sample-major loop (4 or 8; 8 spills a few ring slots around the epilogues)
   int fused_dbg = 0;         // "fused_dbg": measurement builds of the split-mode loop (results are wrong): 1 no weight stream, 2 no MFMAs
-  int fused_min_batch = 1024;// "fused_min_batch": auto picks the sample-major loop from this many motions per call up
+  int fused_min_batch = 0;   // "fused_min_batch": auto picks the sample-major loop from this many motions per call up; 0 = by operand format (320 split-f16, 1 280 fp32)
   int strip_min_rows = 768;  // "strip_min_rows": auto switches to the throughput kernels at 6B >= this many token rows
   int strip_wide = 0;        // "strip_wide": 32 x 128 strip tiles for the wide GEMMs: 0 auto (N >= 512), 1 never, 2 whenever N % 128 == 0
   int strip_waves = 8;       // "strip_waves": waves per workgroup of the 32 x 128 strip tiles: 4 (two row tiles per wave) or 8 (one)

@@ -315,7 +315,7 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "fused_ring must be 4 or 8");
     e->fused_ring = (int)value;
   } else if (n == "fused_min_batch") {
-    if (value < 1) return e->fail(MLDHIP_EINVAL, "fused_min_batch must be >= 1");
+    if (value < 0) return e->fail(MLDHIP_EINVAL, "fused_min_batch must be >= 0 (0 = automatic)");
     e->fused_min_batch = (int)std::min<int64_t>(value, 1 << 30);
   } else if (n == "strip_min_rows") {
     if (value < 1) return e->fail(MLDHIP_EINVAL, "strip_min_rows must be >= 1");
