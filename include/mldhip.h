@@ -147,8 +147,12 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "fused_x3"        F16X3 mode: 1 (default) = the persistent loop multiplies on split-f16 MFMAs, 0 = on exact-fp32 MFMAs
  *   "fused_ring"      persistent loop: weight items in flight per lane, 4 (default) or 8
  *   "fused_dbg"       measurement builds of the persistent loop (WRONG results): 1 = no weight stream, 2 = no MFMAs
- *   "ffn_strip"       F16X3 / FP8 modes, feed-forward block of a decoder / encoder layer: 6 (default) / 4 = register-direct kernel on
- *                     96- / 64-row strips (kernels/ffn_strip.hpp), 0 = kernels/ffn_fused.hpp or the two staged GEMMs ("fused_ffn")
+ *   "ffn_strip"       F16X3 / FP8 modes, decoder / encoder layers: strip height of the register-direct kernels (kernels/ffn_strip.hpp,
+ *                     kernels/gemm_strip_x3.hpp): 1 (default) = 96 rows when the launch has more than 512 strips of 64, else 64 (one bs-64
+ *                     request: 196 strips on 256 CUs instead of 131 longer ones); 6 / 4 = 96 / 64 rows always; 0 = feed-forward block by
+ *                     kernels/ffn_fused.hpp or the two staged GEMMs ("fused_ffn")
+ *   "tile_x3"         F16X3 mode: 1 (default) = the latency kernels of the reverse loop (kernels/tile32.hpp, one request at a time) multiply
+ *                     on split-f16 MFMAs reading the pre-split weight image, 0 = on exact-fp32 MFMAs
  *   "strip_gemm"      F16X3 / FP8 modes, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:
  *                     1 (default) = row-strip kernels with register-direct weights (kernels/gemm_strip_x3.hpp), 0 = staged tiles
  *   "strip_ring"      row-strip GEMMs: weight items in flight per lane, 8 (default) or 4 (measured equal: r03_decoder_ab.json)

@@ -67,6 +67,13 @@ int loop_prec(const E* e) {
   return e->cfg.precision == MLDHIP_PREC_BF16 ? PREC_BF16 : e->cfg.precision == MLDHIP_PREC_FP8_DENOISER ? PREC_FP8 : PREC_F32;
 }
 
+// Operand format of the LATENCY family (tile32.hpp: one bs-64 batch at a time): the split-f16 mode runs them on split-f16 MFMAs too
+// (option "tile_x3", on by default) -- 24 matrix instructions of 16 cycles per wave instead of 64 of 32, same 22-bit products as the
+// persistent loop of that mode
+int latency_prec(const E* e) {
+  return (e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE && e->tile_x3) ? PREC_BF16X3 : loop_prec(e);
+}
+
 // split-bf16 mode: read W from the pre-split image of the weight arena when it lives there (derived tables in a workspace do not)
 void use_split_weights(const E* e, GemmArgs& a, int prec) {
   // the image holds one (hi | lo) record per ALIGNED group of 32 floats of the arena: a weight view that does not start on a

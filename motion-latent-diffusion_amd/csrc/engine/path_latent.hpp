@@ -21,14 +21,24 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
   const int mt = mt16 ? 16 : 32;
   dim3 grid((a.M + mt - 1) / mt, (a.N + 63) / 64, nz);
   const int ns = a.src[0].attn_R > 0 ? 0 : a.src[0].nsplit;
-  const int prec = loop_prec(c.e);
-#define MLD_T32(MT, NS)                                                                                          \
+  const int prec = latency_prec(c.e);
+  if (prec == PREC_BF16X3 && c.e->split_weights && c.e->arena_x3 && a.W >= c.e->arena && a.W < c.e->arena + c.e->arena_floats &&
+      (a.W - c.e->arena) % 32 == 0 && a.ldw % 32 == 0) {
+    a.W = c.e->arena_x3 + (a.W - c.e->arena);
+    a.w_split = 1;
+  }
+  const bool attn = a.src[0].attn_R > 0, two = ns > 0 && nz > a.nz0;
+#define MLD_T32P(MT, NS, MODE)                                                                                   \
   do {                                                                                                           \
-    if (a.trace) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, true>), grid, dim3(512), kT32LdsBytes, c.stream, a); }       \
-    else if (prec == PREC_BF16) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, PREC_BF16>), grid, dim3(512), kT32LdsBytes, c.stream, a); } \
-    else if (prec == PREC_FP8) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, PREC_FP8>), grid, dim3(512), kT32LdsBytes, c.stream, a); }   \
-    else { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false>), grid, dim3(512), kT32LdsBytes, c.stream, a); }              \
+    if (a.trace && prec == PREC_BF16X3) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, true, PREC_BF16X3, MODE>), grid, dim3(512), kT32LdsBytes, c.stream, a); } \
+    else if (a.trace) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, true, PREC_F32, MODE>), grid, dim3(512), kT32LdsBytes, c.stream, a); }  \
+    else if (prec == PREC_BF16) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, PREC_BF16, MODE>), grid, dim3(512), kT32LdsBytes, c.stream, a); } \
+    else if (prec == PREC_FP8) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, PREC_FP8, MODE>), grid, dim3(512), kT32LdsBytes, c.stream, a); }   \
+    else if (prec == PREC_BF16X3) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, PREC_BF16X3, MODE>), grid, dim3(512), kT32LdsBytes, c.stream, a); } \
+    else { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, PREC_F32, MODE>), grid, dim3(512), kT32LdsBytes, c.stream, a); }              \
   } while (0)
+#define MLD_T32(MT, NS)                                                                                          \
+  do { if ((NS) == 0 ? attn : two) MLD_T32P(MT, NS, 1); else MLD_T32P(MT, NS, 0); } while (0)
 #define MLD_T32_NS(MT)                                                                                           \
   switch (ns) {                                                                                                  \
     case 0: MLD_T32(MT, 0); break;                                                                               \
@@ -40,6 +50,7 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
   if (mt16) { MLD_T32_NS(16) } else { MLD_T32_NS(32) }
 #undef MLD_T32_NS
 #undef MLD_T32
+#undef MLD_T32P
   count(c);
   check_launch(c, "gemm_tile32");
 }
@@ -443,8 +454,17 @@ void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr) {
 
 // Row-strip form of a decoder / encoder GEMM in the split modes (kernels/gemm_strip_x3.hpp) when the shape is one it is built for
 // and the weight has a fragment-ordered stream; returns false when the caller should take the staged tiles instead.
+// rows per strip of the register-direct decoder kernels: 96 (six row tiles: 2 MB of weights per 96 rows) when the launch fills the chip
+// several times over, 64 when it would not -- one bs-64 request is 12 544 frame rows = 131 strips of 96 on 256 CUs, but 196 of 64,
+// each a third shorter ("ffn_strip" 1 = this rule, 4 / 6 = always)
+int strip_rows_rt(const E* e, int M) {
+  if (e->ffn_strip == 4 || e->ffn_strip == 6) return e->ffn_strip;
+  return (M + 63) / 64 <= 512 ? 4 : 6;
+}
+
 bool strip_gemm(Ctx& c, const GemmArgs& g, bool ln) {
   E* e = c.e;
+  const int rt = strip_rows_rt(e, g.M);
   if (!e->strip_gemm || staged_prec(e) != PREC_BF16X3 || e->trace_on || g.M <= e->small_m) return false;
   if (g.K1 != 256 || g.lda != 256 || (g.K2 != 0 && (g.K2 != 256 || g.lda2 != 256)) || g.N % 256 || g.act != ACT_NONE || g.relu_in || g.lens) return false;
   auto it = e->gemm_stream_of.find(g.W);
@@ -456,11 +476,14 @@ bool strip_gemm(Ctx& c, const GemmArgs& g, bool ln) {
     if (g.N != 256 || g.K2 != 0 || !g.res || g.ldres != 256 || !g.g1) return false;
     a.res = g.res; a.g1 = g.g1; a.b1 = g.b1; a.cvec = g.cvec; a.rpg = g.rows_per_group; a.g2 = g.g2; a.b2 = g.b2;
     if (g.cvec && (g.ldcvec != 256 || !g.g2)) return false;
-    MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, true, false>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, false>()), c.stream, a);
+    if (rt == 4) MLD_LAUNCH((strip_gemm_x3_kernel<4, 1, true, false>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 1, false>()), c.stream, a);
+    else MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, true, false>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, false>()), c.stream, a);
   } else if (g.K2 == 256) {
     if (g.N != 256) return false;
     if (e->strip_ring == 8) MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 8>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
     else MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 4>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
+  } else if (rt == 4) {
+    MLD_LAUNCH((strip_gemm_x3_kernel<4, 1, false, true, 8>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 1, true>()), c.stream, a);
   } else {
     if (e->strip_ring == 8) MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true, 8>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
     else MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true, 4>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
@@ -483,7 +506,7 @@ void ffn_block(Ctx& c, const float* x, float* y, int M, const float* w1, const f
     FfnArgs a;
     a.X = x; a.W1 = e->ffn_stream_of[w1]; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.Y = y; a.M = M;
     if (ragged_T > 0) { a.skip_lens = e->lens_dev; a.skip_rpg = ragged_T; }
-    if (e->ffn_strip == 6) MLD_LAUNCH(ffn_strip_x3_kernel<6>, dim3((M + 95) / 96), dim3(512), (ffn_strip_lds_bytes<6>()), c.stream, a);
+    if (strip_rows_rt(e, M) == 6) MLD_LAUNCH(ffn_strip_x3_kernel<6>, dim3((M + 95) / 96), dim3(512), (ffn_strip_lds_bytes<6>()), c.stream, a);
     else MLD_LAUNCH(ffn_strip_x3_kernel<4>, dim3((M + 63) / 64), dim3(512), (ffn_strip_lds_bytes<4>()), c.stream, a);
     count(c);
     check_launch(c, "ffn_strip_x3");

@@ -175,6 +175,14 @@ __device__ __forceinline__ void split_hi_lo_x8(const float (&x)[8], U4& hi, U4& 
   split16_pair(x[6], x[7], hi.w, lo.w);
 }
 
+// the same for softmax numerators (values in [0, 1]: no range clamp needed)
+__device__ __forceinline__ void split_hi_lo_x8_unit(const float (&x)[8], U4& hi, U4& lo) {
+  split16_two(x[0], x[1], hi.x, lo.x);
+  split16_two(x[2], x[3], hi.y, lo.y);
+  split16_two(x[4], x[5], hi.z, lo.z);
+  split16_two(x[6], x[7], hi.w, lo.w);
+}
+
 template <int NKT, int NW = 8>
 __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                              const int* __restrict__ lens, int T, int H) {
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __
         const float pf[8] = {s[2 * kb][0] * inv, s[2 * kb][1] * inv, s[2 * kb][2] * inv, s[2 * kb][3] * inv,
                              s[2 * kb + 1][0] * inv, s[2 * kb + 1][1] * inv, s[2 * kb + 1][2] * inv, s[2 * kb + 1][3] * inv};
         U4 ph, pl;
-        split_hi_lo_x8(pf, ph, pl);
+        split_hi_lo_x8_unit(pf, ph, pl);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const unsigned* vh = Vh + (dt * 16 + r) * VST + kb * 16 + g * 2;     // keys 32kb + 4g .. + 3 (2 words), + 16 keys (8 words) for the second tile
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
         psum = sum_groups(psum);
         lrun[t] = lrun[t] * alpha + psum;
         mrun[t] = mnew;
-        split_hi_lo_x8(pf, ph[t], pl[t]);
+        split_hi_lo_x8_unit(pf, ph[t], pl[t]);
         // accumulator row i of this lane is query 4 g + i: its rescale factor sits in lane 4 g + i
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

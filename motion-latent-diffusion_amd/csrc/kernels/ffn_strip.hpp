@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void ffn_strip_x3_kernel(FfnArgs p) {
   const int hw0 = ((wave >> 1) * 32 + (wave & 1) * 8 + (r >> 1)) * 2 + (r & 1);     // half-word offset of column col0 in a row image
 
   f32x4 h[RT], y0[RT], y1[RT];
-  unsigned hv[RT][4];                  // one hidden block after bias + GELU: packed (low half | high half << 16)
+  unsigned hvh[RT][2], hvl[RT][2];     // one hidden block after bias + GELU: high / low halves of elements (i, i + 1) packed per word
 #pragma unroll
   for (int t = 0; t < RT; ++t) { y0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; y1[t] = y0[t]; }
   auto run1 = [&]() __attribute__((always_inline)) {
@@ -131,20 +131,21 @@ __global__ __launch_bounds__(512, 2) void ffn_strip_x3_kernel(FfnArgs p) {
     }
   };
   constexpr int NB = RT <= 4 ? 2 : 1;
-  auto gelu_one = [&](int t, int i, float b1) __attribute__((always_inline)) {
-    unsigned short hi, lo;
-    split16_one(gelu_erf(h[t][i] + b1), hi, lo);
-    hv[t][i] = (unsigned)hi | ((unsigned)lo << 16);
+  auto gelu_two = [&](int t, int ip, float b1) __attribute__((always_inline)) {      // elements 2 ip, 2 ip + 1 of tile t
+    split16_two(gelu_erf(h[t][2 * ip] + b1), gelu_erf(h[t][2 * ip + 1] + b1), hvh[t][ip], hvl[t][ip]);
   };
   auto write_block = [&]() __attribute__((always_inline)) {
     __syncthreads();                   // every wave has left run2 of the previous block
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        unsigned short* q = reinterpret_cast<unsigned short*>(Hs + (t * 16 + g * 4 + i) * HS) + hw0;
-        q[0] = (unsigned short)(hv[t][i] & 0xFFFFu);
-        q[32] = (unsigned short)(hv[t][i] >> 16);
+      for (int ip = 0; ip < 2; ++ip) {
+        unsigned short* q0 = reinterpret_cast<unsigned short*>(Hs + (t * 16 + g * 4 + 2 * ip) * HS) + hw0;
+        unsigned short* q1 = reinterpret_cast<unsigned short*>(Hs + (t * 16 + g * 4 + 2 * ip + 1) * HS) + hw0;
+        q0[0] = (unsigned short)(hvh[t][ip] & 0xFFFFu);
+        q0[32] = (unsigned short)(hvl[t][ip] & 0xFFFFu);
+        q1[0] = (unsigned short)(hvh[t][ip] >> 16);
+        q1[32] = (unsigned short)(hvl[t][ip] >> 16);
       }
     __syncthreads();
   };
@@ -155,14 +156,14 @@ __global__ __launch_bounds__(512, 2) void ffn_strip_x3_kernel(FfnArgs p) {
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) gelu_one(t, i, b1);
+      for (int ip = 0; ip < 2; ++ip) gelu_two(t, ip, b1);
   }
   for (int hb = 1; hb < 8; ++hb) {
     write_block();                     // block hb - 1 -> LDS
     const float b1 = p.b1[hb * 128 + col0];
     run1();                            // linear1 of block hb
     // linear2's share of block hb - 1 (8 items: 4 chunks x 2 column blocks) with the GELU of block hb spread between its items
-    constexpr int PER = (RT * 4 + 7) / 8;
+    constexpr int PER = (RT * 2 + 7) / 8;     // element PAIRS per item
     F4 x[NB][RT][2];
     if constexpr (NB == 2) frags(ha, HS, 0, x[0]);
 #pragma unroll
@@ -172,11 +173,11 @@ __global__ __launch_bounds__(512, 2) void ffn_strip_x3_kernel(FfnArgs p) {
       mma_item(2 * c, x[c & (NB - 1)], y0);
 #pragma unroll
       for (int e = (2 * c) * PER; e < (2 * c + 1) * PER; ++e)
-        if (e < RT * 4) gelu_one(e >> 2, e & 3, b1);
+        if (e < RT * 2) gelu_two(e >> 1, e & 1, b1);
       mma_item(2 * c + 1, x[c & (NB - 1)], y1);
 #pragma unroll
       for (int e = (2 * c + 1) * PER; e < (2 * c + 2) * PER; ++e)
-        if (e < RT * 4) gelu_one(e >> 2, e & 3, b1);
+        if (e < RT * 2) gelu_two(e >> 1, e & 1, b1);
     }
   }
   write_block();

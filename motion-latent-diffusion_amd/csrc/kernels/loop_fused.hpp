@@ -249,11 +249,27 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
       row[col0] = val;
     }
   };
+  // two elements of one tile (rows 16t + 4g + i, i + 1): one packed split, four 16-bit stores
+  auto put_two = [&](float* buf, int st, int cw, int t, int i, float v0, float v1) __attribute__((always_inline)) {
+    if constexpr (X3) {
+      unsigned hi, lo;
+      split16_two(v0, v1, hi, lo);
+      unsigned short* h0 = reinterpret_cast<unsigned short*>(buf + (t * 16 + g * 4 + i) * st + cw) + hw0;
+      unsigned short* h1 = reinterpret_cast<unsigned short*>(buf + (t * 16 + g * 4 + i + 1) * st + cw) + hw0;
+      h0[0] = (unsigned short)(hi & 0xFFFFu);
+      h0[32] = (unsigned short)(lo & 0xFFFFu);
+      h1[0] = (unsigned short)(hi >> 16);
+      h1[32] = (unsigned short)(lo >> 16);
+    } else {
+      put_one(buf, st, cw, t, i, v0);
+      put_one(buf, st, cw, t, i + 1, v1);
+    }
+  };
   auto put = [&](float* buf, int st, int cw, const float (&val)[3][4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) put_one(buf, st, cw, t, i, val[t][i]);
+      for (int i = 0; i < 4; i += 2) put_two(buf, st, cw, t, i, val[t][i], val[t][i + 1]);
   };
   // ... and back: the residual of a LayerNorm is read from the operand buffer it was multiplied from (split mode: high + low
   // half, the value the GEMMs saw, 2^-22 from the fp32 one), so no activation stays in registers across a GEMM phase
@@ -454,7 +470,8 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
             }
             if (c < 6) {
 #pragma unroll
-              for (int e = 2 * c; e < 2 * c + 2; ++e) put_one(hbuf, kLfHs, 0, e >> 2, e & 3, gelu_erf(cur[e >> 2][e & 3] + b1));
+              for (int e = 2 * c; e < 2 * c + 2; e += 2)
+                put_two(hbuf, kLfHs, 0, e >> 2, e & 3, gelu_erf(cur[e >> 2][e & 3] + b1), gelu_erf(cur[e >> 2][(e & 3) + 1] + b1));
             }
           }
           __syncthreads();

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(NW * 64) void attn_seq_x3_kernel(const float* __res
       const float pf[8] = {s[2 * kb][0] * inv, s[2 * kb][1] * inv, s[2 * kb][2] * inv, s[2 * kb][3] * inv,
                            s[2 * kb + 1][0] * inv, s[2 * kb + 1][1] * inv, s[2 * kb + 1][2] * inv, s[2 * kb + 1][3] * inv};
       U4 ph, pl;
-      split_hi_lo_x8(pf, ph, pl);
+      split_hi_lo_x8_unit(pf, ph, pl);
 #pragma unroll
       for (int dt = 0; dt < HD / 16; ++dt) {
         const unsigned* vh = Vh + (dt * 16 + r) * VST + kb * 16 + g * 2;

@@ -162,7 +162,25 @@ __device__ __forceinline__ float erf_as(float x) {
   return copysignf(y, x);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+// GELU(x) = x/2 (1 + erf(x/sqrt2)) on the same erf (A&S 7.1.26, z = |x|/sqrt2), arranged for the epilogues that evaluate it once per
+// hidden activation: erf(z) = sign(x) y, y = 1 - p(t) t e^(-z^2), so GELU = h + |h| y with h = x/2 -- no copysign, no (1 + erf),
+// and e^(-z^2) = 2^(-w^2), w = x sqrt(log2(e)/2), straight on v_exp_f32: 12 VALU + 2 transcendental instructions (15 + 2 before).
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float h = 0.5f * x;
+  const float t = fast_rcp(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752440f, 1.0f));
+  const float w = x * 0.84932180028801904272f;           // sqrt(log2(e) / 2)
+#if defined(MLDHIP_SIM)
+  const float e = exp2f(-(w * w));
+#else
+  const float e = __builtin_amdgcn_exp2f(-(w * w));
+#endif
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float y = fmaf(-e, p * t, 1.0f);
+  return fmaf(fabsf(h), y, h);
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
 struct alignas(16) F4 { float x, y, z, w; };
@@ -193,13 +211,27 @@ __device__ __forceinline__ unsigned f16_rne_bits(float x) {       // IEEE half, 
 __device__ __forceinline__ float f16_bits_value(unsigned b) {
   return (float)__builtin_bit_cast(_Float16, (unsigned short)(b & 0xFFFFu));
 }
-// two floats -> packed half pair of the high parts and of the low parts (element 0 in the low half of the word)
-__device__ __forceinline__ void split16_pair(float a, float b, unsigned& hi, unsigned& lo) {
-  const float ca = fminf(fmaxf(a, -65504.f), 65504.f), cb = fminf(fmaxf(b, -65504.f), 65504.f);
-  const unsigned ha = f16_rne_bits(ca), hb = f16_rne_bits(cb);
-  const float ra = ca - f16_bits_value(ha), rb = cb - f16_bits_value(hb);
+// two floats -> packed half pair of the high parts and of the low parts (element 0 in the low half of the word), NO range clamp:
+// five instructions on gfx950 (v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32).  For values produced inside
+// a kernel (GELU / LayerNorm / attention outputs): anything beyond +-65 504 becomes inf and then NaN, loudly, instead of saturating.
+__device__ __forceinline__ void split16_two(float a, float b, unsigned& hi, unsigned& lo) {
+#if defined(MLDHIP_SIM)
+  const unsigned ha = f16_rne_bits(a), hb = f16_rne_bits(b);
   hi = ha | (hb << 16);
-  lo = f16_rne_bits(ra) | (f16_rne_bits(rb) << 16);
+  lo = f16_rne_bits(a - f16_bits_value(ha)) | (f16_rne_bits(b - f16_bits_value(hb)) << 16);
+#else
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+  const f32x2_t rem = v - __builtin_convertvector(h, f32x2_t);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(rem, f16x2_t));
+#endif
+}
+// the same for values that arrive from outside (input rows, weights): clamped to the half range first
+__device__ __forceinline__ void split16_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  split16_two(fminf(fmaxf(a, -65504.f), 65504.f), fminf(fmaxf(b, -65504.f), 65504.f), hi, lo);
 }
 // one float -> (high, low) half bits (kernels that write 16-bit elements of a split image one at a time)
 __device__ __forceinline__ void split16_one(float a, unsigned short& hi, unsigned short& lo) {

@@ -47,6 +47,7 @@ struct Tile32Args {
   long long pstride = 0;
   int M = 0, N = 0;
   float wscale = 1.f;            // PREC_FP8: per-tensor power-of-two scale of W (the A rows are scaled per row in-kernel)
+  int w_split = 0;               // PREC_BF16X3: W points into the pre-split (hi | lo half) image of the weight arena (elementwise.hpp)
   unsigned long long* trace = nullptr;   // measurement only: 8 timestamps per wave (see mldhip_profile_trace)
 };
 
@@ -64,15 +65,31 @@ __device__ __forceinline__ void st_operand(float* row, int lane, F4 v, float sca
     st4(row + lane * 4, v);
   } else if constexpr (PREC == PREC_BF16) {
     *reinterpret_cast<U2*>(reinterpret_cast<unsigned*>(row) + lane * 2) = U2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+  } else if constexpr (PREC == PREC_BF16X3) {
+    // split-f16 image, the one split_bf16_weights_kernel writes: per 32-wide K chunk 16 words of high halves, then 16 of low halves
+    unsigned h0, l0, h1, l1;
+    split16_pair(v.x, v.y, h0, l0);
+    split16_pair(v.z, v.w, h1, l1);
+    unsigned* d = reinterpret_cast<unsigned*>(row) + (lane >> 3) * 32 + (lane & 7) * 2;
+    *reinterpret_cast<U2*>(d) = U2{h0, h1};
+    *reinterpret_cast<U2*>(d + 16) = U2{l0, l1};
   } else {
     reinterpret_cast<unsigned*>(row)[lane] = pack_fp8x4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
   }
 }
 // one 32-wide K chunk of a 16x16 tile: acc += A_frag . B_frag (fp32: 8 MFMAs alternating over two accumulators to hide
-// the dependent-issue latency; bf16 / fp8: one MFMA, accumulators alternate by chunk parity)
+// the dependent-issue latency; bf16 / fp8: one MFMA, accumulators alternate by chunk parity; split-f16: three MFMAs, the two
+// cross terms in acc0 and the hi x hi term in acc1)
 template <int PREC>
 __device__ __forceinline__ void mma_chunk(const float* arow, const float* wrow, int kc, int g, f32x4& acc0, f32x4& acc1) {
-  if constexpr (PREC == PREC_F32) {
+  if constexpr (PREC == PREC_BF16X3) {
+    const U4* ar = reinterpret_cast<const U4*>(arow) + kc * 8 + g;
+    const U4* wr = reinterpret_cast<const U4*>(wrow) + kc * 8 + g;
+    const U4 ah = ar[0], al = ar[4], wh = wr[0], wl = wr[4];
+    acc0 = mfma_x3_16x16x32(al, wh, acc0);
+    acc1 = mfma_x3_16x16x32(ah, wh, acc1);
+    acc0 = mfma_x3_16x16x32(ah, wl, acc0);
+  } else if constexpr (PREC == PREC_F32) {
     const F4 a0 = ld4(arow + kc * 32 + g * 4), a1 = ld4(arow + kc * 32 + 16 + g * 4);   // k-slots 4g .. + 3 and 16 + 4g .. + 3 (A and W alike)
     const F4 b0 = ld4(wrow + kc * 32 + g * 4), b1 = ld4(wrow + kc * 32 + 16 + g * 4);
     acc0 = mfma_f32_16x16x4(a0.x, b0.x, acc0);
@@ -120,11 +137,21 @@ __device__ __forceinline__ F4 f4add(F4 a, F4 b) { return F4{a.x + b.x, a.y + b.y
 // wait per element -- cdna_hip_programming.md, "three .s-level traps" (c)).
 // (Passing K through LDS in two 128-wide pieces so that two workgroups fit a CU was measured: +2.9 % with four batches in
 // flight, -10 % for one batch; removed -- kernels/strip.hpp is the throughput form.  profiles/r01_v17_xcd_kh_ab.txt.)
-// PREC: operand format of the MFMAs (rt.hpp PREC_F32 / PREC_BF16 / PREC_FP8; the A prologue and the epilogue stay fp32).
-template <int MT, int NS0, bool TRACE, int PREC = PREC_F32>
+// PREC: operand format of the MFMAs (rt.hpp PREC_F32 / PREC_BF16 / PREC_FP8 / PREC_BF16X3 = split-f16, 3 MFMAs of 16 cycles per 32-wide
+// K chunk instead of 8 of 32; the A prologue and the epilogue stay fp32).
+// MODE: how the A rows are obtained is a COMPILE-TIME property of the launch.  NS0 = 0: MODE 0 = plain rows (src[0] / src[1] by K slice),
+// MODE 1 = 3-token attention outputs; NS0 > 0: MODE 0 = every K slice combines src[0]'s slabs, MODE 1 = slices >= nz0 read src[1] as
+// plain rows (the skip linear).  As run-time branches the three source paths cost a second memory round trip per kernel: hipcc lays
+// them out as successors of each other (an `s_cbranch_execz` skip edge), so the wait-count pass sees the OTHER path's row loads as
+// pending writes of the registers this path re-uses and waits `vmcnt(0)` -- i.e. for the weight loads issued at the top -- before it
+// issues its own loads (r03: FFN1 prologue 5 230 cycles against 2 152 for the plain-row FFN2; profiles/r03_tile32_phase_trace.json).
+template <int MT, int NS0, bool TRACE, int PREC = PREC_F32, int MODE = 0>
 __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
   static_assert(MT == 16 || MT == 32, "row tile");
-  static_assert(PREC == PREC_F32 || PREC == PREC_BF16 || PREC == PREC_FP8, "operand format");
+  static_assert(MODE == 0 || MODE == 1, "source mode");
+  constexpr bool kAttn = NS0 == 0 && MODE == 1;       // A rows = attention outputs
+  constexpr bool kTwo = NS0 > 0 && MODE == 1;         // combine source + a plain second source
+  static_assert(PREC == PREC_F32 || PREC == PREC_BF16 || PREC == PREC_FP8 || PREC == PREC_BF16X3, "operand format");
   constexpr int RPW = MT / 8;                 // A rows assembled per wave
   constexpr int KW = 256, ST = kT32Stride;    // K columns resident in LDS, LDS row stride (floats)
 #if defined(MLDHIP_SIM)
@@ -142,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
   // instant; in dispatch order the reads spread over every channel of every XCD.  profiles/r01_v17_xcd_kh_ab.txt.)
   const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   const int m0 = bx * MT, n0 = by * 64, z = bz;
-  const bool second = z >= p.nz0;
+  const bool second = (NS0 == 0 || kTwo) ? z >= p.nz0 : false;
   const ASrc& src = second ? p.src[1] : p.src[0];
   const int acol = (second ? z - p.nz0 : z) * 256;
   const int wcol = z * 256;
@@ -171,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
     rows[i] = live[i] ? row : p.M - 1;
   }
   F4 areg[RPW];
-  if (src.attn_R > 0) {
+  if constexpr (kAttn) {
     // nn.MultiheadAttention over the 3 tokens of one sample (cross_attention.py:265-266): head = lane >> 4
     // (64 dims = 16 lanes x 4), q pre-scaled by 1/sqrt(64), softmax over the 3 keys, all in registers.
     const int R = src.attn_R;
@@ -211,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
       areg[i].z = p0 * v[i][0].z + p1 * v[i][1].z + p2 * v[i][2].z;
       areg[i].w = p0 * v[i][0].w + p1 * v[i][1].w + p2 * v[i][2].w;
     }
-  } else if (NS0 == 0 || second) {
+  } else if (NS0 == 0 || (kTwo && second)) {
 #pragma unroll
     for (int i = 0; i < RPW; ++i) areg[i] = ld4(src.base + (long long)rows[i] * src.ld + acol + lane * 4);
   } else {
@@ -289,7 +316,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) st_operand<PREC>(Ws + (wave + i * 8) * ST, lane, wreg[i], p.wscale);
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (PREC == PREC_BF16X3) break;
+      st_operand<PREC>(Ws + (wave + i * 8) * ST, lane, wreg[i], p.wscale);
+    }
+    if constexpr (PREC == PREC_BF16X3) {
+      if (p.w_split) {                          // W came from the pre-split image: the loaded words ARE the row image
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * ST + lane * 4, wreg[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st_operand<PREC>(Ws + (wave + i * 8) * ST, lane, wreg[i], p.wscale);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * 8) * ST, lane, areg[i], ascale[i]);
     if constexpr (tracing) ts[2] = clock_pinned();      // tile parked in LDS (this wave)

@@ -269,7 +269,7 @@ def test_mld_module_surface_on_gpu(dev):
 
 def test_split_f16_decode_mode_meets_the_joint_tolerance(dev, golden_dir):
     """precision = F16X3: the decoder on split-f16 MFMAs, every kernel choice: the row-strip GEMMs + register-direct feed-forward
-    kernel (defaults: "strip_gemm" = 1, "ffn_strip" = 6), the 64-row strips, and round 2's staged tiles + fused feed-forward; against
+    kernel ("strip_gemm" = 1, "ffn_strip" = 6; the default 1 picks 64-row strips at this size), the 64-row strips, and round 2's staged tiles + fused feed-forward; against
     the reference's own features / joints (pipeline_b64 fixture) and its ragged MldVae.decode fixture; the three builds agree to
     fp32-rounding class differences."""
     e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=1)

@@ -7,7 +7,8 @@ import numpy as np, torch
 from mld_hip import _lib, synthetic as syn
 
 B, T = 64, 196
-eng = _lib.Engine(device=0, max_batch=B, max_frames=T)
+PREC = int(os.environ.get("TRACE_PREC", "1"))                  # 1 = split-f16 (the latency kernels on split-f16 MFMAs), 0 = exact fp32
+eng = _lib.Engine(device=0, max_batch=B, max_frames=T, precision=PREC)
 eng.load_state_dict(syn.make_denoiser_state_dict(), "denoiser."); eng.load_state_dict(syn.make_vae_state_dict(), "vae.")
 m, s = syn.make_mean_std(); eng.load_tensor("mean", m); eng.load_tensor("std", s); eng.finalize()
 b = syn.make_batch(B)
@@ -36,4 +37,4 @@ for name in ("den_qkv", "den_outproj", "den_ffn1", "den_ffn2"):
                  "phase_cycles_p90": {n: int(np.percentile(d[:, :, i], 90)) for i, n in enumerate(names)}}
     print(name, json.dumps(out[name]))
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(REPO, "gpurun_out", "tile32_trace.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(REPO, "gpurun_out", "tile32_trace_prec%d.json" % PREC), "w"), indent=1)
