@@ -175,7 +175,7 @@ __device__ __forceinline__ void split_hi_lo_x8(const float (&x)[8], U4& hi, U4& 
   split16_pair(x[6], x[7], hi.w, lo.w);
 }
 
-// the same for softmax numerators (values in [0, 1]: no range clamp needed)
+// the same for softmax numerators (bounded by construction -- [0, 1], or [0, 2^8] under the lazy reference of the key-blocked kernel: no range clamp)
 __device__ __forceinline__ void split_hi_lo_x8_unit(const float (&x)[8], U4& hi, U4& lo) {
   split16_two(x[0], x[1], hi.x, lo.x);
   split16_two(x[2], x[3], hi.y, lo.y);
@@ -264,7 +264,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const F4 t0 = ld4(qp + c * 32), t1 = ld4(qp + c * 32 + 4);
-      const float x[8] = {t0.x * 0.125f, t0.y * 0.125f, t0.z * 0.125f, t0.w * 0.125f, t1.x * 0.125f, t1.y * 0.125f, t1.z * 0.125f, t1.w * 0.125f};
+      // 1/sqrt(64) and log2(e) in one factor: the scores come out in the log2 domain and the softmax runs on v_exp_f32 (2^x) directly
+      constexpr float qs = 0.125f * 1.44269504088896340736f;
+      const float x[8] = {t0.x * qs, t0.y * qs, t0.z * qs, t0.w * qs, t1.x * qs, t1.y * qs, t1.z * qs, t1.w * qs};
       split_hi_lo_x8(x, qh[c], ql[c]);
     }
     f32x4 s[2 * NKB];
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __
     for (int kt = 0; kt < 2 * NKB; ++kt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float e = expf(s[kt][i] - m);   // exp(-inf) = 0 for masked keys
+        const float e = fast_exp2(s[kt][i] - m);   // 2^(-inf) = 0 for masked keys
         s[kt][i] = e;
         den += e;
       }
@@ -417,7 +419,8 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const F4 t0 = ld4(qp + c * 32), t1 = ld4(qp + c * 32 + 4);
-      const float x[8] = {t0.x * 0.125f, t0.y * 0.125f, t0.z * 0.125f, t0.w * 0.125f, t1.x * 0.125f, t1.y * 0.125f, t1.z * 0.125f, t1.w * 0.125f};
+      constexpr float qs = 0.125f * 1.44269504088896340736f;     // 1/sqrt(64) x log2(e): scores in the log2 domain (softmax on v_exp_f32)
+      const float x[8] = {t0.x * qs, t0.y * qs, t0.z * qs, t0.w * qs, t1.x * qs, t1.y * qs, t1.z * qs, t1.w * qs};
       split_hi_lo_x8(x, qh[t][c], ql[t][c]);
     }
   }
@@ -464,40 +467,44 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if (t >= nt) continue;
-        // online softmax of query r over this block's keys 32 kb + 16 k2 + 4 g + i
-        float mx = -INFINITY;
+        // online softmax of query r over this block's keys 32 kb + 16 k2 + 4 g + i, in the log2 domain.  The reference point m of a
+        // query moves LAZILY: only when a block's maximum exceeds it by more than 8 (any reference is exact as long as 2^(s - m) stays
+        // in range: here <= 2^8, far inside the half range of the split P), so after the first block or two the rescale of l and of
+        // the 16 output accumulators -- and the four lane shuffles that fetch its factors -- is skipped by a wave-uniform branch.
+        if (kb * 32 + 32 > len) {                 // the block that crosses the length: keys past it get -inf (wave-uniform test)
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
+          for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[t][k2][i] = kb * 32 + k2 * 16 + g * 4 + i < len ? s[t][k2][i] : -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3])),
+                         fmaxf(fmaxf(s[t][1][0], s[t][1][1]), fmaxf(s[t][1][2], s[t][1][3])));
+        mx = max_groups(mx);                       // finite: key 32 kb < len
+        if (wave_any(mx > mrun[t] + 8.0f)) {       // first block: mrun = -inf
+          const float mnew = fmaxf(mrun[t], mx);
+          const float alpha = fast_exp2(mrun[t] - mnew);   // 2^(-inf) = 0 on the first block
+          lrun[t] *= alpha;
+          mrun[t] = mnew;
+          // accumulator row i of this lane is query 4 g + i: its rescale factor sits in lane 4 g + i
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const bool valid = kb * 32 + k2 * 16 + g * 4 + i < len;
-            s[t][k2][i] = valid ? s[t][k2][i] : -INFINITY;
-            mx = fmaxf(mx, s[t][k2][i]);
+            const float a = wave_bcast(alpha, g * 4 + i);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[t][dt][i] *= a;
           }
-        mx = max_groups(mx);
-        const float mnew = fmaxf(mrun[t], mx);     // finite: key 32 kb < len
-        const float alpha = expf(mrun[t] - mnew);  // exp(-inf) = 0 on the first block
+        }
         float psum = 0.f;
         float pf[8];
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float e = expf(s[t][k2][i] - mnew);   // exp(-inf) = 0 for masked keys
+            const float e = fast_exp2(s[t][k2][i] - mrun[t]);   // 2^(-inf) = 0 for masked keys
             pf[k2 * 4 + i] = e;
             psum += e;
           }
-        psum = sum_groups(psum);
-        lrun[t] = lrun[t] * alpha + psum;
-        mrun[t] = mnew;
+        lrun[t] += sum_groups(psum);
         split_hi_lo_x8_unit(pf, ph[t], pl[t]);
-        // accumulator row i of this lane is query 4 g + i: its rescale factor sits in lane 4 g + i
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float a = wave_bcast(alpha, g * 4 + i);
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) oacc[t][dt][i] *= a;
-        }
       }
       // O += P V_blk: k-slot 8 g + j <-> key (j >> 2) * 16 + 4 g + (j & 3) of the block
 #pragma unroll

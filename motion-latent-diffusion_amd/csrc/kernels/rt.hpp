@@ -141,6 +141,23 @@ __device__ __forceinline__ float fast_rcp(float x) {
   return __builtin_amdgcn_rcpf(x);
 #endif
 }
+// 2^x (v_exp_f32) and "true in any lane" (wave-uniform)
+__device__ __forceinline__ float fast_exp2(float x) {
+#if defined(MLDHIP_SIM)
+  return exp2f(x);
+#else
+  return __builtin_amdgcn_exp2f(x);
+#endif
+}
+__device__ __forceinline__ bool wave_any(bool p) {
+#if defined(MLDHIP_SIM)
+  float f = p ? 1.f : 0.f;
+  for (int m = 1; m < 64; m <<= 1) f = fmaxf(f, hipsim::shfl_xor(f, m));
+  return f > 0.f;
+#else
+  return __builtin_amdgcn_ballot_w64(p) != 0;
+#endif
+}
 __device__ __forceinline__ float fast_exp(float x) {
 #if defined(MLDHIP_SIM)
   return expf(x);

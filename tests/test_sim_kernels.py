@@ -684,6 +684,45 @@ def test_key_blocked_attention_matches_whole_kv_attention_sim(ow):
         e.close()
 
 
+def test_key_blocked_attention_moves_its_reference_point_sim():
+    """The online softmax of attn_flash_x3_kernel keeps a LAZY reference (it moves only when a key block's maximum exceeds it by more
+    than 8 in the log2 domain).  With the synthetic weights the scores of a query differ by less than that, so only the first block
+    ever takes the rescale branch; here the self-attention in-projections are scaled x12 (score spread ~ x144): references move in
+    later blocks too, P reaches its 2^8 bound, and the result must still match the whole-K/V kernel and the oracle."""
+    sdd, sdv = simlib.text_weights()
+    sdv = dict(sdv)
+    scaled = 0
+    for k in sdv:
+        if "self_attn.in_proj_weight" in k and k.startswith("decoder."):
+            w = sdv[k].copy()
+            w[:512] *= 12.0                       # q and k rows
+            sdv[k] = w
+            scaled += 1
+    assert scaled > 0
+    ops = O.NumpyOps(np.float32)
+    bv = O.to_backend(ops, sdv)
+    B, T, lens = 1, 132, [130]
+    e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=B, max_frames=T, num_inference_steps=2, num_layers=simlib.SIM_LAYERS, precision=1)
+    e.load_state_dict(sdd, "denoiser.")
+    e.load_state_dict(sdv, "vae.")
+    mean, std = syn.make_mean_std()
+    e.load_tensor("mean", mean)
+    e.load_tensor("std", std)
+    e.finalize()
+    e.set_option("gemm_small_m", 0)
+    z = syn._rng(8, "x3attn").standard_normal((B, 1, 256)).astype(np.float32)
+    ref = np.asarray(O.vae_decode(ops, bv, z, lens))
+    outs = []
+    for fl in (2, 0):
+        e.set_option("flash_attn", fl)
+        feats = np.zeros((B, T, 263), np.float32)
+        e.vae_decode(z, lens, feats)
+        assert np.isfinite(feats).all() and np.abs(feats[:, :130] - ref).max() < 5e-4
+        outs.append(feats)
+    assert 0 < np.abs(outs[0] - outs[1]).max() < 1e-4
+    e.close()
+
+
 @pytest.mark.parametrize("prec", [0, 1])
 def test_sample_major_persistent_loop_sim(prec):
     """loop_kernel = 3 (kernels/loop_fused.hpp): the whole reverse loop as ONE launch, a workgroup per 8 motions -- B = 11 (two
