@@ -148,9 +148,10 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "fused_ring"      persistent loop: weight items in flight per lane, 4 (default) or 8
  *   "fused_dbg"       measurement builds of the persistent loop (WRONG results): 1 = no weight stream, 2 = no MFMAs
  *   "ffn_strip"       F16X3 / FP8 modes, decoder / encoder layers: strip height of the register-direct kernels (kernels/ffn_strip.hpp,
- *                     kernels/gemm_strip_x3.hpp): 1 (default) = 96 rows when the launch has more than 512 strips of 64, else 64 (one bs-64
- *                     request: 196 strips on 256 CUs instead of 131 longer ones); 6 / 4 = 96 / 64 rows always; 0 = feed-forward block by
- *                     kernels/ffn_fused.hpp or the two staged GEMMs ("fused_ffn")
+ *                     kernels/gemm_strip_x3.hpp): 1 (default) = by launch size -- more than 512 strips of 64 rows: 96-row strips for the
+ *                     GEMMs, 48-row strips at two workgroups per CU for the feed-forward block; else 64 rows (one bs-64 request: 196
+ *                     strips on 256 CUs instead of 131 longer ones); 6 / 4 = 96 / 64 rows always, 3 = 48 rows for the feed-forward
+ *                     block (96 for the GEMMs); 0 = feed-forward block by kernels/ffn_fused.hpp or the two staged GEMMs ("fused_ffn")
  *   "tile_x3"         F16X3 mode: 1 (default) = the latency kernels of the reverse loop (kernels/tile32.hpp, one request at a time) multiply
  *                     on split-f16 MFMAs reading the pre-split weight image, 0 = on exact-fp32 MFMAs
  *   "strip_gemm"      F16X3 / FP8 modes, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:

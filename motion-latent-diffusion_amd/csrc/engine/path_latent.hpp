@@ -506,7 +506,10 @@ void ffn_block(Ctx& c, const float* x, float* y, int M, const float* w1, const f
     FfnArgs a;
     a.X = x; a.W1 = e->ffn_stream_of[w1]; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.Y = y; a.M = M;
     if (ragged_T > 0) { a.skip_lens = e->lens_dev; a.skip_rpg = ragged_T; }
-    if (strip_rows_rt(e, M) == 6) MLD_LAUNCH(ffn_strip_x3_kernel<6>, dim3((M + 95) / 96), dim3(512), (ffn_strip_lds_bytes<6>()), c.stream, a);
+    // auto: 48-row strips, two workgroups per CU (four waves per SIMD, 128 registers each) for launches that fill the chip: 2 % off the
+    // decoder against 96-row strips (r03, 2 048 motions: 25.2 vs 25.8 ms) although the weights are streamed twice as often
+    if (e->ffn_strip == 3 || (e->ffn_strip == 1 && strip_rows_rt(e, M) == 6)) MLD_LAUNCH(ffn_strip_x3_kernel<3>, dim3((M + 47) / 48), dim3(512), (ffn_strip_lds_bytes<3>()), c.stream, a);
+    else if (strip_rows_rt(e, M) == 6) MLD_LAUNCH(ffn_strip_x3_kernel<6>, dim3((M + 95) / 96), dim3(512), (ffn_strip_lds_bytes<6>()), c.stream, a);
     else MLD_LAUNCH(ffn_strip_x3_kernel<4>, dim3((M + 63) / 64), dim3(512), (ffn_strip_lds_bytes<4>()), c.stream, a);
     count(c);
     check_launch(c, "ffn_strip_x3");

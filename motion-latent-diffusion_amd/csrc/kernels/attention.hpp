@@ -229,27 +229,33 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __
         *reinterpret_cast<U2*>(Kl + key * KST + c4 * 2) = U2{l0, l1};
       }
     }
+    // V^T: a thread owns one head dim and FOUR consecutive keys -- four coalesced 4-byte loads (a wave covers 256 contiguous bytes of
+    // a key's row) and, after the split, ONE 8-byte LDS store per plane: the (key pair | key pair) words of its row.  (Owning four
+    // dims of one key, as for K, means eight 2-byte stores per thread that land 8-way on the same banks: 4 x VST words apart.)
+    constexpr int NVG = NKB * 8, NVI = (NVG + NW - 1) / NW;     // groups of 4 keys; iterations (a wave takes one group per iteration)
+    const int vd = tid & 63, vg0 = tid >> 6;
+    const float* vbase = qkv + (long long)b * T * 3 * D + h * HD + 2 * D + vd;
+    float vv[NVI][4];
 #pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-      const int key = j * KPI + k0;
-      const int kc = key < len ? key : len - 1;
-      v[j] = ld4(base + 2 * D + (long long)kc * 3 * D);
-    }
+    for (int it = 0; it < NVI; ++it)
 #pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-      const int key = j * KPI + k0;
-      const float m = key < len ? 1.f : 0.f;
-      if (key < nkb * 32) {                  // keys of the (possibly half-empty) last 32-key block are zero
+      for (int q = 0; q < 4; ++q) {
+        const int key = (it * NW + vg0) * 4 + q;
+        const int kc = key < len ? key : len - 1;
+        vv[it][q] = vbase[(long long)kc * 3 * D];
+      }
+#pragma unroll
+    for (int it = 0; it < NVI; ++it) {
+      const int vg = it * NW + vg0;
+      if (vg < nkb * 8) {                    // keys of the (possibly half-empty) last 32-key block are zero
+        float vm[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vm[q] = vg * 4 + q < len ? vv[it][q] : 0.f;
         unsigned h0, l0, h1, l1;
-        split16_pair(v[j].x * m, v[j].y * m, h0, l0);
-        split16_pair(v[j].z * m, v[j].w * m, h1, l1);
-        unsigned short* vh = reinterpret_cast<unsigned short*>(Vh) + key;
-        unsigned short* vl = reinterpret_cast<unsigned short*>(Vl) + key;
-        const int d0 = c4 * 4;
-        vh[(d0 + 0) * VST * 2] = (unsigned short)(h0 & 0xFFFFu); vh[(d0 + 1) * VST * 2] = (unsigned short)(h0 >> 16);
-        vh[(d0 + 2) * VST * 2] = (unsigned short)(h1 & 0xFFFFu); vh[(d0 + 3) * VST * 2] = (unsigned short)(h1 >> 16);
-        vl[(d0 + 0) * VST * 2] = (unsigned short)(l0 & 0xFFFFu); vl[(d0 + 1) * VST * 2] = (unsigned short)(l0 >> 16);
-        vl[(d0 + 2) * VST * 2] = (unsigned short)(l1 & 0xFFFFu); vl[(d0 + 3) * VST * 2] = (unsigned short)(l1 >> 16);
+        split16_pair(vm[0], vm[1], h0, l0);
+        split16_pair(vm[2], vm[3], h1, l1);
+        *reinterpret_cast<U2*>(Vh + vd * VST + vg * 2) = U2{h0, h1};
+        *reinterpret_cast<U2*>(Vl + vd * VST + vg * 2) = U2{l0, l1};
       }
     }
   }

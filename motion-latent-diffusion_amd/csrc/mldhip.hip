@@ -204,6 +204,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 1, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 1, true>()));
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<6>());
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<4>());
+  (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<3>());
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
@@ -344,7 +345,7 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "strip_gemm must be 0 or 1");
     e->strip_gemm = (int)value;
   } else if (n == "ffn_strip") {
-    if (value != 0 && value != 1 && value != 4 && value != 6) return e->fail(MLDHIP_EINVAL, "ffn_strip must be 0 (off), 1 (auto: 64- or 96-row strips by launch size), 4 or 6");
+    if (value != 0 && value != 1 && value != 3 && value != 4 && value != 6) return e->fail(MLDHIP_EINVAL, "ffn_strip must be 0 (off), 1 (auto: 64- or 96-row strips by launch size), 3, 4 or 6");
     e->ffn_strip = (int)value;
   } else if (n == "fused_ffn") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "fused_ffn must be 0 or 1");

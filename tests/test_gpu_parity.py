@@ -269,7 +269,7 @@ def test_mld_module_surface_on_gpu(dev):
 
 def test_split_f16_decode_mode_meets_the_joint_tolerance(dev, golden_dir):
     """precision = F16X3: the decoder on split-f16 MFMAs, every kernel choice: the row-strip GEMMs + register-direct feed-forward
-    kernel ("strip_gemm" = 1, "ffn_strip" = 6; the default 1 picks 64-row strips at this size), the 64-row strips, and round 2's staged tiles + fused feed-forward; against
+    kernel ("strip_gemm" = 1, "ffn_strip" = 6; the default 1 picks 64-row strips at this size), the 64- and 48-row strips, and round 2's staged tiles + fused feed-forward; against
     the reference's own features / joints (pipeline_b64 fixture) and its ragged MldVae.decode fixture; the three builds agree to
     fp32-rounding class differences."""
     e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=1)
@@ -278,7 +278,7 @@ def test_split_f16_decode_mode_meets_the_joint_tolerance(dev, golden_dir):
     gd = _gold(golden_dir, "vae_decode_b3.npz")
     b = syn.make_batch(64)
     feats_by = {}
-    for sg, fs in ((1, 6), (1, 4), (0, 0)):
+    for sg, fs in ((1, 6), (1, 4), (1, 3), (0, 0)):
         e.set_option("strip_gemm", sg)
         e.set_option("ffn_strip", fs)
         lat, feats, joints, _ = _run_sample(e, dev, b)

@@ -782,7 +782,7 @@ def test_register_direct_ffn_kernel_sim(ow):
     eps = g.standard_normal((3, 1, 256)).astype(np.float32)
     ref = np.asarray(O.vae_decode(ops, bv, z, lens))
     outs = {}
-    for opt in (0, 6, 4):
+    for opt in (0, 6, 4, 3):
         e.set_option("ffn_strip", opt)
         feats = np.full((3, 40, 263), np.nan, np.float32)
         e.vae_decode(z, lens, feats)
@@ -792,7 +792,7 @@ def test_register_direct_ffn_kernel_sim(ow):
         for i, n in enumerate(lens):
             assert np.all(feats[i, n:] == 0)
         outs[opt] = (feats, mu.copy())
-    for opt in (6, 4):
+    for opt in (6, 4, 3):
         assert 0 < np.abs(outs[opt][0] - outs[0][0]).max() < 5e-5 and 0 < np.abs(outs[opt][1] - outs[0][1]).max() < 5e-5
     with pytest.raises(_lib.MldHipError):
         e.set_option("ffn_strip", 5)
