@@ -73,15 +73,26 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
     ring[slot][1] = ld4(s + 4);
     ++gitem;
   };
-  auto mma_item = [&](int j, const F4 (&x)[RT][2], f32x4 (&acc)[RT]) __attribute__((always_inline)) {
+  // tr: the transposed product (loop_fused.hpp mma_item): lane (r, g) holds row r, columns 4g .. 4g + 3 of the wave's 16 -- linear1,
+  // whose outputs go through GELU into the hidden image as 8-byte row stores instead of 2-byte ones that collide on the banks
+  auto mma_item = [&](int j, const F4 (&x)[RT][2], f32x4 (&acc)[RT], bool tr = false) __attribute__((always_inline)) {
     const int slot = j % RING;
     const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
+    if (tr) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][1]), acc[t]);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = mfma_x3_16x16x32(wl, __builtin_bit_cast(U4, x[t][0]), acc[t]);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][0]), acc[t]);
+    } else {
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][1]), wh, acc[t]);
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][0]), wl, acc[t]);
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][0]), wh, acc[t]);
+    }
     gload(slot);
     sched_fence();                     // keeps the ring's loads where they are written (rt.hpp)
   };
@@ -128,32 +139,30 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
     for (int c = 0; c < 8; ++c) {
       if constexpr (NB == 2) { if (c + 1 < 8) frags(xa, XS, c + 1, x[(c + 1) & 1]); }
       else frags(xa, XS, c, x[0]);
-      mma_item(c, x[c & (NB - 1)], h);
+      mma_item(c, x[c & (NB - 1)], h, true);
     }
   };
   constexpr int NB = RT == 4 ? 2 : 1;
-  auto gelu_two = [&](int t, int ip, float b1) __attribute__((always_inline)) {      // elements 2 ip, 2 ip + 1 of tile t
-    split16_two(gelu_erf(h[t][2 * ip] + b1), gelu_erf(h[t][2 * ip + 1] + b1), hvh[t][ip], hvl[t][ip]);
+  // elements 2 ip, 2 ip + 1 of tile t: row 16 t + r, hidden columns 16 wave + 4 g + 2 ip, + 1 (transposed linear1 accumulators)
+  auto gelu_two = [&](int t, int ip, F4 b1) __attribute__((always_inline)) {
+    split16_two(gelu_erf(h[t][2 * ip] + (ip ? b1.z : b1.x)), gelu_erf(h[t][2 * ip + 1] + (ip ? b1.w : b1.y)), hvh[t][ip], hvl[t][ip]);
   };
   auto write_block = [&]() __attribute__((always_inline)) {
     __syncthreads();                   // every wave has left run2 of the previous block
 #pragma unroll
     for (int t = 0; t < RT; ++t)
-#pragma unroll
-      for (int ip = 0; ip < 2; ++ip) {
-        unsigned short* q0 = reinterpret_cast<unsigned short*>(Hs + (t * 16 + g * 4 + 2 * ip) * HS) + hw0;
-        unsigned short* q1 = reinterpret_cast<unsigned short*>(Hs + (t * 16 + g * 4 + 2 * ip + 1) * HS) + hw0;
-        q0[0] = (unsigned short)(hvh[t][ip] & 0xFFFFu);
-        q0[32] = (unsigned short)(hvl[t][ip] & 0xFFFFu);
-        q1[0] = (unsigned short)(hvh[t][ip] >> 16);
-        q1[32] = (unsigned short)(hvl[t][ip] >> 16);
-      }
+    {
+      // four consecutive columns of row 16 t + r: words (wave >> 1) 32 + (wave & 1) 8 + 2 g, + 1 of the high plane, + 16 for the low one
+      unsigned* w = reinterpret_cast<unsigned*>(Hs + (t * 16 + r) * HS) + (wave >> 1) * 32 + (wave & 1) * 8 + g * 2;
+      *reinterpret_cast<U2*>(w) = U2{hvh[t][0], hvh[t][1]};
+      *reinterpret_cast<U2*>(w + 16) = U2{hvl[t][0], hvl[t][1]};
+    }
     __syncthreads();
   };
 
   run1();
   {
-    const float b1 = p.b1[col0];
+    const F4 b1 = ld4(p.b1 + wave * 16 + g * 4);
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
   }
   for (int hb = 1; hb < 8; ++hb) {
     write_block();                     // block hb - 1 -> LDS
-    const float b1 = p.b1[hb * 128 + col0];
+    const F4 b1 = ld4(p.b1 + hb * 128 + wave * 16 + g * 4);
     run1();                            // linear1 of block hb
     // linear2's share of block hb - 1 (8 items: 4 chunks x 2 column blocks) with the GELU of block hb spread between its items
     constexpr int PER = (RT * 2 + 7) / 8;     // element PAIRS per item

@@ -64,6 +64,7 @@ struct LoopArgs {
   const float* ddim;       // [n][4] DdimCoef per step
   int B, L, n;
   float guidance, init_sigma;
+  unsigned long long* trace = nullptr;   // DBG 5 (measurement build): [workgroup < 64][wave][8] shader cycles per phase, summed over steps and layers
 };
 
 constexpr int kLfXs = 264;                                // LDS row stride (words), = 8 mod 16: conflict-free fragment reads (strip.hpp)
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(512) void pack_loop_stream_kernel(const float* __re
 
 // grid = ceil(B / 8), block = 512 (8 waves, two per SIMD).  X3 = false: exact-fp32 MFMAs; true: split-f16 MFMAs.
 // kLoopRing = items in flight per lane (8 VGPRs each; 4 or 8: every group of items is a multiple of 8 long).
-// DBG (measurement builds, mldhip_set_option "fused_dbg"): 1 = the weight ring is loaded once and never refreshed (matrix +
+// DBG (measurement builds, mldhip_set_option "fused_dbg"; 3 = identity instead of GELU, 4 = no feed-forward epilogue): 1 = the weight ring is loaded once and never refreshed (matrix +
 // LDS + epilogue time without the stream), 2 = the stream is loaded but not multiplied (one VALU add per item keeps the loads live).
 template <bool X3, int kLoopRing, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
@@ -125,6 +126,16 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
 
   // ---- weight ring: this lane's two MFMA operands (32 bytes) of the next kLoopRing items, straight from the fragment-ordered stream
   const float* gsrc = p.stream + tid * 8;
+  // DBG 5: cycles per phase (0 QKV products, 1 scores + softmax + attention output, 2 out-projection, 3 residual + norm1, 4 feed-forward,
+  // 5 residual + norm2 + skip handling, 6 end of step), each stamp behind s_waitcnt 0 -- the counters perturb the overlap they measure
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tph = 0;
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if constexpr (DBG == 5) {
+      const unsigned long long t = clock_pinned();
+      ph[k] += t - tph;
+      tph = t;
+    }
+  };
   int gitem = 0;
   F4 ring[kLoopRing][2];
   auto gload = [&](int slot) __attribute__((always_inline)) {
@@ -137,18 +148,51 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   // and is replaced by item j + kLoopRing as soon as its MFMAs are issued.
   // One item: this wave's 16 weight rows (= output columns) x 32 k against the three row tiles, whose fragments the caller read
   // from LDS: both operand formats keep a chunk of a row as 32 words read as words 4g .. 4g + 3 and 16 + 4g .. + 3.
-  auto mma_item = [&](int j, const F4 (&x)[3][2], f32x4 (&acc)[3]) __attribute__((always_inline)) {
+  // tr: the TRANSPOSED product (weights as the A operand, the rows as B -- the same fragment registers in the other argument): lane
+  // (r, g) then holds row r of the tile, columns 4g .. 4g + 3 of this wave's 16, i.e. four CONSECUTIVE elements of one row, which
+  // leave for an operand image as one 8-byte store per plane.  In the plain layout (rows 4g + i, column r) every element is its own
+  // 2-byte store, and the four g groups of a store hit the same banks (row stride = 8 mod 32 words): the feed-forward epilogue's
+  // stores alone were 6.8 of the loop's 29.3 ms (r03 measurement builds fused_dbg 3 / 4).  Used for linear1, whose output only feeds
+  // GELU and the hidden image.
+  auto mma_item = [&](int j, const F4 (&x)[3][2], f32x4 (&acc)[3], bool tr = false) __attribute__((always_inline)) {
     const int slot = j % kLoopRing;
     if constexpr (DBG == 2) {
       acc[0][0] += ring[slot][0].x + ring[slot][1].w + x[0][0].x;
     } else if constexpr (X3) {
       const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
+      if (tr) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][1]), acc[t]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wl, __builtin_bit_cast(U4, x[t][0]), acc[t]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][0]), acc[t]);
+      } else {
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][1]), wh, acc[t]);
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][0]), wl, acc[t]);
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][0]), wh, acc[t]);
+      }
+    } else if (tr) {
+      const F4 y0 = ring[slot][0], y1 = ring[slot][1];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(y0.x, x[t][0].x, acc[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(y0.y, x[t][0].y, acc[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(y0.z, x[t][0].z, acc[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(y0.w, x[t][0].w, acc[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(y1.x, x[t][1].x, acc[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(y1.y, x[t][1].y, acc[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(y1.z, x[t][1].z, acc[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(y1.w, x[t][1].w, acc[t]);
     } else {
       const F4 y0 = ring[slot][0], y1 = ring[slot][1];
 #pragma unroll
@@ -167,6 +211,42 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
       for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].z, y1.z, acc[t]);
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].w, y1.w, acc[t]);
+    }
+    if constexpr (DBG != 1) gload(slot);
+    sched_fence();
+  };
+  // The transposed item with an epilogue threaded through it: `epi(k)`, k = 0 .. 8, is a few VALU / LDS instructions of work that does
+  // not depend on this item; slice k is issued right behind the item's k-th group of matrix instructions and a scheduling fence pins
+  // the pair.  MFMA and the other VALU instructions share a SIMD's issue port but not its pipes: behind every 16-cycle matrix
+  // instruction there are three free issue slots, and an in-order wave fills them only if the next instructions in ITS stream are
+  // not matrix instructions.  (r03 phase counters: the feed-forward phase took 14.2 ms of the loop's 29.8 where its matrix
+  // instructions need 7.9 -- the compiler's own interleave left MFMA and GELU time adding up.)
+  auto mma_item_sliced = [&](int j, const F4 (&x)[3][2], f32x4 (&acc)[3], auto&& epi) __attribute__((always_inline)) {
+    const int slot = j % kLoopRing;
+    if constexpr (DBG == 2) {
+      acc[0][0] += ring[slot][0].x + ring[slot][1].w + x[0][0].x;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) epi(k);
+    } else if constexpr (X3) {
+      const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][1]), acc[t]); epi(t); sched_fence(); }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { acc[t] = mfma_x3_16x16x32(wl, __builtin_bit_cast(U4, x[t][0]), acc[t]); epi(3 + t); sched_fence(); }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][0]), acc[t]); epi(6 + t); sched_fence(); }
+    } else {
+      const F4 y0 = ring[slot][0], y1 = ring[slot][1];
+      const float yv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float xs[3] = {q < 4 ? (&x[0][0].x)[q] : (&x[0][1].x)[q - 4], q < 4 ? (&x[1][0].x)[q] : (&x[1][1].x)[q - 4], q < 4 ? (&x[2][0].x)[q] : (&x[2][1].x)[q - 4]};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(yv[q], xs[t], acc[t]);
+        epi(q);
+        sched_fence();
+      }
+      epi(8);
     }
     if constexpr (DBG != 1) gload(slot);
     sched_fence();
@@ -200,13 +280,13 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     }
   };
   // one column block against 8 chunks (linear1 of one 128-wide hidden block)
-  auto run1 = [&](const float* a0, f32x4 (&acc0)[3]) __attribute__((always_inline)) {
+  auto run1 = [&](const float* a0, f32x4 (&acc0)[3]) __attribute__((always_inline)) {      // transposed accumulators (mma_item)
     F4 x[2][3][2];
     afrag(a0, 16 * kLfXs, 0, x[0]);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       if (c + 1 < 8) afrag(a0, 16 * kLfXs, c + 1, x[(c + 1) & 1]);
-      mma_item(c, x[c & 1], acc0);
+      mma_item(c, x[c & 1], acc0, true);
     }
   };
   // both column blocks of linear2 against the 4 chunks of one hidden block (row stride kLfHs)
@@ -378,6 +458,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   const float* xa = Xs + r * kLfXs + g * 4;        // A fragments of the layer input
   const float* aa = As + r * kLfXs + g * 4;        // ... of the attention output / the hidden-activation blocks
 
+  if constexpr (DBG == 5) tph = clock_pinned();
   for (int step = 0; step < p.n; ++step) {
     float x[2][3][4];                              // norm2 output of the current layer at this lane's positions
     for (int l = 0; l < p.L; ++l) {
@@ -388,6 +469,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         f32x4 q[3], k[3], vv[3];
         zero3(q); zero3(k); zero3(vv);
         run3(xa, q, k, vv);
+        stamp(0);
         // partial scores over this wave's 16 columns of the head: s[t][u] for the CFG rows 4g .. 4g + 3
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -421,6 +503,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         }
         put(As, kLfXs, hp * 128, o);
         __syncthreads();       // hp = 0: `sc` may be rewritten; hp = 1: the attention output is complete before anybody multiplies it
+        stamp(1);
       }
       // ================= out-projection + residual + norm1 -> Xs
       {
@@ -428,6 +511,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         f32x4 o0[3], o1[3];
         zero3(o0); zero3(o1);
         run2(aa, o0, o1);
+        stamp(2);
         float u[2][3][4];
         get(Xs, kLfXs, 0, u[0]);
         get(Xs, kLfXs, 128, u[1]);
@@ -444,6 +528,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         put(Xs, kLfXs, 0, u[0]);
         put(Xs, kLfXs, 128, u[1]);
         __syncthreads();
+        stamp(3);
       }
       // ================= feed-forward, software pipelined over the eight 128-wide blocks of the hidden activation: the GELU /
       // split / store epilogue of block hb (VALU + LDS) is issued in the same region as linear1's MFMAs of block hb + 1 -- the two
@@ -455,23 +540,80 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         const float* ha = As + r * kLfHs + g * 4;
         // block hb: epilogue of `cur` (its linear1 accumulators) next to linear1 of block hb + 1 into `nxt`, barrier, linear2's share
         auto ffn_stage = [&](int hb, f32x4 (&cur)[3], f32x4 (&nxt)[3], bool more) __attribute__((always_inline)) {
-          const float b1 = sm[kLsL1B + hb * 128 + col0];
+          const F4 b1 = ld4(sm + kLsL1B + hb * 128 + wave * 16 + g * 4);       // biases of this lane's four columns (transposed tile)
           float* hbuf = As + (hb & 1) * kLfHFloats;
           zero3(nxt);
-          // the epilogue's 12 elements are written out between the 8 items of the next block's linear1: two elements after each of
-          // the first six items, so the VALU / LDS work sits in the shadow of matrix instructions that do not depend on it
+          // the epilogue's three tiles leave between the matrix instructions of the next block's linear1: half a tile (two GELUs and a
+          // split) per item over the first six items, in nine slices of two to five instructions (mma_item_sliced); the tile's two
+          // 8-byte stores go out with the odd items
           F4 x[2][3][2];
           if (more) afrag(xa, 16 * kLfXs, 0, x[0]);
+          unsigned ph = 0, pl = 0, qh = 0, ql = 0;
+          float f0 = 0.f, f1 = 0.f;
+          float u0 = 0.f, u1 = 0.f, hh0 = 0.f, hh1 = 0.f, tt0 = 0.f, tt1 = 0.f, ee0 = 0.f, ee1 = 0.f, pp0 = 0.f, pp1 = 0.f;
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
+            auto epi = [&](int k) __attribute__((always_inline)) {
+              if (c >= 6 || DBG == 4) return;                          // DBG 4 (measurement build): no feed-forward epilogue at all
+              const int t = c >> 1, i0 = (c & 1) * 2;
+              constexpr bool kGelu = DBG != 3;                         // DBG 3 (measurement build): identity for GELU
+              if (k == 0) {
+                u0 = cur[t][i0] + (i0 ? b1.z : b1.x);
+                u1 = cur[t][i0 + 1] + (i0 ? b1.w : b1.y);
+                hh0 = 0.5f * u0;
+                hh1 = 0.5f * u1;
+              } else if (k == 1 && kGelu) {                            // rt.hpp gelu_erf, two values side by side
+                tt0 = fast_rcp(fmaf(fabsf(u0), 0.3275911f * 0.70710678118654752440f, 1.0f));
+                tt1 = fast_rcp(fmaf(fabsf(u1), 0.3275911f * 0.70710678118654752440f, 1.0f));
+              } else if (k == 2 && kGelu) {
+                const float w0 = u0 * 0.84932180028801904272f, w1 = u1 * 0.84932180028801904272f;
+                ee0 = fast_exp2(-(w0 * w0));
+                ee1 = fast_exp2(-(w1 * w1));
+              } else if (k == 3 && kGelu) {
+                pp0 = fmaf(1.061405429f, tt0, -1.453152027f);
+                pp1 = fmaf(1.061405429f, tt1, -1.453152027f);
+                pp0 = fmaf(pp0, tt0, 1.421413741f);
+                pp1 = fmaf(pp1, tt1, 1.421413741f);
+              } else if (k == 4 && kGelu) {
+                pp0 = fmaf(pp0, tt0, -0.284496736f);
+                pp1 = fmaf(pp1, tt1, -0.284496736f);
+                pp0 = fmaf(pp0, tt0, 0.254829592f);
+                pp1 = fmaf(pp1, tt1, 0.254829592f);
+              } else if (k == 5 && kGelu) {
+                pp0 = fmaf(-ee0, pp0 * tt0, 1.0f);
+                pp1 = fmaf(-ee1, pp1 * tt1, 1.0f);
+              } else if (k == 6) {
+                if constexpr (kGelu) {
+                  u0 = fmaf(fabsf(hh0), pp0, hh0);
+                  u1 = fmaf(fabsf(hh1), pp1, hh1);
+                }
+                if constexpr (X3) qh = split16_hi(u0, u1);
+              } else if (k == 7) {
+                if constexpr (X3) {
+                  ql = split16_lo(u0, u1, qh);
+                  if (i0 == 0) { ph = qh; pl = ql; }
+                }
+              } else if (k == 8) {
+                // row 16 t + r of the hidden image, columns 16 wave + 4 g .. + 3 of the 128: words (wave >> 1) 32 + (wave & 1) 8 + 2 g, + 1
+                float* hrow = hbuf + (t * 16 + r) * kLfHs;
+                if constexpr (X3) {
+                  if (i0 != 0) {
+                    unsigned* w = reinterpret_cast<unsigned*>(hrow) + (wave >> 1) * 32 + (wave & 1) * 8 + g * 2;
+                    *reinterpret_cast<U2*>(w) = U2{ph, qh};
+                    *reinterpret_cast<U2*>(w + 16) = U2{pl, ql};
+                  }
+                } else {
+                  if (i0 == 0) { f0 = u0; f1 = u1; }
+                  else st4(hrow + wave * 16 + g * 4, F4{f0, f1, u0, u1});
+                }
+              }
+            };
             if (more) {
               if (c + 1 < 8) afrag(xa, 16 * kLfXs, c + 1, x[(c + 1) & 1]);
-              mma_item(c, x[c & 1], nxt);
-            }
-            if (c < 6) {
+              mma_item_sliced(c, x[c & 1], nxt, epi);
+            } else {
 #pragma unroll
-              for (int e = 2 * c; e < 2 * c + 2; e += 2)
-                put_two(hbuf, kLfHs, 0, e >> 2, e & 3, gelu_erf(cur[e >> 2][e & 3] + b1), gelu_erf(cur[e >> 2][(e & 3) + 1] + b1));
+              for (int k = 0; k < 9; ++k) epi(k);
             }
           }
           __syncthreads();
@@ -484,6 +626,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         }
         ffn_stage(6, hA, hB, true);
         ffn_stage(7, hB, hA, false);
+        stamp(4);
         const float lb0 = sm[kLsL2B + col0], lb1 = sm[kLsL2B + 128 + col0];
         get(Xs, kLfXs, 0, x[0]);
         get(Xs, kLfXs, 128, x[1]);
@@ -556,6 +699,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
           __syncthreads();
         }
       }
+      stamp(5);
     }
     // ================= end of the step: encoder.norm on the latent token (mld_denoiser.py:206), CFG (mld.py:339-342), DDIM eta = 0
     {
@@ -581,11 +725,19 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         assemble(step + 1);
         __syncthreads();
       }
+      stamp(6);
     }
   }
   {
     const int c = tid >> 6, c4 = tid & 63;
     if (s0 + c < p.B) st4(p.lat + (long long)(s0 + c) * 256 + c4 * 4, ld4(lats + c * 256 + c4 * 4));
+  }
+  if constexpr (DBG == 5) {
+    if (p.trace && blockIdx.x < 64 && lane == 0) {
+      unsigned long long* o = p.trace + ((long long)blockIdx.x * 8 + wave) * 8;
+      for (int k = 0; k < 7; ++k) o[k] = ph[k];
+      o[7] = ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5] + ph[6];
+    }
   }
 }
 

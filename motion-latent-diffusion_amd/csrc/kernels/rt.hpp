@@ -246,6 +246,28 @@ __device__ __forceinline__ void split16_two(float a, float b, unsigned& hi, unsi
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(rem, f16x2_t));
 #endif
 }
+// split16_two in two pieces (epilogues that spread the work between matrix instructions): the packed high halves, then the packed low ones
+__device__ __forceinline__ unsigned split16_hi(float a, float b) {
+#if defined(MLDHIP_SIM)
+  return f16_rne_bits(a) | (f16_rne_bits(b) << 16);
+#else
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+#endif
+}
+__device__ __forceinline__ unsigned split16_lo(float a, float b, unsigned hi) {
+#if defined(MLDHIP_SIM)
+  return f16_rne_bits(a - f16_bits_value(hi & 0xFFFFu)) | (f16_rne_bits(b - f16_bits_value(hi >> 16)) << 16);
+#else
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  const f32x2_t rem = v - __builtin_convertvector(__builtin_bit_cast(f16x2_t, hi), f32x2_t);
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(rem, f16x2_t));
+#endif
+}
 // the same for values that arrive from outside (input rows, weights): clamped to the half range first
 __device__ __forceinline__ void split16_pair(float a, float b, unsigned& hi, unsigned& lo) {
   split16_two(fminf(fmaxf(a, -65504.f), 65504.f), fminf(fmaxf(b, -65504.f), 65504.f), hi, lo);

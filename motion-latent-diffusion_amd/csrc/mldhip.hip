@@ -209,6 +209,9 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
 #define MLD_T32_ATTR1(MT, NS, TR, PR) \
@@ -315,7 +318,8 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "fused_x3 must be 0 or 1");
     e->fused_x3 = (int)value;
   } else if (n == "fused_dbg") {
-    if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "fused_dbg must be 0, 1 or 2");
+    if (value < 0 || value > 5) return e->fail(MLDHIP_EINVAL, "fused_dbg must be 0 .. 5");
+    if (value == 5 && !e->trace_buf && hipMalloc((void**)&e->trace_buf, (size_t)512 * 8 * 8 * sizeof(uint64_t)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(trace)");
     e->fused_dbg = (int)value;
   } else if (n == "fused_ring") {
     if (value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "fused_ring must be 4 or 8");
@@ -1014,6 +1018,13 @@ int mldhip_profile_trace(mldhip_handle* e, const char* name, int32_t B, int32_t 
   DeviceGuard dg(e->device);
   constexpr int64_t kMax = 512 * 8 * 8;
   if (!e->trace_buf && hipMalloc((void**)&e->trace_buf, kMax * sizeof(uint64_t)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(trace)");
+  if (std::string(name) == "den_loop_phases") {
+    // the persistent loop's own phase counters ("fused_dbg" 5): written by the last sample call, 8 values per wave of the first 64 workgroups
+    HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream_));
+    const int64_t n = std::min<int64_t>(cap_u64, 64 * 8 * 8);
+    HIP_TRY(e, hipMemcpy(out_host, e->trace_buf, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return (int)(n / 64);
+  }
   double fl = 0;
   if (int rc = mldhip_profile_kernel(e, name, B, T, 3, &fl, stream_)) return rc;
   // the traced build is its own kernel: two launches of it first (code fetched, instruction cache warm), then the one that is kept

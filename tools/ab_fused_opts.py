@@ -30,7 +30,7 @@ for x3 in (0, 1):
         out[f"x3={x3},ring={ring}"] = dict(loop_ms=round(min(ts) * 1e3, 2), latents_err=err)
         print(f"x3={x3} ring={ring}", out[f"x3={x3},ring={ring}"], flush=True)
 eng.set_option("fused_x3", 1); eng.set_option("fused_ring", 4)
-for dbg, what in ((1, "no_weight_stream"), (2, "no_mfma")):
+for dbg, what in ((1, "no_weight_stream"), (2, "no_mfma"), (3, "identity_for_gelu"), (4, "no_ffn_epilogue")):
     eng.set_option("fused_dbg", dbg)
     eng.sample_many(reqs); torch.cuda.synchronize()
     ts = []
