@@ -275,22 +275,24 @@ int build_loop_stream(Ctx& c) {
           for (int cb = 0; cb < 2; ++cb) push(w, 512, cb * 128, half * 256 + kc * 32);
     }
   }
-  const size_t ips = items.size(), small_floats = (size_t)L * kLsLayer + (size_t)nb * 256 + 768, tail = (size_t)n * 4;
+  const size_t ips = items.size();
+  for (int j = 0; j < 8; ++j) items.push_back(items[j]);      // the ring's look-ahead across the end of a step (loop_fused.hpp gload)
+  const size_t nit = items.size(), small_floats = (size_t)L * kLsLayer + (size_t)nb * 256 + 768, tail = (size_t)n * 4;
   if (e->loop_stream) { (void)hipFree(e->loop_stream); e->loop_stream = nullptr; }
   if (e->loop_small) { (void)hipFree(e->loop_small); e->loop_small = nullptr; }
   if (e->loop_stream_x3) { (void)hipFree(e->loop_stream_x3); e->loop_stream_x3 = nullptr; }
   const bool want_x3 = e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE;      // the split mode: a second image of the stream
   LoopItem* items_dev = nullptr;
-  if (hipMalloc((void**)&e->loop_stream, ips * kLoopItemFloats * sizeof(float)) != hipSuccess ||
-      (want_x3 && hipMalloc((void**)&e->loop_stream_x3, ips * kLoopItemFloats * sizeof(float)) != hipSuccess) ||
+  if (hipMalloc((void**)&e->loop_stream, nit * kLoopItemFloats * sizeof(float)) != hipSuccess ||
+      (want_x3 && hipMalloc((void**)&e->loop_stream_x3, nit * kLoopItemFloats * sizeof(float)) != hipSuccess) ||
       hipMalloc((void**)&e->loop_small, (small_floats + tail) * sizeof(float)) != hipSuccess ||
-      hipMalloc((void**)&items_dev, ips * sizeof(LoopItem)) != hipSuccess)
+      hipMalloc((void**)&items_dev, nit * sizeof(LoopItem)) != hipSuccess)
     return e->fail(MLDHIP_EHIP, "hipMalloc(sample-major loop tables)");
   e->loop_ddim = e->loop_small + small_floats;
-  hipError_t st = hipMemcpy(items_dev, items.data(), ips * sizeof(LoopItem), hipMemcpyHostToDevice);
+  hipError_t st = hipMemcpy(items_dev, items.data(), nit * sizeof(LoopItem), hipMemcpyHostToDevice);
   if (st == hipSuccess) {
-    MLD_LAUNCH(pack_loop_stream_kernel<false>, dim3((unsigned)ips), dim3(512), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->loop_stream);
-    if (want_x3) MLD_LAUNCH(pack_loop_stream_kernel<true>, dim3((unsigned)ips), dim3(512), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->loop_stream_x3);
+    MLD_LAUNCH(pack_loop_stream_kernel<false>, dim3((unsigned)nit), dim3(512), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->loop_stream);
+    if (want_x3) MLD_LAUNCH(pack_loop_stream_kernel<true>, dim3((unsigned)nit), dim3(512), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->loop_stream_x3);
     check_launch(c, "pack_loop_stream");
     st = hipStreamSynchronize(c.stream);
   }

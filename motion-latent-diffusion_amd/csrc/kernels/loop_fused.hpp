@@ -53,7 +53,7 @@ constexpr int kLoopItemsLayer = 192, kLoopItemsSkip = 32, kLoopItemFloats = 128 
 struct LoopItem { long long src; int ld; int pad; };   // element [row0][k0] of a weight (floats into the arena), row stride
 
 struct LoopArgs {
-  const float* stream;     // [ips][8 waves][64 lanes][8 words] weight items in consumption order, fragment layout (fp32 or split halves)
+  const float* stream;     // [ips + 8][8 waves][64 lanes][8 words] weight items in consumption order, fragment layout (fp32 or split halves); the last 8 repeat the first 8
   int ips;                 // items per reverse step
   const float* small;      // packed small parameters (layout above)
   const float* T1;         // [n][256] time-token rows (time MLP + pe[1]) of the scheduler's timesteps
@@ -114,21 +114,19 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
 #endif
   float* Xs = smem;                       // [48][264] layer input / norm1 output (the A operand; fp32, or the split image)
   float* As = Xs + kLfXFloats;            // [48][264] attention output, then [2][48][136]: two 128-wide blocks of the hidden activation in turn
-  float* sc = As + kLfAFloats;            // [8][9][16] per-wave partial attention scores
-  float* red = sc + kLfScFloats;          // [2][8][48] per-wave LayerNorm partial sums
+  float* sc = As + kLfAFloats;            // [2 heads of the pair][9 (t, u)][16 rows][4 waves of the head] partial attention scores
+  float* red = sc + kLfScFloats;          // [2 passes][48 rows][8 waves] LayerNorm partial sums
   float* lats = red + kLfRedFloats;       // [8][256] the workgroup's latents
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int s0 = blockIdx.x * 8, nb = (p.L - 1) / 2;
   const float* sm_skip = p.small + (long long)p.L * kLsLayer;
   const float* sm_fin = sm_skip + nb * 256;
-  const int col0 = wave * 16 + r;                  // this lane's column inside a 128-column block
 
   // ---- weight ring: this lane's two MFMA operands (32 bytes) of the next kLoopRing items, straight from the fragment-ordered stream
-  const float* gsrc = p.stream + tid * 8;
   // DBG 5: cycles per phase (0 QKV products, 1 scores + softmax + attention output, 2 out-projection, 3 residual + norm1, 4 feed-forward,
   // 5 residual + norm2 + skip handling, 6 end of step), each stamp behind s_waitcnt 0 -- the counters perturb the overlap they measure
-  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tph = 0;
+  unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tph = 0;
   auto stamp = [&](int k) __attribute__((always_inline)) {
     if constexpr (DBG == 5) {
       const unsigned long long t = clock_pinned();
@@ -136,46 +134,45 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
       tph = t;
     }
   };
-  int gitem = 0;
+  // The stream holds ips + kLoopRing items: the first kLoopRing of a step once more behind the last, so the ring's look-ahead
+  // runs off the end of a step without a wrap test per load; the pointer goes back to item kLoopRing at the top of every step
+  // (the ring then holds items 0 .. kLoopRing - 1, loaded through the copies).
+  unsigned goff = (unsigned)tid * 8u;       // this lane's word offset into the stream (< 2^31: the stream is ~30 MB)
   F4 ring[kLoopRing][2];
   auto gload = [&](int slot) __attribute__((always_inline)) {
-    const float* s = gsrc + (long long)gitem * kLoopItemFloats;
+    const float* s = p.stream + goff;
     ring[slot][0] = ld4(s);
     ring[slot][1] = ld4(s + 4);
-    gitem = gitem + 1 == p.ips ? 0 : gitem + 1;
+    goff += (unsigned)kLoopItemFloats;
+#if !defined(MLDHIP_SIM)
+    asm volatile("" : "+v"(goff));     // one running offset: without this hipcc rewrites every load as base + constant, computes the
+                                       // addresses of a whole phase ahead of its matrix instructions and spills them (r03: 2.5x on the skip
+                                       // linears).  (An opaque POINTER loses its address space: flat loads, which count on lgkmcnt.)
+#endif
   };
   // Items are numbered j = 0 .. inside a group (every group is a multiple of kLoopRing items); item j sits in ring slot j % kLoopRing
   // and is replaced by item j + kLoopRing as soon as its MFMAs are issued.
   // One item: this wave's 16 weight rows (= output columns) x 32 k against the three row tiles, whose fragments the caller read
   // from LDS: both operand formats keep a chunk of a row as 32 words read as words 4g .. 4g + 3 and 16 + 4g .. + 3.
-  // tr: the TRANSPOSED product (weights as the A operand, the rows as B -- the same fragment registers in the other argument): lane
-  // (r, g) then holds row r of the tile, columns 4g .. 4g + 3 of this wave's 16, i.e. four CONSECUTIVE elements of one row, which
-  // leave for an operand image as one 8-byte store per plane.  In the plain layout (rows 4g + i, column r) every element is its own
-  // 2-byte store, and the four g groups of a store hit the same banks (row stride = 8 mod 32 words): the feed-forward epilogue's
-  // stores alone were 6.8 of the loop's 29.3 ms (r03 measurement builds fused_dbg 3 / 4).  Used for linear1, whose output only feeds
-  // GELU and the hidden image.
-  auto mma_item = [&](int j, const F4 (&x)[3][2], f32x4 (&acc)[3], bool tr = false) __attribute__((always_inline)) {
+  // Every product is taken TRANSPOSED (weights as the A operand, the token rows as B -- the same fragment registers in the other
+  // argument): lane (r, g) of wave w then holds row r of a tile, columns 16 w + 4 g .. + 3 of a 128-column block, i.e. four
+  // CONSECUTIVE elements of one row.  Everything around the products is cheaper in that layout: a row's statistics (LayerNorm,
+  // attention scores) are four in-lane terms and two lane shuffles over g instead of sixteen-lane reductions per element, a softmax
+  // is worked out by 4 lanes per row instead of 16, and a row's elements reach an operand image as one 8-byte store per plane instead
+  // of eight 2-byte ones (r03 phase counters, plain layout: attention 4.2 ms, the two LayerNorm phases 6.8 ms of the loop's 29.8).
+  auto mma_item = [&](int j, const F4 (&x)[3][2], f32x4 (&acc)[3]) __attribute__((always_inline)) {
     const int slot = j % kLoopRing;
     if constexpr (DBG == 2) {
       acc[0][0] += ring[slot][0].x + ring[slot][1].w + x[0][0].x;
     } else if constexpr (X3) {
       const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
-      if (tr) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][1]), acc[t]);
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][1]), acc[t]);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wl, __builtin_bit_cast(U4, x[t][0]), acc[t]);
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wl, __builtin_bit_cast(U4, x[t][0]), acc[t]);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][0]), acc[t]);
-      } else {
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][1]), wh, acc[t]);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][0]), wl, acc[t]);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][0]), wh, acc[t]);
-      }
-    } else if (tr) {
+      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][0]), acc[t]);
+    } else {
       const F4 y0 = ring[slot][0], y1 = ring[slot][1];
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(y0.x, x[t][0].x, acc[t]);
@@ -193,29 +190,11 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
       for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(y1.z, x[t][1].z, acc[t]);
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(y1.w, x[t][1].w, acc[t]);
-    } else {
-      const F4 y0 = ring[slot][0], y1 = ring[slot][1];
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].x, y0.x, acc[t]);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].y, y0.y, acc[t]);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].z, y0.z, acc[t]);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][0].w, y0.w, acc[t]);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].x, y1.x, acc[t]);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].y, y1.y, acc[t]);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].z, y1.z, acc[t]);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(x[t][1].w, y1.w, acc[t]);
     }
     if constexpr (DBG != 1) gload(slot);
     sched_fence();
   };
-  // The transposed item with an epilogue threaded through it: `epi(k)`, k = 0 .. 8, is a few VALU / LDS instructions of work that does
+  // An item with an epilogue threaded through it: `epi(k)`, k = 0 .. 8, is a few VALU / LDS instructions of work that does
   // not depend on this item; slice k is issued right behind the item's k-th group of matrix instructions and a scheduling fence pins
   // the pair.  MFMA and the other VALU instructions share a SIMD's issue port but not its pipes: behind every 16-cycle matrix
   // instruction there are three free issue slots, and an in-order wave fills them only if the next instructions in ITS stream are
@@ -280,13 +259,13 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     }
   };
   // one column block against 8 chunks (linear1 of one 128-wide hidden block)
-  auto run1 = [&](const float* a0, f32x4 (&acc0)[3]) __attribute__((always_inline)) {      // transposed accumulators (mma_item)
+  auto run1 = [&](const float* a0, f32x4 (&acc0)[3]) __attribute__((always_inline)) {
     F4 x[2][3][2];
     afrag(a0, 16 * kLfXs, 0, x[0]);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       if (c + 1 < 8) afrag(a0, 16 * kLfXs, c + 1, x[(c + 1) & 1]);
-      mma_item(c, x[c & 1], acc0, true);
+      mma_item(c, x[c & 1], acc0);
     }
   };
   // both column blocks of linear2 against the 4 chunks of one hidden block (row stride kLfHs)
@@ -313,130 +292,108 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     for (int t = 0; t < 3; ++t) a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  // ---- this lane's elements (row 16t + 4g + i, column 128cb + col0) of an operand buffer with row stride `st` words:
-  // fp32: one word; split: one half-word in the chunk's high words and one in its low words (chunk = 32 words per 32 columns).
-  // `cw` = the block's first word in the row (128 cb for a 256-wide buffer, 0 for the hidden block).
-  const int hw0 = ((wave >> 1) * 32 + (wave & 1) * 8 + (r >> 1)) * 2 + (r & 1);     // half-word offset of column col0 in its row
-  auto put_one = [&](float* buf, int st, int cw, int t, int i, float val) __attribute__((always_inline)) {
-    float* row = buf + (t * 16 + g * 4 + i) * st + cw;
+  // ---- this lane's elements of an operand buffer with row stride `st` words: row 16t + r, columns cw + 16 wave + 4g .. + 3 (`cw` = the
+  // block's first column: 128 cb for a 256-wide buffer, 0 for the hidden block).  fp32: four consecutive words; split: two words (two
+  // column pairs) in the chunk's high plane and two in its low plane (chunk = 32 words per 32 columns).
+  const int rw0 = (wave >> 1) * 32 + (wave & 1) * 8 + g * 2;      // split image: word of the first column pair inside the 128-wide block
+  const int cq0 = wave * 16 + g * 4;                              // first of this lane's four columns inside a 128-column block
+  auto put_row = [&](float* buf, int st, int cw, int t, const float (&v)[4]) __attribute__((always_inline)) {
+    float* row = buf + (t * 16 + r) * st + cw;
     if constexpr (X3) {
-      unsigned short hi, lo;
-      split16_one(val, hi, lo);
-      unsigned short* h = reinterpret_cast<unsigned short*>(row) + hw0;
-      h[0] = hi;
-      h[32] = lo;
+      unsigned h0, l0, h1, l1;
+      split16_two(v[0], v[1], h0, l0);
+      split16_two(v[2], v[3], h1, l1);
+      unsigned* w = reinterpret_cast<unsigned*>(row) + rw0;
+      *reinterpret_cast<U2*>(w) = U2{h0, h1};
+      *reinterpret_cast<U2*>(w + 16) = U2{l0, l1};
     } else {
-      row[col0] = val;
-    }
-  };
-  // two elements of one tile (rows 16t + 4g + i, i + 1): one packed split, four 16-bit stores
-  auto put_two = [&](float* buf, int st, int cw, int t, int i, float v0, float v1) __attribute__((always_inline)) {
-    if constexpr (X3) {
-      unsigned hi, lo;
-      split16_two(v0, v1, hi, lo);
-      unsigned short* h0 = reinterpret_cast<unsigned short*>(buf + (t * 16 + g * 4 + i) * st + cw) + hw0;
-      unsigned short* h1 = reinterpret_cast<unsigned short*>(buf + (t * 16 + g * 4 + i + 1) * st + cw) + hw0;
-      h0[0] = (unsigned short)(hi & 0xFFFFu);
-      h0[32] = (unsigned short)(lo & 0xFFFFu);
-      h1[0] = (unsigned short)(hi >> 16);
-      h1[32] = (unsigned short)(lo >> 16);
-    } else {
-      put_one(buf, st, cw, t, i, v0);
-      put_one(buf, st, cw, t, i + 1, v1);
+      st4(row + cq0, F4{v[0], v[1], v[2], v[3]});
     }
   };
   auto put = [&](float* buf, int st, int cw, const float (&val)[3][4]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int i = 0; i < 4; i += 2) put_two(buf, st, cw, t, i, val[t][i], val[t][i + 1]);
+    for (int t = 0; t < 3; ++t) put_row(buf, st, cw, t, val[t]);
   };
   // ... and back: the residual of a LayerNorm is read from the operand buffer it was multiplied from (split mode: high + low
   // half, the value the GEMMs saw, 2^-22 from the fp32 one), so no activation stays in registers across a GEMM phase
   auto get = [&](const float* buf, int st, int cw, float (&val)[3][4]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* row = buf + (t * 16 + g * 4 + i) * st + cw;
-        if constexpr (X3) {
-          const unsigned short* h = reinterpret_cast<const unsigned short*>(row) + hw0;
-          val[t][i] = f16_bits_value(h[0]) + f16_bits_value(h[32]);
-        } else {
-          val[t][i] = row[col0];
-        }
+    for (int t = 0; t < 3; ++t) {
+      const float* row = buf + (t * 16 + r) * st + cw;
+      if constexpr (X3) {
+        const unsigned* w = reinterpret_cast<const unsigned*>(row) + rw0;
+        const U2 h = *reinterpret_cast<const U2*>(w), l = *reinterpret_cast<const U2*>(w + 16);
+        val[t][0] = f16_bits_value(h.x) + f16_bits_value(l.x);
+        val[t][1] = f16_bits_value(h.x >> 16) + f16_bits_value(l.x >> 16);
+        val[t][2] = f16_bits_value(h.y) + f16_bits_value(l.y);
+        val[t][3] = f16_bits_value(h.y >> 16) + f16_bits_value(l.y >> 16);
+      } else {
+        const F4 v = ld4(row + cq0);
+        val[t][0] = v.x; val[t][1] = v.y; val[t][2] = v.z; val[t][3] = v.w;
       }
+    }
   };
 
-  // LayerNorm over the 256 columns of rows 16t + 4g + i, t < nt; v[cb][t][i] = this lane's element.  Part 1 publishes the per-wave
-  // row sums (the caller then passes a barrier); part 2 finishes (one more barrier inside).
+  // LayerNorm over the 256 columns of rows 16t + r, t < nt; v[cb][t][i] = this lane's elements (columns 128 cb + 16 wave + 4g + i).
+  // Part 1 publishes the per-wave row sums -- eight in-lane terms, two shuffles over g -- as red[row][wave] (the caller then passes a
+  // barrier); part 2 finishes (one more barrier inside).
   auto ln_part1 = [&](const float (&v)[2][3][4], int nt) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       if (t < nt) {
-        F4 s;
-        s.x = sum16(v[0][t][0] + v[1][t][0]); s.y = sum16(v[0][t][1] + v[1][t][1]);
-        s.z = sum16(v[0][t][2] + v[1][t][2]); s.w = sum16(v[0][t][3] + v[1][t][3]);
-        if (r == 0) st4(red + wave * 48 + t * 16 + g * 4, s);
+        float sum = ((v[0][t][0] + v[0][t][1]) + (v[0][t][2] + v[0][t][3])) + ((v[1][t][0] + v[1][t][1]) + (v[1][t][2] + v[1][t][3]));
+        sum = sum_groups(sum);
+        if (g == 0) red[(t * 16 + r) * 8 + wave] = sum;
       }
     }
   };
   auto ln_part2 = [&](float (&v)[2][3][4], int nt, const float* gamma, const float* beta) __attribute__((always_inline)) {
-    const float g0 = gamma[col0], g1 = gamma[128 + col0], b0 = beta[col0], b1 = beta[128 + col0];
+    const F4 g0 = ld4(gamma + cq0), g1 = ld4(gamma + 128 + cq0), b0 = ld4(beta + cq0), b1 = ld4(beta + 128 + cq0);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       if (t < nt) {
-        F4 m = ld4(red + t * 16 + g * 4);
-#pragma unroll
-        for (int w = 1; w < 8; ++w) m = f4add(m, ld4(red + w * 48 + t * 16 + g * 4));
-        const float mean[4] = {m.x * (1.0f / 256.0f), m.y * (1.0f / 256.0f), m.z * (1.0f / 256.0f), m.w * (1.0f / 256.0f)};
-        float sq[4];
+        const F4 ma = ld4(red + (t * 16 + r) * 8), mb = ld4(red + (t * 16 + r) * 8 + 4);
+        const float mean = (((ma.x + ma.y) + (ma.z + ma.w)) + ((mb.x + mb.y) + (mb.z + mb.w))) * (1.0f / 256.0f);
+        float sq = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          v[0][t][i] -= mean[i];
-          v[1][t][i] -= mean[i];
-          sq[i] = sum16(v[0][t][i] * v[0][t][i] + v[1][t][i] * v[1][t][i]);
+          v[0][t][i] -= mean;
+          v[1][t][i] -= mean;
+          sq += v[0][t][i] * v[0][t][i] + v[1][t][i] * v[1][t][i];
         }
-        if (r == 0) st4(red + 384 + wave * 48 + t * 16 + g * 4, F4{sq[0], sq[1], sq[2], sq[3]});
+        sq = sum_groups(sq);
+        if (g == 0) red[384 + (t * 16 + r) * 8 + wave] = sq;
       }
     }
     __syncthreads();
+    const float gm0[4] = {g0.x, g0.y, g0.z, g0.w}, gm1[4] = {g1.x, g1.y, g1.z, g1.w}, bt0[4] = {b0.x, b0.y, b0.z, b0.w}, bt1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       if (t < nt) {
-        F4 q = ld4(red + 384 + t * 16 + g * 4);
-#pragma unroll
-        for (int w = 1; w < 8; ++w) q = f4add(q, ld4(red + 384 + w * 48 + t * 16 + g * 4));
-        const float rs[4] = {rsqrtf(q.x * (1.0f / 256.0f) + kLnEps), rsqrtf(q.y * (1.0f / 256.0f) + kLnEps),
-                             rsqrtf(q.z * (1.0f / 256.0f) + kLnEps), rsqrtf(q.w * (1.0f / 256.0f) + kLnEps)};
+        const F4 qa = ld4(red + 384 + (t * 16 + r) * 8), qb = ld4(red + 384 + (t * 16 + r) * 8 + 4);
+        const float rs = rsqrtf((((qa.x + qa.y) + (qa.z + qa.w)) + ((qb.x + qb.y) + (qb.z + qb.w))) * (1.0f / 256.0f) + kLnEps);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          v[0][t][i] = v[0][t][i] * rs[i] * g0 + b0;
-          v[1][t][i] = v[1][t][i] * rs[i] * g1 + b1;
+          v[0][t][i] = v[0][t][i] * rs * gm0[i] + bt0[i];
+          v[1][t][i] = v[1][t][i] * rs * gm1[i] + bt1[i];
         }
       }
     }
   };
 
-  // token rows of one reverse step, each lane its own elements: row 16t + c; t = 0: latent + pe[0] (both CFG halves), 1: the
+  // token rows of one reverse step, each lane its own elements: row 16t + c, c = r; t = 0: latent + pe[0] (both CFG halves), 1: the
   // step's time row, 2: the condition rows (mld_denoiser.py:143-196; rows beyond B repeat motion B - 1, never written back)
   auto assemble = [&](int step) __attribute__((always_inline)) {
     const float* pe0 = sm_fin + 512;
-    const int gq = opaque(g), cq = opaque(col0);
+    const int rq = opaque(r), cq = opaque(cq0);
+    int sidx = s0 + (rq & 7);
+    sidx = sidx < p.B ? sidx : p.B - 1;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       const unsigned col = cb * 128 + cq;
-      const float pe = pe0[col], tt = p.T1[(unsigned)step * 256u + col];
-      float xv[3][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = gq * 4 + i;
-        int sidx = s0 + (c & 7);
-        sidx = sidx < p.B ? sidx : p.B - 1;
-        xv[0][i] = lats[(c & 7) * 256 + col] + pe;
-        xv[1][i] = tt;
-        xv[2][i] = p.TP[(unsigned)((c < 8 ? 0 : p.B) + sidx) * 256u + col];
-      }
+      const F4 pe = ld4(pe0 + col), tt = ld4(p.T1 + (unsigned)step * 256u + col), la = ld4(lats + (rq & 7) * 256 + col);
+      const F4 tx = ld4(p.TP + (unsigned)((rq < 8 ? 0 : p.B) + sidx) * 256u + col);
+      const float xv[3][4] = {{la.x + pe.x, la.y + pe.y, la.z + pe.z, la.w + pe.w}, {tt.x, tt.y, tt.z, tt.w}, {tx.x, tx.y, tx.z, tx.w}};
       put(Xs, kLfXs, cb * 128, xv);
     }
   };
@@ -460,46 +417,50 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
 
   if constexpr (DBG == 5) tph = clock_pinned();
   for (int step = 0; step < p.n; ++step) {
+    goff = (unsigned)tid * 8u + (unsigned)(kLoopRing * kLoopItemFloats);
     float x[2][3][4];                              // norm2 output of the current layer at this lane's positions
     for (int l = 0; l < p.L; ++l) {
       const float* sm = p.small + (unsigned)l * (unsigned)kLsLayer;
       // ================= self-attention: two heads at a time (cross_attention.py:265-266; nn.MultiheadAttention, 4 heads of 64)
       for (int hp = 0; hp < 2; ++hp) {
-        const float bq = sm[kLsInB + hp * 128 + col0], bk = sm[kLsInB + 256 + hp * 128 + col0], bv = sm[kLsInB + 512 + hp * 128 + col0];
+        const F4 bq = ld4(sm + kLsInB + hp * 128 + cq0), bk = ld4(sm + kLsInB + 256 + hp * 128 + cq0), bv = ld4(sm + kLsInB + 512 + hp * 128 + cq0);
         f32x4 q[3], k[3], vv[3];
         zero3(q); zero3(k); zero3(vv);
         run3(xa, q, k, vv);
         stamp(0);
-        // partial scores over this wave's 16 columns of the head: s[t][u] for the CFG rows 4g .. 4g + 3
+        // partial scores of row r over this lane's four columns of the head, summed over g: the wave's 16 columns; the four waves of
+        // a head meet in sc[head of the pair][(t, u)][row][wave of the head]
+        const float bqv[4] = {bq.x, bq.y, bq.z, bq.w}, bkv[4] = {bk.x, bk.y, bk.z, bk.w}, bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { q[t][i] += bqv[i]; k[t][i] += bkv[i]; vv[t][i] += bvv[i]; }
+        float* sw = sc + (wave >> 2) * 576 + r * 4 + (wave & 3);
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
           for (int u = 0; u < 3; ++u) {
-            F4 s;
-            s.x = sum16((q[t][0] + bq) * (k[u][0] + bk)); s.y = sum16((q[t][1] + bq) * (k[u][1] + bk));
-            s.z = sum16((q[t][2] + bq) * (k[u][2] + bk)); s.w = sum16((q[t][3] + bq) * (k[u][3] + bk));
-            if (r == 0) st4(sc + wave * 144 + (t * 3 + u) * 16 + g * 4, s);
+            float sp = (q[t][0] * k[u][0] + q[t][1] * k[u][1]) + (q[t][2] * k[u][2] + q[t][3] * k[u][3]);
+            sp = sum_groups(sp);
+            if (g == 0) sw[(t * 3 + u) * 64] = sp;
           }
         __syncthreads();
-        const float* sb = sc + (wave & 4) * 144 + g * 4;   // the four waves of this head
+        const float* sb = sc + (wave >> 2) * 576 + r * 4;
         float o[3][4];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-          F4 s[3];
+          float a[3];
 #pragma unroll
           for (int u = 0; u < 3; ++u) {
-            const float* e = sb + (t * 3 + u) * 16;
-            s[u] = f4add(f4add(ld4(e), ld4(e + 144)), f4add(ld4(e + 288), ld4(e + 432)));
+            const F4 e = ld4(sb + (t * 3 + u) * 64);
+            a[u] = ((e.x + e.y) + (e.z + e.w)) * (0.125f * 1.44269504088896340736f);      // 1/sqrt(64), log2 domain
           }
-          const float s0v[4] = {s[0].x, s[0].y, s[0].z, s[0].w}, s1v[4] = {s[1].x, s[1].y, s[1].z, s[1].w}, s2v[4] = {s[2].x, s[2].y, s[2].z, s[2].w};
+          const float m = fmaxf(a[0], fmaxf(a[1], a[2]));
+          const float e0 = fast_exp2(a[0] - m), e1 = fast_exp2(a[1] - m), e2 = fast_exp2(a[2] - m);
+          const float inv = fast_rcp(e0 + e1 + e2);
+          const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float a0 = s0v[i] * 0.125f, a1 = s1v[i] * 0.125f, a2 = s2v[i] * 0.125f;
-            const float m = fmaxf(a0, fmaxf(a1, a2));
-            const float e0 = fast_exp(a0 - m), e1 = fast_exp(a1 - m), e2 = fast_exp(a2 - m);
-            const float inv = fast_rcp(e0 + e1 + e2);
-            o[t][i] = (e0 * inv) * (vv[0][i] + bv) + (e1 * inv) * (vv[1][i] + bv) + (e2 * inv) * (vv[2][i] + bv);
-          }
+          for (int i = 0; i < 4; ++i) o[t][i] = p0 * vv[0][i] + p1 * vv[1][i] + p2 * vv[2][i];
         }
         put(As, kLfXs, hp * 128, o);
         __syncthreads();       // hp = 0: `sc` may be rewritten; hp = 1: the attention output is complete before anybody multiplies it
@@ -507,7 +468,8 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
       }
       // ================= out-projection + residual + norm1 -> Xs
       {
-        const float ob0 = sm[kLsOutB + col0], ob1 = sm[kLsOutB + 128 + col0];
+        const F4 ob0 = ld4(sm + kLsOutB + cq0), ob1 = ld4(sm + kLsOutB + 128 + cq0);
+        const float ob0v[4] = {ob0.x, ob0.y, ob0.z, ob0.w}, ob1v[4] = {ob1.x, ob1.y, ob1.z, ob1.w};
         f32x4 o0[3], o1[3];
         zero3(o0); zero3(o1);
         run2(aa, o0, o1);
@@ -519,8 +481,8 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         for (int t = 0; t < 3; ++t)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            u[0][t][i] += o0[t][i] + ob0;
-            u[1][t][i] += o1[t][i] + ob1;
+            u[0][t][i] += o0[t][i] + ob0v[i];
+            u[1][t][i] += o1[t][i] + ob1v[i];
           }
         ln_part1(u, 3);
         __syncthreads();
@@ -627,19 +589,21 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         ffn_stage(6, hA, hB, true);
         ffn_stage(7, hB, hA, false);
         stamp(4);
-        const float lb0 = sm[kLsL2B + col0], lb1 = sm[kLsL2B + 128 + col0];
+        const F4 lb0 = ld4(sm + kLsL2B + cq0), lb1 = ld4(sm + kLsL2B + 128 + cq0);
+        const float lb0v[4] = {lb0.x, lb0.y, lb0.z, lb0.w}, lb1v[4] = {lb1.x, lb1.y, lb1.z, lb1.w};
         get(Xs, kLfXs, 0, x[0]);
         get(Xs, kLfXs, 128, x[1]);
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            x[0][t][i] += y0[t][i] + lb0;
-            x[1][t][i] += y1[t][i] + lb1;
+            x[0][t][i] += y0[t][i] + lb0v[i];
+            x[1][t][i] += y1[t][i] + lb1v[i];
           }
         ln_part1(x, 3);
         __syncthreads();
         ln_part2(x, 3, sm + kLsN2W, sm + kLsN2B);
+        stamp(7);
       }
       if (l + 1 < p.L) {
         // layer output -> Xs; first half of the stack: also parked for the skip connection (cross_attention.py:48-52)
@@ -647,25 +611,26 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
         put(Xs, kLfXs, 128, x[1]);
         if (l < nb) {
           float* sk = p.skip + (size_t)(blockIdx.x * nb + l) * (48 * 256);
-          const int gq = opaque(g), cq = opaque(col0);
+          const int rq = opaque(r), cq = opaque(cq0);
 #pragma unroll
-          for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              float* o = sk + (unsigned)((t * 16 + gq * 4 + i) * 256 + cq);
-              o[0] = x[0][t][i];
-              o[128] = x[1][t][i];
-            }
+          for (int t = 0; t < 3; ++t) {
+            float* o = sk + (unsigned)((t * 16 + rq) * 256 + cq);
+            st4(o, F4{x[0][t][0], x[0][t][1], x[0][t][2], x[0][t][3]});
+            st4(o + 128, F4{x[1][t][0], x[1][t][1], x[1][t][2], x[1][t][3]});
+          }
         }
         __syncthreads();
+        stamp(8);
         if (l >= nb) {
           // x = Linear(cat[x, skip]) (cross_attention.py:56-58): the x half of K from Xs, then the parked activation takes
           // its place in Xs for the second half
           const int si = l - nb;
-          const float sb0 = sm_skip[si * 256 + col0], sb1 = sm_skip[si * 256 + 128 + col0];
+          const F4 sb0 = ld4(sm_skip + si * 256 + cq0), sb1 = ld4(sm_skip + si * 256 + 128 + cq0);
+          const float sb0v[4] = {sb0.x, sb0.y, sb0.z, sb0.w}, sb1v[4] = {sb1.x, sb1.y, sb1.z, sb1.w};
           f32x4 z0[3], z1[3];
           zero3(z0); zero3(z1);
           run2(xa, z0, z1);
+          stamp(9);
           __syncthreads();                               // everybody is done reading x
           const float* sk = p.skip + (size_t)(blockIdx.x * nb + (nb - 1 - si)) * (48 * 256);
           const int tq = opaque(tid);
@@ -685,13 +650,15 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
             }
           }
           __syncthreads();
+          stamp(10);
           run2(xa, z0, z1);
+          stamp(11);
 #pragma unroll
           for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              x[0][t][i] = z0[t][i] + sb0;
-              x[1][t][i] = z1[t][i] + sb1;
+              x[0][t][i] = z0[t][i] + sb0v[i];
+              x[1][t][i] = z1[t][i] + sb1v[i];
             }
           __syncthreads();                               // everybody is done reading the parked rows
           put(Xs, kLfXs, 0, x[0]);
@@ -708,18 +675,25 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
       ln_part2(x, 1, sm_fin, sm_fin + 256);
       const float sat = p.ddim[step * 4], s1mat = p.ddim[step * 4 + 1], sap = p.ddim[step * 4 + 2], s1map = p.ddim[step * 4 + 3];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+      for (int cb = 0; cb < 2; ++cb) {
+        float ec[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float eu = x[cb][0][i], ec = wave_xor(eu, 32);     // CFG row c + 8 lives in lane + 32
-          if (g < 2) {
-            float* lp = lats + (g * 4 + i) * 256 + cb * 128 + col0;
-            const float eps = eu + p.guidance * (ec - eu);
-            const float xt = lp[0];
-            const float x0 = (xt - s1mat * eps) / sat;
-            lp[0] = sap * x0 + s1map * eps;
+        for (int i = 0; i < 4; ++i) ec[i] = wave_xor(x[cb][0][i], 8);     // CFG row c + 8 lives in lane + 8 (same g)
+        if (r < 8) {
+          float* lp = lats + r * 256 + cb * 128 + cq0;
+          const F4 xt = ld4(lp);
+          const float xtv[4] = {xt.x, xt.y, xt.z, xt.w};
+          float nv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float eu = x[cb][0][i];
+            const float eps = eu + p.guidance * (ec[i] - eu);
+            const float x0 = (xtv[i] - s1mat * eps) / sat;
+            nv[i] = sap * x0 + s1map * eps;
           }
+          st4(lp, F4{nv[0], nv[1], nv[2], nv[3]});
         }
+      }
       __syncthreads();
       if (step + 1 < p.n) {
         assemble(step + 1);
@@ -734,9 +708,10 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   }
   if constexpr (DBG == 5) {
     if (p.trace && blockIdx.x < 64 && lane == 0) {
-      unsigned long long* o = p.trace + ((long long)blockIdx.x * 8 + wave) * 8;
-      for (int k = 0; k < 7; ++k) o[k] = ph[k];
-      o[7] = ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5] + ph[6];
+      unsigned long long* o = p.trace + ((long long)blockIdx.x * 8 + wave) * 16;
+      unsigned long long tot = 0;
+      for (int k = 0; k < 15; ++k) { o[k] = ph[k]; tot += ph[k]; }
+      o[15] = tot;
     }
   }
 }

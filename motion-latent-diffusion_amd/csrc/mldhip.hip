@@ -1019,9 +1019,9 @@ int mldhip_profile_trace(mldhip_handle* e, const char* name, int32_t B, int32_t 
   constexpr int64_t kMax = 512 * 8 * 8;
   if (!e->trace_buf && hipMalloc((void**)&e->trace_buf, kMax * sizeof(uint64_t)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(trace)");
   if (std::string(name) == "den_loop_phases") {
-    // the persistent loop's own phase counters ("fused_dbg" 5): written by the last sample call, 8 values per wave of the first 64 workgroups
+    // the persistent loop's own phase counters ("fused_dbg" 5): written by the last sample call, 16 values per wave of the first 64 workgroups
     HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream_));
-    const int64_t n = std::min<int64_t>(cap_u64, 64 * 8 * 8);
+    const int64_t n = std::min<int64_t>(cap_u64, 64 * 8 * 16);      // 16 counters per wave: two 8-value records
     HIP_TRY(e, hipMemcpy(out_host, e->trace_buf, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return (int)(n / 64);
   }

@@ -34,9 +34,10 @@ ref = reqs[0]["latents_out"].cpu().numpy().copy()
 eng.set_option("fused_dbg", 5)
 out["loop_ms_traced_build"] = round(best(), 2)
 assert np.array_equal(ref, reqs[0]["latents_out"].cpu().numpy()), "the traced build computes the same latents"
-tr = eng.profile_trace("den_loop_phases", 64, 196).astype(np.float64)      # [64 workgroups, 8 waves, 8]
-names = ["qkv_products", "scores_softmax_attention_output", "out_projection", "residual_norm1", "feed_forward", "residual_norm2_skip", "end_of_step"]
-tot = tr[:, :, 7].mean()
+tr = eng.profile_trace("den_loop_phases", 64, 196).astype(np.float64).reshape(64, 8, 16)      # [64 workgroups, 8 waves, 16 counters]
+names = ["qkv_products", "scores_softmax_attention_output", "out_projection", "residual_norm1", "feed_forward", "skip_linear_epilogue_and_store", "end_of_step",
+         "residual_norm2", "layer_output_store_skip_park", "skip_linear_first_half", "parked_rows_reload", "skip_linear_second_half"]
+tot = tr[:, :, 15].mean()
 out["cycles_per_wave_total"] = int(tot)
 out["share"] = {n: round(float(tr[:, :, i].mean() / tot), 4) for i, n in enumerate(names)}
 out["ms_at_traced_total"] = {n: round(float(tr[:, :, i].mean() / tot) * out["loop_ms_traced_build"], 2) for i, n in enumerate(names)}
