@@ -152,6 +152,9 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     GEMMs, 48-row strips at two workgroups per CU for the feed-forward block; else 64 rows (one bs-64 request: 196
  *                     strips on 256 CUs instead of 131 longer ones); 6 / 4 = 96 / 64 rows always, 3 = 48 rows for the feed-forward
  *                     block (96 for the GEMMs); 0 = feed-forward block by kernels/ffn_fused.hpp or the two staged GEMMs ("fused_ffn")
+ *   "dec_tail"        F16X3 / FP8 modes, chip-filling launches: 1 (default) = a decoder layer's out-projection + residual + norm1 +
+ *                     cross-attention vector + norm2 + feed-forward block as ONE launch (kernels/ffn_strip.hpp TAIL form: the block
+ *                     input never goes to HBM), 0 = two launches
  *   "tile_x3"         F16X3 mode: 1 (default) = the latency kernels of the reverse loop (kernels/tile32.hpp, one request at a time) multiply
  *                     on split-f16 MFMAs reading the pre-split weight image, 0 = on exact-fp32 MFMAs
  *   "strip_gemm"      F16X3 / FP8 modes, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:

@@ -550,6 +550,20 @@ void dec_layer(Ctx& c, int l, const float* xin, float* xout, int B, int T) {
     if (!strip_gemm(c, q, false)) gemm(c, q);
   }
   dec_attention(c, B, T);
+  // Chip-filling launches of the split modes: the rest of the layer in ONE launch (kernels/ffn_strip.hpp, TAIL form) -- the H1 tensor
+  // between the out-projection kernel and the feed-forward kernel is not written and read back ("dec_tail", on by default)
+  if (e->dec_tail && staged_prec(e) == PREC_BF16X3 && e->strip_gemm && (e->ffn_strip == 3 || (e->ffn_strip == 1 && strip_rows_rt(e, M) == 6)) &&
+      D == 256 && e->cfg.ff_size == 1024 && !e->trace_on && M > e->small_m && e->ffn_stream_of.count(L.l1_w) && e->gemm_stream_of.count(L.out_w)) {
+    FfnArgs a;
+    a.W1 = e->ffn_stream_of[L.l1_w]; a.b1 = L.l1_b; a.b2 = L.l2_b; a.gamma = L.n3_w; a.beta = L.n3_b; a.Y = xout; a.M = M;
+    a.skip_lens = e->lens_dev; a.skip_rpg = T;
+    a.AO = e->AO; a.Wo = e->gemm_stream_of[L.out_w]; a.bo = L.out_b; a.res = xin; a.g1 = L.n1_w; a.be1 = L.n1_b;
+    a.cvec = e->cvec + (size_t)l * e->cfg.max_batch * D; a.rpg = T; a.g2 = L.n2_w; a.be2 = L.n2_b;
+    MLD_LAUNCH((ffn_strip_x3_kernel<3, true>), dim3((M + 47) / 48), dim3(512), (ffn_strip_lds_bytes<3>()), c.stream, a);
+    count(c);
+    check_launch(c, "dec_tail_x3");
+    return;
+  }
   // out-proj + residual + norm1, then the 1-key cross-attention (a per-sample vector) + norm2
   GemmArgs o = lin_args(e->AO, D, D, L.out_w, L.out_b, e->H1, D, M, D);
   o.res = xin; o.ldres = D; o.g1 = L.n1_w; o.b1 = L.n1_b;

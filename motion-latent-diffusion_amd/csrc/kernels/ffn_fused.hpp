@@ -33,6 +33,15 @@ struct FfnArgs {
   int M = 0;
   const int* skip_lens = nullptr;  // skip row tiles made only of rows (row % rpg) >= skip_lens[row / rpg] (padded frames)
   int skip_rpg = 1;
+  // ffn_strip_x3_kernel<RT, true> ("decoder tail": the self-attention out-projection + residual + norm1 + cross-attention vector + norm2 in
+  // front of the feed-forward block, one launch; X is not read, the block input is produced in LDS)
+  const float* AO = nullptr;       // [M][256] attention output (A operand of the out-projection)
+  const float* Wo = nullptr;       // fragment-ordered stream of out_proj.weight (16 items: 8 chunks x [block 0, block 1])
+  const float* bo = nullptr;       // [256]
+  const float* res = nullptr;      // [M][256] the layer input (residual of norm1)
+  const float* g1 = nullptr; const float* be1 = nullptr;      // norm1
+  const float* cvec = nullptr; int rpg = 1;                   // + cvec[row / rpg][256] before norm2
+  const float* g2 = nullptr; const float* be2 = nullptr;      // norm2
 };
 
 constexpr int kFfnXStride = 264;   // words per X row image: 8 K chunks x 32 words + 8 pad (strides = 8 mod 16: conflict-free ds_read_b128

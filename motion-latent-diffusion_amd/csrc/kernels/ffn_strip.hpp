@@ -28,13 +28,17 @@ namespace mld {
 
 constexpr int kFsXs = 264, kFsHs = 136;      // row strides (words), = 8 mod 16 (conflict-free fragment reads)
 template <int RT>
-constexpr int ffn_strip_lds_bytes() { return (RT * 16 * kFsXs + RT * 16 * kFsHs + 2 * 8 * RT * 16) * 4; }   // RT = 6: 159 744 B; RT = 4: 106 496 B
+constexpr int ffn_strip_lds_bytes() { return (RT * 16 * kFsXs + RT * 16 * kFsHs + 2 * 8 * RT * 16 + RT * 16) * 4; }   // RT = 6: 160 128 B; RT = 4: 106 752 B; RT = 3: 80 064 B (two per CU)
 
 // items of one layer's stream: run1(0), then [run1(hb), run2(hb - 1)] for hb = 1..7, then run2(7); 128 items of 16 KB
 constexpr int kFfnStripItems = 128;
 
 // grid = ceil(M / (16 RT)); block = 512.  p.W1 = the layer's fragment-ordered stream (W2 unused).
-template <int RT>
+// TAIL: the rest of a decoder layer behind its self-attention in ONE launch -- out-projection (16 more items, from the row-strip GEMM's
+// stream of out_proj.weight) + residual + norm1 + cross-attention vector + norm2 produce the block input in LDS instead of reading it:
+// the layer's H1 tensor (M x 256 fp32, written by one launch and read by the next) disappears, 0.8 GB of the decoder's 5.3 GB of HBM
+// traffic per layer at 2 048 motions -- and the decoder's row-strip kernels are bound by exactly that traffic (~3.1 TB/s, r03).
+template <int RT, bool TAIL = false>
 __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnArgs p) {
   constexpr int BM = RT * 16, XS = kFsXs, HS = kFsHs;
 #if defined(MLDHIP_SIM)
@@ -46,6 +50,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
   float* Xs = smem;                    // [BM][264] split image of the strip (A operand of linear1, residual)
   float* Hs = Xs + BM * XS;            // [BM][136] split image of one hidden block (A operand of linear2)
   float* red = Hs + BM * HS;           // [2][8][BM] LayerNorm partial sums
+  int* sidx = reinterpret_cast<int*>(red + 2 * 8 * BM);     // [BM] sample of each row (TAIL: which cvec row to add)
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * BM;
@@ -66,9 +71,11 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
   const float* gsrc = p.W1 + tid * 8;
   F4 ring[RING][2];
   int gitem = 0;
+  constexpr int kItems = kFfnStripItems + (TAIL ? 16 : 0);
   auto gload = [&](int slot) __attribute__((always_inline)) {
-    const int it = gitem < kFfnStripItems ? gitem : kFfnStripItems - 1;     // past the end: a redundant load, never multiplied
-    const float* s = gsrc + (unsigned)it * (unsigned)kLoopItemFloats;
+    const int it = gitem < kItems ? gitem : kItems - 1;     // past the end: a redundant load, never multiplied
+    const float* s = (TAIL && it < 16) ? p.Wo + tid * 8 + (unsigned)it * (unsigned)kLoopItemFloats
+                                       : gsrc + (unsigned)(it - (TAIL ? 16 : 0)) * (unsigned)kLoopItemFloats;
     ring[slot][0] = ld4(s);
     ring[slot][1] = ld4(s + 4);
     ++gitem;
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
     for (int t = 0; t < RT; ++t) { x[t][0] = ld4(a0 + t * 16 * st + 32 * c); x[t][1] = ld4(a0 + t * 16 * st + 32 * c + 16); }
   };
 
-  // ---- prologue: the strip -> split image; the first items of the stream are in flight meanwhile
+  // ---- prologue: the strip (TAIL: of the attention output) -> split image; the first items of the stream are in flight meanwhile
 #pragma unroll
   for (int j = 0; j < RING; ++j) gload(j);
 #pragma unroll
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
     const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
-    const F4 v = ld4(p.X + (size_t)m * 256 + c4 * 4);
+    const F4 v = ld4((TAIL ? p.AO : p.X) + (size_t)m * 256 + c4 * 4);
     unsigned h0, l0, h1, l1;
     split16_pair(v.x, v.y, h0, l0);
     split16_pair(v.z, v.w, h1, l1);
@@ -117,10 +124,108 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
     *reinterpret_cast<U2*>(d) = U2{h0, h1};
     *reinterpret_cast<U2*>(d + 16) = U2{l0, l1};
   }
+  if constexpr (TAIL) {
+    if (p.cvec && tid < BM) {          // one division per row, not per element
+      const int m = m0 + tid < p.M ? m0 + tid : p.M - 1;
+      sidx[tid] = m / p.rpg;
+    }
+  }
   __syncthreads();
 
   const float* xa = Xs + r * XS + g * 4;
   const float* ha = Hs + r * HS + g * 4;
+  if constexpr (TAIL) {
+    // ---- out-projection (transposed products: lane (r, g) holds row r, columns 16 wave + 4g .. + 3 of each 128-column block) + bias +
+    //      residual, LayerNorm(g1), + cvec[sample], LayerNorm(g2) (gemm_strip_x3.hpp's LN form), result -> the strip's image in Xs
+    const int cq0 = wave * 16 + g * 4;
+    f32x4 o0[RT], o1[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) { o0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; o1[t] = o0[t]; }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      F4 x[RT][2];
+      frags(xa, XS, c, x);
+      mma_item(2 * c, x, o0, true);
+      mma_item(2 * c + 1, x, o1, true);
+    }
+    {
+      const F4 ba = ld4(p.bo + cq0), bb = ld4(p.bo + 128 + cq0);
+      const float bav[4] = {ba.x, ba.y, ba.z, ba.w}, bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        int m = m0 + t * 16 + r;
+        m = m < p.M ? m : p.M - 1;
+        const F4 ra = ld4(p.res + (size_t)m * 256 + cq0), rb = ld4(p.res + (size_t)m * 256 + 128 + cq0);
+        const float rav[4] = {ra.x, ra.y, ra.z, ra.w}, rbv[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o0[t][i] += bav[i] + rav[i]; o1[t][i] += bbv[i] + rbv[i]; }
+      }
+    }
+    auto layer_norm = [&](const float* gamma, const float* beta) __attribute__((always_inline)) {
+      const F4 ga = ld4(gamma + cq0), gb = ld4(gamma + 128 + cq0), ba = ld4(beta + cq0), bb = ld4(beta + 128 + cq0);
+      const float gav[4] = {ga.x, ga.y, ga.z, ga.w}, gbv[4] = {gb.x, gb.y, gb.z, gb.w}, bav[4] = {ba.x, ba.y, ba.z, ba.w}, bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        float sum = ((o0[t][0] + o0[t][1]) + (o0[t][2] + o0[t][3])) + ((o1[t][0] + o1[t][1]) + (o1[t][2] + o1[t][3]));
+        sum = sum_groups(sum);
+        if (g == 0) red[(t * 16 + r) * 8 + wave] = sum;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const F4 ma = ld4(red + (t * 16 + r) * 8), mb = ld4(red + (t * 16 + r) * 8 + 4);
+        const float mean = (((ma.x + ma.y) + (ma.z + ma.w)) + ((mb.x + mb.y) + (mb.z + mb.w))) * (1.0f / 256.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o0[t][i] -= mean;
+          o1[t][i] -= mean;
+          sq += o0[t][i] * o0[t][i] + o1[t][i] * o1[t][i];
+        }
+        sq = sum_groups(sq);
+        if (g == 0) red[8 * BM + (t * 16 + r) * 8 + wave] = sq;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const F4 qa = ld4(red + 8 * BM + (t * 16 + r) * 8), qb = ld4(red + 8 * BM + (t * 16 + r) * 8 + 4);
+        const float rs = rsqrtf((((qa.x + qa.y) + (qa.z + qa.w)) + ((qb.x + qb.y) + (qb.z + qb.w))) * (1.0f / 256.0f) + kLnEps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o0[t][i] = o0[t][i] * rs * gav[i] + bav[i];
+          o1[t][i] = o1[t][i] * rs * gbv[i] + bbv[i];
+        }
+      }
+    };
+    layer_norm(p.g1, p.be1);
+    if (p.cvec) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const float* cv = p.cvec + (size_t)sidx[t * 16 + r] * 256 + cq0;
+        const F4 ca = ld4(cv), cb = ld4(cv + 128);
+        o0[t][0] += ca.x; o0[t][1] += ca.y; o0[t][2] += ca.z; o0[t][3] += ca.w;
+        o1[t][0] += cb.x; o1[t][1] += cb.y; o1[t][2] += cb.z; o1[t][3] += cb.w;
+      }
+      __syncthreads();                 // norm1's second pass has been read by every wave before `red` is rewritten
+      layer_norm(p.g2, p.be2);
+    }
+    // every wave left the out-projection before norm1's first barrier: the attention-output image is dead; the block input takes its place
+    const int rw0 = (wave >> 1) * 32 + (wave & 1) * 8 + g * 2;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      unsigned h0, l0, h1, l1;
+      unsigned* w = reinterpret_cast<unsigned*>(Xs + (t * 16 + r) * XS) + rw0;
+      split16_two(o0[t][0], o0[t][1], h0, l0);
+      split16_two(o0[t][2], o0[t][3], h1, l1);
+      *reinterpret_cast<U2*>(w) = U2{h0, h1};
+      *reinterpret_cast<U2*>(w + 16) = U2{l0, l1};
+      split16_two(o1[t][0], o1[t][1], h0, l0);
+      split16_two(o1[t][2], o1[t][3], h1, l1);
+      *reinterpret_cast<U2*>(w + 128) = U2{h0, h1};
+      *reinterpret_cast<U2*>(w + 144) = U2{l0, l1};
+    }
+    __syncthreads();
+  }
   const int hw0 = ((wave >> 1) * 32 + (wave & 1) * 8 + (r >> 1)) * 2 + (r & 1);     // half-word offset of column col0 in a row image
 
   f32x4 h[RT], y0[RT], y1[RT];

@@ -205,6 +205,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<6>());
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<4>());
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<3>());
+  (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<3>());
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
@@ -339,6 +340,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "flash_attn") {
     if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "flash_attn must be 0 (never), 1 (auto) or 2 (always)");
     e->flash_attn = (int)value;
+  } else if (n == "dec_tail") {
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "dec_tail must be 0 or 1");
+    e->dec_tail = (int)value;
   } else if (n == "tile_x3") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "tile_x3 must be 0 or 1");
     e->tile_x3 = (int)value;

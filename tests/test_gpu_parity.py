@@ -278,9 +278,10 @@ def test_split_f16_decode_mode_meets_the_joint_tolerance(dev, golden_dir):
     gd = _gold(golden_dir, "vae_decode_b3.npz")
     b = syn.make_batch(64)
     feats_by = {}
-    for sg, fs in ((1, 6), (1, 4), (1, 3), (0, 0)):
+    for sg, fs, tail in ((1, 6, 1), (1, 4, 1), (1, 3, 1), (1, 3, 0), (0, 0, 1)):      # (1, 3, 1): the one-launch decoder tail ("dec_tail")
         e.set_option("strip_gemm", sg)
         e.set_option("ffn_strip", fs)
+        e.set_option("dec_tail", tail)
         lat, feats, joints, _ = _run_sample(e, dev, b)
         err_f = np.abs(feats.cpu().numpy()[:, -1] - g["feats_frame_last"]).max()
         err_j = np.abs(joints.cpu().numpy()[:, ::4] - g["joints_every4"]).max()

@@ -792,6 +792,14 @@ def test_register_direct_ffn_kernel_sim(ow):
         for i, n in enumerate(lens):
             assert np.all(feats[i, n:] == 0)
         outs[opt] = (feats, mu.copy())
+    # "ffn_strip" 3 ran the decoder layers' TAIL form (out-projection + norms + feed-forward in one launch, "dec_tail" on by default):
+    # the two-launch form of the same strips must agree with it to fp32 rounding
+    e.set_option("ffn_strip", 3)
+    e.set_option("dec_tail", 0)
+    feats2 = np.full((3, 40, 263), np.nan, np.float32)
+    e.vae_decode(z, lens, feats2)
+    assert 0 < np.abs(feats2 - outs[3][0]).max() < 5e-5
+    e.set_option("dec_tail", 1)
     for opt in (6, 4, 3):
         assert 0 < np.abs(outs[opt][0] - outs[0][0]).max() < 5e-5 and 0 < np.abs(outs[opt][1] - outs[0][1]).max() < 5e-5
     with pytest.raises(_lib.MldHipError):
