@@ -143,10 +143,12 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     elsewhere).  Its run time does not depend on the batch up to 8 x #CUs = 2 048 motions, so it wins from ~1 000
  *                     motions per call up.
  *   "fused_min_batch" auto picks the persistent loop from this many motions per call up; 0 (default) = by operand format: 320 on
- *                     split-f16 MFMAs (29 ms per call whatever the batch), 1 280 on exact-fp32 MFMAs (77 ms)
+ *                     split-f16 MFMAs (27 ms per call whatever the batch), 1 280 on exact-fp32 MFMAs (77 ms)
  *   "fused_x3"        F16X3 mode: 1 (default) = the persistent loop multiplies on split-f16 MFMAs, 0 = on exact-fp32 MFMAs
  *   "fused_ring"      persistent loop: weight items in flight per lane, 4 (default) or 8
- *   "fused_dbg"       measurement builds of the persistent loop (WRONG results): 1 = no weight stream, 2 = no MFMAs
+ *   "fused_dbg"       measurement builds of the persistent loop: 1 = no weight stream, 2 = no MFMAs, 3 = identity for GELU, 4 = no
+ *                     feed-forward epilogue (1 - 4: WRONG results); 5 = correct results + per-phase cycle counters of the first 64
+ *                     workgroups, read back with mldhip_profile_trace("den_loop_phases") (tools/trace_loop.py)
  *   "ffn_strip"       F16X3 / FP8 modes, decoder / encoder layers: strip height of the register-direct kernels (kernels/ffn_strip.hpp,
  *                     kernels/gemm_strip_x3.hpp): 1 (default) = by launch size -- more than 512 strips of 64 rows: 96-row strips for the
  *                     GEMMs, 48-row strips at two workgroups per CU for the feed-forward block; else 64 rows (one bs-64 request: 196

@@ -12,18 +12,25 @@
 //   = 24 FLOP per byte.  On exact-fp32 MFMAs (256 FLOP/clk/CU) the stream needs 10.7 B/clk/CU, well under what the register-ring
 //   + ds_write staging sustains: MFMA bound (measured r03: 77 ms for 50 steps at ANY batch up to 2 048 motions = 0.77 of the fp32
 //   MFMA peak).  On split-f16 MFMAs (rt.hpp: 3 instead of 8 matrix instructions per chunk, each twice as fast) the matrix work
-//   shrinks 5x: 30 ms, of which the matrix pipe is busy 42 % and the VALU (GELU, hi / lo splits, LayerNorm, the 3-token softmax)
-//   about as long -- the epilogues of a phase cannot overlap the next phase's products, which depend on them.
+//   shrinks 5x: 27 ms, of which the matrix pipe is busy ~45 %.  Phase counters of the kernel itself (fused_dbg 5, tools/trace_loop.py,
+//   profiles/r03_loop_phase_trace.json): the product-only phases (QKV, out-projection, skip linears) run at 82-84 % of the matrix
+//   rate; the feed-forward phase, whose GELU / split / hidden-image stores and eight barriers share the issue ports with its matrix
+//   instructions, at 56 %; attention scores + softmax, the two LayerNorm phases and the skip handling -- no matrix work at all -- take
+//   a quarter of the time.  The epilogues of a phase cannot overlap the next phase's products, which depend on them.
 // It wins once a call carries enough motions to give most CUs a workgroup (2 048 motions = 256 workgroups = one per CU); below
-// ~1 000 motions the column-split families finish sooner (path_latent.hpp use_fused).
+// a few hundred motions the column-split families finish sooner (path_latent.hpp use_fused).
 //
 // Row order inside the workgroup: row = 16 t + c, t = token, c = row of the CFG batch (c < 8: unconditional half of the 8
-// motions, c >= 8: conditional half).  A 16-row MFMA tile is then ONE token of all 16 CFG rows, so the accumulator registers of
-// lane (r, g) for the three row tiles hold the three tokens of the SAME (CFG row 4g + i, column r): the 3-token attention, the
-// softmax and P.V are in-lane arithmetic on accumulators (only the 64-column dot products cross lanes: 4 DPP adds + one LDS
-// exchange among the four waves of a head), and q, k, v never exist in memory.  For the same reason every residual stays in
-// registers: the lane that produces element (row, column) of a LayerNorm output is the lane that needs it as the residual of
-// the next one.
+// motions, c >= 8: conditional half).  A 16-row MFMA tile is then ONE token of all 16 CFG rows.  Every product is taken TRANSPOSED
+// (weights as the A operand, the rows as B): the accumulator registers of lane (r, g) of wave w hold, for each of the three row
+// tiles, row c = r and columns 16 w + 4 g .. + 3 of a 128-column block -- the three tokens of the SAME CFG row and the same four
+// consecutive columns.  The 3-token attention, the softmax and P.V are in-lane arithmetic on accumulators (the 64-column dot products
+// are four in-lane terms, two shuffles over g and one LDS exchange among the four waves of a head; a softmax is worked out by 4 lanes
+// per row), q, k, v never exist in memory, a LayerNorm's row statistics are eight in-lane terms and two shuffles per tile, and a
+// row's elements enter an operand image as one 8-byte store per plane.  (The first form of this kernel kept the plain accumulator
+// layout -- rows 4g + i, one column per lane: sixteen-lane DPP reductions per element, softmaxes repeated in 16 lanes, 2-byte
+// image stores; attention 4.2 -> 2.6 ms, loop 29.7 -> 26.7 ms with the transposed one.)  Residuals are re-read from the operand
+// image they were multiplied from (high + low half, the value the GEMMs saw), so no activation stays in registers across a phase.
 //
 // Weight stream: a weight element is used by exactly ONE wave (wave w owns columns 16w .. 16w + 15 of every 128-column block), so
 // staging weights through LDS would buy nothing and cost a store, a read and a barrier per item (the first build of this kernel
@@ -34,8 +41,8 @@
 // into an 8-deep register ring: 2 KB contiguous per wave and item, no LDS, no barrier.  Waves only meet where activations
 // change hands (17 barriers per layer).  Items that multiply the same 32 columns of A are adjacent in the stream ([Q, K, V] of a
 // chunk; both column blocks of the out-projection, linear2 and the skip linears; two hidden blocks of linear1), so an A fragment
-// read from LDS feeds 2-3 items.  The sequence is uniform over phases, layers and steps (it wraps at the end of a step): the
-// prefetch never drains.  Bound in split mode: the L2 -> CU path (16 KB per item and CU at 64 B/clk) next to 9 MFMAs per item and wave.
+// read from LDS feeds 2-3 items.  The sequence is uniform over phases, layers and steps (the first items of a step are repeated
+// behind its last one, so the look-ahead needs no wrap test): the prefetch never drains.  Bound in split mode: the L2 -> CU path (16 KB per item and CU at 64 B/clk) next to 9 MFMAs per item and wave.
 //
 // Replaces, per step: mld_denoiser.py:143-228 (token assembly, SkipTransformerEncoder, final norm), mld.py:325-346 (CFG + DDIM).
 #pragma once

@@ -38,6 +38,8 @@ for opt in OPTS:
     t_all = best(lambda: eng.sample_many(reqs))
     err = float(np.abs(reqs[0]["joints_out"].cpu().numpy()[:, ::4] - g["joints_every4"]).max())
     key = ",".join(f"{k}={v}" for k, v in opt.items())
+    while key in out:
+        key += "#"                                   # a repeated variant (interleaved rounds) keeps its own entry
     out[key] = dict(all_ms=round(t_all * 1e3, 2), decode_ms=round((t_all - t_loop) * 1e3, 2), motions_per_s=round(N / t_all, 1), joints_err=err)
     print(key, out[key], flush=True)
 print(json.dumps(out))

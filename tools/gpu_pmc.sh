@@ -26,8 +26,8 @@ for f in glob.glob(f"gpurun_out/pmc_{tag}_*/**/*counter_collection*.csv", recurs
         e = a[(row["Kernel_Name"], row["Counter_Name"])]; e[0] += 1; e[1] += float(row["Counter_Value"])
     for (k, c), (n, v) in a.items():
         agg[k][c] = (n, v / n)
-NAMES = {"den_loop": "den_loop_kernel", "dec_ffn": "ffn_strip_x3_kernel", "dec_qkv": "strip_gemm_x3_kernel<6, 1, false, true>",
-         "dec_outproj_ln": "strip_gemm_x3_kernel<6, 1, true, false>", "dec_skip": "strip_gemm_x3_kernel<4, 2, false, false>", "dec_attn": "attn_flash_x3_kernel"}
+NAMES = {"den_loop": "den_loop_kernel", "dec_ffn": "ffn_strip_x3_kernel", "dec_qkv": "strip_gemm_x3_kernel<6, 1, false, true",
+         "dec_outproj_ln": "strip_gemm_x3_kernel<6, 1, true, false", "dec_skip": "strip_gemm_x3_kernel<4, 2, false, false", "dec_attn": "attn_flash_x3_kernel"}
 traffic, sq = {}, {}
 for short, pat in NAMES.items():
     hits = [k for k in agg if pat in k]
