@@ -621,16 +621,20 @@ int sample_many_impl(mldhip_handle* e, const mldhip_request* rq, int nreq, hipSt
     for (int i = 0; i < nreq; ++i) { std::copy(rq[i].actions_host, rq[i].actions_host + rq[i].B, lab.begin() + Btot + o); o += rq[i].B; }
     HIP_TRY(e, hipMemcpyAsync(e->labels_dev, lab.data(), lab.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   }
-  int o = 0;
-  for (int i = 0; i < nreq; ++i) {
-    const mldhip_request& r = rq[i];
-    const size_t b = (size_t)r.B;
-    if (!action) {
-      HIP_TRY(e, hipMemcpyAsync(e->text_in + (size_t)o * TD, r.text_emb_dev, b * TD * sizeof(float), hipMemcpyDeviceToDevice, stream));
-      HIP_TRY(e, hipMemcpyAsync(e->text_in + ((size_t)Btot + o) * TD, r.text_emb_dev + b * TD, b * TD * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  Ctx cio{e, stream};
+  {
+    GatherArgs ga;
+    int o = 0, bmax = 0;
+    for (int i = 0; i < kMaxRequests; ++i) { ga.text[i] = nullptr; ga.lat[i] = nullptr; ga.off[i] = 0; ga.nb[i] = 0; }
+    for (int i = 0; i < nreq; ++i) {
+      ga.text[i] = action ? nullptr : rq[i].text_emb_dev; ga.lat[i] = rq[i].init_latents_dev; ga.off[i] = o; ga.nb[i] = rq[i].B;
+      o += rq[i].B; bmax = std::max(bmax, (int)rq[i].B);
     }
-    HIP_TRY(e, hipMemcpyAsync(e->lat_in + (size_t)o * D, r.init_latents_dev, b * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    o += r.B;
+    ga.text_in = e->text_in; ga.lat_in = e->lat_in; ga.Btot = Btot; ga.TD = (int)TD; ga.D = (int)D;
+    const long long per = (action ? 0 : 2LL * bmax * (long long)TD) + (long long)bmax * (long long)D;      // elements of the largest request
+    const unsigned chunks = (unsigned)std::min<long long>(64, std::max<long long>(1, (per + 2047) / 2048));
+    MLD_LAUNCH(gather_requests_kernel, dim3((unsigned)nreq, chunks), dim3(256), 0, stream, ga);
+    if (check_launch(cio, "gather_requests")) return cio.rc;
   }
   const float* text = action ? nullptr : e->text_in;
   bool replayed = false;
@@ -645,18 +649,18 @@ int sample_many_impl(mldhip_handle* e, const mldhip_request* rq, int nreq, hipSt
   if (!replayed) {
     if (int rc = enqueue_sample(e, stream, text, e->lat_in, Btot, T, nullptr, want_f ? e->feats_int : nullptr, want_j ? e->joints_int : nullptr)) return rc;
   }
-  o = 0;
-  for (int i = 0; i < nreq; ++i) {
-    const mldhip_request& r = rq[i];
-    const size_t b = (size_t)r.B, ti = (size_t)tmax[i];
-    if (r.latents_out_dev) HIP_TRY(e, hipMemcpyAsync(r.latents_out_dev, e->lat + (size_t)o * D, b * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    if (r.feats_out_dev)
-      HIP_TRY(e, hipMemcpy2DAsync(r.feats_out_dev, ti * NF * sizeof(float), e->feats_int + (size_t)o * T * NF, (size_t)T * NF * sizeof(float),
-                                  ti * NF * sizeof(float), b, hipMemcpyDeviceToDevice, stream));
-    if (r.joints_out_dev)
-      HIP_TRY(e, hipMemcpy2DAsync(r.joints_out_dev, ti * NJ * sizeof(float), e->joints_int + (size_t)o * T * NJ, (size_t)T * NJ * sizeof(float),
-                                  ti * NJ * sizeof(float), b, hipMemcpyDeviceToDevice, stream));
-    o += r.B;
+  {
+    ScatterArgs sa;
+    int o = 0, bmax = 0;
+    for (int i = 0; i < kMaxRequests; ++i) { sa.lat_out[i] = nullptr; sa.feats_out[i] = nullptr; sa.joints_out[i] = nullptr; sa.off[i] = 0; sa.nb[i] = 0; sa.tmax[i] = 0; }
+    for (int i = 0; i < nreq; ++i) {
+      sa.lat_out[i] = rq[i].latents_out_dev; sa.feats_out[i] = rq[i].feats_out_dev; sa.joints_out[i] = rq[i].joints_out_dev;
+      sa.off[i] = o; sa.nb[i] = rq[i].B; sa.tmax[i] = tmax[i];
+      o += rq[i].B; bmax = std::max(bmax, (int)rq[i].B);
+    }
+    sa.lat = e->lat; sa.feats = e->feats_int; sa.joints = e->joints_int; sa.T = T; sa.D = (int)D; sa.NF = (int)NF; sa.NJ = (int)NJ;
+    MLD_LAUNCH(scatter_results_kernel, dim3((unsigned)nreq, (unsigned)bmax), dim3(256), 0, stream, sa);
+    if (check_launch(cio, "scatter_results")) return cio.rc;
   }
   return MLDHIP_OK;
 }
