@@ -124,6 +124,38 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def kernel_code_hash(name_part="den_loop_kernelILb1ELi4ELi0E"):
+    """Hash of the gfx950 MACHINE CODE of one kernel inside libmldhip.so (the persistent loop by default): the identity that ties a
+    PMC summary to the build it is quoted for.  The whole-source hash above goes stale with any edit anywhere in csrc/; this one only
+    when the compiled kernel itself changes.  None when the LLVM tools are missing."""
+    tmp = tempfile.mkdtemp(prefix="mld_co_")
+    try:
+        fat, co = os.path.join(tmp, "fatbin"), os.path.join(tmp, "gfx950.co")
+        subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", _lib.DEFAULT_LIB, os.path.join(tmp, "copy.so")],
+                       check=True, capture_output=True)
+        subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}", f"--output={co}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True, capture_output=True)
+        syms = subprocess.run([os.path.join(LLVM_BIN, "llvm-readelf"), "-s", "--wide", co], check=True, capture_output=True, text=True).stdout
+        hits = {ln.split()[-1] for ln in syms.splitlines() if name_part in ln and " FUNC " in ln}      # (.dynsym and .symtab both list it)
+        if len(hits) != 1:
+            return None
+        sym = hits.pop()
+        dis = subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--no-leading-addr", "--no-show-raw-insn", f"--disassemble-symbols={sym}", co],
+                             check=True, capture_output=True, text=True).stdout
+        body = [ln.split("//")[0].strip() for ln in dis.splitlines() if ln.startswith((" ", "\t"))]
+        body = [ln for ln in body if ln]
+        if len(body) < 100:
+            return None
+        return hashlib.sha256("\n".join(body).encode()).hexdigest()[:16]
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def synthetic_state():
     t = {**{"denoiser." + k: v for k, v in syn.make_denoiser_state_dict().items()},
          **{"vae." + k: v for k, v in syn.make_vae_state_dict().items()}}
@@ -618,12 +650,16 @@ def main():
         traffic, traffic_note = None, "no PMC summary (profiles/r03_pmc_traffic.json)"
         try:
             pmc = json.load(open(os.path.join(REPO, "profiles", "r03_pmc_traffic.json")))
-            if pmc.get("source_hash") == source_hash() and pmc.get("requests_per_call") == coalesce:
+            code = kernel_code_hash()
+            same_code = code is not None and pmc.get("loop_kernel_code_hash") == code
+            if (same_code or pmc.get("source_hash") == source_hash()) and pmc.get("requests_per_call") == coalesce:
                 traffic = pmc["kernels"]["den_loop"]["traffic_bytes_per_launch"]
-                traffic_note = "profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on THIS source hash and call shape; L2<->fabric bytes per launch"
+                traffic_note = ("profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on THIS %s and call shape; L2<->fabric bytes per launch"
+                                % ("machine code of the kernel (loop_kernel_code_hash %s)" % code if same_code else "source hash"))
             else:
-                traffic_note = "profiles/r03_pmc_traffic.json was collected on source hash %s / %s requests per call, this run is %s / %d: refused as stale" % (
-                    pmc.get("source_hash"), pmc.get("requests_per_call"), source_hash(), coalesce)
+                traffic_note = "profiles/r03_pmc_traffic.json was collected on kernel code %s / source hash %s / %s requests per call, this run is %s / %s / %d: refused as stale" % (
+                    pmc.get("loop_kernel_code_hash"), pmc.get("source_hash"), pmc.get("requests_per_call"), code, source_hash(), coalesce)
+            roof["loop_kernel_code_hash"] = code
         except Exception:
             pass
         roof["traffic"], roof["traffic_source"] = traffic, traffic_note

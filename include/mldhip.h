@@ -157,6 +157,13 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "dec_tail"        F16X3 / FP8 modes, chip-filling launches: 1 (default) = a decoder layer's out-projection + residual + norm1 +
  *                     cross-attention vector + norm2 + feed-forward block as ONE launch (kernels/ffn_strip.hpp TAIL form: the block
  *                     input never goes to HBM), 0 = two launches
+ *   "dec_l0_once"     every mode: 1 (default) = the first decoder layer's in-projection runs over ONE sample's rows: its input is
+ *                     zeros + the positional rows (mld_vae.py:216-222, actor_vae.py:221-222), the same for every sample, so Q, K, V of
+ *                     layer 0 are computed for [T] rows and every (sample, head) attention workgroup reads them (exact: same numbers,
+ *                     B times less work and no [B T][3 D] round trip through HBM for that layer); 0 = per sample like the other layers
+ *   "nt_hints"        F16X3 / FP8 modes, measurement option: streaming (`nt`) global accesses for the activations of the decoder's
+ *                     row-strip kernels, bit mask: 1 = GEMM output stores, 2 = GEMM strip loads, 4 = feed-forward / tail strip and
+ *                     residual loads, 8 = feed-forward / tail output stores; default 0 (results are identical either way)
  *   "tile_x3"         F16X3 mode: 1 (default) = the latency kernels of the reverse loop (kernels/tile32.hpp, one request at a time) multiply
  *                     on split-f16 MFMAs reading the pre-split weight image, 0 = on exact-fp32 MFMAs
  *   "strip_gemm"      F16X3 / FP8 modes, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:

@@ -416,7 +416,8 @@ void time_mlp(Ctx& c, const float* temb0, float* mid, float* out, int n) {
 // One decoder layer over M = B*T frame rows with memory = the sample's latent (cross_attention.py:323-345).
 int pick_nkt(int T) { return T <= 64 ? 4 : T <= 112 ? 7 : T <= 208 ? 13 : 18; }
 
-void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr) {
+// shared_qkv: QKV holds ONE sample's projections [T][3D], read by every (sample, head) workgroup (decoder layer 0, dec_layer)
+void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr, int shared_qkv = 0) {
   if (!lens) lens = c.e->lens_dev;
   E* e = c.e;
   const int H = e->cfg.num_heads;
@@ -428,16 +429,16 @@ void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr) {
     // (B H >= 512: 108 vs 133 us at 1 280 workgroups); with one per CU the whole-K/V kernel below is 5 % faster (28.9 vs 30.3 us)
     // (it covers 16 query tiles = 256 frames per (sample, head); longer sequences take the whole-K/V kernel)
     if (T <= 256 && (e->flash_attn == 2 || (e->flash_attn == 1 && B * H >= 512))) {
-      MLD_LAUNCH(attn_flash_x3_kernel, grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H);
+      MLD_LAUNCH(attn_flash_x3_kernel, grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv);
       count(c);
       check_launch(c, "attn_flash_x3");
       return;
     }
     switch (nkt) {
-      case 4: MLD_LAUNCH((attn_decode_x3_kernel<4>), grid, block, attn_x3_lds_bytes<4>(), c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
-      case 7: MLD_LAUNCH((attn_decode_x3_kernel<7>), grid, block, attn_x3_lds_bytes<7>(), c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
-      case 13: MLD_LAUNCH((attn_decode_x3_kernel<13>), grid, block, attn_x3_lds_bytes<13>(), c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
-      default: MLD_LAUNCH((attn_decode_x3_kernel<18>), grid, block, attn_x3_lds_bytes<18>(), c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
+      case 4: MLD_LAUNCH((attn_decode_x3_kernel<4>), grid, block, attn_x3_lds_bytes<4>(), c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
+      case 7: MLD_LAUNCH((attn_decode_x3_kernel<7>), grid, block, attn_x3_lds_bytes<7>(), c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
+      case 13: MLD_LAUNCH((attn_decode_x3_kernel<13>), grid, block, attn_x3_lds_bytes<13>(), c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
+      default: MLD_LAUNCH((attn_decode_x3_kernel<18>), grid, block, attn_x3_lds_bytes<18>(), c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
     }
     count(c);
     check_launch(c, "attn_decode_x3");
@@ -445,10 +446,10 @@ void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr) {
   }
   const size_t shmem = (size_t)2 * nkt * 16 * 68 * sizeof(float);
   switch (nkt) {
-    case 4: MLD_LAUNCH((attn_decode_kernel<4>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
-    case 7: MLD_LAUNCH((attn_decode_kernel<7>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
-    case 13: MLD_LAUNCH((attn_decode_kernel<13>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
-    default: MLD_LAUNCH((attn_decode_kernel<18>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H); break;
+    case 4: MLD_LAUNCH((attn_decode_kernel<4>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
+    case 7: MLD_LAUNCH((attn_decode_kernel<7>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
+    case 13: MLD_LAUNCH((attn_decode_kernel<13>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
+    default: MLD_LAUNCH((attn_decode_kernel<18>), grid, block, shmem, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
   }
   count(c);
   check_launch(c, "attn_decode");
@@ -473,7 +474,7 @@ bool strip_gemm(Ctx& c, const GemmArgs& g, bool ln) {
   if (it == e->gemm_stream_of.end()) return false;
   StripGemmArgs a;
   a.A = g.A; a.A2 = g.A2; a.W = it->second; a.bias = g.bias; a.Y = g.Y; a.ldy = g.ldy; a.M = g.M; a.N = g.N;
-  a.skip_lens = g.skip_lens; a.skip_rpg = g.skip_rpg;
+  a.skip_lens = g.skip_lens; a.skip_rpg = g.skip_rpg; a.nt = e->nt_hints;
   if (ln) {
     if (g.N != 256 || g.K2 != 0 || !g.res || g.ldres != 256 || !g.g1) return false;
     a.res = g.res; a.g1 = g.g1; a.b1 = g.b1; a.cvec = g.cvec; a.rpg = g.rows_per_group; a.g2 = g.g2; a.b2 = g.b2;
@@ -506,7 +507,7 @@ void ffn_block(Ctx& c, const float* x, float* y, int M, const float* w1, const f
   if (staged_prec(e) == PREC_BF16X3 && e->ffn_strip && D == 256 && F == 1024 && M > e->small_m && !e->trace_on && e->ffn_stream_of.count(w1)) {
     // register-direct form (kernels/ffn_strip.hpp): weights from the layer's fragment-ordered stream, 96- or 64-row strips
     FfnArgs a;
-    a.X = x; a.W1 = e->ffn_stream_of[w1]; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.Y = y; a.M = M;
+    a.X = x; a.W1 = e->ffn_stream_of[w1]; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.Y = y; a.M = M; a.nt = e->nt_hints;
     if (ragged_T > 0) { a.skip_lens = e->lens_dev; a.skip_rpg = ragged_T; }
     // auto: 48-row strips, two workgroups per CU (four waves per SIMD, 128 registers each) for launches that fill the chip: 2 % off the
     // decoder against 96-row strips (r03, 2 048 motions: 25.2 vs 25.8 ms) although the weights are streamed twice as often
@@ -540,23 +541,29 @@ void ffn_block(Ctx& c, const float* x, float* y, int M, const float* w1, const f
   gemm_ln(c, f2);
 }
 
-void dec_layer(Ctx& c, int l, const float* xin, float* xout, int B, int T) {
+// pos_input: xin holds the time queries themselves (zeros + positional rows, init_queries_kernel): row t of EVERY sample is pe[t], so
+// the layer's Q, K, V depend on t only.  They are then projected once, for sample 0's T rows, and read by every (sample, head)
+// attention workgroup (which still applies its own sample's length mask): exact, and the [B T][3 D] tensor of that layer -- 1.23 GB
+// written and read back at 2 048 motions -- never exists ("dec_l0_once").
+void dec_layer(Ctx& c, int l, const float* xin, float* xout, int B, int T, bool pos_input = false) {
   E* e = c.e;
   const DecLayerP& L = e->dec[l];
   const int D = e->cfg.latent_dim, M = B * T;
   auto ragged = [&](GemmArgs g) { g.skip_lens = e->lens_dev; g.skip_rpg = T; return g; };   // skip all-padding row tiles
+  const bool once = pos_input && e->dec_l0_once && B > 1;
   {
-    const GemmArgs q = ragged(lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
+    // once: all T rows (no ragged skip: sample 0 may be shorter than the samples that read its rows)
+    const GemmArgs q = once ? lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, T, 3 * D) : ragged(lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
     if (!strip_gemm(c, q, false)) gemm(c, q);
   }
-  dec_attention(c, B, T);
+  dec_attention(c, B, T, nullptr, once ? 1 : 0);
   // Chip-filling launches of the split modes: the rest of the layer in ONE launch (kernels/ffn_strip.hpp, TAIL form) -- the H1 tensor
   // between the out-projection kernel and the feed-forward kernel is not written and read back ("dec_tail", on by default)
   if (e->dec_tail && staged_prec(e) == PREC_BF16X3 && e->strip_gemm && (e->ffn_strip == 3 || (e->ffn_strip == 1 && strip_rows_rt(e, M) == 6)) &&
       D == 256 && e->cfg.ff_size == 1024 && !e->trace_on && M > e->small_m && e->ffn_stream_of.count(L.l1_w) && e->gemm_stream_of.count(L.out_w)) {
     FfnArgs a;
     a.W1 = e->ffn_stream_of[L.l1_w]; a.b1 = L.l1_b; a.b2 = L.l2_b; a.gamma = L.n3_w; a.beta = L.n3_b; a.Y = xout; a.M = M;
-    a.skip_lens = e->lens_dev; a.skip_rpg = T;
+    a.skip_lens = e->lens_dev; a.skip_rpg = T; a.nt = e->nt_hints;
     a.AO = e->AO; a.Wo = e->gemm_stream_of[L.out_w]; a.bo = L.out_b; a.res = xin; a.g1 = L.n1_w; a.be1 = L.n1_b;
     a.cvec = e->cvec + (size_t)l * e->cfg.max_batch * D; a.rpg = T; a.g2 = L.n2_w; a.be2 = L.n2_b;
     MLD_LAUNCH((ffn_strip_x3_kernel<3, true>), dim3((M + 47) / 48), dim3(512), (ffn_strip_lds_bytes<3>()), c.stream, a);
@@ -613,7 +620,7 @@ void decode_body(Ctx& c, const float* z, int B, int T, float* feats_out) {
     const float* xin = e->X0;
     for (int l = 0; l < L; ++l) {
       float* xout = (l & 1) ? e->Hb : e->Ha;
-      dec_layer(c, l, xin, xout, B, T);
+      dec_layer(c, l, xin, xout, B, T, l == 0);
       xin = xout;
     }
     GemmArgs f = lin_args(xin, D, D, P(e, "vae.decoder.final_layer.weight"), P(e, "vae.decoder.final_layer.bias"), feats_out, NF, M, NF);
@@ -623,10 +630,10 @@ void decode_body(Ctx& c, const float* z, int B, int T, float* feats_out) {
   }
   const float* x = e->X0;
   for (int l = 0; l < nb; ++l) {
-    dec_layer(c, l, x, e->S[l], B, T);
+    dec_layer(c, l, x, e->S[l], B, T, l == 0);
     x = e->S[l];
   }
-  dec_layer(c, nb, x, e->Ha, B, T);
+  dec_layer(c, nb, x, e->Ha, B, T, nb == 0);
   for (int i = 0; i < nb; ++i) {
     skip_linear(c, "vae.decoder", i, e->Ha, e->S[nb - 1 - i], e->Hb, M, T);
     dec_layer(c, nb + 1 + i, e->Hb, e->Ha, B, T);

@@ -30,7 +30,7 @@ namespace mld {
 // other's MFMAs -- with one wave per SIMD they serialise and the kernel runs at ~2.4x its MFMA time.
 template <int NKT, int NW = 8>   // max key tiles (NKT*16 >= T); waves per workgroup
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                          const int* __restrict__ lens, int T, int H) {
+                                                          const int* __restrict__ lens, int T, int H, int shared_qkv = 0) {
   constexpr int HD = 64, LDS_STRIDE = 68;
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
@@ -39,6 +39,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* __res
 #endif
   const int D = H * HD;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int bq = shared_qkv ? 0 : b;          // shared_qkv: every sample reads sample 0's projections (decoder layer 0: its input is the positional rows, the same for every sample)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = lens[b] < T ? lens[b] : T;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* __res
   {
     constexpr int KPI = NW * 4, NIT = (NKT * 16 + KPI - 1) / KPI;   // keys per pass (16 float4 per 64-wide row); passes
     const int c4 = tid & 15, k0 = tid >> 4;
-    const float* base = qkv + (long long)b * T * 3 * D + h * HD + c4 * 4;
+    const float* base = qkv + (long long)bq * T * 3 * D + h * HD + c4 * 4;
 #pragma unroll
     for (int op = 0; op < 2; ++op) {
       float* dst = op == 0 ? Ks : Vs;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* __res
     // Q fragment: query q0+r, head dims g*16 .. g*16+15, pre-scaled by 1/sqrt(64)
     int qrow = qt * 16 + r;
     qrow = qrow < T ? qrow : T - 1;
-    const float* qp = qkv + (long long)(b * T + qrow) * 3 * D + h * HD + g * 16;
+    const float* qp = qkv + (long long)(bq * T + qrow) * 3 * D + h * HD + g * 16;
     float qf[16];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -185,7 +186,7 @@ __device__ __forceinline__ void split_hi_lo_x8_unit(const float (&x)[8], U4& hi,
 
 template <int NKT, int NW = 8>
 __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                             const int* __restrict__ lens, int T, int H) {
+                                                             const int* __restrict__ lens, int T, int H, int shared_qkv = 0) {
   constexpr int HD = 64, KST = kAttnX3KStride, VST = attn_x3_vt_stride<NKT>(), NKB = (NKT + 1) / 2;
 #if defined(MLDHIP_SIM)
   unsigned* smem = reinterpret_cast<unsigned*>(hipsim::blk().dyn_smem.data());
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __
   unsigned* Vl = Vh + 64 * VST;
   const int D = H * HD;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int bq = shared_qkv ? 0 : b;          // shared_qkv: every sample reads sample 0's projections (decoder layer 0: its input is the positional rows, the same for every sample)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = lens[b] < T ? lens[b] : T;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __
   {
     constexpr int KPI = NW * 4, NIT = (NKB * 32 + KPI - 1) / KPI;
     const int c4 = tid & 15, k0 = tid >> 4;
-    const float* base = qkv + (long long)b * T * 3 * D + h * HD + c4 * 4;
+    const float* base = qkv + (long long)bq * T * 3 * D + h * HD + c4 * 4;
     F4 v[NIT];
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __
     // dims of one key, as for K, means eight 2-byte stores per thread that land 8-way on the same banks: 4 x VST words apart.)
     constexpr int NVG = NKB * 8, NVI = (NVG + NW - 1) / NW;     // groups of 4 keys; iterations (a wave takes one group per iteration)
     const int vd = tid & 63, vg0 = tid >> 6;
-    const float* vbase = qkv + (long long)b * T * 3 * D + h * HD + 2 * D + vd;
+    const float* vbase = qkv + (long long)bq * T * 3 * D + h * HD + 2 * D + vd;
     float vv[NVI][4];
 #pragma unroll
     for (int it = 0; it < NVI; ++it)
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_x3_kernel(const float* __
     // Q fragments: query q0 + r, dims 32c + 8g .. + 7, pre-scaled by 1/sqrt(64), split hi / lo
     int qrow = qt * 16 + r;
     qrow = qrow < T ? qrow : T - 1;
-    const float* qp = qkv + (long long)(b * T + qrow) * 3 * D + h * HD + g * 8;
+    const float* qp = qkv + (long long)(bq * T + qrow) * 3 * D + h * HD + g * 8;
     U4 qh[2], ql[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -363,7 +365,7 @@ constexpr int kFlashStageWords = 2 * 32 * kFlashKStride + 2 * 64 * kFlashVStride
 constexpr int kFlashLdsBytes = 2 * kFlashStageWords * 4;   // 40 960 B
 
 __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                            const int* __restrict__ lens, int T, int H) {
+                                                            const int* __restrict__ lens, int T, int H, int shared_qkv = 0) {
   constexpr int HD = 64, KST = kFlashKStride, VST = kFlashVStride, NW = 8;
 #if defined(MLDHIP_SIM)
   unsigned* smem = reinterpret_cast<unsigned*>(hipsim::blk().dyn_smem.data());
@@ -373,11 +375,12 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
 #endif
   const int D = H * HD;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int bq = shared_qkv ? 0 : b;          // shared_qkv: every sample reads sample 0's projections (decoder layer 0: its input is the positional rows, the same for every sample)
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int len = lens[b] < T ? lens[b] : T;
   const int nkt = (len + 15) >> 4, nkb = (nkt + 1) >> 1, nqt = nkt;
-  const float* base = qkv + (long long)b * T * 3 * D + h * HD;
+  const float* base = qkv + (long long)bq * T * 3 * D + h * HD;
 
   // ---- staging: thread t owns key (t >> 4) of the block, dims 4 (t & 15) .. + 3 of K and of V
   const int skey = tid >> 4, c4 = tid & 15;

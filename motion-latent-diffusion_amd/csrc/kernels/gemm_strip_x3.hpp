@@ -26,6 +26,7 @@ struct StripGemmArgs {
   const float* g1 = nullptr; const float* b1 = nullptr;
   const float* cvec = nullptr; int rpg = 1;              // + cvec[row / rpg][256] before the second LayerNorm
   const float* g2 = nullptr; const float* b2 = nullptr;
+  int nt = 0;                        // "nt_hints" bits (state.hpp): 1 = output stores streaming, 2 = strip loads streaming
 };
 
 template <int RT, int NSEG, bool STAGE>
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
       const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;
-      const F4 v = ld4(src + (size_t)m * 256 + c4 * 4);
+      const F4 v = ld4_if_nt(src + (size_t)m * 256 + c4 * 4, p.nt & 2);
       unsigned h0, l0, h1, l1;
       split16_pair(v.x, v.y, h0, l0);
       split16_pair(v.z, v.w, h1, l1);
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
 #pragma unroll
           for (int j = 0; j < RT; ++j) {
             const int idx = tid + j * 512, row = idx >> 5, c4 = idx & 31;
-            if (m0 + row < p.M) st4(p.Y + (size_t)(m0 + row) * p.ldy + pr * 256 + cb * 128 + c4 * 4, ld4(St + row * HS + c4 * 4));
+            if (m0 + row < p.M) st4_if_nt(p.Y + (size_t)(m0 + row) * p.ldy + pr * 256 + cb * 128 + c4 * 4, ld4(St + row * HS + c4 * 4), p.nt & 1);
           }
         }
       } else {
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
 #pragma unroll
         for (int j = 0; j < RT * 2; ++j) {
           const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
-          if (m0 + row < p.M) st4(p.Y + (size_t)(m0 + row) * p.ldy + c4 * 4, ld4(Xs + row * XS + c4 * 4));
+          if (m0 + row < p.M) st4_if_nt(p.Y + (size_t)(m0 + row) * p.ldy + c4 * 4, ld4(Xs + row * XS + c4 * 4), p.nt & 1);
         }
       }
     } else {

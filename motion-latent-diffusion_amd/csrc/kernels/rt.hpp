@@ -203,6 +203,25 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 struct alignas(16) F4 { float x, y, z, w; };
 __device__ __forceinline__ F4 ld4(const float* p) { return *reinterpret_cast<const F4*>(p); }
 __device__ __forceinline__ void st4(float* p, F4 v) { *reinterpret_cast<F4*>(p) = v; }
+// streaming ("nt") forms for activations that one workgroup touches once per launch (the decoder's row strips): `nt` on the
+// global_load / global_store, i.e. no reuse expected -- the weight streams every workgroup re-reads keep the default policy.
+// Measurement option "nt_hints" (state.hpp); the simulator has no cache model: plain accesses there.
+__device__ __forceinline__ F4 ld4_nt(const float* p) {
+#if defined(MLDHIP_SIM)
+  return ld4(p);
+#else
+  return __builtin_bit_cast(F4, __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)));
+#endif
+}
+__device__ __forceinline__ void st4_nt(float* p, F4 v) {
+#if defined(MLDHIP_SIM)
+  st4(p, v);
+#else
+  __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v), reinterpret_cast<f32x4*>(p));
+#endif
+}
+__device__ __forceinline__ F4 ld4_if_nt(const float* p, bool nt) { return nt ? ld4_nt(p) : ld4(p); }
+__device__ __forceinline__ void st4_if_nt(float* p, F4 v, bool nt) { if (nt) st4_nt(p, v); else st4(p, v); }
 
 constexpr float kLnEps = 1e-5f;
 

@@ -343,6 +343,12 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "dec_tail") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "dec_tail must be 0 or 1");
     e->dec_tail = (int)value;
+  } else if (n == "dec_l0_once") {
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "dec_l0_once must be 0 or 1");
+    e->dec_l0_once = (int)value;
+  } else if (n == "nt_hints") {
+    if (value < 0 || value > 15) return e->fail(MLDHIP_EINVAL, "nt_hints is a bit mask 0..15");
+    e->nt_hints = (int)value;
   } else if (n == "tile_x3") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "tile_x3 must be 0 or 1");
     e->tile_x3 = (int)value;

@@ -296,6 +296,43 @@ def test_split_f16_decode_mode_meets_the_joint_tolerance(dev, golden_dir):
     e.close()
 
 
+def test_first_decoder_layer_projected_once_and_streaming_hints_change_nothing(dev, golden_dir):
+    """"dec_l0_once" (default on): decoder layer 0's in-projection over ONE sample's positional rows, read by every (sample, head)
+    attention workgroup -- against the per-sample form: same kernels and products, so the reference's ragged MldVae.decode fixture
+    (sample 0 is NOT the longest) and a 64-motion decode agree to the bit in exact fp32 and to fp32 rounding in the split mode (the
+    shared projection takes the small-M GEMM shape there); "nt_hints" (streaming loads / stores in the row-strip kernels) is bitwise
+    neutral."""
+    gd = _gold(golden_dir, "vae_decode_b3.npz")
+    b = syn.make_batch(64, "ragged", seed=77)
+    lens64 = [int(x) for x in b.lengths]
+    lens64[0] = 40                                 # sample 0 (whose rows carry the shared projection) is the shortest
+    tm = max(lens64)
+    for prec in (0, 1):
+        e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=prec)
+        _load(e)
+        outs = []
+        for once in (1, 0):
+            e.set_option("dec_l0_once", once)
+            f3 = torch.full((3, 100, 263), float("nan"), device=dev)
+            e.vae_decode(_cuda(gd["z"], dev), [int(x) for x in gd["lengths"]], f3)
+            z = _cuda(syn._rng(5, "l0z").standard_normal((64, 1, 256)).astype(np.float32), dev)
+            f64 = torch.full((64, tm, 263), float("nan"), device=dev)
+            e.vae_decode(z, lens64, f64)
+            torch.cuda.synchronize()
+            assert np.abs(f3.cpu().numpy() - gd["feats"]).max() < 1e-4
+            outs.append((f3.clone(), f64.clone()))
+        d3, d64 = (outs[0][0] - outs[1][0]).abs().max().item(), (outs[0][1] - outs[1][1]).abs().max().item()
+        print("dec_l0_once on vs off, precision %d: max diff %.3e (3 ragged) %.3e (64 motions)" % (prec, d3, d64))
+        assert d3 < 2e-5 and d64 < 2e-5
+        if prec == 1:
+            e.set_option("nt_hints", 15)
+            f64n = torch.full((64, tm, 263), float("nan"), device=dev)
+            e.vae_decode(z, lens64, f64n)
+            torch.cuda.synchronize()
+            assert torch.equal(f64n, outs[1][1])
+        e.close()
+
+
 def test_vae_encode_vs_reference_golden(eng, dev, golden_dir, oracle_weights):
     """Scope row 8f.1: MldVae.encode vs the reference's own Normal(mu, std) on the frozen inputs."""
     ops, _, bv = oracle_weights

@@ -808,3 +808,51 @@ def test_register_direct_ffn_kernel_sim(ow):
     with pytest.raises(_lib.MldHipError):
         e.set_option("ffn_strip", 5)
     e.close()
+
+
+def test_first_decoder_layer_projects_its_input_once_sim(ow, aow):
+    """"dec_l0_once" (default 1): decoder layer 0's input is zeros + the positional rows (mld_vae.py:216-222, actor_vae.py:221-222) --
+    the same for every sample -- so its in-projection runs over ONE sample's T rows and every (sample, head) attention workgroup reads
+    those (with its own sample's length mask).  Sample 0 is the SHORTEST here: the shared projection must still cover the T rows the
+    longer samples read.  Exactly the per-sample computation (same kernels, same products) in all three attention kernels, the
+    TransformerDecoder stack of the action VAE included."""
+    ops, _, bv = ow
+    z = syn._rng(11, "l0once").standard_normal((3, 1, 256)).astype(np.float32)
+    lens = [5, 40, 23]
+    ref = np.asarray(O.vae_decode(ops, bv, z, lens))
+    for prec, opts, tol in ((0, {}, 5e-5), (1, {"gemm_small_m": 0, "flash_attn": 0}, 2e-4), (1, {"gemm_small_m": 0, "flash_attn": 2}, 2e-4)):
+        e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2, precision=prec)
+        for k, v in opts.items():
+            e.set_option(k, v)
+        outs = []
+        for once in (1, 0):
+            e.set_option("dec_l0_once", once)
+            feats = np.full((3, 40, 263), np.nan, np.float32)
+            e.vae_decode(z, lens, feats)
+            assert np.isfinite(feats).all() and np.abs(feats - ref).max() < tol
+            for i, n in enumerate(lens):
+                assert np.all(feats[i, n:] == 0)
+            outs.append(feats)
+        assert np.array_equal(outs[0], outs[1]), np.abs(outs[0] - outs[1]).max()
+        if prec == 1:                      # streaming-access hints change no number
+            e.set_option("nt_hints", 15)
+            feats = np.full((3, 40, 263), np.nan, np.float32)
+            e.vae_decode(z, lens, feats)
+            assert np.array_equal(feats, outs[1])
+        with pytest.raises(_lib.MldHipError):
+            e.set_option("dec_l0_once", 2)
+        e.close()
+    ops, _, abv = aow
+    ae = simlib.sim_action_engine(max_batch=4, max_frames=24, num_inference_steps=2)
+    za = syn._rng(12, "l0once_a").standard_normal((3, 1, 256)).astype(np.float32)
+    alens = [7, 24, 16]
+    aref = np.asarray(O.actor_decode(ops, abv, za, alens))
+    outs = []
+    for once in (1, 0):
+        ae.set_option("dec_l0_once", once)
+        feats = np.full((3, 24, 150), np.nan, np.float32)
+        ae.vae_decode(za, alens, feats)
+        assert np.abs(feats - aref).max() < 5e-5
+        outs.append(feats)
+    assert np.array_equal(outs[0], outs[1])
+    ae.close()

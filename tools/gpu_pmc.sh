@@ -1,14 +1,16 @@
 #!/bin/bash
 # PMC passes (separate runs, --kernel-trace only, as MI355X_MICROARCH.md prescribes): FETCH_SIZE and WRITE_SIZE per kernel of the
 # headline call shape (ONE mldhip_sample_many call of 32 x 64 motions), then the SQ counters that say where the time goes.  Writes
-# gpurun_out/<TAG>_pmc_traffic.json stamped with the hash of the engine sources it ran on (bench.py refuses a summary whose hash
-# differs from the build it benches) and gpurun_out/<TAG>_pmc_sq.json.
+# gpurun_out/<TAG>_pmc_traffic.json stamped with the hash of the engine sources AND of the loop kernel's machine code it ran on (bench.py
+# refuses a summary that matches neither) and gpurun_out/<TAG>_pmc_sq.json.
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 TAG=${1:-r03}
 COAL=${PMC_COALESCE:-32}
-for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
+PASSES=("FETCH_SIZE" "WRITE_SIZE")
+[ "${PMC_TRAFFIC_ONLY:-0}" = 1 ] || PASSES+=("SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE")
+for C in "${PASSES[@]}"; do
   T=$(echo $C | tr ' ' '_' | cut -c1-48)
   cd /tmp && timeout ${PMC_TIMEOUT:-180} rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$T -o pmc -- \
     python $GRAFT_REPO_ROOT/bench.py --profile-child --precision ${PMC_PRECISION:-f16x3} --coalesce $COAL --steps 1 > $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$T.log 2>&1
@@ -50,8 +52,9 @@ for short, pat in NAMES.items():
 note = ("rocprofv3 --pmc, separate passes with --kernel-trace only, over bench.py --profile-child --coalesce N --steps 1 (the headline call shape, one call).  "
         "FETCH/WRITE_SIZE are KB; fetch bytes = 2 x FETCH_SIZE x 1024 (gfx950 wide-read correction of MI355X_MICROARCH.md); weights and the working set of the loop are "
         "Infinity-Cache resident, so this is L2<->fabric traffic, not DRAM traffic.")
-json.dump({"source_hash": bench.source_hash(), "requests_per_call": coalesce, "note": note, "kernels": traffic}, open(f"gpurun_out/{tag}_pmc_traffic.json", "w"), indent=1)
-json.dump({"source_hash": bench.source_hash(), "requests_per_call": coalesce,
+json.dump({"source_hash": bench.source_hash(), "loop_kernel_code_hash": bench.kernel_code_hash(), "requests_per_call": coalesce, "note": note, "kernels": traffic}, open(f"gpurun_out/{tag}_pmc_traffic.json", "w"), indent=1)
+if any(len(v) > 1 for v in sq.values()):      # (PMC_TRAFFIC_ONLY=1: no SQ passes ran, keep the previous SQ summary)
+  json.dump({"source_hash": bench.source_hash(), "requests_per_call": coalesce,
            "note": "SQ counters per dispatch (averages).  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles (16 per "
                    "v_mfma_f32_16x16x32_f16); GRBM_GUI_ACTIVE is summed over the 8 XCDs.", "kernels": sq}, open(f"gpurun_out/{tag}_pmc_sq.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1)[:2500])
