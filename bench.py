@@ -98,7 +98,7 @@ KERNEL_DECODE_X3 = {   # split-bf16 modes: the feed-forward block is ONE launch 
 def kernel_table(batch, precision="f16x3"):
     dec = KERNEL_DECODE_X3 if precision in ("f16x3", "fp8_denoiser") else KERNEL_DECODE
     if dec is KERNEL_DECODE_X3 and batch * 4 >= 512:     # >= 512 (sample, head) pairs: the key-blocked attention kernel (mldhip.h "flash_attn")
-        dec = {**dec, "dec_attn": ("mld::attn_flash_x3_kernel", 9)}
+        dec = {**dec, "dec_attn": ("void mld::attn_flash_x3_kernel<", 9)}
     return {**(KERNEL_THROUGHPUT if 6 * batch >= 768 else KERNEL_LATENCY), **dec}
 
 

@@ -429,7 +429,8 @@ void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr, int shar
     // (B H >= 512: 108 vs 133 us at 1 280 workgroups); with one per CU the whole-K/V kernel below is 5 % faster (28.9 vs 30.3 us)
     // (it covers 16 query tiles = 256 frames per (sample, head); longer sequences take the whole-K/V kernel)
     if (T <= 256 && (e->flash_attn == 2 || (e->flash_attn == 1 && B * H >= 512))) {
-      MLD_LAUNCH(attn_flash_x3_kernel, grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv);
+      if (e->attn_tr) MLD_LAUNCH((attn_flash_x3_kernel<true>), grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv);
+      else MLD_LAUNCH((attn_flash_x3_kernel<false>), grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv);
       count(c);
       check_launch(c, "attn_flash_x3");
       return;

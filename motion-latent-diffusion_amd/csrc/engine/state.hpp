@@ -123,6 +123,7 @@ struct mldhip_engine {
   int strip_waves = 8;       // "strip_waves": waves per workgroup of the 32 x 128 strip tiles: 4 (two row tiles per wave) or 8 (one)
   int flash_attn = 1;        // "flash_attn": split-bf16 frame-level self-attention key-blocked (attention.hpp attn_flash_x3_kernel): 0 never, 1 auto (>= 512 (sample, head) pairs), 2 always
   int ffn_strip = 1;         // "ffn_strip": register-direct decoder kernels (ffn_strip.hpp, gemm_strip_x3.hpp): 0 off, 1 auto strip height, 4 / 6 = 64 / 96 rows always
+  int attn_tr = 0;           // "attn_tr": key-blocked attention stages V row-major and reads its P V fragments with ds_read_b64_tr_b16 (attention.hpp TRV)
   int dec_tail = 1;          // "dec_tail": out-projection + norms + feed-forward block of a decoder layer as one launch (chip-filling launches, split modes)
   int dec_l0_once = 1;       // "dec_l0_once": decoder layer 0 projects its input -- the positional rows, the same for every sample -- once per call ([T] rows instead of [B T])
   int nt_hints = 0;         // "nt_hints": streaming (`nt`) accesses in the decoder's row-strip kernels, bit mask: 1 = GEMM output stores, 2 = GEMM strip loads, 4 = feed-forward / tail strip + residual loads, 8 = its output stores

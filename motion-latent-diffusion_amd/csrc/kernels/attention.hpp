@@ -364,6 +364,10 @@ constexpr int kFlashVStride = 20;    // words per V^T row of a block: 32 keys = 
 constexpr int kFlashStageWords = 2 * 32 * kFlashKStride + 2 * 64 * kFlashVStride;
 constexpr int kFlashLdsBytes = 2 * kFlashStageWords * 4;   // 40 960 B
 
+// TRV: V is staged ROW-major like K ([key][64 dims] halves, 40-word rows, one 8-byte store per plane and thread) and the P V products
+// read their B fragments -- four keys of one head dim per lane -- with ds_read_b64_tr_b16 (rt.hpp lds_read_tr16_b64); false: V^T planes
+// written with eight 2-byte stores per thread (8-way bank conflicts) and read with plain ds_read_b64.  Same LDS footprint, same numbers.
+template <bool TRV = false>
 __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                             const int* __restrict__ lens, int T, int H, int shared_qkv = 0) {
   constexpr int HD = 64, KST = kFlashKStride, VST = kFlashVStride, NW = 8;
@@ -405,6 +409,11 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
     *reinterpret_cast<U2*>(Kl + skey * KST + c4 * 2) = U2{l0, l1};
     split16_pair(vreg.x * m, vreg.y * m, h0, l0);
     split16_pair(vreg.z * m, vreg.w * m, h1, l1);
+    if constexpr (TRV) {               // row-major, K's row stride (the two V planes take 2 x 32 x 40 = 2 x 64 x 20 words either way)
+      *reinterpret_cast<U2*>(Vh + skey * KST + c4 * 2) = U2{h0, h1};
+      *reinterpret_cast<U2*>(Vl + skey * KST + c4 * 2) = U2{l0, l1};
+      return;
+    }
     unsigned short* vh = reinterpret_cast<unsigned short*>(Vh) + skey;
     unsigned short* vl = reinterpret_cast<unsigned short*>(Vl) + skey;
     const int d0 = c4 * 4;
@@ -518,10 +527,19 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
       // O += P V_blk: k-slot 8 g + j <-> key (j >> 2) * 16 + 4 g + (j & 3) of the block
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const unsigned* vh = Vh + (dt * 16 + r) * VST + g * 2;
-        const unsigned* vl = Vl + (dt * 16 + r) * VST + g * 2;
-        const U2 a0 = *reinterpret_cast<const U2*>(vh), a1 = *reinterpret_cast<const U2*>(vh + 8);
-        const U2 b0 = *reinterpret_cast<const U2*>(vl), b1 = *reinterpret_cast<const U2*>(vl + 8);
+        U2 a0, a1, b0, b1;
+        if constexpr (TRV) {
+          // lane (r, g) supplies row = key 4 g + (r >> 2) of the 16-key tile, dims 16 dt + 4 (r & 3) .. + 3, and receives dim 16 dt + r of
+          // keys 4 g .. 4 g + 3 (8-byte aligned: even word offsets; rows 0 .. 7 of a 32-lane half sit 40 words apart: all 64 banks once)
+          const int tro = (g * 4 + (r >> 2)) * KST + dt * 8 + (r & 3) * 2;
+          a0 = lds_read_tr16_b64(Vh + tro); a1 = lds_read_tr16_b64(Vh + tro + 16 * KST);
+          b0 = lds_read_tr16_b64(Vl + tro); b1 = lds_read_tr16_b64(Vl + tro + 16 * KST);
+        } else {
+          const unsigned* vh = Vh + (dt * 16 + r) * VST + g * 2;
+          const unsigned* vl = Vl + (dt * 16 + r) * VST + g * 2;
+          a0 = *reinterpret_cast<const U2*>(vh); a1 = *reinterpret_cast<const U2*>(vh + 8);
+          b0 = *reinterpret_cast<const U2*>(vl); b1 = *reinterpret_cast<const U2*>(vl + 8);
+        }
         const U4 vhh = U4{a0.x, a0.y, a1.x, a1.y}, vll = U4{b0.x, b0.y, b1.x, b1.y};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {

@@ -350,6 +350,21 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 }
 // v_mfma_f32_16x16x32_fp8_fp8: lane l supplies A[row = l&15][k = 8*(l>>4) + j] and B[k][col = l&15], j = 0..7 as 8 bytes
 struct alignas(8) U2 { unsigned x, y; };
+// ds_read_b64_tr_b16: the LDS transpose read of gfx950.  Inside each 16-lane group the lanes' 8-byte reads form a [4][16] block of
+// 16-bit elements (lane L supplies row L / 4, columns 4 (L % 4) .. + 3: its own 8-byte aligned address, any row stride) and lane i
+// receives COLUMN i: element j = row j.  With V staged ROW-major [key][dim] this yields an MFMA B fragment (four keys of one head
+// dim per lane) without a transposed image (attention.hpp).  Returns the four halves as two words {(e0, e1), (e2, e3)}.
+__device__ __forceinline__ U2 lds_read_tr16_b64(const unsigned* p) {
+#if defined(MLDHIP_SIM)
+  U2 r;
+  hipsim::ds_read_tr16_b64(p, &r.x);
+  return r;
+#else
+  typedef short v4s_t __attribute__((ext_vector_type(4)));
+  const v4s_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)p);
+  return __builtin_bit_cast(U2, v);
+#endif
+}
 __device__ __forceinline__ f32x4 mfma_fp8_16x16x32(U2 a, U2 b, f32x4 c) {
 #if defined(MLDHIP_SIM)
   const unsigned av[2] = {a.x, a.y}, bv[2] = {b.x, b.y};

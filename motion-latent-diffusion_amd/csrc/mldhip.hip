@@ -346,6 +346,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "dec_l0_once") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "dec_l0_once must be 0 or 1");
     e->dec_l0_once = (int)value;
+  } else if (n == "attn_tr") {
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "attn_tr must be 0 or 1");
+    e->attn_tr = (int)value;
   } else if (n == "nt_hints") {
     if (value < 0 || value > 15) return e->fail(MLDHIP_EINVAL, "nt_hints is a bit mask 0..15");
     e->nt_hints = (int)value;

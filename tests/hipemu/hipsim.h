@@ -81,6 +81,24 @@ inline float shfl(float v, int src) {
   return r;
 }
 
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read, cdna_hip_programming.md "LDS"): inside each 16-lane group the lanes' 8-byte reads
+// form a [4][16] block of 16-bit elements -- lane L supplies row L / 4, columns 4 (L % 4) .. + 3 -- and lane i receives COLUMN i of
+// it: element j = row j, i.e. element (i % 4) of what lane 4 j + i / 4 fetched.  `own` = the 8 bytes at this lane's own address.
+inline void ds_read_tr16_b64(const void* own, unsigned out[2]) {
+  BlockState& b = blk();
+  int slot = wave_arrive(own, 8, 0);
+  WaveState& w = b.waves[b.cur->wave];
+  const int lane = b.cur->lane, i = lane & 15, base = lane & ~15;
+  unsigned short e[4];
+  for (int j = 0; j < 4; ++j) {
+    unsigned short h[4];
+    std::memcpy(h, w.buf[slot][base + 4 * j + (i >> 2)], 8);
+    e[j] = h[i & 3];
+  }
+  out[0] = (unsigned)e[0] | ((unsigned)e[1] << 16);
+  out[1] = (unsigned)e[2] | ((unsigned)e[3] << 16);
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C/D col=l&15,row=(l>>4)*4+reg
 inline f32x4 mfma_f32_16x16x4(float a, float bb, f32x4 c) {

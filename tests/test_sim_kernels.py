@@ -856,3 +856,28 @@ def test_first_decoder_layer_projects_its_input_once_sim(ow, aow):
         outs.append(feats)
     assert np.array_equal(outs[0], outs[1])
     ae.close()
+
+
+def test_key_blocked_attention_transpose_read_v_sim(ow):
+    """"attn_tr" = 1: attn_flash_x3_kernel<true> stages V row-major like K and reads its P V fragments with ds_read_b64_tr_b16 (the
+    simulator models the instruction as the guide documents it: inside a 16-lane group lane i receives column i of the [4][16] block the
+    group's 8-byte reads form).  Same products in the same order as the transposed-plane form: bit-identical features, on ragged
+    lengths with an odd number of key tiles and more query tiles than waves' first slots."""
+    ops, _, bv = ow
+    for B, T, lens in ((2, 68, [37, 68]),):
+        e = simlib.sim_engine(max_batch=B, max_frames=T, num_inference_steps=2, precision=1)
+        e.set_option("gemm_small_m", 0)
+        e.set_option("flash_attn", 2)
+        z = syn._rng(9, "trv").standard_normal((B, 1, 256)).astype(np.float32)
+        ref = np.asarray(O.vae_decode(ops, bv, z, lens))
+        outs = []
+        for tr in (1, 0):
+            e.set_option("attn_tr", tr)
+            feats = np.zeros((B, T, 263), np.float32)
+            e.vae_decode(z, lens, feats)
+            assert 1e-7 < np.abs(feats[:, :max(lens)] - ref).max() < 2e-4
+            outs.append(feats)
+        assert np.array_equal(outs[0], outs[1]), np.abs(outs[0] - outs[1]).max()
+        with pytest.raises(_lib.MldHipError):
+            e.set_option("attn_tr", 2)
+        e.close()
