@@ -161,12 +161,14 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     zeros + the positional rows (mld_vae.py:216-222, actor_vae.py:221-222), the same for every sample, so Q, K, V of
  *                     layer 0 are computed for [T] rows and every (sample, head) attention workgroup reads them (exact: same numbers,
  *                     B times less work and no [B T][3 D] round trip through HBM for that layer); 0 = per sample like the other layers
- *   "attn_tr"         F16X3 / FP8 modes, key-blocked attention ("flash_attn"): 1 = V staged row-major (one 8-byte LDS store per plane and
- *                     thread) and read as MFMA fragments with the gfx950 transpose read ds_read_b64_tr_b16; 0 (default) = transposed
- *                     V planes written with 2-byte stores.  Same products, same results
- *   "nt_hints"        F16X3 / FP8 modes, measurement option: streaming (`nt`) global accesses for the activations of the decoder's
- *                     row-strip kernels, bit mask: 1 = GEMM output stores, 2 = GEMM strip loads, 4 = feed-forward / tail strip and
- *                     residual loads, 8 = feed-forward / tail output stores; default 0 (results are identical either way)
+ *   "attn_tr"         F16X3 / FP8 modes, key-blocked attention ("flash_attn"), bit mask: 1 = V staged row-major (one 8-byte LDS store
+ *                     per plane and thread) and read as MFMA fragments with the gfx950 transpose read ds_read_b64_tr_b16 (0: transposed
+ *                     V planes written with 2-byte stores); 2 = Q / K / V loads and output stores with the streaming hint.  Same
+ *                     products, same results; default: see engine/state.hpp
+ *   "nt_hints"        F16X3 / FP8 modes: 1 = the decoder's row-strip GEMMs (in-projection, skip linears: kernels/gemm_strip_x3.hpp)
+ *                     load their row strips and store their outputs with the streaming (`nt`) hint -- activations one workgroup
+ *                     touches once, next to weight streams every workgroup re-reads; 0 = default cache policy.  Results are
+ *                     identical either way
  *   "tile_x3"         F16X3 mode: 1 (default) = the latency kernels of the reverse loop (kernels/tile32.hpp, one request at a time) multiply
  *                     on split-f16 MFMAs reading the pre-split weight image, 0 = on exact-fp32 MFMAs
  *   "strip_gemm"      F16X3 / FP8 modes, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:

@@ -429,8 +429,12 @@ void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr, int shar
     // (B H >= 512: 108 vs 133 us at 1 280 workgroups); with one per CU the whole-K/V kernel below is 5 % faster (28.9 vs 30.3 us)
     // (it covers 16 query tiles = 256 frames per (sample, head); longer sequences take the whole-K/V kernel)
     if (T <= 256 && (e->flash_attn == 2 || (e->flash_attn == 1 && B * H >= 512))) {
-      if (e->attn_tr) MLD_LAUNCH((attn_flash_x3_kernel<true>), grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv);
-      else MLD_LAUNCH((attn_flash_x3_kernel<false>), grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv);
+      switch (e->attn_tr) {      // bit 0: transpose-read V; bit 1: streaming hints
+        case 1: MLD_LAUNCH((attn_flash_x3_kernel<true, false>), grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
+        case 2: MLD_LAUNCH((attn_flash_x3_kernel<false, true>), grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
+        case 3: MLD_LAUNCH((attn_flash_x3_kernel<true, true>), grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
+        default: MLD_LAUNCH((attn_flash_x3_kernel<false, false>), grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
+      }
       count(c);
       check_launch(c, "attn_flash_x3");
       return;
@@ -475,7 +479,7 @@ bool strip_gemm(Ctx& c, const GemmArgs& g, bool ln) {
   if (it == e->gemm_stream_of.end()) return false;
   StripGemmArgs a;
   a.A = g.A; a.A2 = g.A2; a.W = it->second; a.bias = g.bias; a.Y = g.Y; a.ldy = g.ldy; a.M = g.M; a.N = g.N;
-  a.skip_lens = g.skip_lens; a.skip_rpg = g.skip_rpg; a.nt = e->nt_hints;
+  a.skip_lens = g.skip_lens; a.skip_rpg = g.skip_rpg;
   if (ln) {
     if (g.N != 256 || g.K2 != 0 || !g.res || g.ldres != 256 || !g.g1) return false;
     a.res = g.res; a.g1 = g.g1; a.b1 = g.b1; a.cvec = g.cvec; a.rpg = g.rows_per_group; a.g2 = g.g2; a.b2 = g.b2;
@@ -484,12 +488,15 @@ bool strip_gemm(Ctx& c, const GemmArgs& g, bool ln) {
     else MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, true, false>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, false>()), c.stream, a);
   } else if (g.K2 == 256) {
     if (g.N != 256) return false;
-    if (e->strip_ring == 8) MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 8>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
+    if (e->strip_ring == 8 && e->nt_hints) MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 8, 3>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
+    else if (e->strip_ring == 8) MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 8>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
     else MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 4>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
   } else if (rt == 4) {
-    MLD_LAUNCH((strip_gemm_x3_kernel<4, 1, false, true, 8>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 1, true>()), c.stream, a);
+    if (e->nt_hints) MLD_LAUNCH((strip_gemm_x3_kernel<4, 1, false, true, 8, 3>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 1, true>()), c.stream, a);
+    else MLD_LAUNCH((strip_gemm_x3_kernel<4, 1, false, true, 8>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 1, true>()), c.stream, a);
   } else {
-    if (e->strip_ring == 8) MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true, 8>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
+    if (e->strip_ring == 8 && e->nt_hints) MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true, 8, 3>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
+    else if (e->strip_ring == 8) MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true, 8>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
     else MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true, 4>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
   }
   count(c);
@@ -508,7 +515,7 @@ void ffn_block(Ctx& c, const float* x, float* y, int M, const float* w1, const f
   if (staged_prec(e) == PREC_BF16X3 && e->ffn_strip && D == 256 && F == 1024 && M > e->small_m && !e->trace_on && e->ffn_stream_of.count(w1)) {
     // register-direct form (kernels/ffn_strip.hpp): weights from the layer's fragment-ordered stream, 96- or 64-row strips
     FfnArgs a;
-    a.X = x; a.W1 = e->ffn_stream_of[w1]; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.Y = y; a.M = M; a.nt = e->nt_hints;
+    a.X = x; a.W1 = e->ffn_stream_of[w1]; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.Y = y; a.M = M;
     if (ragged_T > 0) { a.skip_lens = e->lens_dev; a.skip_rpg = ragged_T; }
     // auto: 48-row strips, two workgroups per CU (four waves per SIMD, 128 registers each) for launches that fill the chip: 2 % off the
     // decoder against 96-row strips (r03, 2 048 motions: 25.2 vs 25.8 ms) although the weights are streamed twice as often
@@ -564,7 +571,7 @@ void dec_layer(Ctx& c, int l, const float* xin, float* xout, int B, int T, bool 
       D == 256 && e->cfg.ff_size == 1024 && !e->trace_on && M > e->small_m && e->ffn_stream_of.count(L.l1_w) && e->gemm_stream_of.count(L.out_w)) {
     FfnArgs a;
     a.W1 = e->ffn_stream_of[L.l1_w]; a.b1 = L.l1_b; a.b2 = L.l2_b; a.gamma = L.n3_w; a.beta = L.n3_b; a.Y = xout; a.M = M;
-    a.skip_lens = e->lens_dev; a.skip_rpg = T; a.nt = e->nt_hints;
+    a.skip_lens = e->lens_dev; a.skip_rpg = T;
     a.AO = e->AO; a.Wo = e->gemm_stream_of[L.out_w]; a.bo = L.out_b; a.res = xin; a.g1 = L.n1_w; a.be1 = L.n1_b;
     a.cvec = e->cvec + (size_t)l * e->cfg.max_batch * D; a.rpg = T; a.g2 = L.n2_w; a.be2 = L.n2_b;
     MLD_LAUNCH((ffn_strip_x3_kernel<3, true>), dim3((M + 47) / 48), dim3(512), (ffn_strip_lds_bytes<3>()), c.stream, a);

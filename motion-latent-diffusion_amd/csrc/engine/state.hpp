@@ -126,7 +126,7 @@ struct mldhip_engine {
   int attn_tr = 0;           // "attn_tr": key-blocked attention stages V row-major and reads its P V fragments with ds_read_b64_tr_b16 (attention.hpp TRV)
   int dec_tail = 1;          // "dec_tail": out-projection + norms + feed-forward block of a decoder layer as one launch (chip-filling launches, split modes)
   int dec_l0_once = 1;       // "dec_l0_once": decoder layer 0 projects its input -- the positional rows, the same for every sample -- once per call ([T] rows instead of [B T])
-  int nt_hints = 0;         // "nt_hints": streaming (`nt`) accesses in the decoder's row-strip kernels, bit mask: 1 = GEMM output stores, 2 = GEMM strip loads, 4 = feed-forward / tail strip + residual loads, 8 = its output stores
+  int nt_hints = 0;          // "nt_hints": 1 = the decoder's row-strip GEMMs (in-projection, skip linears) load their strips and store their outputs with the streaming hint (gemm_strip_x3.hpp NT)
   int tile_x3 = 1;           // "tile_x3": split-f16 mode runs the latency kernels (tile32.hpp) on split-f16 MFMAs too (0: exact fp32)
   int strip_ring = 8;        // "strip_ring": weight items in flight per lane in the plain row-strip GEMMs (4 or 8)
   int strip_gemm = 1;        // "strip_gemm": split modes, decoder / encoder in-projection, out-projection (+ LayerNorms) and skip linears on the row-strip kernels (kernels/gemm_strip_x3.hpp); 0 = the staged 64 x 128 / 64 x 256 tiles

@@ -367,7 +367,8 @@ constexpr int kFlashLdsBytes = 2 * kFlashStageWords * 4;   // 40 960 B
 // TRV: V is staged ROW-major like K ([key][64 dims] halves, 40-word rows, one 8-byte store per plane and thread) and the P V products
 // read their B fragments -- four keys of one head dim per lane -- with ds_read_b64_tr_b16 (rt.hpp lds_read_tr16_b64); false: V^T planes
 // written with eight 2-byte stores per thread (8-way bank conflicts) and read with plain ds_read_b64.  Same LDS footprint, same numbers.
-template <bool TRV = false>
+// NTH: the Q / K / V loads and the output stores carry the streaming hint (every element is touched by exactly one workgroup).
+template <bool TRV = false, bool NTH = false>
 __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                             const int* __restrict__ lens, int T, int H, int shared_qkv = 0) {
   constexpr int HD = 64, KST = kFlashKStride, VST = kFlashVStride, NW = 8;
@@ -393,8 +394,8 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
     const int key = kb * 32 + skey;
     const int kc = key < len ? key : len - 1;
     const float* p = base + (long long)kc * 3 * D + c4 * 4;
-    kreg = ld4(p + D);
-    vreg = ld4(p + 2 * D);
+    kreg = ld4_hint<NTH>(p + D);
+    vreg = ld4_hint<NTH>(p + 2 * D);
   };
   auto kvstore = [&](int kb) {
     unsigned* Kh = smem + (kb & 1) * kFlashStageWords;
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
     const float* qp = base + (long long)qrow * 3 * D + g * 8;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const F4 t0 = ld4(qp + c * 32), t1 = ld4(qp + c * 32 + 4);
+      const F4 t0 = ld4_hint<NTH>(qp + c * 32), t1 = ld4_hint<NTH>(qp + c * 32 + 4);
       constexpr float qs = 0.125f * 1.44269504088896340736f;     // 1/sqrt(64) x log2(e): scores in the log2 domain (softmax on v_exp_f32)
       const float x[8] = {t0.x * qs, t0.y * qs, t0.z * qs, t0.w * qs, t1.x * qs, t1.y * qs, t1.z * qs, t1.w * qs};
       split_hi_lo_x8(x, qh[t][c], ql[t][c]);
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
       const int q = qt * 16 + g * 4 + i;
       if (q < T) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[(long long)(b * T + q) * D + h * HD + dt * 16 + r] = oacc[t][dt][i] * inv;
+        for (int dt = 0; dt < 4; ++dt) st1_hint<NTH>(o + (long long)(b * T + q) * D + h * HD + dt * 16 + r, oacc[t][dt][i] * inv);
       }
     }
   }

@@ -42,7 +42,6 @@ struct FfnArgs {
   const float* g1 = nullptr; const float* be1 = nullptr;      // norm1
   const float* cvec = nullptr; int rpg = 1;                   // + cvec[row / rpg][256] before norm2
   const float* g2 = nullptr; const float* be2 = nullptr;      // norm2
-  int nt = 0;                      // "nt_hints" bits (state.hpp): 4 = strip / residual loads streaming, 8 = output stores streaming
 };
 
 constexpr int kFfnXStride = 264;   // words per X row image: 8 K chunks x 32 words + 8 pad (strides = 8 mod 16: conflict-free ds_read_b128

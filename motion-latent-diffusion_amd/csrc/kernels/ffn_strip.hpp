@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
     const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
-    const F4 v = ld4_if_nt((TAIL ? p.AO : p.X) + (size_t)m * 256 + c4 * 4, p.nt & 4);
+    const F4 v = ld4((TAIL ? p.AO : p.X) + (size_t)m * 256 + c4 * 4);
     unsigned h0, l0, h1, l1;
     split16_pair(v.x, v.y, h0, l0);
     split16_pair(v.z, v.w, h1, l1);
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
       for (int t = 0; t < RT; ++t) {
         int m = m0 + t * 16 + r;
         m = m < p.M ? m : p.M - 1;
-        const F4 ra = ld4_if_nt(p.res + (size_t)m * 256 + cq0, p.nt & 4), rb = ld4_if_nt(p.res + (size_t)m * 256 + 128 + cq0, p.nt & 4);
+        const F4 ra = ld4(p.res + (size_t)m * 256 + cq0), rb = ld4(p.res + (size_t)m * 256 + 128 + cq0);
         const float rav[4] = {ra.x, ra.y, ra.z, ra.w}, rbv[4] = {rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { o0[t][i] += bav[i] + rav[i]; o1[t][i] += bbv[i] + rbv[i]; }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
 #pragma unroll
   for (int j = 0; j < RT * 2; ++j) {
     const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
-    if (m0 + row < p.M) st4_if_nt(p.Y + (size_t)(m0 + row) * 256 + c4 * 4, ld4(Xs + row * XS + c4 * 4), p.nt & 8);
+    if (m0 + row < p.M) st4(p.Y + (size_t)(m0 + row) * 256 + c4 * 4, ld4(Xs + row * XS + c4 * 4));
   }
 }
 

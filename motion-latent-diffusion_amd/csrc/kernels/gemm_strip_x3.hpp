@@ -26,7 +26,6 @@ struct StripGemmArgs {
   const float* g1 = nullptr; const float* b1 = nullptr;
   const float* cvec = nullptr; int rpg = 1;              // + cvec[row / rpg][256] before the second LayerNorm
   const float* g2 = nullptr; const float* b2 = nullptr;
-  int nt = 0;                        // "nt_hints" bits (state.hpp): 1 = output stores streaming, 2 = strip loads streaming
 };
 
 template <int RT, int NSEG, bool STAGE>
@@ -34,7 +33,11 @@ constexpr int strip_gemm_lds_bytes() { return (NSEG * RT * 16 * kFsXs + (STAGE ?
 
 // grid = ceil(M / (16 RT)); block = 512.  STAGE: a separate [rows][136] staging tile for the output (needed when A must survive
 // the first pair: N > 256); otherwise the output is parked in A's own rows once the last product is done.
-template <int RT, int NSEG, bool LN, bool STAGE, int RING = 4>
+// NT ("nt_hints"): the strip's loads (bit 2) and the output stores (bit 1) carry the streaming hint -- activations that exactly one
+// workgroup touches once per launch, next to weight streams every workgroup re-reads.  A COMPILE-time choice: as a run-time branch
+// around each access (the first form, r03_late_options_ab.json) it made the whole kernel 12-30 % slower -- a `cond ? load : load`
+// per element drains the memory counter per access (DESIGN.md point 8).
+template <int RT, int NSEG, bool LN, bool STAGE, int RING = 4, int NT = 0>
 __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) {
   static_assert(!(LN && (NSEG != 1 || STAGE)), "the LayerNorm form is the N = 256, K = 256 out-projection");
   static_assert(RING == 4 || RING == 8, "weight items in flight per lane");
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
       const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;
-      const F4 v = ld4_if_nt(src + (size_t)m * 256 + c4 * 4, p.nt & 2);
+      const F4 v = ld4_hint<(NT & 2) != 0>(src + (size_t)m * 256 + c4 * 4);
       unsigned h0, l0, h1, l1;
       split16_pair(v.x, v.y, h0, l0);
       split16_pair(v.z, v.w, h1, l1);
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
 #pragma unroll
           for (int j = 0; j < RT; ++j) {
             const int idx = tid + j * 512, row = idx >> 5, c4 = idx & 31;
-            if (m0 + row < p.M) st4_if_nt(p.Y + (size_t)(m0 + row) * p.ldy + pr * 256 + cb * 128 + c4 * 4, ld4(St + row * HS + c4 * 4), p.nt & 1);
+            if (m0 + row < p.M) st4_hint<(NT & 1) != 0>(p.Y + (size_t)(m0 + row) * p.ldy + pr * 256 + cb * 128 + c4 * 4, ld4(St + row * HS + c4 * 4));
           }
         }
       } else {
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
 #pragma unroll
         for (int j = 0; j < RT * 2; ++j) {
           const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
-          if (m0 + row < p.M) st4_if_nt(p.Y + (size_t)(m0 + row) * p.ldy + c4 * 4, ld4(Xs + row * XS + c4 * 4), p.nt & 1);
+          if (m0 + row < p.M) st4_hint<(NT & 1) != 0>(p.Y + (size_t)(m0 + row) * p.ldy + c4 * 4, ld4(Xs + row * XS + c4 * 4));
         }
       }
     } else {

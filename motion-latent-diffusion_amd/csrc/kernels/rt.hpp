@@ -205,7 +205,7 @@ __device__ __forceinline__ F4 ld4(const float* p) { return *reinterpret_cast<con
 __device__ __forceinline__ void st4(float* p, F4 v) { *reinterpret_cast<F4*>(p) = v; }
 // streaming ("nt") forms for activations that one workgroup touches once per launch (the decoder's row strips): `nt` on the
 // global_load / global_store, i.e. no reuse expected -- the weight streams every workgroup re-reads keep the default policy.
-// Measurement option "nt_hints" (state.hpp); the simulator has no cache model: plain accesses there.
+// Option "nt_hints" (state.hpp; a template parameter of the kernels that take it); the simulator has no cache model: plain accesses there.
 __device__ __forceinline__ F4 ld4_nt(const float* p) {
 #if defined(MLDHIP_SIM)
   return ld4(p);
@@ -220,8 +220,17 @@ __device__ __forceinline__ void st4_nt(float* p, F4 v) {
   __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v), reinterpret_cast<f32x4*>(p));
 #endif
 }
-__device__ __forceinline__ F4 ld4_if_nt(const float* p, bool nt) { return nt ? ld4_nt(p) : ld4(p); }
-__device__ __forceinline__ void st4_if_nt(float* p, F4 v, bool nt) { if (nt) st4_nt(p, v); else st4(p, v); }
+template <bool NT_>
+__device__ __forceinline__ F4 ld4_hint(const float* p) { if constexpr (NT_) return ld4_nt(p); else return ld4(p); }
+template <bool NT_>
+__device__ __forceinline__ void st1_hint(float* p, float v) {
+#if !defined(MLDHIP_SIM)
+  if constexpr (NT_) { __builtin_nontemporal_store(v, p); return; }
+#endif
+  *p = v;
+}
+template <bool NT_>
+__device__ __forceinline__ void st4_hint(float* p, F4 v) { if constexpr (NT_) st4_nt(p, v); else st4(p, v); }
 
 constexpr float kLnEps = 1e-5f;
 

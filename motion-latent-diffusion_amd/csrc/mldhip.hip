@@ -347,10 +347,10 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "dec_l0_once must be 0 or 1");
     e->dec_l0_once = (int)value;
   } else if (n == "attn_tr") {
-    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "attn_tr must be 0 or 1");
+    if (value < 0 || value > 3) return e->fail(MLDHIP_EINVAL, "attn_tr is a bit mask 0..3 (1 = transpose-read V, 2 = streaming hints)");
     e->attn_tr = (int)value;
   } else if (n == "nt_hints") {
-    if (value < 0 || value > 15) return e->fail(MLDHIP_EINVAL, "nt_hints is a bit mask 0..15");
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "nt_hints must be 0 or 1");
     e->nt_hints = (int)value;
   } else if (n == "tile_x3") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "tile_x3 must be 0 or 1");

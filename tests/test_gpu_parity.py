@@ -296,7 +296,7 @@ def test_split_f16_decode_mode_meets_the_joint_tolerance(dev, golden_dir):
     e.close()
 
 
-def test_first_decoder_layer_projected_once_and_streaming_hints_change_nothing(dev, golden_dir):
+def test_first_decoder_layer_projected_once_and_access_options_change_nothing(dev, golden_dir):
     """"dec_l0_once" (default on): decoder layer 0's in-projection over ONE sample's positional rows, read by every (sample, head)
     attention workgroup -- against the per-sample form: same kernels and products, so the reference's ragged MldVae.decode fixture
     (sample 0 is NOT the longest) and a 64-motion decode agree to the bit in exact fp32 and to fp32 rounding in the split mode (the
@@ -325,11 +325,25 @@ def test_first_decoder_layer_projected_once_and_streaming_hints_change_nothing(d
         print("dec_l0_once on vs off, precision %d: max diff %.3e (3 ragged) %.3e (64 motions)" % (prec, d3, d64))
         assert d3 < 2e-5 and d64 < 2e-5
         if prec == 1:
-            e.set_option("nt_hints", 15)
+            e.set_option("nt_hints", 1)
             f64n = torch.full((64, tm, 263), float("nan"), device=dev)
             e.vae_decode(z, lens64, f64n)
             torch.cuda.synchronize()
             assert torch.equal(f64n, outs[1][1])
+            # key-blocked attention: V read with ds_read_b64_tr_b16 from a row-major image ("attn_tr" bit 0), streaming hints (bit 1):
+            # the same products in the same order as the transposed-plane form
+            e.set_option("nt_hints", 0)
+            e.set_option("flash_attn", 2)
+            fl = []
+            for tr in (0, 1, 2, 3):
+                e.set_option("attn_tr", tr)
+                f = torch.full((64, tm, 263), float("nan"), device=dev)
+                e.vae_decode(z, lens64, f)
+                torch.cuda.synchronize()
+                fl.append(f)
+            assert (fl[0] - outs[1][1]).abs().max().item() < 5e-5        # (another attention kernel than the auto choice at 256 pairs)
+            for tr in (1, 2, 3):
+                assert torch.equal(fl[tr], fl[0]), "attn_tr %d" % tr
         e.close()
 
 
