@@ -164,11 +164,11 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "attn_tr"         F16X3 / FP8 modes, key-blocked attention ("flash_attn"), bit mask: 1 = V staged row-major (one 8-byte LDS store
  *                     per plane and thread) and read as MFMA fragments with the gfx950 transpose read ds_read_b64_tr_b16 (0: transposed
  *                     V planes written with 2-byte stores); 2 = Q / K / V loads and output stores with the streaming hint.  Same
- *                     products, same results; default: see engine/state.hpp
- *   "nt_hints"        F16X3 / FP8 modes: 1 = the decoder's row-strip GEMMs (in-projection, skip linears: kernels/gemm_strip_x3.hpp)
- *                     load their row strips and store their outputs with the streaming (`nt`) hint -- activations one workgroup
- *                     touches once, next to weight streams every workgroup re-reads; 0 = default cache policy.  Results are
- *                     identical either way
+ *                     products, same results.  Default 1 (454 -> 417 us per launch at 2 048 motions; bit 1 measured level)
+ *   "nt_hints"        F16X3 / FP8 modes: 1 (default) = the decoder's / encoder's in-projection (kernels/gemm_strip_x3.hpp, N = 768) loads
+ *                     its row strips and stores its output with the streaming (`nt`) hint -- activations one workgroup touches
+ *                     once, next to a weight stream every workgroup re-reads (527 -> 504 us per launch at 2 048 motions);
+ *                     0 = default cache policy.  Results are identical either way
  *   "tile_x3"         F16X3 mode: 1 (default) = the latency kernels of the reverse loop (kernels/tile32.hpp, one request at a time) multiply
  *                     on split-f16 MFMAs reading the pre-split weight image, 0 = on exact-fp32 MFMAs
  *   "strip_gemm"      F16X3 / FP8 modes, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:

@@ -488,8 +488,8 @@ bool strip_gemm(Ctx& c, const GemmArgs& g, bool ln) {
     else MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, true, false>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, false>()), c.stream, a);
   } else if (g.K2 == 256) {
     if (g.N != 256) return false;
-    if (e->strip_ring == 8 && e->nt_hints) MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 8, 3>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
-    else if (e->strip_ring == 8) MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 8>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
+    // (streaming hints measured level on this form -- 414.6 vs 413.7 us, r03c_kernel_stats_ab.csv -- so it has no NT build)
+    if (e->strip_ring == 8) MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 8>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
     else MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 4>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
   } else if (rt == 4) {
     if (e->nt_hints) MLD_LAUNCH((strip_gemm_x3_kernel<4, 1, false, true, 8, 3>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 1, true>()), c.stream, a);
