@@ -127,7 +127,17 @@ def source_hash():
 LLVM_BIN = "/opt/rocm/lib/llvm/bin"
 
 
-def kernel_code_hash(name_part="den_loop_kernelILb1ELi4ELi0E"):
+def mangled_part(kernel_name):
+    """'void mld::den_loop_kernel<true, 4, 0, false>(mld::LoopArgs)' (a rocprofv3 kernel name) -> 'den_loop_kernelILb1ELi4ELi0ELb0EE':
+    the piece of the Itanium-mangled symbol that identifies the instantiation (bool / int template arguments only)."""
+    base, _, rest = kernel_name.partition("<")
+    base = base.split("::")[-1].split()[-1]
+    args = [a.strip() for a in rest.split(">")[0].split(",")] if rest else []
+    enc = "".join("Lb%dE" % (a == "true") if a in ("true", "false") else "Li%sE" % a for a in args)
+    return base + ("I" + enc + "E" if args else "")
+
+
+def kernel_code_hash(name_part="den_loop_kernelILb1ELi4ELi0ELb0EE"):
     """Hash of the gfx950 MACHINE CODE of one kernel inside libmldhip.so (the persistent loop by default): the identity that ties a
     PMC summary to the build it is quoted for.  The whole-source hash above goes stale with any edit anywhere in csrc/; this one only
     when the compiled kernel itself changes.  None when the LLVM tools are missing."""
@@ -452,6 +462,9 @@ def profile_child(a):
     torch.cuda.set_device(0)
     c = max(1, a.coalesce)
     eng = make_engine(0, synthetic_state(), a.precision, max_batch=BATCH * c)
+    for kv in filter(None, os.environ.get("MLD_BENCH_SET", "").split(",")):      # per-handle options for A/B profiles: "attn_tr=0,nt_hints=0"
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     reqs = make_requests(dev, c, 0)
     for _ in range(max(1, a.steps if a.steps < 20 else 3)):
         if c == 1:
@@ -650,7 +663,7 @@ def main():
         traffic, traffic_note = None, "no PMC summary (profiles/r03_pmc_traffic.json)"
         try:
             pmc = json.load(open(os.path.join(REPO, "profiles", "r03_pmc_traffic.json")))
-            code = kernel_code_hash()
+            code = kernel_code_hash(mangled_part(loop_rows[0][0])) if loop_rows else None      # the loop kernel this build launches by default
             same_code = code is not None and pmc.get("loop_kernel_code_hash") == code
             if (same_code or pmc.get("source_hash") == source_hash()) and pmc.get("requests_per_call") == coalesce:
                 traffic = pmc["kernels"]["den_loop"]["traffic_bytes_per_launch"]

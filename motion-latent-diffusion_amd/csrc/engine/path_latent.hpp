@@ -774,6 +774,7 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
     else if (x3 && e->fused_dbg == 4) MLD_LAUNCH((den_loop_kernel<true, 4, 4>), grid, dim3(512), kLoopLdsBytes, stream, a);
     else if (x3 && e->fused_dbg == 5) { a.trace = reinterpret_cast<unsigned long long*>(e->trace_buf); MLD_LAUNCH((den_loop_kernel<true, 4, 5>), grid, dim3(512), kLoopLdsBytes, stream, a); }
     else if (x3 && e->fused_ring == 8) MLD_LAUNCH((den_loop_kernel<true, 8>), grid, dim3(512), kLoopLdsBytes, stream, a);
+    else if (x3 && e->fused_swz) MLD_LAUNCH((den_loop_kernel<true, 4, 0, true>), grid, dim3(512), kLoopLdsBytes, stream, a);
     else if (x3) MLD_LAUNCH((den_loop_kernel<true, 4>), grid, dim3(512), kLoopLdsBytes, stream, a);
     else if (e->fused_ring == 8) MLD_LAUNCH((den_loop_kernel<false, 8>), grid, dim3(512), kLoopLdsBytes, stream, a);
     else MLD_LAUNCH((den_loop_kernel<false, 4>), grid, dim3(512), kLoopLdsBytes, stream, a);

@@ -111,7 +111,12 @@ __global__ __launch_bounds__(512) void pack_loop_stream_kernel(const float* __re
 // kLoopRing = items in flight per lane (8 VGPRs each; 4 or 8: every group of items is a multiple of 8 long).
 // DBG (measurement builds, mldhip_set_option "fused_dbg"; 3 = identity instead of GELU, 4 = no feed-forward epilogue): 1 = the weight ring is loaded once and never refreshed (matrix +
 // LDS + epilogue time without the stream), 2 = the stream is loaded but not multiplied (one VALU add per item keeps the loads live).
-template <bool X3, int kLoopRing, int DBG = 0>
+// SWZ (split mode): the 16-byte groups of an operand row are stored XOR-swizzled by the row -- physical word = logical word ^ 4 ((row >> 2) & 3),
+// i.e. group (g ^ (r >> 2)) of each 16-word half chunk.  The image's 8-byte row stores (put_row: sixteen rows 264 = 8 mod 32 words
+// apart per 16-lane group) hit each bank pair four times (ds_write_b64 is served per 16 contiguous lanes over 32 banks); swizzled,
+// twice -- the best an 8-byte store at this stride can do -- while the fragments' ds_read_b128 stay conflict free (slot
+// 2 r + (g ^ (r >> 2)) mod 16 is still a permutation inside each of the instruction's four lane groups; tests/test_lds_layout.py).
+template <bool X3, int kLoopRing, int DBG = 0, bool SWZ = false>
 __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   static_assert(kLoopRing == 4 || kLoopRing == 8, "ring depth");
 #if defined(MLDHIP_SIM)
@@ -302,7 +307,8 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   // ---- this lane's elements of an operand buffer with row stride `st` words: row 16t + r, columns cw + 16 wave + 4g .. + 3 (`cw` = the
   // block's first column: 128 cb for a 256-wide buffer, 0 for the hidden block).  fp32: four consecutive words; split: two words (two
   // column pairs) in the chunk's high plane and two in its low plane (chunk = 32 words per 32 columns).
-  const int rw0 = (wave >> 1) * 32 + (wave & 1) * 8 + g * 2;      // split image: word of the first column pair inside the 128-wide block
+  const int swz4 = (X3 && SWZ) ? ((r >> 2) << 2) : 0;             // SWZ: XOR of a word offset inside rows 16 t + r (bits 2-3: the 16-byte group)
+  const int rw0 = ((wave >> 1) * 32 + (wave & 1) * 8 + g * 2) ^ swz4;      // split image: word of the first column pair inside the 128-wide block
   const int cq0 = wave * 16 + g * 4;                              // first of this lane's four columns inside a 128-column block
   auto put_row = [&](float* buf, int st, int cw, int t, const float (&v)[4]) __attribute__((always_inline)) {
     float* row = buf + (t * 16 + r) * st + cw;
@@ -419,8 +425,9 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
 #pragma unroll
   for (int j = 0; j < kLoopRing; ++j) gload(j);
 
-  const float* xa = Xs + r * kLfXs + g * 4;        // A fragments of the layer input
-  const float* aa = As + r * kLfXs + g * 4;        // ... of the attention output / the hidden-activation blocks
+  const int gs4 = X3 && SWZ ? ((g ^ (r >> 2)) << 2) : g * 4;      // this lane's 16-byte group of a half chunk (swizzled by the row)
+  const float* xa = Xs + r * kLfXs + gs4;          // A fragments of the layer input
+  const float* aa = As + r * kLfXs + gs4;          // ... of the attention output / the hidden-activation blocks
 
   if constexpr (DBG == 5) tph = clock_pinned();
   for (int step = 0; step < p.n; ++step) {
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
       {
         f32x4 y0[3], y1[3], hA[3], hB[3];
         zero3(y0); zero3(y1); zero3(hA);
-        const float* ha = As + r * kLfHs + g * 4;
+        const float* ha = As + r * kLfHs + gs4;
         // block hb: epilogue of `cur` (its linear1 accumulators) next to linear1 of block hb + 1 into `nxt`, barrier, linear2's share
         auto ffn_stage = [&](int hb, f32x4 (&cur)[3], f32x4 (&nxt)[3], bool more) __attribute__((always_inline)) {
           const F4 b1 = ld4(sm + kLsL1B + hb * 128 + wave * 16 + g * 4);       // biases of this lane's four columns (transposed tile)
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
                 float* hrow = hbuf + (t * 16 + r) * kLfHs;
                 if constexpr (X3) {
                   if (i0 != 0) {
-                    unsigned* w = reinterpret_cast<unsigned*>(hrow) + (wave >> 1) * 32 + (wave & 1) * 8 + g * 2;
+                    unsigned* w = reinterpret_cast<unsigned*>(hrow) + rw0;
                     *reinterpret_cast<U2*>(w) = U2{ph, qh};
                     *reinterpret_cast<U2*>(w + 16) = U2{pl, ql};
                   }
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
               unsigned h0, l0, h1, l1;
               split16_pair(sv.x, sv.y, h0, l0);
               split16_pair(sv.z, sv.w, h1, l1);
-              unsigned* d = reinterpret_cast<unsigned*>(Xs) + row * kLfXs + (c4 >> 3) * 32 + (c4 & 7) * 2;
+              unsigned* d = reinterpret_cast<unsigned*>(Xs) + row * kLfXs + (((c4 >> 3) * 32 + (c4 & 7) * 2) ^ ((X3 && SWZ) ? (((row >> 2) & 3) << 2) : 0));
               *reinterpret_cast<U2*>(d) = U2{h0, h1};
               *reinterpret_cast<U2*>(d + 16) = U2{l0, l1};
             } else {

@@ -208,6 +208,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<3>());
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
@@ -322,6 +323,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value < 0 || value > 5) return e->fail(MLDHIP_EINVAL, "fused_dbg must be 0 .. 5");
     if (value == 5 && !e->trace_buf && hipMalloc((void**)&e->trace_buf, (size_t)512 * 8 * 8 * sizeof(uint64_t)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(trace)");
     e->fused_dbg = (int)value;
+  } else if (n == "fused_swz") {
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "fused_swz must be 0 or 1");
+    e->fused_swz = (int)value;
   } else if (n == "fused_ring") {
     if (value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "fused_ring must be 4 or 8");
     e->fused_ring = (int)value;

@@ -78,3 +78,53 @@ def test_sources_read_fp32_fragments_at_the_conflict_free_slots():
     gemm = open(os.path.join(CSRC, "gemm.hpp")).read()
     lf = gemm.split("auto lfrags = [&](int buf)")[1].split("};")[0]
     assert "+ g * 4;" in lf and "+ 16)" in lf and "g * 8" not in lf
+
+
+def lds_cycles_write_b64(stride_words, word_of_lane):
+    """LDS-array cycles of one wave64 ds_write_b64 (MI355X_MICROARCH.md: served per 16 CONTIGUOUS lanes, 32 banks): lane (r, g) stores
+    two words at r * stride + word_of_lane(r, g).  4 = conflict free (one cycle per lane group)."""
+    total = 0
+    for grp in range(4):
+        banks = {}
+        for lane in range(grp * 16, grp * 16 + 16):
+            g, r = lane >> 4, lane & 15
+            a = r * stride_words + word_of_lane(r, g)
+            for w in range(2):
+                banks.setdefault((a + w) % 32, set()).add(a + w)
+        total += max(len(v) for v in banks.values())
+    return total
+
+
+def lds_cycles_b128_lane(stride_words, word_of_lane, base=0):
+    """as lds_cycles_b128 with a lane-dependent word offset inside the row (swizzled images)"""
+    total = 0
+    for grp in GROUPS_B128:
+        banks = {}
+        for lane in grp:
+            g, r = lane >> 4, lane & 15
+            a = base + r * stride_words + word_of_lane(r, g)
+            for w in range(4):
+                banks.setdefault((a + w) % 64, set()).add(a + w)
+        total += max(len(v) for v in banks.values())
+    return total
+
+
+def test_row_swizzled_operand_images_of_the_persistent_loop():
+    """loop_fused.hpp SWZ ("fused_swz"): lane (r, g) of wave w stores its four columns of row 16 t + r as 8 bytes at word
+    32 (w >> 1) + 8 (w & 1) + 2 g of the chunk's plane.  Sixteen rows 264 (136) = 8 mod 32 words apart: every bank pair is hit four
+    times per 16-lane group; with the word offset XORed by 4 (r >> 2), twice -- and the fragment reads (group g ^ (r >> 2) of the half
+    chunk) stay conflict free for every chunk and both halves."""
+    src = open(os.path.join(CSRC, "loop_fused.hpp")).read()
+    assert "^ swz4" in src and "((g ^ (r >> 2)) << 2)" in src and "((r >> 2) << 2)" in src
+    for name in ("kLfXs", "kLfHs"):
+        stride = constant("loop_fused.hpp", name)
+        for wave in range(8):
+            plain = lambda r, g: (wave >> 1) * 32 + (wave & 1) * 8 + 2 * g
+            swz = lambda r, g: plain(r, g) ^ ((r >> 2) << 2)
+            for plane in (0, 16):
+                assert lds_cycles_write_b64(stride, lambda r, g: plain(r, g) + plane) == 16      # 4-way
+                assert lds_cycles_write_b64(stride, lambda r, g: swz(r, g) + plane) == 8         # 2-way
+        # (no 8-byte store of one column group can do better at a stride = 8 mod 16 words: 16 rows reach only 8 distinct bank pairs)
+        for c in range(8 if name == "kLfXs" else 4):
+            for half in (0, 16):
+                assert lds_cycles_b128_lane(stride, lambda r, g: (g ^ (r >> 2)) << 2, c * 32 + half) == 4

@@ -749,6 +749,14 @@ def test_sample_major_persistent_loop_sim(prec):
         e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
         assert e.launch_counts()[0] == 2
         assert np.abs(lat - ref).max() < 2e-4 and np.abs(lat - lat1).max() < 2e-4, (prec, x3, ring)
+        if (x3, ring) == (1, 4):
+            # "fused_swz": the operand images stored XOR-swizzled by the row (a permutation of where words sit in LDS, written and read
+            # through the same map -- the parked skip rows included): the same numbers to the bit
+            e.set_option("fused_swz", 1)
+            lat_s = np.full((11, 1, 256), np.nan, np.float32)
+            e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat_s)
+            e.set_option("fused_swz", 0)
+            assert np.array_equal(lat_s, lat)
     with pytest.raises(_lib.MldHipError):
         e.set_option("fused_ring", 6)
     e.close()

@@ -52,7 +52,7 @@ for short, pat in NAMES.items():
 note = ("rocprofv3 --pmc, separate passes with --kernel-trace only, over bench.py --profile-child --coalesce N --steps 1 (the headline call shape, one call).  "
         "FETCH/WRITE_SIZE are KB; fetch bytes = 2 x FETCH_SIZE x 1024 (gfx950 wide-read correction of MI355X_MICROARCH.md); weights and the working set of the loop are "
         "Infinity-Cache resident, so this is L2<->fabric traffic, not DRAM traffic.")
-json.dump({"source_hash": bench.source_hash(), "loop_kernel_code_hash": bench.kernel_code_hash(), "requests_per_call": coalesce, "note": note, "kernels": traffic}, open(f"gpurun_out/{tag}_pmc_traffic.json", "w"), indent=1)
+json.dump({"source_hash": bench.source_hash(), "loop_kernel_code_hash": bench.kernel_code_hash(bench.mangled_part(next(k for k in agg if "den_loop_kernel" in k))) if any("den_loop_kernel" in k for k in agg) else None, "requests_per_call": coalesce, "note": note, "kernels": traffic}, open(f"gpurun_out/{tag}_pmc_traffic.json", "w"), indent=1)
 if any(len(v) > 1 for v in sq.values()):      # (PMC_TRAFFIC_ONLY=1: no SQ passes ran, keep the previous SQ summary)
   json.dump({"source_hash": bench.source_hash(), "requests_per_call": coalesce,
            "note": "SQ counters per dispatch (averages).  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles (16 per "
