@@ -152,6 +152,9 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "fused_swz"       F16X3 mode, persistent loop: 1 = the operand images in LDS are stored XOR-swizzled by the row (the 8-byte row stores
  *                     of sixteen rows 264 words apart hit each bank pair twice instead of four times; fragment reads stay conflict
  *                     free); same numbers to the bit.  Default 1 (27.15 -> 26.75 ms per 2 048-motion call, profiles/r03c_loop_swz_ab.json)
+ *   "ffn_swz"         F16X3 / FP8 modes, one-launch decoder tail ("dec_tail"): 1 = its LDS images row-swizzled like the loop's ("fused_swz");
+ *                     same numbers to the bit.  Default 0: built and checked on the simulator after round 3's GPU budget was spent,
+ *                     not yet measured (the tail's SQ counters show the same 4-way store conflicts: profiles/r03c_pmc_sq_ab.json)
  *   "ffn_strip"       F16X3 / FP8 modes, decoder / encoder layers: strip height of the register-direct kernels (kernels/ffn_strip.hpp,
  *                     kernels/gemm_strip_x3.hpp): 1 (default) = by launch size -- more than 512 strips of 64 rows: 96-row strips for the
  *                     GEMMs, 48-row strips at two workgroups per CU for the feed-forward block; else 64 rows (one bs-64 request: 196

@@ -574,7 +574,8 @@ void dec_layer(Ctx& c, int l, const float* xin, float* xout, int B, int T, bool 
     a.skip_lens = e->lens_dev; a.skip_rpg = T;
     a.AO = e->AO; a.Wo = e->gemm_stream_of[L.out_w]; a.bo = L.out_b; a.res = xin; a.g1 = L.n1_w; a.be1 = L.n1_b;
     a.cvec = e->cvec + (size_t)l * e->cfg.max_batch * D; a.rpg = T; a.g2 = L.n2_w; a.be2 = L.n2_b;
-    MLD_LAUNCH((ffn_strip_x3_kernel<3, true>), dim3((M + 47) / 48), dim3(512), (ffn_strip_lds_bytes<3>()), c.stream, a);
+    if (e->ffn_swz) MLD_LAUNCH((ffn_strip_x3_kernel<3, true, true>), dim3((M + 47) / 48), dim3(512), (ffn_strip_lds_bytes<3>()), c.stream, a);
+    else MLD_LAUNCH((ffn_strip_x3_kernel<3, true>), dim3((M + 47) / 48), dim3(512), (ffn_strip_lds_bytes<3>()), c.stream, a);
     count(c);
     check_launch(c, "dec_tail_x3");
     return;

@@ -38,7 +38,9 @@ constexpr int kFfnStripItems = 128;
 // stream of out_proj.weight) + residual + norm1 + cross-attention vector + norm2 produce the block input in LDS instead of reading it:
 // the layer's H1 tensor (M x 256 fp32, written by one launch and read by the next) disappears, 0.8 GB of the decoder's 5.3 GB of HBM
 // traffic per layer at 2 048 motions -- and the decoder's row-strip kernels are bound by exactly that traffic (~3.1 TB/s, r03).
-template <int RT, bool TAIL = false>
+// SWZ: the strip's and the hidden block's images are stored XOR-swizzled by the row, exactly as in the persistent loop (loop_fused.hpp
+// SWZ: physical word = logical word ^ 4 ((row >> 2) & 3); 8-byte row stores 4-way -> 2-way, fragment reads stay conflict free).
+template <int RT, bool TAIL = false, bool SWZ = false>
 __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnArgs p) {
   constexpr int BM = RT * 16, XS = kFsXs, HS = kFsHs;
 #if defined(MLDHIP_SIM)
@@ -121,6 +123,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
     split16_pair(v.x, v.y, h0, l0);
     split16_pair(v.z, v.w, h1, l1);
     unsigned* d = reinterpret_cast<unsigned*>(Xs) + row * XS + (c4 >> 3) * 32 + (c4 & 7) * 2;
+    if constexpr (SWZ) d = reinterpret_cast<unsigned*>(Xs) + row * XS + (((c4 >> 3) * 32 + (c4 & 7) * 2) ^ (((row >> 2) & 3) << 2));
     *reinterpret_cast<U2*>(d) = U2{h0, h1};
     *reinterpret_cast<U2*>(d + 16) = U2{l0, l1};
   }
@@ -132,8 +135,9 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
   }
   __syncthreads();
 
-  const float* xa = Xs + r * XS + g * 4;
-  const float* ha = Hs + r * HS + g * 4;
+  // SWZ: this lane's 16-byte group of a half chunk is g ^ (r >> 2) in rows 16 t + r
+  const float* xa = SWZ ? Xs + r * XS + ((g ^ (r >> 2)) << 2) : Xs + r * XS + g * 4;
+  const float* ha = SWZ ? Hs + r * HS + ((g ^ (r >> 2)) << 2) : Hs + r * HS + g * 4;
   if constexpr (TAIL) {
     // ---- out-projection (transposed products: lane (r, g) holds row r, columns 16 wave + 4g .. + 3 of each 128-column block) + bias +
     //      residual, LayerNorm(g1), + cvec[sample], LayerNorm(g2) (gemm_strip_x3.hpp's LN form), result -> the strip's image in Xs
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
       layer_norm(p.g2, p.be2);
     }
     // every wave left the out-projection before norm1's first barrier: the attention-output image is dead; the block input takes its place
-    const int rw0 = (wave >> 1) * 32 + (wave & 1) * 8 + g * 2;
+    const int rw0 = SWZ ? (((wave >> 1) * 32 + (wave & 1) * 8 + g * 2) ^ ((r >> 2) << 2)) : (wave >> 1) * 32 + (wave & 1) * 8 + g * 2;
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
       unsigned h0, l0, h1, l1;
@@ -226,7 +230,8 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
     }
     __syncthreads();
   }
-  const int hw0 = ((wave >> 1) * 32 + (wave & 1) * 8 + (r >> 1)) * 2 + (r & 1);     // half-word offset of column col0 in a row image
+  // half-word offset of column col0 in a row image; the rows read with it are 16 t + 4 g + i (plain accumulator layout): swizzled by g
+  const int hw0 = SWZ ? ((((wave >> 1) * 32 + (wave & 1) * 8 + (r >> 1)) ^ (g << 2)) * 2 + (r & 1)) : ((wave >> 1) * 32 + (wave & 1) * 8 + (r >> 1)) * 2 + (r & 1);
 
   f32x4 h[RT], y0[RT], y1[RT];
   unsigned hvh[RT][2], hvl[RT][2];     // one hidden block after bias + GELU: high / low halves of elements (i, i + 1) packed per word
@@ -259,6 +264,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
     {
       // four consecutive columns of row 16 t + r: words (wave >> 1) 32 + (wave & 1) 8 + 2 g, + 1 of the high plane, + 16 for the low one
       unsigned* w = reinterpret_cast<unsigned*>(Hs + (t * 16 + r) * HS) + (wave >> 1) * 32 + (wave & 1) * 8 + g * 2;
+      if constexpr (SWZ) w = reinterpret_cast<unsigned*>(Hs + (t * 16 + r) * HS) + (((wave >> 1) * 32 + (wave & 1) * 8 + g * 2) ^ ((r >> 2) << 2));
       *reinterpret_cast<U2*>(w) = U2{hvh[t][0], hvh[t][1]};
       *reinterpret_cast<U2*>(w + 16) = U2{hvl[t][0], hvl[t][1]};
     }

@@ -323,6 +323,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value < 0 || value > 5) return e->fail(MLDHIP_EINVAL, "fused_dbg must be 0 .. 5");
     if (value == 5 && !e->trace_buf && hipMalloc((void**)&e->trace_buf, (size_t)512 * 8 * 8 * sizeof(uint64_t)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(trace)");
     e->fused_dbg = (int)value;
+  } else if (n == "ffn_swz") {
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "ffn_swz must be 0 or 1");
+    e->ffn_swz = (int)value;
   } else if (n == "fused_swz") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "fused_swz must be 0 or 1");
     e->fused_swz = (int)value;

@@ -889,3 +889,29 @@ def test_key_blocked_attention_transpose_read_v_sim(ow):
         with pytest.raises(_lib.MldHipError):
             e.set_option("attn_tr", 4)
         e.close()
+
+
+def test_decoder_tail_with_row_swizzled_images_sim(ow):
+    """"ffn_swz" = 1: ffn_strip_x3_kernel<3, true, true> -- the one-launch decoder tail with its strip image and hidden-block image stored
+    XOR-swizzled by the row (the loop's "fused_swz" map: every write and read of an image goes through it -- the prologue's element-wise
+    image, the out-projection's A fragments, the block input written by lanes in the transposed layout, the hidden blocks, the residual
+    read back in the plain accumulator layout).  A permutation of where words sit in LDS: features identical to the bit, ragged lengths,
+    a partial last strip."""
+    ops, _, bv = ow
+    e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2, precision=1)
+    e.set_option("gemm_small_m", 0)
+    e.set_option("ffn_strip", 3)
+    z = syn._rng(13, "ffnswz").standard_normal((3, 1, 256)).astype(np.float32)
+    lens = [40, 23, 7]
+    ref = np.asarray(O.vae_decode(ops, bv, z, lens))
+    outs = []
+    for swz in (1, 0):
+        e.set_option("ffn_swz", swz)
+        feats = np.full((3, 40, 263), np.nan, np.float32)
+        e.vae_decode(z, lens, feats)
+        assert np.isfinite(feats).all() and np.abs(feats - ref).max() < 2e-4
+        outs.append(feats)
+    assert np.array_equal(outs[0], outs[1]), np.abs(outs[0] - outs[1]).max()
+    with pytest.raises(_lib.MldHipError):
+        e.set_option("ffn_swz", 2)
+    e.close()
