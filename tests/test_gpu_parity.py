@@ -1069,6 +1069,17 @@ def test_headline_serving_shape_every_motion_within_tolerance(dev, golden_dir):
             big.sample_many(reqs)
         torch.cuda.synchronize()
         assert big.launch_counts()[0] <= 4              # the loop really ran as the persistent launch
+        if mix == "full":
+            # "fused_swz" (default on: the loop's LDS images stored XOR-swizzled by the row) is a permutation of where words sit in LDS:
+            # the plain-image build of the same kernel gives the same latents to the bit (profiles/r03c_loop_swz_ab.json)
+            lat_swz = torch.cat([q["latents_out"] for q in reqs]).clone()
+            big.set_option("fused_swz", 0)
+            big.sample_many(reqs)
+            torch.cuda.synchronize()
+            assert torch.equal(torch.cat([q["latents_out"] for q in reqs]), lat_swz)
+            big.set_option("fused_swz", 1)
+            big.sample_many(reqs)                       # back to the default build: its outputs are what is checked below
+            torch.cuda.synchronize()
         worst = 0.0
         for b, q in zip(batches, reqs):
             T = max(b.lengths)
