@@ -57,3 +57,17 @@ def test_product_never_imports_oracle_or_simulator():
             src = open(os.path.join(pkg, f)).read()
             assert "import oracle" not in src and "from oracle" not in src, f
             assert "libmldhip_sim" not in src and "hipemu" not in src, f
+
+
+def test_every_option_of_set_option_is_documented_in_the_header_and_vice_versa():
+    """mldhip_set_option's names (csrc/mldhip.hip) == the names the header documents, and each has a default in engine/state.hpp."""
+    import re
+    src = open(os.path.join(REPO, "motion-latent-diffusion_amd", "csrc", "mldhip.hip")).read()
+    body = src.split("int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {")[1].split("\n}\n")[0]
+    code = set(re.findall(r'n == "([a-z0-9_]+)"', body))
+    hdr = open(os.path.join(REPO, "include", "mldhip.h")).read()
+    doc = set(re.findall(r'^ \*   "([a-z0-9_]+)"', hdr.split("int mldhip_set_option(")[0], re.M))
+    assert code and code == doc, (sorted(code - doc), sorted(doc - code))
+    state = open(os.path.join(REPO, "motion-latent-diffusion_amd", "csrc", "engine", "state.hpp")).read()
+    named = set(re.findall(r'//\s*"([a-z0-9_]+)"', state))
+    assert code <= named, sorted(code - named)
