@@ -152,6 +152,11 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "fused_swz"       F16X3 mode, persistent loop: 1 = the operand images in LDS are stored XOR-swizzled by the row (the 8-byte row stores
  *                     of sixteen rows 264 words apart hit each bank pair twice instead of four times; fragment reads stay conflict
  *                     free); same numbers to the bit.  Default 1 (27.15 -> 26.75 ms per 2 048-motion call, profiles/r03c_loop_swz_ab.json)
+ *   "final_strip"     F16X3 / FP8 modes, MldVae.decode: 1 = decoder.norm + final_layer + the zeroing of padded frames (mld_vae.py:240-245)
+ *                     as ONE row-strip launch (kernels/final_strip.hpp: the decoder output is read once and the features leave as
+ *                     contiguous 48-row blocks) instead of a LayerNorm launch + the staged GEMM, whose three 128-column tiles each
+ *                     re-read the normalised rows.  Default 0: built and checked on the simulator after round 3's GPU budget was
+ *                     spent, not yet measured
  *   "ffn_swz"         F16X3 / FP8 modes, one-launch decoder tail ("dec_tail"): 1 = its LDS images row-swizzled like the loop's ("fused_swz");
  *                     same numbers to the bit.  Default 0: built and checked on the simulator after round 3's GPU budget was spent,
  *                     not yet measured (the tail's SQ counters show the same 4-way store conflicts: profiles/r03c_pmc_sq_ab.json)

@@ -330,6 +330,7 @@ int build_ffn_streams(Ctx& c) {
   E* e = c.e;
   e->ffn_stream_of.clear();
   e->gemm_stream_of.clear();
+  e->final_stream = nullptr;
   if (e->ffn_streams) { (void)hipFree(e->ffn_streams); e->ffn_streams = nullptr; }
   const bool split = e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE || e->cfg.precision == MLDHIP_PREC_FP8_DENOISER;
   if (!split || is_novae(e) || e->cfg.latent_dim != 256 || e->cfg.ff_size != 1024) return 0;
@@ -366,20 +367,38 @@ int build_ffn_streams(Ctx& c) {
     if (!is_actor(e)) for (int i = 0; i < nbv; ++i) gstream(P(e, "vae.encoder.linear_blocks." + std::to_string(i) + ".weight"), 256, 512);
   }
   (void)ffn_items;
+  // kernels/final_strip.hpp: vae.final_layer.weight [NF][256], 256 < NF <= 384, zero-padded to three 128-row blocks: per chunk [block 0, 1, 2]
+  e->final_stream = nullptr;
+  const size_t final_first = items.size();
+  const int NFv = e->cfg.nfeats;
+  if (e->group_ready[1] && !is_actor(e) && NFv > 256 && NFv <= 384) {
+    const float* wf = P(e, "vae.final_layer.weight");
+    for (int kc = 0; kc < 8; ++kc)
+      for (int blk = 0; blk < 3; ++blk) {
+        push(wf, 256, blk * 128, kc * 32);
+        items.back().pad = std::min(128, NFv - blk * 128);     // valid rows of the block (pack_stream_rows_kernel zero-fills the rest)
+      }
+  }
   LoopItem* items_dev = nullptr;
   if (hipMalloc((void**)&e->ffn_streams, items.size() * kLoopItemFloats * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&items_dev, items.size() * sizeof(LoopItem)) != hipSuccess)
     return e->fail(MLDHIP_EHIP, "hipMalloc(feed-forward weight streams)");
   hipError_t st = hipMemcpy(items_dev, items.data(), items.size() * sizeof(LoopItem), hipMemcpyHostToDevice);
   if (st == hipSuccess) {
-    MLD_LAUNCH(pack_loop_stream_kernel<true>, dim3((unsigned)items.size()), dim3(512), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->ffn_streams);
+    MLD_LAUNCH(pack_loop_stream_kernel<true>, dim3((unsigned)final_first), dim3(512), 0, c.stream, (const float*)e->arena, (const LoopItem*)items_dev, e->ffn_streams);
     check_launch(c, "pack_ffn_streams");
+    if (items.size() > final_first) {
+      MLD_LAUNCH(pack_stream_rows_kernel, dim3((unsigned)(items.size() - final_first)), dim3(512), 0, c.stream, (const float*)e->arena,
+                 (const LoopItem*)(items_dev + final_first), e->ffn_streams + final_first * (size_t)kLoopItemFloats);
+      check_launch(c, "pack_final_stream");
+    }
     st = hipStreamSynchronize(c.stream);
   }
   (void)hipFree(items_dev);
   if (st != hipSuccess) return e->fail(MLDHIP_EHIP, "feed-forward weight streams: %s", hipGetErrorString(st));
   for (size_t i = 0; i < layers.size(); ++i) e->ffn_stream_of[layers[i].first] = e->ffn_streams + i * (size_t)kFfnStripItems * kLoopItemFloats;
   for (auto& gf : gemm_first) e->gemm_stream_of[gf.first] = e->ffn_streams + gf.second * (size_t)kLoopItemFloats;
+  if (items.size() > final_first) e->final_stream = e->ffn_streams + final_first * (size_t)kLoopItemFloats;
   return c.rc;
 }
 
@@ -646,6 +665,16 @@ void decode_body(Ctx& c, const float* z, int B, int T, float* feats_out) {
   for (int i = 0; i < nb; ++i) {
     skip_linear(c, "vae.decoder", i, e->Ha, e->S[nb - 1 - i], e->Hb, M, T);
     dec_layer(c, nb + 1 + i, e->Hb, e->Ha, B, T);
+  }
+  if (e->final_strip && e->final_stream && staged_prec(e) == PREC_BF16X3 && D == 256 && !e->trace_on && M > e->small_m) {
+    // decoder.norm + final_layer + output[~mask.T] = 0 as one row-strip launch (kernels/final_strip.hpp, "final_strip")
+    FinalStripArgs a;
+    a.X = e->Ha; a.gamma = P(e, "vae.decoder.norm.weight"); a.beta = P(e, "vae.decoder.norm.bias"); a.W = e->final_stream;
+    a.bias = P(e, "vae.final_layer.bias"); a.Y = feats_out; a.M = M; a.NF = NF; a.lens = e->lens_dev; a.rpg = T;
+    MLD_LAUNCH(final_strip_x3_kernel, dim3((M + kFinalStripRows - 1) / kFinalStripRows), dim3(512), final_strip_lds_bytes(), c.stream, a);
+    count(c);
+    check_launch(c, "final_strip_x3");
+    return;
   }
   MLD_LAUNCH(layernorm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, c.stream, (const float*)e->Ha, e->LNO,
              P(e, "vae.decoder.norm.weight"), P(e, "vae.decoder.norm.bias"), M);

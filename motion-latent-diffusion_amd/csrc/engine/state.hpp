@@ -65,6 +65,7 @@ struct mldhip_engine {
   std::vector<Param> params;
   std::map<std::string, int> index;
   float* arena = nullptr;
+  const float* final_stream = nullptr;   // split modes, MldVae: vae.final_layer.weight zero-padded to 384 rows as a fragment-ordered stream (kernels/final_strip.hpp); inside ffn_streams
   float* ffn_streams = nullptr;   // split modes: linear1 / linear2 of every decoder / encoder layer as fragment-ordered item streams (kernels/ffn_strip.hpp)
   std::map<const float*, const float*> ffn_stream_of;   // linear1.weight (arena pointer) -> its layer's stream
   std::map<const float*, const float*> gemm_stream_of;  // in_proj / out_proj / skip-linear weight -> its stream (kernels/gemm_strip_x3.hpp)
@@ -126,6 +127,7 @@ struct mldhip_engine {
   int ffn_strip = 1;         // "ffn_strip": register-direct decoder kernels (ffn_strip.hpp, gemm_strip_x3.hpp): 0 off, 1 auto strip height, 4 / 6 = 64 / 96 rows always
   int attn_tr = 1;           // "attn_tr": key-blocked attention, bit 0: V staged row-major and read with ds_read_b64_tr_b16 (attention.hpp TRV: 454 -> 417 us per launch at 2 048 motions); bit 1: streaming hints on its loads / stores (level: off)
   int dec_tail = 1;          // "dec_tail": out-projection + norms + feed-forward block of a decoder layer as one launch (chip-filling launches, split modes)
+  int final_strip = 0;       // "final_strip": decoder.norm + final_layer + padded-frame zeroing of MldVae.decode as one row-strip launch (final_strip.hpp; built after the round-3 GPU budget ran out: NOT yet measured, off)
   int ffn_swz = 0;           // "ffn_swz": the one-launch decoder tail with row-swizzled LDS images (ffn_strip.hpp SWZ; built and simulator-checked after the round-3 GPU budget ran out: NOT yet measured, off)
   int dec_l0_once = 1;       // "dec_l0_once": decoder layer 0 projects its input -- the positional rows, the same for every sample -- once per call ([T] rows instead of [B T])
   int nt_hints = 1;          // "nt_hints": the decoder's in-projection (gemm_strip_x3.hpp, N = 768) loads its row strips and stores its output with the streaming hint (527 -> 504 us per launch at 2 048 motions; level on the skip linears, which do not take it)

@@ -39,6 +39,7 @@
 #include "kernels/loop_fused.hpp"
 #include "kernels/ffn_strip.hpp"
 #include "kernels/gemm_strip_x3.hpp"
+#include "kernels/final_strip.hpp"
 
 using namespace mld;
 
@@ -323,6 +324,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value < 0 || value > 5) return e->fail(MLDHIP_EINVAL, "fused_dbg must be 0 .. 5");
     if (value == 5 && !e->trace_buf && hipMalloc((void**)&e->trace_buf, (size_t)512 * 8 * 8 * sizeof(uint64_t)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(trace)");
     e->fused_dbg = (int)value;
+  } else if (n == "final_strip") {
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "final_strip must be 0 or 1");
+    e->final_strip = (int)value;
   } else if (n == "ffn_swz") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "ffn_swz must be 0 or 1");
     e->ffn_swz = (int)value;

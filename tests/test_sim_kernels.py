@@ -915,3 +915,39 @@ def test_decoder_tail_with_row_swizzled_images_sim(ow):
     with pytest.raises(_lib.MldHipError):
         e.set_option("ffn_swz", 2)
     e.close()
+
+
+def test_final_norm_and_linear_as_one_strip_launch_sim(ow):
+    """"final_strip" = 1 (kernels/final_strip.hpp): decoder.norm + final_layer + output[~mask.T] = 0 of MldVae.decode (mld_vae.py:240-245) as
+    one row-strip launch -- rows normalised while loaded (the LayerNorm kernel's arithmetic), multiplied with the weight zero-padded to
+    three 128-column blocks, features written as contiguous 48-row blocks of 263-float rows -- against the LayerNorm launch + staged GEMM
+    it replaces and the oracle: ragged lengths (M = 120 rows: two full strips and a partial one whose block ends off a 16-byte boundary:
+    24 rows x 263 floats), a caller's output buffer that is only 4-byte aligned, one launch less."""
+    ops, _, bv = ow
+    e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2, precision=1)
+    e.set_option("gemm_small_m", 0)
+    z = syn._rng(17, "finstrip").standard_normal((3, 1, 256)).astype(np.float32)
+    for lens in ([40, 23, 7], [37, 5, 21]):
+        T = max(lens)
+        ref = np.asarray(O.vae_decode(ops, bv, z, lens))
+        outs, launches = [], []
+        for fs in (1, 0):
+            e.set_option("final_strip", fs)
+            before = e.launch_counts()[1]                 # (the per-op entry points add to the decode counter)
+            raw = np.full(3 * T * 263 + 1, np.nan, np.float32)
+            feats = raw[1:].reshape(3, T, 263)            # float-aligned only (base + 4 bytes)
+            e.vae_decode(z, lens, feats)
+            assert np.isnan(raw[0]) and np.isfinite(feats).all() and np.abs(feats - ref).max() < 2e-4
+            for i, n in enumerate(lens):
+                assert np.all(feats[i, n:] == 0)
+            outs.append(feats.copy())
+            launches.append(e.launch_counts()[1] - before)
+        assert launches[0] == launches[1] - 1, launches
+        assert np.abs(outs[0] - outs[1]).max() < 2e-5, np.abs(outs[0] - outs[1]).max()
+    al = np.full((3, 37, 263), np.nan, np.float32)        # and a 16-byte aligned buffer (numpy's own allocation)
+    e.set_option("final_strip", 1)
+    e.vae_decode(z, [37, 5, 21], al)
+    assert np.array_equal(al, outs[0])
+    with pytest.raises(_lib.MldHipError):
+        e.set_option("final_strip", 3)
+    e.close()
