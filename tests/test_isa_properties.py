@@ -1,0 +1,50 @@
+"""Static checks of the gfx950 machine code (no GPU): tools/isa_report.py disassembles libmldhip.so and this test pins the properties
+of the hot kernels that earlier rounds paid for on the profiler -- a ring pointer that keeps its address space (no flat loads), no
+scratch where there was none, the V operand through the transpose read, the expected number of matrix instructions."""
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+import isa_report  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def rep():
+    if not os.path.exists(isa_report.DEFAULT_LIB) or not os.path.exists(os.path.join(isa_report.LLVM, "llvm-objdump")):
+        pytest.skip("libmldhip.so / the LLVM binary tools are not here")
+    return isa_report.report()
+
+
+def one(rep, part):
+    hits = [v for k, v in rep.items() if part in k]
+    assert len(hits) == 1, (part, [k for k in rep if part in k])
+    return hits[0]
+
+
+def test_persistent_loop_code(rep):
+    for swz in ("false", "true"):
+        k = one(rep, f"den_loop_kernel<true, 4, 0, {swz}>")
+        assert k["flat"] == 0                      # DESIGN.md point 34: an opaque POINTER turned the ring into flat loads (+8 %)
+        assert k["mfma"] == 1224 and k["ds_write_b16"] == 0
+        assert k["scratch"] <= 256 and k["vgpr"] == 256
+    assert one(rep, "den_loop_kernel<false, 4, 0, false>")["flat"] == 0
+
+
+def test_key_blocked_attention_reads_v_through_the_transpose_read(rep):
+    tr = one(rep, "attn_flash_x3_kernel<true, false>")
+    assert tr["ds_read_tr"] == 16 and tr["ds_write_b16"] == 0 and tr["scratch"] == 0 and tr["vgpr"] <= 128
+    old = one(rep, "attn_flash_x3_kernel<false, false>")
+    assert old["ds_read_tr"] == 0 and old["ds_write_b16"] == 16 and old["mfma"] == tr["mfma"] == 48
+
+
+def test_row_strip_kernels_have_no_scratch_and_no_flat_accesses(rep):
+    for part in ("strip_gemm_x3_kernel<6, 1, false, true, 8, 3>", "strip_gemm_x3_kernel<6, 1, false, true, 8, 0>", "strip_gemm_x3_kernel<4, 2, false, false, 8, 0>",
+                 "ffn_strip_x3_kernel<3, true, false>", "final_strip_x3_kernel"):
+        k = one(rep, part)
+        assert k["scratch"] == 0 and k["flat"] == 0, (part, k)
+    assert one(rep, "final_strip_x3_kernel")["mfma"] == 8 * 3 * 3 * 3          # chunks x column blocks x row tiles x split products
+    nt, plain = one(rep, "strip_gemm_x3_kernel<6, 1, false, true, 8, 3>"), one(rep, "strip_gemm_x3_kernel<6, 1, false, true, 8, 0>")
+    assert nt["branches"] == plain["branches"]     # DESIGN.md point 40: the streaming hints are not run-time branches around the accesses
