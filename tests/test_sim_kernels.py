@@ -818,7 +818,7 @@ def test_register_direct_ffn_kernel_sim(ow):
     e.close()
 
 
-def test_first_decoder_layer_projects_its_input_once_sim(ow, aow):
+def test_first_decoder_layer_projects_its_input_once_sim(eng, aeng, ow, aow):
     """"dec_l0_once" (default 1): decoder layer 0's input is zeros + the positional rows (mld_vae.py:216-222, actor_vae.py:221-222) --
     the same for every sample -- so its in-projection runs over ONE sample's T rows and every (sample, head) attention workgroup reads
     those (with its own sample's length mask).  Sample 0 is the SHORTEST here: the shared projection must still cover the T rows the
@@ -826,44 +826,49 @@ def test_first_decoder_layer_projects_its_input_once_sim(ow, aow):
     TransformerDecoder stack of the action VAE included."""
     ops, _, bv = ow
     z = syn._rng(11, "l0once").standard_normal((3, 1, 256)).astype(np.float32)
-    lens = [5, 40, 23]
+    lens = [5, 24, 17]
     ref = np.asarray(O.vae_decode(ops, bv, z, lens))
-    for prec, opts, tol in ((0, {}, 5e-5), (1, {"gemm_small_m": 0, "flash_attn": 0}, 2e-4), (1, {"gemm_small_m": 0, "flash_attn": 2}, 2e-4)):
-        e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2, precision=prec)
-        for k, v in opts.items():
-            e.set_option(k, v)
+
+    def both_forms(e, tol):
         outs = []
         for once in (1, 0):
             e.set_option("dec_l0_once", once)
-            feats = np.full((3, 40, 263), np.nan, np.float32)
+            feats = np.full((3, 24, 263), np.nan, np.float32)
             e.vae_decode(z, lens, feats)
             assert np.isfinite(feats).all() and np.abs(feats - ref).max() < tol
             for i, n in enumerate(lens):
                 assert np.all(feats[i, n:] == 0)
             outs.append(feats)
+        e.set_option("dec_l0_once", 1)
         assert np.array_equal(outs[0], outs[1]), np.abs(outs[0] - outs[1]).max()
-        if prec == 1:                      # streaming-access hints change no number
-            e.set_option("nt_hints", 1)
-            feats = np.full((3, 40, 263), np.nan, np.float32)
-            e.vae_decode(z, lens, feats)
-            assert np.array_equal(feats, outs[1])
-        with pytest.raises(_lib.MldHipError):
-            e.set_option("dec_l0_once", 2)
-        e.close()
+        return outs[1]
+
+    both_forms(eng, 5e-5)                                  # exact fp32 (attn_decode_kernel)
+    e = simlib.sim_engine(max_batch=4, max_frames=24, num_inference_steps=2, precision=1)
+    e.set_option("gemm_small_m", 0)
+    for fl in (0, 2):                                      # split mode: whole-K/V kernel, key-blocked kernel
+        e.set_option("flash_attn", fl)
+        plain = both_forms(e, 2e-4)
+    e.set_option("nt_hints", 0)                            # streaming-access hints change no number
+    feats = np.full((3, 24, 263), np.nan, np.float32)
+    e.vae_decode(z, lens, feats)
+    assert np.array_equal(feats, plain)
+    with pytest.raises(_lib.MldHipError):
+        e.set_option("dec_l0_once", 2)
+    e.close()
     ops, _, abv = aow
-    ae = simlib.sim_action_engine(max_batch=4, max_frames=24, num_inference_steps=2)
     za = syn._rng(12, "l0once_a").standard_normal((3, 1, 256)).astype(np.float32)
     alens = [7, 24, 16]
     aref = np.asarray(O.actor_decode(ops, abv, za, alens))
     outs = []
     for once in (1, 0):
-        ae.set_option("dec_l0_once", once)
+        aeng.set_option("dec_l0_once", once)
         feats = np.full((3, 24, 150), np.nan, np.float32)
-        ae.vae_decode(za, alens, feats)
+        aeng.vae_decode(za, alens, feats)
         assert np.abs(feats - aref).max() < 5e-5
         outs.append(feats)
+    aeng.set_option("dec_l0_once", 1)
     assert np.array_equal(outs[0], outs[1])
-    ae.close()
 
 
 def test_key_blocked_attention_transpose_read_v_sim(ow):
@@ -872,7 +877,7 @@ def test_key_blocked_attention_transpose_read_v_sim(ow):
     group's 8-byte reads form).  Same products in the same order as the transposed-plane form: bit-identical features, on ragged
     lengths with an odd number of key tiles and more query tiles than waves' first slots."""
     ops, _, bv = ow
-    for B, T, lens in ((2, 68, [37, 68]),):
+    for B, T, lens in ((1, 68, [53]),):           # four key tiles = two 32-key blocks, the second one crossing the length
         e = simlib.sim_engine(max_batch=B, max_frames=T, num_inference_steps=2, precision=1)
         e.set_option("gemm_small_m", 0)
         e.set_option("flash_attn", 2)
@@ -898,16 +903,16 @@ def test_decoder_tail_with_row_swizzled_images_sim(ow):
     read back in the plain accumulator layout).  A permutation of where words sit in LDS: features identical to the bit, ragged lengths,
     a partial last strip."""
     ops, _, bv = ow
-    e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2, precision=1)
+    e = simlib.sim_engine(max_batch=4, max_frames=24, num_inference_steps=2, precision=1)
     e.set_option("gemm_small_m", 0)
     e.set_option("ffn_strip", 3)
     z = syn._rng(13, "ffnswz").standard_normal((3, 1, 256)).astype(np.float32)
-    lens = [40, 23, 7]
+    lens = [24, 13, 7]
     ref = np.asarray(O.vae_decode(ops, bv, z, lens))
     outs = []
     for swz in (1, 0):
         e.set_option("ffn_swz", swz)
-        feats = np.full((3, 40, 263), np.nan, np.float32)
+        feats = np.full((3, 24, 263), np.nan, np.float32)
         e.vae_decode(z, lens, feats)
         assert np.isfinite(feats).all() and np.abs(feats - ref).max() < 2e-4
         outs.append(feats)
@@ -921,13 +926,13 @@ def test_final_norm_and_linear_as_one_strip_launch_sim(ow):
     """"final_strip" = 1 (kernels/final_strip.hpp): decoder.norm + final_layer + output[~mask.T] = 0 of MldVae.decode (mld_vae.py:240-245) as
     one row-strip launch -- rows normalised while loaded (the LayerNorm kernel's arithmetic), multiplied with the weight zero-padded to
     three 128-column blocks, features written as contiguous 48-row blocks of 263-float rows -- against the LayerNorm launch + staged GEMM
-    it replaces and the oracle: ragged lengths (M = 120 rows: two full strips and a partial one whose block ends off a 16-byte boundary:
-    24 rows x 263 floats), a caller's output buffer that is only 4-byte aligned, one launch less."""
+    it replaces and the oracle: ragged lengths (M = 72 / 63 rows: a full strip and a partial one -- 15 rows x 263 floats end off a 16-byte
+    boundary), a caller's output buffer that is only 4-byte aligned, one launch less."""
     ops, _, bv = ow
-    e = simlib.sim_engine(max_batch=4, max_frames=40, num_inference_steps=2, precision=1)
+    e = simlib.sim_engine(max_batch=4, max_frames=24, num_inference_steps=2, precision=1)
     e.set_option("gemm_small_m", 0)
     z = syn._rng(17, "finstrip").standard_normal((3, 1, 256)).astype(np.float32)
-    for lens in ([40, 23, 7], [37, 5, 21]):
+    for lens in ([24, 13, 7], [21, 5, 11]):
         T = max(lens)
         ref = np.asarray(O.vae_decode(ops, bv, z, lens))
         outs, launches = [], []
@@ -944,9 +949,9 @@ def test_final_norm_and_linear_as_one_strip_launch_sim(ow):
             launches.append(e.launch_counts()[1] - before)
         assert launches[0] == launches[1] - 1, launches
         assert np.abs(outs[0] - outs[1]).max() < 2e-5, np.abs(outs[0] - outs[1]).max()
-    al = np.full((3, 37, 263), np.nan, np.float32)        # and a 16-byte aligned buffer (numpy's own allocation)
+    al = np.full((3, 21, 263), np.nan, np.float32)        # and a 16-byte aligned buffer (numpy's own allocation)
     e.set_option("final_strip", 1)
-    e.vae_decode(z, [37, 5, 21], al)
+    e.vae_decode(z, [21, 5, 11], al)
     assert np.array_equal(al, outs[0])
     with pytest.raises(_lib.MldHipError):
         e.set_option("final_strip", 3)
