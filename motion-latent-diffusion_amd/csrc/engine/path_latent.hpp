@@ -367,11 +367,12 @@ int build_ffn_streams(Ctx& c) {
     if (!is_actor(e)) for (int i = 0; i < nbv; ++i) gstream(P(e, "vae.encoder.linear_blocks." + std::to_string(i) + ".weight"), 256, 512);
   }
   (void)ffn_items;
-  // kernels/final_strip.hpp: vae.final_layer.weight [NF][256], 256 < NF <= 384, zero-padded to three 128-row blocks: per chunk [block 0, 1, 2]
+  // kernels/final_strip.hpp: vae.final_layer.weight [NF][256], 256 < NF <= 264 (the strip's 48 x NF results are parked in its 48 x 264-word image),
+  // zero-padded to three 128-row blocks: per chunk [block 0, 1, 2]
   e->final_stream = nullptr;
   const size_t final_first = items.size();
   const int NFv = e->cfg.nfeats;
-  if (e->group_ready[1] && !is_actor(e) && NFv > 256 && NFv <= 384) {
+  if (e->group_ready[1] && !is_actor(e) && NFv > 256 && NFv <= kFsXs) {
     const float* wf = P(e, "vae.final_layer.weight");
     for (int kc = 0; kc < 8; ++kc)
       for (int blk = 0; blk < 3; ++blk) {

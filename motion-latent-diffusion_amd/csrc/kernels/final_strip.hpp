@@ -1,6 +1,6 @@
 // The end of MldVae.decode as ONE row-strip launch (split-f16 operands, weights register-direct):
 //   feats[M, NF] = mask( LayerNorm(X; gamma, beta) W^T + bias )          (mld_vae.py:240-245: decoder.norm, final_layer, output[~mask.T] = 0)
-// for D = 256 and NF <= 384 (HumanML3D: 263).  Replaces layernorm_rows_kernel + the staged K = 256 GEMM, whose 64 x 128 tiles re-read the
+// for D = 256 and 256 < NF <= 264 (HumanML3D: 263; the bound is the parking space: 48 x NF results in the strip's 48 x 264-word image).  Replaces layernorm_rows_kernel + the staged K = 256 GEMM, whose 64 x 128 tiles re-read the
 // normalised rows once per 128-column tile (N = 263 -> three tiles: 1.2 GB instead of 0.4 GB at 2 048 motions, the third tile for seven
 // columns) after a 0.4 GB write + read of the normalised tensor itself, and store 263-float rows with 4-byte stores.  Here a workgroup
 // owns 48 rows: it normalises them while it loads them (one wave per row: the same arithmetic, in the same order, as
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512, 4) void final_strip_x3_kernel(FinalStripArgs p
   __syncthreads();                                         // every wave is done with the image: its rows now take the results
 
   // ---- bias, padded-frame zeroing, results parked row-major [48][NF] PACKED (row stride NF): the strip's output block as it lies in memory
-  float* Out = Xs;                                         // 48 NF <= 48 x 264 floats
+  float* Out = Xs;                                         // 48 NF <= 48 x 264 floats (the engine builds the stream only for NF <= 264)
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     const int col = b * 128 + col0;
