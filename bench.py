@@ -442,6 +442,79 @@ def bench_novae(local, dev, full, streams, B=64, T=196):
             "peaks": "f32: fp32 MFMA 157.3 TF; f16x3: dense 16-bit MFMA peak / 3 (three MFMAs per product) = 833 TF; bf16: 2500 TF"}
 
 
+PMC_FILE = os.path.join(REPO, "profiles", "r04_pmc_traffic.json")
+
+
+def pmc_summary(coalesce, loop_code_hash):
+    """The PMC summary (tools/gpu_pmc.sh: separate rocprofv3 --pmc passes) of THIS call shape: profiles/r04_pmc_traffic.json holds one
+    entry per requests-per-call it was collected at (20 = the driver's `--steps 20`, 32 = the chip-filling call).  Refused when it was
+    collected on other machine code of the loop kernel AND on other sources."""
+    try:
+        pmc = json.load(open(PMC_FILE))
+    except Exception:
+        return None, "no PMC summary (%s)" % os.path.relpath(PMC_FILE, REPO)
+    ent = pmc.get("shapes", {}).get(str(coalesce))
+    if ent is None:
+        return None, "%s has no entry for %d requests per call (has: %s)" % (os.path.relpath(PMC_FILE, REPO), coalesce, sorted(pmc.get("shapes", {})))
+    same_code = loop_code_hash is not None and ent.get("loop_kernel_code_hash") == loop_code_hash
+    if not (same_code or ent.get("source_hash") == source_hash()):
+        return None, "%s[%d] was collected on kernel code %s / source hash %s, this run is %s / %s: refused as stale" % (
+            os.path.relpath(PMC_FILE, REPO), coalesce, ent.get("loop_kernel_code_hash"), ent.get("source_hash"), loop_code_hash, source_hash())
+    return ent, ("%s[%d requests per call]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on THIS %s and call shape; L2<->fabric bytes per launch"
+                 % (os.path.relpath(PMC_FILE, REPO), coalesce, "machine code of the loop kernel (%s)" % loop_code_hash if same_code else "source hash"))
+
+
+# decoder kernels of the split-f16 mode at chip-filling launches: rocprofv3 name prefix, launches per call, algorithmic HBM bytes and
+# FLOPs per frame row (fp32 activations, 256 wide: 1 KB per row and tensor) -- DESIGN.md section 3's per-kernel table, computed live
+HBM_PEAK_TBS, HBM_COPY_TBS = 8.0, 6.3            # MI355X_MICROARCH.md: spec peak / measured float4 copy
+DECODER_KERNELS = {
+    "in_projection": ("void mld::strip_gemm_x3_kernel<6, 1, false, true", 8, (256 + 768) * 4, 2.0 * 256 * 768, "dec_qkv",
+                      "row strip in (1 KB / row), packed Q|K|V out (3 KB / row): write-heavy stream"),
+    "self_attention": ("void mld::attn_flash_x3_kernel", 9, (768 + 256) * 4, None, "dec_attn",
+                       "key-blocked online softmax over T = 196: Q|K|V in, attention output out; 4 T 256 FLOP per row"),
+    "decoder_tail": ("void mld::ffn_strip_x3_kernel<3, true", 9, 3 * 256 * 4, 2.0 * (256 * 256 + 2 * 256 * 1024), "dec_ffn",
+                     "out-projection + norms + feed-forward block: attention output + residual in, layer output out"),
+    "skip_linear": ("void mld::strip_gemm_x3_kernel<4, 2, false, false", 4, 3 * 256 * 4, 2.0 * 512 * 256, "dec_skip",
+                    "Linear(cat[x, skip]): two row strips in, one out"),
+    "final_norm_linear": ("mld::final_strip_x3_kernel", 1, (256 + 263) * 4, 2.0 * 256 * 263, None,
+                          "decoder.norm + final_layer (N = 263) + padded-frame zeroing as one row-strip launch"),
+}
+
+
+def decoder_roofline(stats, motions, pmc_shape):
+    """Per decoder kernel of the headline call: algorithmic HBM bytes and FLOPs per launch / the rocprofv3 dispatch average of the SAME
+    child run the loop's roofline uses -> TB/s against the 8 TB/s spec and the 6.3 TB/s a copy reaches, TFLOP/s against the split-f16
+    MFMA roof; measured traffic and MFMA-busy from the PMC summary of this shape when there is one."""
+    if not stats:
+        return {"error": "no rocprofv3 kernel stats"}
+    M = motions * FRAMES
+    out = {"rows_per_launch": M, "unit": "TB/s | TFLOP/s", "hbm_peak_tb_s": HBM_PEAK_TBS, "hbm_copy_tb_s": HBM_COPY_TBS, "mfma_roof_tflops": round(X3_PEAK_TF, 1), "kernels": {}}
+    tot_ms = 0.0
+    for name, (prefix, per_call, bytes_row, flop_row, pmc_key, what) in DECODER_KERNELS.items():
+        hits = [(n, v) for n, v in stats.items() if n.startswith(prefix)]
+        if not hits:
+            continue
+        n, (avg, calls_, total) = max(hits, key=lambda kv: kv[1][2])
+        rows = M if name != "in_projection" else M        # (layer 0 projects ONE sample's rows: a tiny ninth launch, not in this average's class)
+        gb = bytes_row * rows / 1e9
+        fl = (flop_row if flop_row is not None else 4.0 * FRAMES * 256) * rows
+        ent = {"kernel": n[:90], "launches_per_call": per_call, "avg_us": round(avg / 1e3, 1), "algorithmic_gb_per_launch": round(gb, 3),
+               "tb_s": round(gb / (avg * 1e-9) / 1e3, 3), "frac_of_8_tb_s": round(gb / (avg * 1e-9) / 1e3 / HBM_PEAK_TBS, 3),
+               "frac_of_copy_rate": round(gb / (avg * 1e-9) / 1e3 / HBM_COPY_TBS, 3), "tflops": round(fl / (avg * 1e-9) / 1e12, 1),
+               "frac_of_mfma_roof": round(fl / (avg * 1e-9) / 1e12 / X3_PEAK_TF, 3), "what": what}
+        ent["bound"] = "hbm" if ent["frac_of_copy_rate"] >= ent["frac_of_mfma_roof"] else "mfma"
+        k = (pmc_shape or {}).get("kernels", {}).get(pmc_key) if pmc_key else None
+        if k and "traffic_bytes_per_launch" in k:
+            ent["traffic_gb_per_launch_pmc"] = round(k["traffic_bytes_per_launch"] / 1e9, 3)
+        sq = (pmc_shape or {}).get("sq", {}).get(pmc_key) if pmc_key else None
+        if sq:
+            ent.update({kk: sq[kk] for kk in ("mfma_busy_frac", "valu_per_mfma") if kk in sq})
+        tot_ms += avg * per_call / 1e6
+        out["kernels"][name] = ent
+    out["decode_ms_per_call_sum_of_these"] = round(tot_ms, 2)
+    return out
+
+
 def make_requests(dev, n, rank, with_lat=False):
     """n bs-64 requests, each with its own prompts / noise (seeded per rank and slot) and output buffers, all resident in HBM"""
     reqs = []
@@ -533,14 +606,16 @@ def main():
     K = a.steps
     coalesce = max(1, min(32, a.coalesce, K))
     weights, weight_bytes, bcast_s = pack_and_broadcast_weights(rank, dev)
-    eng = make_engine(local, weights, a.precision, max_batch=BATCH * coalesce, graph=not a.eager)
+    MAXC = 32                                    # the engine is sized for the chip-filling call (2 048 motions) whatever K is: the sweep below uses it
+    eng = make_engine(local, weights, a.precision, max_batch=BATCH * MAXC, graph=not a.eager)
     ident = (rank, local) + device_identity(local)
     ranks_seen = [ident]
     if dist:
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, ident)
     stream = torch.cuda.current_stream()
-    reqs = make_requests(dev, coalesce, rank, with_lat=True)
+    reqs_all = make_requests(dev, MAXC, rank, with_lat=True)
+    reqs = reqs_all[:coalesce]
     calls = [coalesce] * (K // coalesce) + ([K % coalesce] if K % coalesce else [])     # requests per call of one timed region: exactly K steps
 
     def issue(e_, lengths=None):
@@ -660,25 +735,15 @@ def main():
             n, (avg, calls_, total) = max(stats.items(), key=lambda kv: kv[1][2])
             roof.update({"kernel": n[:110], "achieved": None, "peak": PEAK_TF[a.precision], "frac": None, "avg_us_rocprof_dispatch": round(avg / 1e3, 2),
                          "note": "column-split kernel families (small calls): see profiles/r02_* for their per-kernel FLOP table"})
-        traffic, traffic_note = None, "no PMC summary (profiles/r03_pmc_traffic.json)"
-        try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r03_pmc_traffic.json")))
-            code = kernel_code_hash(mangled_part(loop_rows[0][0])) if loop_rows else None      # the loop kernel this build launches by default
-            same_code = code is not None and pmc.get("loop_kernel_code_hash") == code
-            if (same_code or pmc.get("source_hash") == source_hash()) and pmc.get("requests_per_call") == coalesce:
-                traffic = pmc["kernels"]["den_loop"]["traffic_bytes_per_launch"]
-                traffic_note = ("profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on THIS %s and call shape; L2<->fabric bytes per launch"
-                                % ("machine code of the kernel (loop_kernel_code_hash %s)" % code if same_code else "source hash"))
-            else:
-                traffic_note = "profiles/r03_pmc_traffic.json was collected on kernel code %s / source hash %s / %s requests per call, this run is %s / %s / %d: refused as stale" % (
-                    pmc.get("loop_kernel_code_hash"), pmc.get("source_hash"), pmc.get("requests_per_call"), code, source_hash(), coalesce)
-            roof["loop_kernel_code_hash"] = code
-        except Exception:
-            pass
+        code = kernel_code_hash(mangled_part(loop_rows[0][0])) if loop_rows else None      # the loop kernel this build launches by default
+        pmc_shape, traffic_note = pmc_summary(coalesce, code)
+        traffic = pmc_shape["kernels"]["den_loop"]["traffic_bytes_per_launch"] if pmc_shape and "den_loop" in pmc_shape.get("kernels", {}) else None
+        roof["loop_kernel_code_hash"] = code
         roof["traffic"], roof["traffic_source"] = traffic, traffic_note
         roof["algorithmic_bytes_per_launch"] = int(STEPS_DDIM * 30.4e6 + PB * 3 * 1024 * 2)     # the weight stream once per step chip-wide + latents / condition rows
         out["roofline"] = roof
         out["kernels"] = kern
+        out["decoder_roofline"] = decoder_roofline(stats, PB, pmc_shape)
         # ---- the configuration BASELINE.json names literally: one bs-64 batch at a time (latency kernels), first-class with its own roofline
         single = {"value": round(world * BATCH / ms1["median"], 2), "unit": "motions/s", "ms_per_batch": {k: (round(v * 1e3, 4) if k != "n" else v) for k, v in ms1.items()},
                   "steps_per_repetition": K1, "shape": "mldhip_sample, B = 64, T = 196: 2 052 dependent launches (hipGraph replay), reverse loop at 384 token rows on the latency kernels (tile32.hpp)"}
@@ -691,13 +756,43 @@ def main():
                     n, (avg, calls_, total) = max(hits, key=lambda kv: kv[1][1])
                     gf = 2.0 * 384 * 256 * 1024 / 1e9
                     tot1 = sum(v[2] for v in st1.values()) or 1.0
-                    single["roofline"] = {"bound": "mfma", "kernel": "den_ffn1 = " + n[:80], "achieved": round(gf / (avg * 1e-9) / 1e3, 2), "peak": FP32_MFMA_PEAK_TF,
-                                          "unit": "TFLOP/s", "frac": round(gf / (avg * 1e-9) / 1e3 / FP32_MFMA_PEAK_TF, 4), "avg_us_rocprof_dispatch": round(avg / 1e3, 2),
+                    # template arguments <rows, source, transposed, PREC, ...>: PREC 1 = split-f16 MFMAs ("tile_x3"), whose roof is the f16 peak / 3
+                    targs = [t.strip() for t in n.split("<", 1)[1].split(">")[0].split(",")]
+                    pk1 = X3_PEAK_TF if len(targs) > 3 and targs[3] == "1" else FP32_MFMA_PEAK_TF
+                    single["roofline"] = {"bound": "mfma", "kernel": "den_ffn1 = " + n[:80], "achieved": round(gf / (avg * 1e-9) / 1e3, 2), "peak": round(pk1, 1),
+                                          "peak_of": "split-f16 MFMA roof (dense f16 peak / 3)" if pk1 == X3_PEAK_TF else "fp32 MFMA peak",
+                                          "unit": "TFLOP/s", "frac": round(gf / (avg * 1e-9) / 1e3 / pk1, 4), "avg_us_rocprof_dispatch": round(avg / 1e3, 2),
                                           "launches_per_batch": 9 * STEPS_DDIM, "gflop_per_launch": round(gf, 4),
                                           "share_of_gpu_time": round(total / tot1, 4), "rocprof": where1,
                                           "note": "one request is a chain of 2 052 dependent launches of ~5-8 us: launch-latency bound, not MFMA bound (DESIGN.md §3 point 3 / 17c)"}
         out["single_batch"] = single
         out["value_single_batch"], out["ms_per_step_single_batch"] = single["value"], round(ms1["median"] * 1e3, 4)
+        out["headline_shape"] = ("value = %d bs-64 requests per engine call (%d motions, %d of 256 CUs hold a workgroup of the persistent loop); value_single_batch = one bs-64 "
+                                 "request per call (the literal BASELINE configuration); requests_per_call_sweep carries the shapes in between" % (coalesce, PB, min(256, (PB + 7) // 8)))
+        if solo:
+            # ---- how the rate depends on the requests per call (the loop's run time is flat in the batch up to 2 048 motions; the decoder's is linear)
+            sweep = {}
+            for c_ in (1, 2, 5, 10, 20, 32):
+                rs = reqs_all[:c_]
+                fn = (lambda: eng.sample_many(rs, stream.cuda_stream)) if c_ > 1 else (lambda: eng.sample(rs[0]["text_emb"], rs[0]["init_latents"], rs[0]["lengths"], rs[0]["latents_out"], None, rs[0]["joints_out"], stream.cuda_stream))
+                fn(); fn()
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+                sweep[str(c_)] = {"motions_per_call": BATCH * c_, "ms_per_call": round(min(ts) * 1e3, 3), "value": round(BATCH * c_ / min(ts), 1),
+                                  "loop_workgroups": (BATCH * c_ + 7) // 8 if BATCH * c_ >= 320 else None}
+            out["requests_per_call_sweep"] = {"unit": "motions/s", "note": "one call at a time, best of 3; loop_workgroups = workgroups of the persistent loop "
+                                              "(None: the call is below its 320-motion threshold and runs the column-split / latency kernels)", "shapes": sweep}
+            # ---- BASELINE config 3 (512 prompts over 8 ranks) as seen by ONE rank: its share is one bs-64 batch (world 8) or all 512 (world 1)
+            rs512 = reqs_all[:8]
+            eng.sample_many(rs512, stream.cuda_stream)
+            t512 = min(run_steps(lambda i, st: eng.sample_many(rs512, stream.cuda_stream), 1, [None]) for _ in range(3))
+            out["config3_per_rank"] = {"unit": "motions/s per rank", "world_1_512_prompts_one_call": round(512 / t512, 1),
+                                       "world_8_64_prompts_per_rank": single["value"],
+                                       "world_8_aggregate_if_linear": round(8 * single["value"], 1),
+                                       "note": "DataParallelSampler picks the requests per call by itself (shard size vs engine max_batch); on 8 ranks each rank's share of config 3 "
+                                               "is ONE bs-64 batch, i.e. the single_batch path: 8 x that is the config-3 rate to expect on an 8-GPU node (no data-path collective)"}
 
         cj = None
         if world == 1 and not a.no_cpu_baseline:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MLDHIP_ABI_VERSION 3
+#define MLDHIP_ABI_VERSION 4
 
 enum {
   MLDHIP_OK = 0,
@@ -51,10 +51,12 @@ enum {                     /* arithmetic mode of the matrix kernels.  In EVERY m
   MLDHIP_PREC_F32 = 0,            /* exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere: the parity mode */
   MLDHIP_PREC_F16X3 = 1,          /* split-f16: every GEMM operand x = hi + lo with hi = half(x), lo = half(x - hi) (22 mantissa bits),
                                      lo*hi + hi*lo + hi*hi as 3 x v_mfma_f32_16x16x32_f16 with fp32 accumulation, ~5e-7 relative per
-                                     product.  VAE decoder / encoder, every GEMM of the diffusion-only variant, and -- in calls
-                                     served by the sample-major persistent loop ("loop_kernel" = 3 / auto from "fused_min_batch"
-                                     motions) -- the reverse loop of the latent models; the column-split loop kernels of smaller
-                                     calls stay fp32.  Meets the 1e-3 joint contract with a 5x margin (tests: every motion of a
+                                     product.  VAE decoder / encoder, every GEMM of the diffusion-only variant, and the reverse loop
+                                     of the latent models -- both in calls served by the sample-major persistent loop
+                                     ("loop_kernel" = 3 / auto from "fused_min_batch" motions) and, since ABI 3, in the latency kernels
+                                     that serve ONE bs-64 request ("tile_x3": rounds 1-2 ran that loop in fp32 under the same enum
+                                     value); only the column-split loop kernels of 128-319-motion calls stay fp32.  Guarded by the
+                                     "Range contract" below (probe at finalize, fp32 fallback per stage, run-time counter).  Meets the 1e-3 joint contract with a 5x margin (tests: every motion of a
                                      2 048-motion call).  Rounds 1-2 split into bf16 halves (16 mantissa bits, 30x the error: the
                                      reverse loop could not use it); ABI value and behaviour of the other entry points unchanged. */
   MLDHIP_PREC_BF16X3_DECODE = 1,  /* the name rounds 1-2 gave mode 1 (kept for source compatibility) */
@@ -144,22 +146,21 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     motions per call up.
  *   "fused_min_batch" auto picks the persistent loop from this many motions per call up; 0 (default) = by operand format: 320 on
  *                     split-f16 MFMAs (27 ms per call whatever the batch), 1 280 on exact-fp32 MFMAs (77 ms)
- *   "fused_x3"        F16X3 mode: 1 (default) = the persistent loop multiplies on split-f16 MFMAs, 0 = on exact-fp32 MFMAs
- *   "fused_ring"      persistent loop: weight items in flight per lane, 4 (default) or 8
- *   "fused_dbg"       measurement builds of the persistent loop: 1 = no weight stream, 2 = no MFMAs, 3 = identity for GELU, 4 = no
- *                     feed-forward epilogue (1 - 4: WRONG results); 5 = correct results + per-phase cycle counters of the first 64
- *                     workgroups, read back with mldhip_profile_trace("den_loop_phases") (tools/trace_loop.py)
- *   "fused_swz"       F16X3 mode, persistent loop: 1 = the operand images in LDS are stored XOR-swizzled by the row (the 8-byte row stores
- *                     of sixteen rows 264 words apart hit each bank pair twice instead of four times; fragment reads stay conflict
- *                     free); same numbers to the bit.  Default 1 (27.15 -> 26.75 ms per 2 048-motion call, profiles/r03c_loop_swz_ab.json)
- *   "final_strip"     F16X3 / FP8 modes, MldVae.decode: 1 = decoder.norm + final_layer + the zeroing of padded frames (mld_vae.py:240-245)
- *                     as ONE row-strip launch (kernels/final_strip.hpp: the decoder output is read once and the features leave as
- *                     contiguous 48-row blocks) instead of a LayerNorm launch + the staged GEMM, whose three 128-column tiles each
- *                     re-read the normalised rows.  Default 0: built and checked on the simulator after round 3's GPU budget was
- *                     spent, not yet measured
- *   "ffn_swz"         F16X3 / FP8 modes, one-launch decoder tail ("dec_tail"): 1 = its LDS images row-swizzled like the loop's ("fused_swz");
- *                     same numbers to the bit.  Default 0: built and checked on the simulator after round 3's GPU budget was spent,
- *                     not yet measured (the tail's SQ counters show the same 4-way store conflicts: profiles/r03c_pmc_sq_ab.json)
+ *   "fused_x3"        F16X3 mode: 1 (default) = the persistent loop multiplies on split-f16 MFMAs (row-swizzled operand images, 4 weight
+ *                     items in flight per lane: the settled forms of round 3's "fused_swz" / "fused_ring" knobs), 0 = on exact-fp32 MFMAs
+ *   "fused_dbg"       5 = the F16X3 persistent loop with per-phase cycle counters of the first 64 workgroups (same arithmetic, same
+ *                     results), read back with mldhip_profile_trace("den_loop_phases") (tools/trace_loop.py); 0 (default) = off.  The
+ *                     measurement builds that compute WRONG results (no weight stream, no MFMAs, ...) are not in the library any
+ *                     more: tools/loopbench builds them stand-alone
+ *   "range_probe"     F16X3 mode: 1 (default) = mldhip_finalize_weights runs the range probe of the "Range contract" below, 0 = skips it
+ *                     (the split kernels are used unconditionally).  Setting it un-finalizes the handle
+ *   "final_strip"     F16X3 / FP8 modes, MldVae.decode: 1 (default) = decoder.norm + final_layer + the zeroing of padded frames
+ *                     (mld_vae.py:240-245) as ONE row-strip launch (kernels/final_strip.hpp: the decoder output is read once and the
+ *                     features leave as contiguous 48-row blocks; 397 us at 2 048 motions) instead of a LayerNorm launch + the staged
+ *                     GEMM, whose three 128-column tiles each re-read the normalised rows (131 + 480 us; profiles/r04a_kernel_stats_ab.csv)
+ *   "ffn_swz"         F16X3 / FP8 modes, one-launch decoder tail ("dec_tail"): 1 (default) = its LDS images row-swizzled like the
+ *                     persistent loop's (8-byte row stores 2-way instead of 4-way bank conflicted); same numbers to the bit; 1 476 ->
+ *                     1 457 us per launch at 2 048 motions (profiles/r04a_kernel_stats_ab.csv)
  *   "ffn_strip"       F16X3 / FP8 modes, decoder / encoder layers: strip height of the register-direct kernels (kernels/ffn_strip.hpp,
  *                     kernels/gemm_strip_x3.hpp): 1 (default) = by launch size -- more than 512 strips of 64 rows: 96-row strips for the
  *                     GEMMs, 48-row strips at two workgroups per CU for the feed-forward block; else 64 rows (one bs-64 request: 196
@@ -200,6 +201,42 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "gemm_small_m"    row count up to which one-off GEMMs use the register-direct 16x64 shape (default 256; tests set 0
  *                     to drive the LDS-staged kernels at simulator-sized shapes) */
 int mldhip_set_option(mldhip_handle* h, const char* name, int64_t value);
+
+/* Range contract of MLDHIP_PREC_F16X3 (ABI 4).  A split operand x = hi + lo keeps 22 mantissa bits only while x sits inside the
+ * half format's comfortable range: |x| > 65 504 has no high half (operands produced inside a kernel -- LayerNorm / GELU /
+ * attention outputs -- are not clamped: they become inf, then NaN; weights and caller inputs saturate), and the low half of
+ * |x| < 2^-3 is a half subnormal (absolute error <= 3e-8 -- harmless for an O(1) tensor, NOT for one that lives at 1e-4: a
+ * LayerNorm further down rescales the relative error).  Released checkpoints are unreachable offline, so instead of evidence
+ * there is a guard, in three parts:
+ *  1. PROBE (mldhip_finalize_weights, option "range_probe"): the handle runs its own split-f16 kernels and its exact-fp32
+ *     kernels on one probe batch built from the loaded weights (8 motions, seeded unit-normal latents / condition rows: two
+ *     reverse steps of the persistent loop and one denoiser call of the latency kernels at the first and last timestep; one
+ *     decode of 4 x 64 frames) and compares: err = max|split - fp32| / max|fp32|.
+ *  2. FALLBACK: a stage whose err exceeds MLDHIP_PROBE_TOL (or is not finite) runs on the exact-fp32 kernels from then on --
+ *     loop_split_ok = 0: reverse loop (persistent loop and latency kernels on v_mfma_f32_16x16x4_f32, ~3x slower);
+ *     decode_split_ok = 0: decoder / encoder / diffusion-only GEMMs and attention.  Results then equal MLDHIP_PREC_F32's.
+ *  3. RUN TIME: every sample call counts the non-finite values of the latents and joints it produced into a sticky device
+ *     counter (two small launches); mldhip_numeric_status reads it.  A prompt that drives an activation out of range although
+ *     the probe passed is therefore reported, not hidden.
+ * MLDHIP_PROBE_TOL: on the seeded synthetic weights the probe reads 1.4e-6 .. 1.7e-6 (loop) and 5e-7 (decoder) and the joints of a
+ * full-length call end 1.9e-4 from the reference, i.e. ~100x the probe; 6e-6 keeps a 5x margin under the 1e-3 joint contract.  Measured
+ * on MI355X (tests/test_gpu_parity.py::test_split_f16_range_contract_out_of_comfort_zone, profiles/r04_range_contract_test.log):
+ * LayerNorm gains x 2^+-10 read 1.4e-6 and stay split; weight matrices x 2^-12 read 1.2e-5 and fall back (joints 9e-5 off if forced to
+ * stay split); a feed-forward layer whose hidden activation passes 65 504 reads 2.2e-3 / 5e-5 and falls back in both stages (joints 1e-2
+ * off without the guard, finite: the conversions saturate before the matrix instructions see an inf).
+ * The other modes: F32 has no such limits; BF16 / FP8 are reported-only modes whose errors bench.py prints. */
+#define MLDHIP_PROBE_TOL 6e-6f
+typedef struct mldhip_numeric_info {
+  int32_t struct_size;        /* sizeof(mldhip_numeric_info), set by the caller */
+  int32_t probed;             /* 1: finalize ran the probe (F16X3 mode, "range_probe" 1) */
+  int32_t loop_split_ok;      /* 1: the reverse loop multiplies on split-f16 MFMAs; 0: fell back to exact fp32 */
+  int32_t decode_split_ok;    /* the same for decoder / encoder / diffusion-only GEMMs and attention */
+  float probe_err_loop;       /* err of part 1 (-1: not probed) */
+  float probe_err_decode;
+  int64_t nonfinite_values;   /* non-finite latents / joints elements counted since the previous mldhip_numeric_status call */
+} mldhip_numeric_info;
+/* Synchronises the device (it reads the counter), fills *out and resets nonfinite_values.  No reference counterpart. */
+int mldhip_numeric_status(mldhip_handle* h, mldhip_numeric_info* out);
 
 /* Number of tensors the engine requires / names of those still missing (NUL-separated list
  * written to buf, returns the count missing). */

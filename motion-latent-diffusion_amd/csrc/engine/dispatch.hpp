@@ -56,7 +56,7 @@ void launch_staged(Ctx& c, const GemmArgs& a, dim3 grid) {
 int staged_prec(const E* e) {
   const bool big = e->phase == 1 || e->cfg.vae_arch == MLDHIP_VAE_NONE;
   switch (e->cfg.precision) {
-    case MLDHIP_PREC_BF16X3_DECODE: return big ? PREC_BF16X3 : PREC_F32;
+    case MLDHIP_PREC_BF16X3_DECODE: return (big && e->split_decode_ok) ? PREC_BF16X3 : PREC_F32;   // split_decode_ok: finalize's range probe
     case MLDHIP_PREC_BF16: return PREC_BF16;
     case MLDHIP_PREC_FP8_DENOISER: return big ? PREC_BF16X3 : PREC_F32;
     default: return PREC_F32;
@@ -71,8 +71,10 @@ int loop_prec(const E* e) {
 // (option "tile_x3", on by default) -- 24 matrix instructions of 16 cycles per wave instead of 64 of 32, same 22-bit products as the
 // persistent loop of that mode
 int latency_prec(const E* e) {
-  return (e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE && e->tile_x3) ? PREC_BF16X3 : loop_prec(e);
+  return (e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE && e->tile_x3 && e->split_loop_ok) ? PREC_BF16X3 : loop_prec(e);
 }
+// ... and the persistent loop (loop_fused.hpp) streams the split-f16 image of its weights
+bool fused_split(const E* e) { return e->loop_stream_x3 && e->fused_x3 && e->split_loop_ok; }
 
 // split-bf16 mode: read W from the pre-split image of the weight arena when it lives there (derived tables in a workspace do not)
 void use_split_weights(const E* e, GemmArgs& a, int prec) {

@@ -239,7 +239,7 @@ bool fused_built(const E* e) {
 bool use_fused(const E* e, int B) {
   // auto: the persistent loop takes the same time for any batch up to 8 x #CUs motions -- 29 ms on split-f16 MFMAs, 77 ms on exact-fp32
   // ones (r03) -- the column-split throughput kernels 30 ms at 320 motions, 65 ms at 1 024, 120 ms at 2 048: cross-over by operand format
-  const int auto_min = e->fused_min_batch > 0 ? e->fused_min_batch : ((e->loop_stream_x3 && e->fused_x3) ? 320 : 1280);
+  const int auto_min = e->fused_min_batch > 0 ? e->fused_min_batch : (fused_split(e) ? 320 : 1280);
   return e->loop_ips > 0 && (e->loop_kernel == 3 || (e->loop_kernel == 0 && B >= auto_min));
 }
 
@@ -780,6 +780,31 @@ void action_rows(Ctx& c, int R, int nuncond, float* dst) {
   check_launch(c, "action_rows");
 }
 
+// run-time part of the F16X3 range contract (mldhip.h): non-finite results are counted, mldhip_numeric_status reports them
+void count_nonfinite(Ctx& c, const float* x, long long n) {
+  E* e = c.e;
+  if (e->cfg.precision != MLDHIP_PREC_BF16X3_DECODE || !e->nonfinite || n <= 0) return;
+  const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 2048);
+  MLD_LAUNCH(count_nonfinite_kernel, dim3(blocks), dim3(256), 0, c.stream, x, n, e->nonfinite);
+  check_launch(c, "count_nonfinite");
+}
+
+// the whole reverse loop (or its first `n` steps: finalize's range probe) as one persistent launch: a workgroup per 8 motions (kernels/loop_fused.hpp)
+void launch_fused_loop(Ctx& c, const float* init_lat, int B, int n, float guidance) {
+  E* e = c.e;
+  LoopArgs a;
+  const bool x3 = fused_split(e);
+  a.stream = x3 ? e->loop_stream_x3 : e->loop_stream; a.ips = e->loop_ips; a.small = e->loop_small; a.T1 = e->T1; a.TP = e->TP; a.init_lat = init_lat;
+  a.lat = e->lat; a.skip = e->FS; a.ddim = e->loop_ddim; a.B = B; a.L = e->cfg.num_layers; a.n = n;
+  a.guidance = guidance; a.init_sigma = 1.0f;
+  const dim3 grid((B + 7) / 8);
+  if (x3 && e->fused_dbg == 5) { a.trace = reinterpret_cast<unsigned long long*>(e->trace_buf); MLD_LAUNCH((den_loop_kernel<true, 5>), grid, dim3(512), kLoopLdsBytes, c.stream, a); }
+  else if (x3) MLD_LAUNCH((den_loop_kernel<true>), grid, dim3(512), kLoopLdsBytes, c.stream, a);
+  else MLD_LAUNCH((den_loop_kernel<false>), grid, dim3(512), kLoopLdsBytes, c.stream, a);
+  count(c);
+  check_launch(c, "den_loop");
+}
+
 // `text` == nullptr selects the action condition (labels_dev holds the 2B labels).
 int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* init_lat, int B, int T,
                    float* lat_out, float* feats_out, float* joints_out) {
@@ -792,25 +817,7 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
   if (text) text_projection(c, text, 2 * B, e->TP);
   else action_rows(c, 2 * B, B, e->TP);
   if (use_fused(e, B)) {
-    // the whole reverse loop as one persistent launch: a workgroup per 8 motions (kernels/loop_fused.hpp)
-    LoopArgs a;
-    const bool x3 = e->loop_stream_x3 && e->fused_x3;
-    a.stream = x3 ? e->loop_stream_x3 : e->loop_stream; a.ips = e->loop_ips; a.small = e->loop_small; a.T1 = e->T1; a.TP = e->TP; a.init_lat = init_lat;
-    a.lat = e->lat; a.skip = e->FS; a.ddim = e->loop_ddim; a.B = B; a.L = e->cfg.num_layers; a.n = n;
-    a.guidance = guidance; a.init_sigma = 1.0f;
-    const dim3 grid((B + 7) / 8);
-    if (x3 && e->fused_dbg == 1) MLD_LAUNCH((den_loop_kernel<true, 4, 1>), grid, dim3(512), kLoopLdsBytes, stream, a);
-    else if (x3 && e->fused_dbg == 2) MLD_LAUNCH((den_loop_kernel<true, 4, 2>), grid, dim3(512), kLoopLdsBytes, stream, a);
-    else if (x3 && e->fused_dbg == 3) MLD_LAUNCH((den_loop_kernel<true, 4, 3>), grid, dim3(512), kLoopLdsBytes, stream, a);
-    else if (x3 && e->fused_dbg == 4) MLD_LAUNCH((den_loop_kernel<true, 4, 4>), grid, dim3(512), kLoopLdsBytes, stream, a);
-    else if (x3 && e->fused_dbg == 5) { a.trace = reinterpret_cast<unsigned long long*>(e->trace_buf); MLD_LAUNCH((den_loop_kernel<true, 4, 5>), grid, dim3(512), kLoopLdsBytes, stream, a); }
-    else if (x3 && e->fused_ring == 8) MLD_LAUNCH((den_loop_kernel<true, 8>), grid, dim3(512), kLoopLdsBytes, stream, a);
-    else if (x3 && e->fused_swz) MLD_LAUNCH((den_loop_kernel<true, 4, 0, true>), grid, dim3(512), kLoopLdsBytes, stream, a);
-    else if (x3) MLD_LAUNCH((den_loop_kernel<true, 4>), grid, dim3(512), kLoopLdsBytes, stream, a);
-    else if (e->fused_ring == 8) MLD_LAUNCH((den_loop_kernel<false, 8>), grid, dim3(512), kLoopLdsBytes, stream, a);
-    else MLD_LAUNCH((den_loop_kernel<false, 4>), grid, dim3(512), kLoopLdsBytes, stream, a);
-    count(c);
-    check_launch(c, "den_loop");
+    launch_fused_loop(c, init_lat, B, n, guidance);
   } else {
     const DenView v = den_view(e, 2 * B);
     MLD_LAUNCH(init_chain_kernel, dim3(B), dim3(256), 0, stream, init_lat, v.lat, v.X0, P(e, "denoiser.query_pos.pe"),
@@ -827,6 +834,7 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
     }
   }
   if (c.rc) return c.rc;
+  count_nonfinite(c, e->lat, (long long)B * D);
   if (lat_out) {
     hipError_t s = hipMemcpyAsync(lat_out, e->lat, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream);
     if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "latents copy: %s", hipGetErrorString(s));
@@ -838,6 +846,7 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
     if (joints_out) {
       e->phase = 2;
       joints_body(c, f, B, T, joints_out);
+      count_nonfinite(c, joints_out, (long long)B * T * e->cfg.njoints * 3);
     }
   }
   return c.rc;

@@ -116,9 +116,7 @@ struct mldhip_engine {
   int small_m = 256;         // "gemm_small_m": row count up to which the register-direct tiny-GEMM shape is used
   int loop_kernel = 0;       // "loop_kernel": 0 auto (by rows / motions), 1 latency kernels (tile32.hpp), 2 throughput kernels (strip.hpp), 3 sample-major persistent loop (loop_fused.hpp)
   int fused_x3 = 1;          // "fused_x3": in the split precision mode the sample-major loop multiplies on split-f16 MFMAs (0: exact fp32 MFMAs)
-  int fused_ring = 4;        // "fused_ring": weight items in flight per lane in the sample-major loop (4 or 8; 8 spills a few ring slots around the epilogues)
-  int fused_swz = 1;         // "fused_swz": split-mode loop with row-swizzled operand images (loop_fused.hpp SWZ: 4-way -> 2-way bank conflicts of the 8-byte image stores; 27.15 -> 26.75 ms per 2 048-motion call, latents identical to the bit)
-  int fused_dbg = 0;         // "fused_dbg": measurement builds of the split-mode loop (results are wrong): 1 no weight stream, 2 no MFMAs
+  int fused_dbg = 0;         // "fused_dbg": 5 = the split-mode loop with its phase counters (same arithmetic, mldhip_profile_trace "den_loop_phases"); 0 = off
   int fused_min_batch = 0;   // "fused_min_batch": auto picks the sample-major loop from this many motions per call up; 0 = by operand format (320 split-f16, 1 280 fp32)
   int strip_min_rows = 768;  // "strip_min_rows": auto switches to the throughput kernels at 6B >= this many token rows
   int strip_wide = 0;        // "strip_wide": 32 x 128 strip tiles for the wide GEMMs: 0 auto (N >= 512), 1 never, 2 whenever N % 128 == 0
@@ -127,8 +125,8 @@ struct mldhip_engine {
   int ffn_strip = 1;         // "ffn_strip": register-direct decoder kernels (ffn_strip.hpp, gemm_strip_x3.hpp): 0 off, 1 auto strip height, 4 / 6 = 64 / 96 rows always
   int attn_tr = 1;           // "attn_tr": key-blocked attention, bit 0: V staged row-major and read with ds_read_b64_tr_b16 (attention.hpp TRV: 454 -> 417 us per launch at 2 048 motions); bit 1: streaming hints on its loads / stores (level: off)
   int dec_tail = 1;          // "dec_tail": out-projection + norms + feed-forward block of a decoder layer as one launch (chip-filling launches, split modes)
-  int final_strip = 0;       // "final_strip": decoder.norm + final_layer + padded-frame zeroing of MldVae.decode as one row-strip launch (final_strip.hpp; built after the round-3 GPU budget ran out: NOT yet measured, off)
-  int ffn_swz = 0;           // "ffn_swz": the one-launch decoder tail with row-swizzled LDS images (ffn_strip.hpp SWZ; built and simulator-checked after the round-3 GPU budget ran out: NOT yet measured, off)
+  int final_strip = 1;       // "final_strip": decoder.norm + final_layer + padded-frame zeroing of MldVae.decode as one row-strip launch (final_strip.hpp; r04: 397 us against 131 + 480 us for the LayerNorm pass + the N = 263 GEMM at 2 048 motions, profiles/r04a_kernel_stats_ab.csv)
+  int ffn_swz = 1;           // "ffn_swz": the one-launch decoder tail with row-swizzled LDS images (ffn_strip.hpp SWZ; r04: 1 476 -> 1 457 us per launch at 2 048 motions, same rocprofv3 run)
   int dec_l0_once = 1;       // "dec_l0_once": decoder layer 0 projects its input -- the positional rows, the same for every sample -- once per call ([T] rows instead of [B T])
   int nt_hints = 1;          // "nt_hints": the decoder's in-projection (gemm_strip_x3.hpp, N = 768) loads its row strips and stores its output with the streaming hint (527 -> 504 us per launch at 2 048 motions; level on the skip linears, which do not take it)
   int tile_x3 = 1;           // "tile_x3": split-f16 mode runs the latency kernels (tile32.hpp) on split-f16 MFMAs too (0: exact fp32)
@@ -137,6 +135,17 @@ struct mldhip_engine {
   int fused_ffn = 1;         // "fused_ffn": split-bf16 decoder / encoder layers run linear1 + GELU + linear2 + residual + LayerNorm as one launch (kernels/ffn_fused.hpp)
   int split_weights = 1;     // "split_weights": split-bf16 staged GEMMs read the weights pre-split at finalize (0: split them in every workgroup)
   int strip_ffn2_split = 2;  // "strip_ffn2_split": K slices (= raw slabs) of FFN2 on the throughput kernels: 1 or 2
+
+  // ---- numeric contract of the split-f16 mode (mldhip_numeric_status; include/mldhip.h "Range contract")
+#if defined(MLDHIP_SIM)
+  int range_probe = 0;       // "range_probe": the functional simulator pays minutes per probe; its tests switch it on where they test it
+#else
+  int range_probe = 1;       // "range_probe": finalize compares the split-f16 kernels with the exact-fp32 ones on a probe batch and falls back per stage
+#endif
+  bool split_loop_ok = true;     // false: the reverse loop runs on exact-fp32 MFMAs although the handle was created in the split mode
+  bool split_decode_ok = true;   // false: decoder / encoder / diffusion-only GEMMs and attention run on exact-fp32 MFMAs
+  float probe_err_loop = -1.f, probe_err_decode = -1.f;   // probe results (max-abs difference / max-abs reference); -1: not probed
+  unsigned* nonfinite = nullptr; // device counter: non-finite values seen in the latents / joints a sample call produced (sticky until read)
 
   int launches[3] = {0, 0, 0};
   int phase = 0;

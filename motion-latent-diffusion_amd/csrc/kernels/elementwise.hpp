@@ -243,6 +243,25 @@ __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
   return v;
 }
 
+// Run-time part of the F16X3 range contract (include/mldhip.h): counts the non-finite elements of a result buffer into a sticky
+// device counter.  An operand that left the half range inside a split-f16 kernel became inf, then NaN, and reached every later
+// value of its motion: the latents after the loop and the joints after the decode are the two places worth looking at.
+__global__ __launch_bounds__(256) void count_nonfinite_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ counter) {
+  float bad = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const unsigned u = __builtin_bit_cast(unsigned, x[i]);
+    bad += ((u & 0x7F800000u) == 0x7F800000u) ? 1.f : 0.f;        // exponent all ones: inf or NaN
+  }
+  bad = sum64(bad);
+  if ((threadIdx.x & 63) == 0 && bad > 0.f) {
+#if defined(MLDHIP_SIM)
+    *counter += (unsigned)bad;
+#else
+    atomicAdd(counter, (unsigned)bad);
+#endif
+  }
+}
+
 template <int MAXT>
 __global__ __launch_bounds__(256) void feats2joints_kernel(const float* __restrict__ feats, float* __restrict__ joints,
                                                            const float* __restrict__ mean, const float* __restrict__ stdv,

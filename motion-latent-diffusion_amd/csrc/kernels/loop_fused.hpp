@@ -74,10 +74,13 @@ struct LoopArgs {
   unsigned long long* trace = nullptr;   // DBG 5 (measurement build): [workgroup < 64][wave][8] shader cycles per phase, summed over steps and layers
 };
 
+#ifndef LF_EXP
+#define LF_EXP 0          // tools/loopbench experiments (measurement only, 0 in the library)
+#endif
 constexpr int kLfXs = 264;                                // LDS row stride (words), = 8 mod 16: conflict-free fragment reads (strip.hpp)
 constexpr int kLfHs = 136;                                // ... of a 128-wide block of the hidden activation
 constexpr int kLfXFloats = 48 * kLfXs, kLfHFloats = 48 * kLfHs, kLfAFloats = 2 * kLfHFloats;     // As: the attention output [48][264], or two hidden blocks
-constexpr int kLfScFloats = 8 * 144, kLfRedFloats = 2 * 8 * 48, kLfLatFloats = 8 * 256;
+constexpr int kLfScFloats = 8 * 144, kLfRedFloats = 2 * 8 * 48, kLfLatFloats = 8 * 256 + ((LF_EXP & 16) ? 4096 : 0);
 static_assert(kLfAFloats >= kLfXFloats, "the attention output and the two hidden-block buffers share one region");
 constexpr int kLoopLdsBytes = (kLfXFloats + kLfAFloats + kLfScFloats + kLfRedFloats + kLfLatFloats) * 4;   // 118 784 B: one workgroup per CU
 
@@ -108,17 +111,19 @@ __global__ __launch_bounds__(512) void pack_loop_stream_kernel(const float* __re
 }
 
 // grid = ceil(B / 8), block = 512 (8 waves, two per SIMD).  X3 = false: exact-fp32 MFMAs; true: split-f16 MFMAs.
-// kLoopRing = items in flight per lane (8 VGPRs each; 4 or 8: every group of items is a multiple of 8 long).
-// DBG (measurement builds, mldhip_set_option "fused_dbg"; 3 = identity instead of GELU, 4 = no feed-forward epilogue): 1 = the weight ring is loaded once and never refreshed (matrix +
-// LDS + epilogue time without the stream), 2 = the stream is loaded but not multiplied (one VALU add per item keeps the loads live).
-// SWZ (split mode): the 16-byte groups of an operand row are stored XOR-swizzled by the row -- physical word = logical word ^ 4 ((row >> 2) & 3),
+// kLoopRing = items in flight per lane (8 VGPRs each; every group of items is a multiple of 8 long).
+// DBG: 0 = the product build; 5 = the same arithmetic with phase counters (mldhip_set_option "fused_dbg" 5, tools/trace_loop.py).  1-4 are
+// measurement builds with WRONG results that only tools/loopbench instantiates -- they are not in libmldhip.so: 1 = the weight ring is
+// loaded once and never refreshed, 2 = the stream is loaded but not multiplied, 3 = identity instead of GELU, 4 = no feed-forward epilogue.
+// SWZ (split mode, always on): the 16-byte groups of an operand row are stored XOR-swizzled by the row -- physical word = logical word ^ 4 ((row >> 2) & 3),
 // i.e. group (g ^ (r >> 2)) of each 16-word half chunk.  The image's 8-byte row stores (put_row: sixteen rows 264 = 8 mod 32 words
 // apart per 16-lane group) hit each bank pair four times (ds_write_b64 is served per 16 contiguous lanes over 32 banks); swizzled,
 // twice -- the best an 8-byte store at this stride can do -- while the fragments' ds_read_b128 stay conflict free (slot
 // 2 r + (g ^ (r >> 2)) mod 16 is still a permutation inside each of the instruction's four lane groups; tests/test_lds_layout.py).
-template <bool X3, int kLoopRing, int DBG = 0, bool SWZ = false>
+template <bool X3, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
-  static_assert(kLoopRing == 4 || kLoopRing == 8, "ring depth");
+  constexpr int kLoopRing = 4;      // items in flight per lane (r03: 8 spills ring slots around the epilogues and loses, 33.1 vs 29.3 ms)
+  constexpr bool SWZ = X3;          // split images are always row-swizzled (r03c: 27.15 -> 26.75 ms; r04a: LDS bank-conflict cycles 1.43e9 -> 0.59e9 per launch)
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
 #else
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(y1.w, x[t][1].w, acc[t]);
     }
-    if constexpr (DBG != 1) gload(slot);
+    if constexpr (DBG != 1 && !(LF_EXP & 8)) gload(slot);
     sched_fence();
   };
   // An item with an epilogue threaded through it: `epi(k)`, k = 0 .. 8, is a few VALU / LDS instructions of work that does
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
       }
       epi(8);
     }
-    if constexpr (DBG != 1) gload(slot);
+    if constexpr (DBG != 1 && !(LF_EXP & 8)) gload(slot);
     sched_fence();
   };
   // A group: 8 chunks of A (row r of tile 0 at a0 + 4g, next tile 16 * kLfXs words on, chunk c at + 32 c) against NP column
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     afrag(a0, 16 * kLfHs, 0, x[0]);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      if (c + 1 < 4) afrag(a0, 16 * kLfHs, c + 1, x[(c + 1) & 1]);
+      if (c + 1 < 4 && (!(LF_EXP & 4) || c == 0)) afrag(a0, 16 * kLfHs, c + 1, x[(c + 1) & 1]);
       mma_item(2 * c, x[c & 1], acc0);
       mma_item(2 * c + 1, x[c & 1], acc1);
     }
@@ -419,6 +424,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     const F4 v = ld4(p.init_lat + (long long)s * 256 + c4 * 4);
     st4(lats + c * 256 + c4 * 4, F4{v.x * p.init_sigma, v.y * p.init_sigma, v.z * p.init_sigma, v.w * p.init_sigma});
   }
+  if (LF_EXP & 16) for (int i = tid; i < 4096; i += 512) lats[2048 + i] = p.small[i];
   __syncthreads();
   assemble(0);
   __syncthreads();
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     goff = (unsigned)tid * 8u + (unsigned)(kLoopRing * kLoopItemFloats);
     float x[2][3][4];                              // norm2 output of the current layer at this lane's positions
     for (int l = 0; l < p.L; ++l) {
-      const float* sm = p.small + (unsigned)l * (unsigned)kLsLayer;
+      const float* sm = (LF_EXP & 16) ? lats + 2048 : p.small + (unsigned)l * (unsigned)kLsLayer;
       // ================= self-attention: two heads at a time (cross_attention.py:265-266; nn.MultiheadAttention, 4 heads of 64)
       for (int hp = 0; hp < 2; ++hp) {
         const F4 bq = ld4(sm + kLsInB + hp * 128 + cq0), bk = ld4(sm + kLsInB + 256 + hp * 128 + cq0), bv = ld4(sm + kLsInB + 512 + hp * 128 + cq0);
@@ -585,14 +591,14 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
               }
             };
             if (more) {
-              if (c + 1 < 8) afrag(xa, 16 * kLfXs, c + 1, x[(c + 1) & 1]);
+              if (c + 1 < 8 && (!(LF_EXP & 1) || c == 0)) afrag(xa, 16 * kLfXs, c + 1, x[(c + 1) & 1]);
               mma_item_sliced(c, x[c & 1], nxt, epi);
             } else {
 #pragma unroll
               for (int k = 0; k < 9; ++k) epi(k);
             }
           }
-          __syncthreads();
+          if (!(LF_EXP & 2)) __syncthreads();
           run2h(ha + (hb & 1) * kLfHFloats, y0, y1);
         };
         run1(xa, hA);

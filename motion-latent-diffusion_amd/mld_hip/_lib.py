@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libmldhip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MldHipError(RuntimeError):
@@ -44,6 +44,13 @@ class Request(C.Structure):
                 ("feats_out_dev", C.c_void_p), ("joints_out_dev", C.c_void_p)]
 
 
+class NumericInfo(C.Structure):
+    """Mirror of ``mldhip_numeric_info`` (include/mldhip.h, "Range contract" of the split-f16 mode)."""
+    _fields_ = [("struct_size", C.c_int32), ("probed", C.c_int32), ("loop_split_ok", C.c_int32), ("decode_split_ok", C.c_int32),
+                ("probe_err_loop", C.c_float), ("probe_err_decode", C.c_float), ("nonfinite_values", C.c_int64)]
+
+
+PROBE_TOL = 6e-6                         # MLDHIP_PROBE_TOL
 COND_TEXT, COND_ACTION = 0, 1            # MLDHIP_COND_*
 VAE_MLD, VAE_ACTOR, VAE_NONE = 0, 1, 2   # MLDHIP_VAE_*
 ARCH_TRANS_ENC, ARCH_TRANS_DEC = 0, 1    # MLDHIP_ARCH_*
@@ -60,6 +67,7 @@ _SYMBOLS = {
     "mldhip_finalize_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mldhip_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "mldhip_missing_keys": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "mldhip_numeric_status": (C.c_int, [C.c_void_p, C.POINTER(NumericInfo)]),
     "mldhip_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "mldhip_sample_many": (C.c_int, [C.c_void_p, C.POINTER(Request), C.c_int32, C.c_void_p]),
@@ -299,6 +307,14 @@ class Engine:
         buf = (C.c_float * n)()
         self._check(self.lib.mldhip_get_alphas_cumprod(self._h, buf, n))
         return np.array(buf[:], dtype=np.float32)
+
+    def numeric_status(self) -> dict:
+        """Range contract of the split-f16 mode (mldhip_numeric_status): what finalize's probe decided and how many non-finite
+        latents / joints values the sample calls since the previous query produced.  Synchronises the device."""
+        info = NumericInfo()
+        info.struct_size = C.sizeof(NumericInfo)
+        self._check(self.lib.mldhip_numeric_status(self._h, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in NumericInfo._fields_ if k != "struct_size"}
 
     def launch_counts(self) -> List[int]:
         buf = (C.c_int32 * 3)()

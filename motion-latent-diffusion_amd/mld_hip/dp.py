@@ -70,15 +70,29 @@ class DataParallelSampler:
     its first use; with fewer workspaces the engine orders the calls behind each other on the device -- a workspace is
     never shared by two calls at once).  Results are identical either way.
 
-    coalesce > 1: `coalesce` consecutive chunks go into ONE engine call (``MLD.sample_many`` -> ``mldhip_sample_many``: one chain over
-    coalesce x batch_size motions; from ~1 000 motions per call the engine runs the reverse loop as one persistent launch, a
-    workgroup per 8 motions -- configure ``max_batch >= coalesce * batch_size``)."""
+    coalesce: how many consecutive chunks go into ONE engine call (``MLD.sample_many`` -> ``mldhip_sample_many``: one chain over
+    coalesce x batch_size motions; from 320 motions per call the split-f16 engine runs the reverse loop as one persistent launch, a
+    workgroup per 8 motions, whose run time does not depend on the batch up to 2 048 motions).  ``None`` (default) = automatic:
+    as many chunks of this rank's shard as the engine's capacity holds, ``min(chunks, engine.max_batch // batch_size)`` -- BASELINE
+    config 3 (512 prompts) on ONE rank is one 512-motion call instead of eight latency-kernel calls when the engine was configured
+    with ``max_batch >= 512``; on eight ranks every rank holds one bs-64 batch and there is nothing to coalesce (the literal
+    ``MLD.forward`` shape).  An int forces that many (the engine refuses more motions than its ``max_batch``)."""
 
-    def __init__(self, model, batch_size: int = 64, in_flight: int = 1, coalesce: int = 1):
+    def __init__(self, model, batch_size: int = 64, in_flight: int = 1, coalesce=None):
         self.model = model
         self.batch_size = batch_size
         self.in_flight = max(1, int(in_flight))
-        self.coalesce = max(1, int(coalesce))
+        self.coalesce = None if coalesce is None else max(1, int(coalesce))
+
+    def pick_coalesce(self, nchunks: int) -> int:
+        """The automatic rule: chunks per engine call from the shard size and the engine's capacity."""
+        if self.coalesce is not None:
+            return self.coalesce
+        try:
+            cap = int(self.model._engine().cfg.max_batch) // self.batch_size
+        except Exception:          # not a fused Hip* model (no engine behind it): one chunk per call, like the reference
+            return 1
+        return max(1, min(nchunks, cap))
 
     def __call__(self, texts: Sequence[str] = None, lengths: Sequence[int] = None, actions: Sequence[int] = None, init_latents=None,
                  step_noise=None):
@@ -105,8 +119,11 @@ class DataParallelSampler:
                 z = z[:, :max(ln)]                   # the chunk's own Tmax (mld.py:296-301)
             return z.to(dev).float().contiguous()
 
-        overlap = ((self.in_flight > 1 or self.coalesce > 1) and torch.cuda.is_available() and getattr(m, "fused", False)
-                   and getattr(m, "condition", None) == "text" and not novae)              # latent text-to-motion only
+        can_overlap = (torch.cuda.is_available() and getattr(m, "fused", False)
+                       and getattr(m, "condition", None) == "text" and not novae)         # latent text-to-motion only
+        coalesce = self.pick_coalesce(len(chunks)) if can_overlap else 1
+        self.last_coalesce = coalesce
+        overlap = can_overlap and (self.in_flight > 1 or coalesce > 1)
         out = []
         if not overlap:
             for s, e in chunks:
@@ -126,7 +143,7 @@ class DataParallelSampler:
         for st in streams:
             st.wait_stream(torch.cuda.current_stream())
         pending = []
-        groups = [chunks[g:g + self.coalesce] for g in range(0, len(chunks), self.coalesce)]
+        groups = [chunks[g:g + coalesce] for g in range(0, len(chunks), coalesce)]
         for i, grp in enumerate(groups):
             with torch.cuda.stream(streams[i % self.in_flight]):
                 reqs, lats = [], []

@@ -24,6 +24,9 @@ def pytest_collection_modifyitems(config, items):
     except Exception:  # pragma: no cover
         has_gpu = False
     if has_gpu:
+        # the GPU box has 256 host threads: MKL / OpenMP oversubscribe badly on the oracle's small GEMMs (bench.py caps its
+        # cpu_baseline leg the same way); the oracle is only the checker here
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
         return
     skip = pytest.mark.skip(reason="no GPU in this environment")
     for it in items:

@@ -71,3 +71,26 @@ def test_every_option_of_set_option_is_documented_in_the_header_and_vice_versa()
     state = open(os.path.join(REPO, "motion-latent-diffusion_amd", "csrc", "engine", "state.hpp")).read()
     named = set(re.findall(r'//\s*"([a-z0-9_]+)"', state))
     assert code <= named, sorted(code - named)
+
+
+def test_every_launch_with_dynamic_lds_has_its_attribute_registered():
+    """Every kernel instantiation the engine launches with a dynamic LDS size (an expression, i.e. possibly > 64 KB) is registered
+    with hipFuncSetAttribute(MaxDynamicSharedMemorySize) at mldhip_create (round-3 advisor finding: four launched
+    instantiations were missing and only ran because the tested runtime does not enforce the default).  Source-level: the
+    MLD_LAUNCH sites of engine/*.hpp against the registration list of mldhip.hip, macros expanded by hand below."""
+    csrc = os.path.join(REPO, "motion-latent-diffusion_amd", "csrc")
+    hip = open(os.path.join(csrc, "mldhip.hip")).read()
+    norm = lambda s: re.sub(r"\s+", "", s)
+    registered = {norm(m) for m in re.findall(r"hipFuncSetAttribute\(\(const void\*\)\(?([A-Za-z0-9_]+(?:<[^;]*?>)?)\)?, hipFuncAttributeMaxDynamicSharedMemorySize", hip)}
+    launched = set()
+    for f in ("path_latent.hpp", "path_novae.hpp", "dispatch.hpp"):
+        src = open(os.path.join(csrc, "engine", f)).read()
+        for m in re.finditer(r"MLD_LAUNCH\(\(?([A-Za-z0-9_]+(?:<[^()]*?>)?)\)?, (?:dim3\([^;]*?\)|grid), (?:dim3\([^;]*?\)|block), ([^;]*?), (?:c\.)?stream", src):
+            kernel, shmem = m.group(1), m.group(2).strip()
+            if shmem == "0" or "<" in kernel and re.search(r"\b(WM|WN|MREP|NREP|LN|PREC|NS|NSRC|ACT|CT|MT|TR|PR)\b", kernel):
+                continue                    # no dynamic LDS / a templated launch helper whose instantiations are registered by macro lists
+            launched.add(norm(kernel))
+    for k in ("den_loop_kernel<true>", "ffn_strip_x3_kernel<3,true,true>", "strip_gemm_x3_kernel<6,1,false,true,8,3>", "final_strip_x3_kernel", "attn_flash_x3_kernel<true,false>"):
+        assert k in launched, (k, sorted(launched))       # the regex really sees the default launches
+    missing = sorted(k for k in launched if k not in registered)
+    assert not missing, missing

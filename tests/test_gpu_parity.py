@@ -1024,22 +1024,27 @@ def test_config3_shape_512_prompts_through_the_dp_sampler(dev):
     orig_sample, orig_many = model.sample, model.sample_many
     model.sample = lambda emb, lens, init_latents=None: orig_sample(emb, lens, noise(lens))
     model.sample_many = lambda reqs, init_latents=None: orig_many(reqs, [noise(l) for _, l in reqs])
-    idx1, one = DataParallelSampler(model, batch_size=64, in_flight=1)(texts, lengths)
+    idx1, one = DataParallelSampler(model, batch_size=64, in_flight=1, coalesce=1)(texts, lengths)
     idx4, many = DataParallelSampler(model, batch_size=64, in_flight=2, coalesce=4)(texts, lengths)
-    assert idx1 == idx4 == list(range(n)) and len(one) == len(many) == n
+    auto = DataParallelSampler(model, batch_size=64)             # coalesce=None: picked from the shard (8 chunks) and the engine (max_batch 256)
+    idxa, manya = auto(texts, lengths)
+    assert auto.last_coalesce == 4
+    assert idx1 == idx4 == idxa == list(range(n)) and len(one) == len(many) == len(manya) == n
     worst = 0.0
-    for a, b, ln in zip(one, many, lengths):
-        assert a.shape == b.shape == (ln, 22, 3) and bool(torch.isfinite(b).all())
-        worst = max(worst, float((a - b).abs().max()))
+    for a, b, c_, ln in zip(one, many, manya, lengths):
+        assert a.shape == b.shape == c_.shape == (ln, 22, 3) and bool(torch.isfinite(b).all())
+        worst = max(worst, float((a - b).abs().max()), float((a - c_).abs().max()))
     print("512 prompts: coalesced x in-flight vs one chunk per call, max-abs joints difference %.3e" % worst)
     assert worst < 1e-3                    # latency vs throughput kernel family: summation order only
     E.configure("text", max_batch=64, max_in_flight=1)
     E.drop_engines()
 
 
-def test_headline_serving_shape_every_motion_within_tolerance(dev, golden_dir):
+@pytest.mark.parametrize("NREQ", [20, 32])
+def test_headline_serving_shape_every_motion_within_tolerance(dev, golden_dir, NREQ):
     """The shape bench.py's headline measures, all of it: split precision mode (precision = 1: split-f16 MFMAs in the reverse loop and
-    the decoder), ONE mldhip_sample_many call of 32 bs-64 requests = 2 048 motions, T = 196 -- the reverse loop runs as the
+    the decoder), ONE mldhip_sample_many call of NREQ bs-64 requests -- 20 = 1 280 motions is what the driver's `bench.py --steps 20`
+    issues (160 workgroups of the persistent loop on 256 CUs), 32 = 2 048 motions fills the chip -- T = 196: the reverse loop runs as the
     sample-major persistent launch (kernels/loop_fused.hpp), the decoder on the throughput shapes (key-blocked attention, fused FFN).
     Checked against (a) the reference's own output for request 0 (the pipeline_b64 fixture: reference MldDenoiser / MldVae /
     recover_from_ric, mld.py:290-360, mld_vae.py:186-248), (b) the CPU oracle for two more requests, (c) for EVERY one of the 2 048
@@ -1051,9 +1056,11 @@ def test_headline_serving_shape_every_motion_within_tolerance(dev, golden_dir):
     bd, bv = O.to_backend(ops, sdd), O.to_backend(ops, sdv)
     mean, std = syn.make_mean_std()
     g = _gold(golden_dir, "pipeline_b64.npz")
-    NREQ = 32
     big = _lib.Engine(device=0, max_batch=64 * NREQ, max_frames=196, precision=1)   # MLDHIP_PREC_F16X3 (split 16-bit arithmetic)
     _load(big)
+    ns = big.numeric_status()              # the range probe of finalize kept both stages on the split kernels (mldhip.h "Range contract")
+    assert ns["probed"] == 1 and ns["loop_split_ok"] == 1 and ns["decode_split_ok"] == 1, ns
+    assert 0 <= ns["probe_err_loop"] <= _lib.PROBE_TOL and 0 <= ns["probe_err_decode"] <= _lib.PROBE_TOL, ns
     exact = _lib.Engine(device=0, max_batch=64, max_frames=196)
     _load(exact)
     report = {}
@@ -1069,17 +1076,6 @@ def test_headline_serving_shape_every_motion_within_tolerance(dev, golden_dir):
             big.sample_many(reqs)
         torch.cuda.synchronize()
         assert big.launch_counts()[0] <= 4              # the loop really ran as the persistent launch
-        if mix == "full":
-            # "fused_swz" (default on: the loop's LDS images stored XOR-swizzled by the row) is a permutation of where words sit in LDS:
-            # the plain-image build of the same kernel gives the same latents to the bit (profiles/r03c_loop_swz_ab.json)
-            lat_swz = torch.cat([q["latents_out"] for q in reqs]).clone()
-            big.set_option("fused_swz", 0)
-            big.sample_many(reqs)
-            torch.cuda.synchronize()
-            assert torch.equal(torch.cat([q["latents_out"] for q in reqs]), lat_swz)
-            big.set_option("fused_swz", 1)
-            big.sample_many(reqs)                       # back to the default build: its outputs are what is checked below
-            torch.cuda.synchronize()
         worst = 0.0
         for b, q in zip(batches, reqs):
             T = max(b.lengths)
@@ -1092,7 +1088,8 @@ def test_headline_serving_shape_every_motion_within_tolerance(dev, golden_dir):
                 worst = max(worst, float(d[i, :n].max()))
         report[mix + "_vs_exact_fp32_engine"] = worst
         assert worst < 8e-4, report
-        for k in ((0, 7, 19) if mix == "full" else (3, 30)):    # direct checks against the oracle / the reference fixture
+        # direct checks against the reference fixture (request 0) / the CPU oracle: eight requests per length mix
+        for k in ((0, 2, 5, 7, 11, 13, 17, 19) if mix == "full" else (1, 3, 6, 9, 12, 15, 16, 18)):
             b, q = batches[k], reqs[k]
             if mix == "full" and k == 0:
                 e = float(np.abs(q["joints_out"].cpu().numpy()[:, ::4] - g["joints_every4"]).max())
@@ -1104,7 +1101,10 @@ def test_headline_serving_shape_every_motion_within_tolerance(dev, golden_dir):
                 e = max(float(np.abs(got[i, :n] - jr[i, :n]).max()) for i, n in enumerate(b.lengths))
             report[f"{mix}_request{k}_vs_reference"] = e
             assert e < 1e-3, report
-    print("headline shape parity:", report)
+    ns = big.numeric_status()
+    assert ns["nonfinite_values"] == 0, ns                 # the run-time counter over every latents / joints value of those calls
+    report["probe"] = {k: ns[k] for k in ("probe_err_loop", "probe_err_decode")}
+    print("headline shape parity:", NREQ, report)
     big.close()
     exact.close()
 
@@ -1129,3 +1129,85 @@ def test_demo_cli_writes_the_reference_files_on_gpu(dev, tmp_path):
         assert j.shape == (n, 22, 3) and j.dtype == np.float32 and np.isfinite(j).all()
         assert os.path.exists(p.replace(".npy", ".txt"))
     assert open(paths[1].replace(".npy", ".txt")).read() == "A person is skipping rope."
+
+
+# ---- the range contract of the split-f16 mode (include/mldhip.h "Range contract"; VERDICT r3 "what's weak" 1b / advisor r3 #1)
+def _scaled_weights(case):
+    """The seeded synthetic weights with one class of tensors pushed out of the half format's comfortable range."""
+    sdd, sdv = syn.make_denoiser_state_dict(), syn.make_vae_state_dict()
+    if case == "ln_gain_up":          # LayerNorm gains x 2^10: post-norm activations |x| ~ 1e3 .. 4e3
+        for sd, keys in ((sdd, ("encoder.input_blocks.1.norm1", "encoder.middle_block.norm2", "encoder.output_blocks.2.norm1")),
+                         (sdv, ("decoder.input_blocks.1.norm2", "decoder.output_blocks.0.norm3"))):
+            for k in keys:
+                sd[k + ".weight"] = sd[k + ".weight"] * np.float32(1024.0)
+                sd[k + ".bias"] = sd[k + ".bias"] * np.float32(1024.0)
+    elif case == "ln_gain_down":      # LayerNorm gains x 2^-10: |x| ~ 1e-3, high halves near / in the half subnormals, low halves gone
+        for sd, keys in ((sdd, ("encoder.input_blocks.1.norm1", "encoder.middle_block.norm2", "encoder.output_blocks.2.norm1")),
+                         (sdv, ("decoder.input_blocks.1.norm2", "decoder.output_blocks.0.norm3"))):
+            for k in keys:
+                sd[k + ".weight"] = sd[k + ".weight"] * np.float32(2.0 ** -10)
+                sd[k + ".bias"] = sd[k + ".bias"] * np.float32(2.0 ** -10)
+    elif case == "ffn_hidden_huge":   # one feed-forward layer with linear1 x 2^14: pre-GELU |h| ~ 1e4 .. 1e5, beyond 65 504 for some
+        for sd, k in ((sdd, "encoder.input_blocks.2"), (sdv, "decoder.input_blocks.2")):
+            sd[k + ".linear1.weight"] = sd[k + ".linear1.weight"] * np.float32(2.0 ** 14)
+            sd[k + ".linear2.weight"] = sd[k + ".linear2.weight"] * np.float32(2.0 ** -14)      # (keeps the block's output O(1))
+    elif case == "weights_tiny":      # weight matrices x 2^-12 (|w| ~ 1e-5: half subnormals), one of them NOT followed by a residual
+        sdd["encoder.linear_blocks.0.weight"] = sdd["encoder.linear_blocks.0.weight"] * np.float32(2.0 ** -12)
+        sdd["encoder.linear_blocks.0.bias"] = sdd["encoder.linear_blocks.0.bias"] * np.float32(2.0 ** -12)
+        sdv["decoder.input_blocks.1.self_attn.in_proj_weight"] = sdv["decoder.input_blocks.1.self_attn.in_proj_weight"] * np.float32(2.0 ** -12)
+        sdv["decoder.linear_blocks.1.weight"] = sdv["decoder.linear_blocks.1.weight"] * np.float32(2.0 ** -12)
+        sdv["decoder.linear_blocks.1.bias"] = sdv["decoder.linear_blocks.1.bias"] * np.float32(2.0 ** -12)
+    else:
+        assert case == "plain"
+    return sdd, sdv
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["plain", "ln_gain_up", "ln_gain_down", "ffn_hidden_huge", "weights_tiny"])
+def test_split_f16_range_contract_out_of_comfort_zone(dev, case):
+    """MLDHIP_PREC_F16X3 outside the range the synthetic weights live in (|activation| < ~100, |w| ~ 0.05): LayerNorm gains x 2^+-10,
+    a feed-forward layer whose hidden activation passes +-65 504, weight matrices at 1e-5.  The contract (mldhip.h): finalize's
+    probe either keeps a stage on the split kernels (probe error <= MLDHIP_PROBE_TOL) or moves it to the exact-fp32 kernels and says
+    so; either way the joints stay within 1e-3 of the reference arithmetic (cross_attention.py:259-272, mld.py:290-360 restated by
+    the oracle on the SAME modified weights) and nothing non-finite is produced.  Runs the persistent loop (loop_kernel 3, 16
+    motions) AND the latency kernels, decoder at 16 x 64 frames."""
+    sdd, sdv = _scaled_weights(case)
+    mean, std = syn.make_mean_std()
+    b = syn.make_batch(16, [64, 57, 64, 33, 64, 64, 12, 64, 40, 64, 64, 64, 25, 64, 64, 1], seed=77)
+    ops = O.TorchOps("float32")
+    jr = ops.to_numpy(O.sample(ops, O.to_backend(ops, sdd), O.to_backend(ops, sdv), ops.asarray(b.text_emb), ops.asarray(b.init_latents), b.lengths,
+                               ops.asarray(mean), ops.asarray(std)))
+    status = {}
+    errs = {}
+    for name, prec, probe in (("f32", 0, 1), ("x3", 1, 1), ("x3_unguarded", 1, 0)):
+        e = _lib.Engine(device=0, max_batch=16, max_frames=64, precision=prec)
+        e.load_state_dict(sdd, "denoiser."); e.load_state_dict(sdv, "vae.")
+        e.load_tensor("mean", mean); e.load_tensor("std", std)
+        e.set_option("range_probe", probe)
+        e.finalize()
+        for lk in (3, 1):
+            e.set_option("loop_kernel", lk)
+            joints = torch.full((16, 64, 22, 3), float("nan"), device=dev)
+            e.sample(_cuda(b.text_emb, dev), _cuda(b.init_latents, dev), b.lengths, None, None, joints)
+            torch.cuda.synchronize()
+            got = joints.cpu().numpy()
+            errs[(name, lk)] = max(float(np.nan_to_num(np.abs(got[i, :n] - jr[i, :n]), nan=np.inf).max()) for i, n in enumerate(b.lengths))
+        status[name] = e.numeric_status()
+        e.close()
+    print("range contract", case, {k: float("%.3g" % v) for k, v in errs.items()}, {k: v for k, v in status.items() if k != "f32"})
+    assert errs[("f32", 3)] < 1e-3 and errs[("f32", 1)] < 1e-3, (case, errs)          # the case itself is well conditioned
+    s = status["x3"]
+    assert s["probed"] == 1
+    for stage in ("loop", "decode"):
+        ok, err = s[stage + "_split_ok"], s["probe_err_" + stage]
+        assert ok == (1 if err <= _lib.PROBE_TOL else 0), (case, s)                     # the decision is the documented rule
+    assert errs[("x3", 3)] < 1e-3 and errs[("x3", 1)] < 1e-3, (case, errs, s)           # the guarded mode keeps the joint contract
+    assert s["nonfinite_values"] == 0, (case, s)
+    if case == "plain":
+        assert s["loop_split_ok"] == 1 and s["decode_split_ok"] == 1, s                 # ... and costs nothing on in-range weights
+    if case == "ffn_hidden_huge":
+        # the case really is out of range: the probe moved the loop AND the decoder to the exact-fp32 kernels, and without the guard the
+        # split kernels are wrong (half saturates / overflows at 65 504) -- by 1e-2 on the joints, or non-finite and then counted
+        assert s["loop_split_ok"] == 0 and s["decode_split_ok"] == 0, s
+        u = status["x3_unguarded"]
+        assert u["probed"] == 0 and (u["nonfinite_values"] > 0 or max(errs[("x3_unguarded", 3)], errs[("x3_unguarded", 1)]) > 1e-3), (errs, u)
