@@ -84,11 +84,44 @@ __device__ __forceinline__ float sum16(float v) {
 #endif
   return v;
 }
+// v + (v of lane ^ 16) and v + (v of lane ^ 32) on the gfx950 lane-swap instructions (v_permlane16_swap / v_permlane32_swap: odd 16-lane
+// rows of one register <-> even rows of the other; upper 32 lanes <-> lower 32 lanes): with both operands = v the two results are
+// {v of the even row / lower half, v of the odd row / upper half} in every lane, so their sum is the xor-16 / xor-32 butterfly -- VALU only.
+// (__shfl_xor across 16-lane rows is ds_bpermute_b32: an LDS-crossbar round trip per shuffle on the dependent chain of every LayerNorm
+// statistic and attention score of the persistent loop: r04 loop 20.55 -> 19.70 ms at 1 280 motions, attention phase 1.82 -> 1.37 ms.)
+// Inline assembly, not __builtin_amdgcn_permlane16_swap: hipcc (ROCm 7.2) reads BOTH results of the builtin from its first result
+// register when they feed one v_add_f32 (build/t/swap_test2: 576 of 576 sums wrong); the s_nop covers the VALU-write -> lane-swap-read
+// hazard the compiler would otherwise pad itself (it does not look inside inline assembly).
+__device__ __forceinline__ float add_xor16(float v) {
+#if defined(MLDHIP_SIM)
+  return v + wave_xor(v, 16);
+#else
+  float a = v, c = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(c));
+  return a + c;
+#endif
+}
+__device__ __forceinline__ float add_xor32(float v) {
+#if defined(MLDHIP_SIM)
+  return v + wave_xor(v, 32);
+#else
+  float a = v, c = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(c));
+  return a + c;
+#endif
+}
 // sum / max over the 4 lanes {l, l^16, l^32, l^48}: the row-group axis of an MFMA C tile
+#ifndef MLD_SUM_GROUPS_BPERMUTE
+#define MLD_SUM_GROUPS_BPERMUTE 0
+#endif
 __device__ __forceinline__ float sum_groups(float v) {
+#if MLD_SUM_GROUPS_BPERMUTE
   v += wave_xor(v, 16);
   v += wave_xor(v, 32);
   return v;
+#else
+  return add_xor32(add_xor16(v));
+#endif
 }
 __device__ __forceinline__ float max_groups(float v) {
   v = fmaxf(v, wave_xor(v, 16));

@@ -507,7 +507,19 @@ int range_probe(mldhip_handle* e, hipStream_t stream) {
         if (c.rc) return c.rc;
         if (down(e->lat, (size_t)Bp * D, split ? ha : hb)) return e->fail(MLDHIP_EHIP, "range probe: copy");
       }
-      worst = std::max(worst, rel_err(ha, hb));
+      // measured against the UPDATE the two steps made (latents - start noise), not against the latents: near t = T a DDIM step moves
+      // x by a few per cent, and how much depends on the schedule; the update is (guided eps) x (step coefficients), so this reads
+      // like (a) times the guidance amplification (2 g - 1 at worst) -- hence the factor on the tolerance
+      float d = 0.f, m = 0.f;
+      bool finite = true;
+      for (size_t i = 0; i < ha.size(); ++i) {
+        finite = finite && std::isfinite(ha[i]) && std::isfinite(hb[i]);
+        d = std::max(d, std::fabs(ha[i] - hb[i]));
+        m = std::max(m, std::fabs(hb[i] - hs[i]));
+      }
+      const float amp = std::max(1.0f, 2.0f * guidance - 1.0f);
+      const float eb = !finite ? std::numeric_limits<float>::infinity() : (m > 0.f ? d / m / amp : (d > 0.f ? std::numeric_limits<float>::infinity() : 0.f));
+      worst = std::max(worst, eb);
     }
     e->probe_err_loop = worst;
     e->split_loop_ok = worst <= MLDHIP_PROBE_TOL;

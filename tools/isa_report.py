@@ -35,7 +35,7 @@ def report(lib=DEFAULT_LIB):
             m = re.match(r"^<(.+)>:$", ln)
             if m:
                 cur = m.group(1)
-                out[cur] = dict(mfma=0, valu=0, ds_read=0, ds_write=0, ds_write_b16=0, ds_read_tr=0, global_load=0, global_store=0, flat=0,
+                out[cur] = dict(mfma=0, valu=0, ds_read=0, ds_write=0, ds_write_b16=0, ds_read_tr=0, ds_bpermute=0, global_load=0, global_store=0, flat=0,
                                 vmcnt0=0, branches=0, barriers=0, insts=0, **meta.get(cur, {}))
                 continue
             if not cur or not ln.startswith(("\t", " ")):
@@ -49,6 +49,7 @@ def report(lib=DEFAULT_LIB):
             if op.startswith("v_mfma"): k["mfma"] += 1
             elif op.startswith("v_"): k["valu"] += 1
             elif op.startswith("ds_read_b64_tr"): k["ds_read_tr"] += 1; k["ds_read"] += 1
+            elif op.startswith("ds_bpermute"): k["ds_bpermute"] += 1
             elif op.startswith("ds_read"): k["ds_read"] += 1
             elif op.startswith("ds_write"):
                 k["ds_write"] += 1

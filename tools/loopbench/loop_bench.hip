@@ -1,7 +1,7 @@
 // Stand-alone timing harness for the sample-major persistent loop (kernels/loop_fused.hpp): the kernel alone, on a random weight stream
 // of the right shape (9 layers, 50 steps, 1 856 items per step), without the engine around it.  Built in seconds, so a kernel variant is
 // one hipcc + one gpurun call:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I motion-latent-diffusion_amd/csrc/kernels [-DLB_VARIANT='true, 4, 0, true'] [-D...] \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I motion-latent-diffusion_amd/csrc/kernels [-DLB_VARIANT='true, 0'] [-D...] \
 //         -o gpurun_out/lb_x tools/loopbench/loop_bench.hip
 //   gpurun -- 'gpurun_out/lb_x [motions=2048] [reps=5] [trace=0|1]'
 // Prints one JSON line: ms per launch (min / median), and with trace=1 the kernel's own phase counters (the DBG 5 build of the same
@@ -15,10 +15,10 @@
 #include "loop_fused.hpp"
 
 #ifndef LB_VARIANT
-#define LB_VARIANT true, 4, 0, true
+#define LB_VARIANT true, 0
 #endif
 #ifndef LB_TRACE_VARIANT
-#define LB_TRACE_VARIANT true, 4, 5, true
+#define LB_TRACE_VARIANT true, 5
 #endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
