@@ -136,7 +136,11 @@ int mldhip_load_tensor(mldhip_handle* h, const char* key, const void* data, cons
 int mldhip_finalize_weights(mldhip_handle* h, void* stream);
 
 /* Per-handle tuning options (ABI 3; no reference counterpart, no process-wide environment knobs).  Changing one drops the
- * handle's captured graphs.  Names:
+ * handle's captured graphs.  Round 4 retired the knobs whose A/B is settled -- each is now simply how the engine works: row-swizzled LDS
+ * images in the persistent loop and in the decoder tail ("fused_swz", "ffn_swz"), 4 / 8 weight items in flight ("fused_ring", "strip_ring"),
+ * decoder.norm + final_layer as one row-strip launch ("final_strip"), V through the gfx950 transpose read ("attn_tr"), streaming hints on
+ * the in-projection's strips ("nt_hints"), pre-split weight images ("split_weights"); round 2's LDS-staged feed-forward kernel
+ * ("fused_ffn", kernels/ffn_fused.hpp) is gone.  Names:
  *   "loop_kernel"     reverse loop of the latent models: 0 = auto (default: by motions per call), 1 = latency kernels
  *                     (kernels/tile32.hpp: one request of <= ~128 motions, 41 launches per step), 2 = column-split throughput kernels
  *                     (kernels/strip.hpp: a few hundred motions per call), 3 = the sample-major persistent loop
@@ -154,18 +158,11 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     more: tools/loopbench builds them stand-alone
  *   "range_probe"     F16X3 mode: 1 (default) = mldhip_finalize_weights runs the range probe of the "Range contract" below, 0 = skips it
  *                     (the split kernels are used unconditionally).  Setting it un-finalizes the handle
- *   "final_strip"     F16X3 / FP8 modes, MldVae.decode: 1 (default) = decoder.norm + final_layer + the zeroing of padded frames
- *                     (mld_vae.py:240-245) as ONE row-strip launch (kernels/final_strip.hpp: the decoder output is read once and the
- *                     features leave as contiguous 48-row blocks; 397 us at 2 048 motions) instead of a LayerNorm launch + the staged
- *                     GEMM, whose three 128-column tiles each re-read the normalised rows (131 + 480 us; profiles/r04a_kernel_stats_ab.csv)
- *   "ffn_swz"         F16X3 / FP8 modes, one-launch decoder tail ("dec_tail"): 1 (default) = its LDS images row-swizzled like the
- *                     persistent loop's (8-byte row stores 2-way instead of 4-way bank conflicted); same numbers to the bit; 1 476 ->
- *                     1 457 us per launch at 2 048 motions (profiles/r04a_kernel_stats_ab.csv)
  *   "ffn_strip"       F16X3 / FP8 modes, decoder / encoder layers: strip height of the register-direct kernels (kernels/ffn_strip.hpp,
  *                     kernels/gemm_strip_x3.hpp): 1 (default) = by launch size -- more than 512 strips of 64 rows: 96-row strips for the
  *                     GEMMs, 48-row strips at two workgroups per CU for the feed-forward block; else 64 rows (one bs-64 request: 196
  *                     strips on 256 CUs instead of 131 longer ones); 6 / 4 = 96 / 64 rows always, 3 = 48 rows for the feed-forward
- *                     block (96 for the GEMMs); 0 = feed-forward block by kernels/ffn_fused.hpp or the two staged GEMMs ("fused_ffn")
+ *                     block (96 for the GEMMs); 0 = feed-forward block as the two staged GEMMs of kernels/gemm.hpp
  *   "dec_tail"        F16X3 / FP8 modes, chip-filling launches: 1 (default) = a decoder layer's out-projection + residual + norm1 +
  *                     cross-attention vector + norm2 + feed-forward block as ONE launch (kernels/ffn_strip.hpp TAIL form: the block
  *                     input never goes to HBM), 0 = two launches
@@ -173,19 +170,10 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     zeros + the positional rows (mld_vae.py:216-222, actor_vae.py:221-222), the same for every sample, so Q, K, V of
  *                     layer 0 are computed for [T] rows and every (sample, head) attention workgroup reads them (exact: same numbers,
  *                     B times less work and no [B T][3 D] round trip through HBM for that layer); 0 = per sample like the other layers
- *   "attn_tr"         F16X3 / FP8 modes, key-blocked attention ("flash_attn"), bit mask: 1 = V staged row-major (one 8-byte LDS store
- *                     per plane and thread) and read as MFMA fragments with the gfx950 transpose read ds_read_b64_tr_b16 (0: transposed
- *                     V planes written with 2-byte stores); 2 = Q / K / V loads and output stores with the streaming hint.  Same
- *                     products, same results.  Default 1 (454 -> 417 us per launch at 2 048 motions; bit 1 measured level)
- *   "nt_hints"        F16X3 / FP8 modes: 1 (default) = the decoder's / encoder's in-projection (kernels/gemm_strip_x3.hpp, N = 768) loads
- *                     its row strips and stores its output with the streaming (`nt`) hint -- activations one workgroup touches
- *                     once, next to a weight stream every workgroup re-reads (527 -> 504 us per launch at 2 048 motions);
- *                     0 = default cache policy.  Results are identical either way
  *   "tile_x3"         F16X3 mode: 1 (default) = the latency kernels of the reverse loop (kernels/tile32.hpp, one request at a time) multiply
  *                     on split-f16 MFMAs reading the pre-split weight image, 0 = on exact-fp32 MFMAs
  *   "strip_gemm"      F16X3 / FP8 modes, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:
  *                     1 (default) = row-strip kernels with register-direct weights (kernels/gemm_strip_x3.hpp), 0 = staged tiles
- *   "strip_ring"      row-strip GEMMs: weight items in flight per lane, 8 (default) or 4 (measured equal: r03_decoder_ab.json)
  *   "strip_min_rows"  auto picks the throughput kernels when the reverse loop has >= this many token rows
  *                     (6 x batch; default 768 = 128 motions)
  *   "strip_wide"      throughput kernels: 32 x 128 tiles for the wide GEMMs: 0 = auto (N >= 512), 1 = never, 2 = whenever N % 128 == 0
@@ -194,10 +182,6 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "flash_attn"      split-f16 modes, frame-level self-attention of the decoder / encoder: key-blocked online-softmax kernel with
  *                     two workgroups per CU (kernels/attention.hpp attn_flash_x3_kernel): 0 = never, 1 = auto (default: calls
  *                     with >= 512 (sample, head) pairs), 2 = always
- *   "fused_ffn"       split-f16 modes ("ffn_strip" = 0): 1 (default) = linear1 + GELU + linear2 + residual + LayerNorm of a decoder / encoder layer as
- *                     ONE launch (kernels/ffn_fused.hpp; the hidden activation stays in LDS), 0 = the two staged GEMMs (A/B knob)
- *   "split_weights"   precision modes whose staged GEMMs run on split-f16 MFMAs: 1 (default) = read the weights from the half
- *                     high / low image finalize builds once, 0 = split them in every workgroup (bit-identical results; A/B knob)
  *   "gemm_small_m"    row count up to which one-off GEMMs use the register-direct 16x64 shape (default 256; tests set 0
  *                     to drive the LDS-staged kernels at simulator-sized shapes) */
 int mldhip_set_option(mldhip_handle* h, const char* name, int64_t value);

@@ -80,7 +80,7 @@ bool fused_split(const E* e) { return e->loop_stream_x3 && e->fused_x3 && e->spl
 void use_split_weights(const E* e, GemmArgs& a, int prec) {
   // the image holds one (hi | lo) record per ALIGNED group of 32 floats of the arena: a weight view that does not start on a
   // group boundary, or whose rows / K slices do not, keeps the in-kernel split
-  if (prec == PREC_BF16X3 && e->split_weights && e->arena_x3 && a.W >= e->arena && a.W < e->arena + e->arena_floats &&
+  if (prec == PREC_BF16X3 && e->arena_x3 && a.W >= e->arena && a.W < e->arena + e->arena_floats &&
       (a.W - e->arena) % 32 == 0 && a.ldw % 32 == 0 && a.sW % 32 == 0) {
     a.W = e->arena_x3 + (a.W - e->arena);
     a.w_split = 1;

@@ -22,7 +22,7 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
   dim3 grid((a.M + mt - 1) / mt, (a.N + 63) / 64, nz);
   const int ns = a.src[0].attn_R > 0 ? 0 : a.src[0].nsplit;
   const int prec = latency_prec(c.e);
-  if (prec == PREC_BF16X3 && c.e->split_weights && c.e->arena_x3 && a.W >= c.e->arena && a.W < c.e->arena + c.e->arena_floats &&
+  if (prec == PREC_BF16X3 && c.e->arena_x3 && a.W >= c.e->arena && a.W < c.e->arena + c.e->arena_floats &&
       (a.W - c.e->arena) % 32 == 0 && a.ldw % 32 == 0) {
     a.W = c.e->arena_x3 + (a.W - c.e->arena);
     a.w_split = 1;
@@ -449,12 +449,9 @@ void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr, int shar
     // (B H >= 512: 108 vs 133 us at 1 280 workgroups); with one per CU the whole-K/V kernel below is 5 % faster (28.9 vs 30.3 us)
     // (it covers 16 query tiles = 256 frames per (sample, head); longer sequences take the whole-K/V kernel)
     if (T <= 256 && (e->flash_attn == 2 || (e->flash_attn == 1 && B * H >= 512))) {
-      switch (e->attn_tr) {      // bit 0: transpose-read V; bit 1: streaming hints
-        case 1: MLD_LAUNCH((attn_flash_x3_kernel<true, false>), grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
-        case 2: MLD_LAUNCH((attn_flash_x3_kernel<false, true>), grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
-        case 3: MLD_LAUNCH((attn_flash_x3_kernel<true, true>), grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
-        default: MLD_LAUNCH((attn_flash_x3_kernel<false, false>), grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv); break;
-      }
+      // V staged row-major and read as MFMA fragments through ds_read_b64_tr_b16 (r03: 454 -> 417 us per launch at 2 048 motions against
+      // transposed V planes written with 2-byte stores; streaming hints on its loads / stores measured level: both alternatives retired in r04)
+      MLD_LAUNCH(attn_flash_x3_kernel, grid, block, kFlashLdsBytes, c.stream, (const float*)e->QKV, e->AO, (const int*)lens, T, H, shared_qkv);
       count(c);
       check_launch(c, "attn_flash_x3");
       return;
@@ -508,16 +505,13 @@ bool strip_gemm(Ctx& c, const GemmArgs& g, bool ln) {
     else MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, true, false>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, false>()), c.stream, a);
   } else if (g.K2 == 256) {
     if (g.N != 256) return false;
-    // (streaming hints measured level on this form -- 414.6 vs 413.7 us, r03c_kernel_stats_ab.csv -- so it has no NT build)
-    if (e->strip_ring == 8) MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 8>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
-    else MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false, 4>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
+    // (streaming hints measured level on this form -- 414.6 vs 413.7 us, r03c_kernel_stats_ab.csv -- so it has no hinted build)
+    MLD_LAUNCH((strip_gemm_x3_kernel<4, 2, false, false>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 2, false>()), c.stream, a);
   } else if (rt == 4) {
-    if (e->nt_hints) MLD_LAUNCH((strip_gemm_x3_kernel<4, 1, false, true, 8, 3>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 1, true>()), c.stream, a);
-    else MLD_LAUNCH((strip_gemm_x3_kernel<4, 1, false, true, 8>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 1, true>()), c.stream, a);
+    // in-projection (N = 768): row strips loaded and outputs stored with the streaming hint (527 -> 504 us per launch at 2 048 motions, r03c)
+    MLD_LAUNCH((strip_gemm_x3_kernel<4, 1, false, true, true>), dim3((g.M + 63) / 64), dim3(512), (strip_gemm_lds_bytes<4, 1, true>()), c.stream, a);
   } else {
-    if (e->strip_ring == 8 && e->nt_hints) MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true, 8, 3>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
-    else if (e->strip_ring == 8) MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true, 8>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
-    else MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true, 4>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
+    MLD_LAUNCH((strip_gemm_x3_kernel<6, 1, false, true, true>), dim3((g.M + 95) / 96), dim3(512), (strip_gemm_lds_bytes<6, 1, true>()), c.stream, a);
   }
   count(c);
   check_launch(c, "strip_gemm_x3");
@@ -525,7 +519,7 @@ bool strip_gemm(Ctx& c, const GemmArgs& g, bool ln) {
 }
 
 // linear1 + GELU + linear2 + residual + LayerNorm of a post-norm layer.  Split-bf16 modes with D = 256, FF = 1024: ONE launch
-// (kernels/ffn_fused.hpp) reading the pre-split weights; otherwise the two staged GEMMs.  ragged_T > 0: skip all-padding row tiles.
+// (kernels/ffn_strip.hpp) reading its fragment-ordered weight stream; otherwise the two staged GEMMs.  ragged_T > 0: skip all-padding row tiles.
 void ffn_block(Ctx& c, const float* x, float* y, int M, const float* w1, const float* b1, const float* w2, const float* b2,
                const float* gamma, const float* beta, int ragged_T) {
   E* e = c.e;
@@ -544,17 +538,6 @@ void ffn_block(Ctx& c, const float* x, float* y, int M, const float* w1, const f
     else MLD_LAUNCH(ffn_strip_x3_kernel<4>, dim3((M + 63) / 64), dim3(512), (ffn_strip_lds_bytes<4>()), c.stream, a);
     count(c);
     check_launch(c, "ffn_strip_x3");
-    return;
-  }
-  if (staged_prec(e) == PREC_BF16X3 && e->fused_ffn && e->split_weights && e->arena_x3 && D == 256 && F == 1024 && M > e->small_m &&
-      !e->trace_on && in_arena(w1) && in_arena(w2)) {
-    FfnArgs a;
-    a.X = x; a.W1 = e->arena_x3 + (w1 - e->arena); a.b1 = b1; a.W2 = e->arena_x3 + (w2 - e->arena); a.b2 = b2;
-    a.gamma = gamma; a.beta = beta; a.Y = y; a.M = M;
-    if (ragged_T > 0) { a.skip_lens = e->lens_dev; a.skip_rpg = ragged_T; }
-    MLD_LAUNCH(ffn_x3_kernel, dim3((M + 63) / 64), dim3(512), kFfnLdsBytes, c.stream, a);
-    count(c);
-    check_launch(c, "ffn_x3");
     return;
   }
   GemmArgs f1 = lin_args(x, D, D, w1, b1, e->FF, F, M, F);
@@ -594,8 +577,8 @@ void dec_layer(Ctx& c, int l, const float* xin, float* xout, int B, int T, bool 
     a.skip_lens = e->lens_dev; a.skip_rpg = T;
     a.AO = e->AO; a.Wo = e->gemm_stream_of[L.out_w]; a.bo = L.out_b; a.res = xin; a.g1 = L.n1_w; a.be1 = L.n1_b;
     a.cvec = e->cvec + (size_t)l * e->cfg.max_batch * D; a.rpg = T; a.g2 = L.n2_w; a.be2 = L.n2_b;
-    if (e->ffn_swz) MLD_LAUNCH((ffn_strip_x3_kernel<3, true, true>), dim3((M + 47) / 48), dim3(512), (ffn_strip_lds_bytes<3>()), c.stream, a);
-    else MLD_LAUNCH((ffn_strip_x3_kernel<3, true>), dim3((M + 47) / 48), dim3(512), (ffn_strip_lds_bytes<3>()), c.stream, a);
+    // (LDS images row-swizzled like the persistent loop's: 1 476 -> 1 457 us per launch at 2 048 motions, r04a; the plain-image build is retired)
+    MLD_LAUNCH((ffn_strip_x3_kernel<3, true, true>), dim3((M + 47) / 48), dim3(512), (ffn_strip_lds_bytes<3>()), c.stream, a);
     count(c);
     check_launch(c, "dec_tail_x3");
     return;
@@ -667,7 +650,7 @@ void decode_body(Ctx& c, const float* z, int B, int T, float* feats_out) {
     skip_linear(c, "vae.decoder", i, e->Ha, e->S[nb - 1 - i], e->Hb, M, T);
     dec_layer(c, nb + 1 + i, e->Hb, e->Ha, B, T);
   }
-  if (e->final_strip && e->final_stream && staged_prec(e) == PREC_BF16X3 && D == 256 && !e->trace_on && M > e->small_m) {
+  if (e->final_stream && staged_prec(e) == PREC_BF16X3 && D == 256 && !e->trace_on && M > e->small_m) {
     // decoder.norm + final_layer + output[~mask.T] = 0 as one row-strip launch (kernels/final_strip.hpp, "final_strip")
     FinalStripArgs a;
     a.X = e->Ha; a.gamma = P(e, "vae.decoder.norm.weight"); a.beta = P(e, "vae.decoder.norm.bias"); a.W = e->final_stream;

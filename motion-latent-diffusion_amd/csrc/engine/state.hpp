@@ -123,17 +123,10 @@ struct mldhip_engine {
   int strip_waves = 8;       // "strip_waves": waves per workgroup of the 32 x 128 strip tiles: 4 (two row tiles per wave) or 8 (one)
   int flash_attn = 1;        // "flash_attn": split-bf16 frame-level self-attention key-blocked (attention.hpp attn_flash_x3_kernel): 0 never, 1 auto (>= 512 (sample, head) pairs), 2 always
   int ffn_strip = 1;         // "ffn_strip": register-direct decoder kernels (ffn_strip.hpp, gemm_strip_x3.hpp): 0 off, 1 auto strip height, 4 / 6 = 64 / 96 rows always
-  int attn_tr = 1;           // "attn_tr": key-blocked attention, bit 0: V staged row-major and read with ds_read_b64_tr_b16 (attention.hpp TRV: 454 -> 417 us per launch at 2 048 motions); bit 1: streaming hints on its loads / stores (level: off)
   int dec_tail = 1;          // "dec_tail": out-projection + norms + feed-forward block of a decoder layer as one launch (chip-filling launches, split modes)
-  int final_strip = 1;       // "final_strip": decoder.norm + final_layer + padded-frame zeroing of MldVae.decode as one row-strip launch (final_strip.hpp; r04: 397 us against 131 + 480 us for the LayerNorm pass + the N = 263 GEMM at 2 048 motions, profiles/r04a_kernel_stats_ab.csv)
-  int ffn_swz = 1;           // "ffn_swz": the one-launch decoder tail with row-swizzled LDS images (ffn_strip.hpp SWZ; r04: 1 476 -> 1 457 us per launch at 2 048 motions, same rocprofv3 run)
   int dec_l0_once = 1;       // "dec_l0_once": decoder layer 0 projects its input -- the positional rows, the same for every sample -- once per call ([T] rows instead of [B T])
-  int nt_hints = 1;          // "nt_hints": the decoder's in-projection (gemm_strip_x3.hpp, N = 768) loads its row strips and stores its output with the streaming hint (527 -> 504 us per launch at 2 048 motions; level on the skip linears, which do not take it)
   int tile_x3 = 1;           // "tile_x3": split-f16 mode runs the latency kernels (tile32.hpp) on split-f16 MFMAs too (0: exact fp32)
-  int strip_ring = 8;        // "strip_ring": weight items in flight per lane in the plain row-strip GEMMs (4 or 8)
   int strip_gemm = 1;        // "strip_gemm": split modes, decoder / encoder in-projection, out-projection (+ LayerNorms) and skip linears on the row-strip kernels (kernels/gemm_strip_x3.hpp); 0 = the staged 64 x 128 / 64 x 256 tiles
-  int fused_ffn = 1;         // "fused_ffn": split-bf16 decoder / encoder layers run linear1 + GELU + linear2 + residual + LayerNorm as one launch (kernels/ffn_fused.hpp)
-  int split_weights = 1;     // "split_weights": split-bf16 staged GEMMs read the weights pre-split at finalize (0: split them in every workgroup)
   int strip_ffn2_split = 2;  // "strip_ffn2_split": K slices (= raw slabs) of FFN2 on the throughput kernels: 1 or 2
 
   // ---- numeric contract of the split-f16 mode (mldhip_numeric_status; include/mldhip.h "Range contract")

@@ -364,11 +364,10 @@ constexpr int kFlashVStride = 20;    // words per V^T row of a block: 32 keys = 
 constexpr int kFlashStageWords = 2 * 32 * kFlashKStride + 2 * 64 * kFlashVStride;
 constexpr int kFlashLdsBytes = 2 * kFlashStageWords * 4;   // 40 960 B
 
-// TRV: V is staged ROW-major like K ([key][64 dims] halves, 40-word rows, one 8-byte store per plane and thread) and the P V products
-// read their B fragments -- four keys of one head dim per lane -- with ds_read_b64_tr_b16 (rt.hpp lds_read_tr16_b64); false: V^T planes
-// written with eight 2-byte stores per thread (8-way bank conflicts) and read with plain ds_read_b64.  Same LDS footprint, same numbers.
-// NTH: the Q / K / V loads and the output stores carry the streaming hint (every element is touched by exactly one workgroup).
-template <bool TRV = false, bool NTH = false>
+// V is staged ROW-major like K ([key][64 dims] halves, 40-word rows, one 8-byte store per plane and thread) and the P V products read
+// their B fragments -- four keys of one head dim per lane -- with ds_read_b64_tr_b16 (rt.hpp lds_read_tr16_b64).  (Rounds 2-3 wrote V^T
+// planes with eight 2-byte stores per thread, 8-way bank conflicted: 454 vs 417 us per launch at 2 048 motions, same numbers to the bit;
+// streaming hints on the loads / stores measured level.  Both alternatives were retired in round 4.)
 __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                             const int* __restrict__ lens, int T, int H, int shared_qkv = 0) {
   constexpr int HD = 64, KST = kFlashKStride, VST = kFlashVStride, NW = 8;
@@ -394,8 +393,8 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
     const int key = kb * 32 + skey;
     const int kc = key < len ? key : len - 1;
     const float* p = base + (long long)kc * 3 * D + c4 * 4;
-    kreg = ld4_hint<NTH>(p + D);
-    vreg = ld4_hint<NTH>(p + 2 * D);
+    kreg = ld4(p + D);
+    vreg = ld4(p + 2 * D);
   };
   auto kvstore = [&](int kb) {
     unsigned* Kh = smem + (kb & 1) * kFlashStageWords;
@@ -410,18 +409,9 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
     *reinterpret_cast<U2*>(Kl + skey * KST + c4 * 2) = U2{l0, l1};
     split16_pair(vreg.x * m, vreg.y * m, h0, l0);
     split16_pair(vreg.z * m, vreg.w * m, h1, l1);
-    if constexpr (TRV) {               // row-major, K's row stride (the two V planes take 2 x 32 x 40 = 2 x 64 x 20 words either way)
-      *reinterpret_cast<U2*>(Vh + skey * KST + c4 * 2) = U2{h0, h1};
-      *reinterpret_cast<U2*>(Vl + skey * KST + c4 * 2) = U2{l0, l1};
-      return;
-    }
-    unsigned short* vh = reinterpret_cast<unsigned short*>(Vh) + skey;
-    unsigned short* vl = reinterpret_cast<unsigned short*>(Vl) + skey;
-    const int d0 = c4 * 4;
-    vh[(d0 + 0) * VST * 2] = (unsigned short)(h0 & 0xFFFFu); vh[(d0 + 1) * VST * 2] = (unsigned short)(h0 >> 16);
-    vh[(d0 + 2) * VST * 2] = (unsigned short)(h1 & 0xFFFFu); vh[(d0 + 3) * VST * 2] = (unsigned short)(h1 >> 16);
-    vl[(d0 + 0) * VST * 2] = (unsigned short)(l0 & 0xFFFFu); vl[(d0 + 1) * VST * 2] = (unsigned short)(l0 >> 16);
-    vl[(d0 + 2) * VST * 2] = (unsigned short)(l1 & 0xFFFFu); vl[(d0 + 3) * VST * 2] = (unsigned short)(l1 >> 16);
+    // row-major, K's row stride (the two V planes take 2 x 32 x 40 = 2 x 64 x 20 words)
+    *reinterpret_cast<U2*>(Vh + skey * KST + c4 * 2) = U2{h0, h1};
+    *reinterpret_cast<U2*>(Vl + skey * KST + c4 * 2) = U2{l0, l1};
   };
   kvload(0);
 
@@ -437,7 +427,7 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
     const float* qp = base + (long long)qrow * 3 * D + g * 8;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const F4 t0 = ld4_hint<NTH>(qp + c * 32), t1 = ld4_hint<NTH>(qp + c * 32 + 4);
+      const F4 t0 = ld4(qp + c * 32), t1 = ld4(qp + c * 32 + 4);
       constexpr float qs = 0.125f * 1.44269504088896340736f;     // 1/sqrt(64) x log2(e): scores in the log2 domain (softmax on v_exp_f32)
       const float x[8] = {t0.x * qs, t0.y * qs, t0.z * qs, t0.w * qs, t1.x * qs, t1.y * qs, t1.z * qs, t1.w * qs};
       split_hi_lo_x8(x, qh[t][c], ql[t][c]);
@@ -529,18 +519,11 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         U2 a0, a1, b0, b1;
-        if constexpr (TRV) {
-          // lane (r, g) supplies row = key 4 g + (r >> 2) of the 16-key tile, dims 16 dt + 4 (r & 3) .. + 3, and receives dim 16 dt + r of
-          // keys 4 g .. 4 g + 3 (8-byte aligned: even word offsets; rows 0 .. 7 of a 32-lane half sit 40 words apart: all 64 banks once)
-          const int tro = (g * 4 + (r >> 2)) * KST + dt * 8 + (r & 3) * 2;
-          a0 = lds_read_tr16_b64(Vh + tro); a1 = lds_read_tr16_b64(Vh + tro + 16 * KST);
-          b0 = lds_read_tr16_b64(Vl + tro); b1 = lds_read_tr16_b64(Vl + tro + 16 * KST);
-        } else {
-          const unsigned* vh = Vh + (dt * 16 + r) * VST + g * 2;
-          const unsigned* vl = Vl + (dt * 16 + r) * VST + g * 2;
-          a0 = *reinterpret_cast<const U2*>(vh); a1 = *reinterpret_cast<const U2*>(vh + 8);
-          b0 = *reinterpret_cast<const U2*>(vl); b1 = *reinterpret_cast<const U2*>(vl + 8);
-        }
+        // lane (r, g) supplies row = key 4 g + (r >> 2) of the 16-key tile, dims 16 dt + 4 (r & 3) .. + 3, and receives dim 16 dt + r of
+        // keys 4 g .. 4 g + 3 (8-byte aligned: even word offsets; rows 0 .. 7 of a 32-lane half sit 40 words apart: all 64 banks once)
+        const int tro = (g * 4 + (r >> 2)) * KST + dt * 8 + (r & 3) * 2;
+        a0 = lds_read_tr16_b64(Vh + tro); a1 = lds_read_tr16_b64(Vh + tro + 16 * KST);
+        b0 = lds_read_tr16_b64(Vl + tro); b1 = lds_read_tr16_b64(Vl + tro + 16 * KST);
         const U4 vhh = U4{a0.x, a0.y, a1.x, a1.y}, vll = U4{b0.x, b0.y, b1.x, b1.y};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -569,7 +552,7 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
       const int q = qt * 16 + g * 4 + i;
       if (q < T) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) st1_hint<NTH>(o + (long long)(b * T + q) * D + h * HD + dt * 16 + r, oacc[t][dt][i] * inv);
+        for (int dt = 0; dt < 4; ++dt) o[(long long)(b * T + q) * D + h * HD + dt * 16 + r] = oacc[t][dt][i] * inv;
       }
     }
   }

@@ -1,11 +1,11 @@
-// Post-norm feed-forward block of a decoder / encoder layer, split-f16 operands, second form (round 3):
+// Post-norm feed-forward block of a decoder / encoder layer, split-f16 operands:
 //   Y = LayerNorm(X + linear2(gelu(linear1(X))))        (cross_attention.py:340-343 decoder layer, :268-271 encoder layer)
-// for D = 256, FF = 1024 -- same contract as ffn_fused.hpp (FfnArgs), restructured with what the sample-major loop taught
+// for D = 256, FF = 1024, structured by what the sample-major loop taught
 // (loop_fused.hpp): a weight element is used by exactly one wave (wave w owns columns 16w .. 16w + 15 of every 128-column block,
 // ALL row tiles of the strip), so weights never go through LDS: every lane loads its two 16-byte MFMA operands per item
 // straight from a fragment-ordered stream (`finalize` re-packs linear1 / linear2 per layer in consumption order) into a register
-// ring -- no weight staging, no barrier per item (ffn_fused.hpp: 128 barriers and 2 MB of LDS stores + 4 MB of LDS reads per
-// workgroup).  What is left in LDS is the strip itself -- RT x 16 rows of X as a split image -- and one 128-wide block of the
+// ring -- no weight staging, no barrier per item (round 2's LDS-staged form, retired in round 4: 128 barriers and 2 MB of LDS stores +
+// 4 MB of LDS reads per workgroup; 1.72 vs 1.10 ms per launch at 2 048 motions).  What is left in LDS is the strip itself -- RT x 16 rows of X as a split image -- and one 128-wide block of the
 // hidden activation at a time.  RT = 6 (96 rows): 2 MB of weights per 96 rows instead of per 64, i.e. 1.5x less L2 -> CU traffic;
 // RT = 3 (48 rows, 80 KB of LDS, 128 registers): two workgroups per CU, four waves per SIMD -- one workgroup's barriers and GELU
 // stretches run under the other's matrix instructions; measured 2 % faster over the decoder than RT = 6.
@@ -18,13 +18,35 @@
 // matrix instructions of run2, which do not depend on it.  The H block is single-buffered: it is rewritten only between the
 // two barriers of W, after every wave has left run2 of the previous block.
 //
-// Summation order differs from ffn_fused.hpp (K chunks in order, one accumulator per tile in both), so results agree to fp32
-// rounding, not bitwise.
+// Summation order differs from the two staged GEMMs of gemm.hpp (the "ffn_strip" = 0 path), so results agree to fp32 rounding, not bitwise.
 #pragma once
-#include "ffn_fused.hpp"
 #include "loop_fused.hpp"
 
 namespace mld {
+
+struct FfnArgs {
+  const float* X = nullptr;        // [M][256] fp32: block input and residual
+  const float* W1 = nullptr;       // split image of linear1.weight [1024][256]
+  const float* b1 = nullptr;       // [1024]
+  const float* W2 = nullptr;       // split image of linear2.weight [256][1024]
+  const float* b2 = nullptr;       // [256]
+  const float* gamma = nullptr;    // LayerNorm after the residual
+  const float* beta = nullptr;
+  float* Y = nullptr;              // [M][256]
+  int M = 0;
+  const int* skip_lens = nullptr;  // skip row tiles made only of rows (row % rpg) >= skip_lens[row / rpg] (padded frames)
+  int skip_rpg = 1;
+  // ffn_strip_x3_kernel<RT, true> ("decoder tail": the self-attention out-projection + residual + norm1 + cross-attention vector + norm2 in
+  // front of the feed-forward block, one launch; X is not read, the block input is produced in LDS)
+  const float* AO = nullptr;       // [M][256] attention output (A operand of the out-projection)
+  const float* Wo = nullptr;       // fragment-ordered stream of out_proj.weight (16 items: 8 chunks x [block 0, block 1])
+  const float* bo = nullptr;       // [256]
+  const float* res = nullptr;      // [M][256] the layer input (residual of norm1)
+  const float* g1 = nullptr; const float* be1 = nullptr;      // norm1
+  const float* cvec = nullptr; int rpg = 1;                   // + cvec[row / rpg][256] before norm2
+  const float* g2 = nullptr; const float* be2 = nullptr;      // norm2
+};
+
 
 constexpr int kFsXs = 264, kFsHs = 136;      // row strides (words), = 8 mod 16 (conflict-free fragment reads)
 template <int RT>

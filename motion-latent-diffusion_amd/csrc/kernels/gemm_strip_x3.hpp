@@ -33,14 +33,16 @@ constexpr int strip_gemm_lds_bytes() { return (NSEG * RT * 16 * kFsXs + (STAGE ?
 
 // grid = ceil(M / (16 RT)); block = 512.  STAGE: a separate [rows][136] staging tile for the output (needed when A must survive
 // the first pair: N > 256); otherwise the output is parked in A's own rows once the last product is done.
-// NT ("nt_hints"): the strip's loads (bit 2) and the output stores (bit 1) carry the streaming hint -- activations that exactly one
+// NT: the strip's loads and the output stores carry the streaming hint -- activations that exactly one
 // workgroup touches once per launch, next to weight streams every workgroup re-reads.  A COMPILE-time choice: as a run-time branch
 // around each access (the first form, r03_late_options_ab.json) it made the whole kernel 12-30 % slower -- a `cond ? load : load`
 // per element drains the memory counter per access (DESIGN.md point 8).
-template <int RT, int NSEG, bool LN, bool STAGE, int RING = 4, int NT = 0>
+// (Round 3 also carried a run-time-selectable ring depth and separate load / store hint bits; round 4 keeps the measured forms only: 8 items in
+// flight per lane -- 4 in the LayerNorm form, whose epilogue needs the registers -- and the hinted build for the N = 768 in-projection.)
+template <int RT, int NSEG, bool LN, bool STAGE, bool NT = false>
 __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) {
   static_assert(!(LN && (NSEG != 1 || STAGE)), "the LayerNorm form is the N = 256, K = 256 out-projection");
-  static_assert(RING == 4 || RING == 8, "weight items in flight per lane");
+  constexpr int RING = LN ? 4 : 8;      // weight items in flight per lane
   constexpr int BM = RT * 16, XS = kFsXs, HS = kFsHs;
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
       const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;
-      const F4 v = ld4_hint<(NT & 2) != 0>(src + (size_t)m * 256 + c4 * 4);
+      const F4 v = ld4_hint<NT>(src + (size_t)m * 256 + c4 * 4);
       unsigned h0, l0, h1, l1;
       split16_pair(v.x, v.y, h0, l0);
       split16_pair(v.z, v.w, h1, l1);
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
 #pragma unroll
           for (int j = 0; j < RT; ++j) {
             const int idx = tid + j * 512, row = idx >> 5, c4 = idx & 31;
-            if (m0 + row < p.M) st4_hint<(NT & 1) != 0>(p.Y + (size_t)(m0 + row) * p.ldy + pr * 256 + cb * 128 + c4 * 4, ld4(St + row * HS + c4 * 4));
+            if (m0 + row < p.M) st4_hint<NT>(p.Y + (size_t)(m0 + row) * p.ldy + pr * 256 + cb * 128 + c4 * 4, ld4(St + row * HS + c4 * 4));
           }
         }
       } else {
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
 #pragma unroll
         for (int j = 0; j < RT * 2; ++j) {
           const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
-          if (m0 + row < p.M) st4_hint<(NT & 1) != 0>(p.Y + (size_t)(m0 + row) * p.ldy + c4 * 4, ld4(Xs + row * XS + c4 * 4));
+          if (m0 + row < p.M) st4_hint<NT>(p.Y + (size_t)(m0 + row) * p.ldy + c4 * 4, ld4(Xs + row * XS + c4 * 4));
         }
       }
     } else {

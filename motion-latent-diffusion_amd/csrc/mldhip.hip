@@ -36,7 +36,6 @@
 #include "kernels/rt.hpp"
 #include "kernels/tile32.hpp"
 #include "kernels/strip.hpp"
-#include "kernels/ffn_fused.hpp"
 #include "kernels/loop_fused.hpp"
 #include "kernels/ffn_strip.hpp"
 #include "kernels/gemm_strip_x3.hpp"
@@ -202,26 +201,17 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<7, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<7, 128>()));
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<13, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<13, 128>()));
   (void)hipFuncSetAttribute((const void*)attn_seq_x3_kernel<18, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (attn_seq_x3_lds_bytes<18, 128>()));
-  (void)hipFuncSetAttribute((const void*)ffn_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLdsBytes);
-  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<6, 1, false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<6, 1, true>()));
-  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 2, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 2, false>()));
-  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<6, 1, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<6, 1, true>()));
-  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 2, false, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 2, false>()));
+  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<6, 1, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<6, 1, true>()));
+  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 1, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 1, true>()));
+  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 2, false>()));
   (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<6, 1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<6, 1, false>()));
   (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 1, false>()));
-  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 1, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 1, true>()));
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<6>());
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<4>());
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<3>());
-  (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<3>());
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<3>());
-  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 1, false, true, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 1, true>()));
-  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<6, 1, false, true, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<6, 1, true>()));
   (void)hipFuncSetAttribute((const void*)final_strip_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, final_strip_lds_bytes());
-  (void)hipFuncSetAttribute((const void*)attn_flash_x3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kFlashLdsBytes);
-  (void)hipFuncSetAttribute((const void*)attn_flash_x3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kFlashLdsBytes);
-  (void)hipFuncSetAttribute((const void*)attn_flash_x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kFlashLdsBytes);
-  (void)hipFuncSetAttribute((const void*)attn_flash_x3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kFlashLdsBytes);
+  (void)hipFuncSetAttribute((const void*)attn_flash_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFlashLdsBytes);
   (void)hipFuncSetAttribute((const void*)attn_decode_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_x3_lds_bytes<4>());
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
@@ -335,12 +325,6 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value != 0 && value != 5) return e->fail(MLDHIP_EINVAL, "fused_dbg must be 0 or 5 (phase counters; the builds with wrong results live in tools/loopbench only)");
     if (value == 5 && !e->trace_buf && hipMalloc((void**)&e->trace_buf, (size_t)512 * 8 * 8 * sizeof(uint64_t)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(trace)");
     e->fused_dbg = (int)value;
-  } else if (n == "final_strip") {
-    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "final_strip must be 0 or 1");
-    e->final_strip = (int)value;
-  } else if (n == "ffn_swz") {
-    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "ffn_swz must be 0 or 1");
-    e->ffn_swz = (int)value;
   } else if (n == "range_probe") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "range_probe must be 0 or 1");
     e->range_probe = (int)value;
@@ -366,30 +350,15 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "dec_l0_once") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "dec_l0_once must be 0 or 1");
     e->dec_l0_once = (int)value;
-  } else if (n == "attn_tr") {
-    if (value < 0 || value > 3) return e->fail(MLDHIP_EINVAL, "attn_tr is a bit mask 0..3 (1 = transpose-read V, 2 = streaming hints)");
-    e->attn_tr = (int)value;
-  } else if (n == "nt_hints") {
-    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "nt_hints must be 0 or 1");
-    e->nt_hints = (int)value;
   } else if (n == "tile_x3") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "tile_x3 must be 0 or 1");
     e->tile_x3 = (int)value;
-  } else if (n == "strip_ring") {
-    if (value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "strip_ring must be 4 or 8");
-    e->strip_ring = (int)value;
   } else if (n == "strip_gemm") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "strip_gemm must be 0 or 1");
     e->strip_gemm = (int)value;
   } else if (n == "ffn_strip") {
     if (value != 0 && value != 1 && value != 3 && value != 4 && value != 6) return e->fail(MLDHIP_EINVAL, "ffn_strip must be 0 (off), 1 (auto: 64- or 96-row strips by launch size), 3, 4 or 6");
     e->ffn_strip = (int)value;
-  } else if (n == "fused_ffn") {
-    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "fused_ffn must be 0 or 1");
-    e->fused_ffn = (int)value;
-  } else if (n == "split_weights") {
-    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "split_weights must be 0 or 1");
-    e->split_weights = (int)value;
   } else if (n == "strip_ffn2_split") {
     if (value != 1 && value != 2) return e->fail(MLDHIP_EINVAL, "strip_ffn2_split must be 1 or 2");
     e->strip_ffn2_split = (int)value;

@@ -90,7 +90,7 @@ def test_every_launch_with_dynamic_lds_has_its_attribute_registered():
             if shmem == "0" or "<" in kernel and re.search(r"\b(WM|WN|MREP|NREP|LN|PREC|NS|NSRC|ACT|CT|MT|TR|PR)\b", kernel):
                 continue                    # no dynamic LDS / a templated launch helper whose instantiations are registered by macro lists
             launched.add(norm(kernel))
-    for k in ("den_loop_kernel<true>", "ffn_strip_x3_kernel<3,true,true>", "strip_gemm_x3_kernel<6,1,false,true,8,3>", "final_strip_x3_kernel", "attn_flash_x3_kernel<true,false>"):
+    for k in ("den_loop_kernel<true>", "ffn_strip_x3_kernel<3,true,true>", "strip_gemm_x3_kernel<6,1,false,true,true>", "final_strip_x3_kernel", "attn_flash_x3_kernel"):
         assert k in launched, (k, sorted(launched))       # the regex really sees the default launches
     missing = sorted(k for k in launched if k not in registered)
     assert not missing, missing

@@ -34,7 +34,7 @@ def lds_cycles_b128(stride_words, word_of_g, base=0):
 
 def constant(fname, name):
     src = open(os.path.join(CSRC, fname)).read()
-    m = re.search(r"constexpr\s+int\s+" + name + r"\s*=\s*(\d+)\s*;", src)
+    m = re.search(r"constexpr\s+int\s+(?:\w+\s*=\s*\d+\s*,\s*)*" + name + r"\s*=\s*(\d+)\s*[;,]", src)
     assert m, (fname, name)
     return int(m.group(1))
 
@@ -48,8 +48,8 @@ def test_the_check_sees_the_round1_conflicts():
 
 
 @pytest.mark.parametrize("fname,name", [("gemm.hpp", "kGemmLdsStride"), ("strip.hpp", "kStripWStride"), ("tile32.hpp", "kT32Stride"),
-                                        ("attention.hpp", "kAttnX3KStride"), ("ffn_fused.hpp", "kFfnXStride"),
-                                        ("ffn_fused.hpp", "kFfnHStride"), ("ffn_fused.hpp", "kFfnWStride")])
+                                        ("attention.hpp", "kAttnX3KStride"), ("ffn_strip.hpp", "kFsXs"), ("ffn_strip.hpp", "kFsHs"),
+                                        ("loop_fused.hpp", "kLfXs"), ("loop_fused.hpp", "kLfHs")])
 def test_fragment_reads_are_conflict_free(fname, name):
     stride = constant(fname, name)
     assert stride % 4 == 0, "rows must stay 16-byte aligned"

@@ -8,7 +8,7 @@ from mld_hip import _lib, synthetic as syn
 
 dev = torch.device("cuda:0")
 N = int(os.environ.get("AB_N", "2048"))
-OPTS = json.loads(os.environ.get("AB_OPTS", '[{"strip_ring": 8}, {"strip_ring": 4}, {"strip_ring": 8}, {"strip_ring": 4}, {"strip_gemm": 0}, {"strip_gemm": 1, "ffn_strip": 0}]'))
+OPTS = json.loads(os.environ.get("AB_OPTS", '[{"dec_tail": 1}, {"dec_tail": 0}, {"dec_tail": 1}, {"dec_tail": 0}, {"dec_tail": 1, "strip_gemm": 0}, {"strip_gemm": 1, "ffn_strip": 0}, {"ffn_strip": 1}]'))
 eng = _lib.Engine(device=0, max_batch=N, max_frames=196, precision=1)
 eng.load_state_dict(syn.make_denoiser_state_dict(), "denoiser."); eng.load_state_dict(syn.make_vae_state_dict(), "vae.")
 m, s = syn.make_mean_std(); eng.load_tensor("mean", m); eng.load_tensor("std", s); eng.finalize()
