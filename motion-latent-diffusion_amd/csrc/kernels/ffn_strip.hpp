@@ -48,6 +48,9 @@ struct FfnArgs {
 };
 
 
+#ifndef TB_EXP
+#define TB_EXP 0          // tools/loopbench/tail_bench.hip experiments (measurement only, 0 in the library)
+#endif
 constexpr int kFsXs = 264, kFsHs = 136;      // row strides (words), = 8 mod 16 (conflict-free fragment reads)
 template <int RT>
 constexpr int ffn_strip_lds_bytes() { return (RT * 16 * kFsXs + RT * 16 * kFsHs + 2 * 8 * RT * 16 + RT * 16) * 4; }   // RT = 6: 160 128 B; RT = 4: 106 752 B; RT = 3: 80 064 B (two per CU)
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][0]), wh, acc[t]);
     }
-    gload(slot);
+    if (!(TB_EXP & 2)) gload(slot);
     sched_fence();                     // keeps the ring's loads where they are written (rt.hpp)
   };
   auto frags = [&](const float* a0, int st, int c, F4 (&x)[RT][2]) __attribute__((always_inline)) {
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
     const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
-    const F4 v = ld4((TAIL ? p.AO : p.X) + (size_t)m * 256 + c4 * 4);
+    const F4 v = (TB_EXP & 4) ? F4{0.1f * c4, 0.2f, -0.3f, 0.01f * row} : ld4((TAIL ? p.AO : p.X) + (size_t)m * 256 + c4 * 4);
     unsigned h0, l0, h1, l1;
     split16_pair(v.x, v.y, h0, l0);
     split16_pair(v.z, v.w, h1, l1);
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
       for (int t = 0; t < RT; ++t) {
         int m = m0 + t * 16 + r;
         m = m < p.M ? m : p.M - 1;
-        const F4 ra = ld4(p.res + (size_t)m * 256 + cq0), rb = ld4(p.res + (size_t)m * 256 + 128 + cq0);
+        const F4 ra = (TB_EXP & 4) ? F4{0.1f, 0.2f, 0.3f, 0.4f} : ld4(p.res + (size_t)m * 256 + cq0), rb = (TB_EXP & 4) ? F4{0.f, 1.f, 0.f, 1.f} : ld4(p.res + (size_t)m * 256 + 128 + cq0);
         const float rav[4] = {ra.x, ra.y, ra.z, ra.w}, rbv[4] = {rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { o0[t][i] += bav[i] + rav[i]; o1[t][i] += bbv[i] + rbv[i]; }
@@ -270,17 +273,18 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       if constexpr (NB == 2) { if (c + 1 < 8) frags(xa, XS, c + 1, x[(c + 1) & 1]); }
-      else frags(xa, XS, c, x[0]);
+      else if (!(TB_EXP & 16) || c == 0) frags(xa, XS, c, x[0]);
       mma_item(c, x[c & (NB - 1)], h, true);
     }
   };
   constexpr int NB = RT == 4 ? 2 : 1;
   // elements 2 ip, 2 ip + 1 of tile t: row 16 t + r, hidden columns 16 wave + 4 g + 2 ip, + 1 (transposed linear1 accumulators)
   auto gelu_two = [&](int t, int ip, F4 b1) __attribute__((always_inline)) {
-    split16_two(gelu_erf(h[t][2 * ip] + (ip ? b1.z : b1.x)), gelu_erf(h[t][2 * ip + 1] + (ip ? b1.w : b1.y)), hvh[t][ip], hvl[t][ip]);
+    if (TB_EXP & 1) split16_two(h[t][2 * ip] + (ip ? b1.z : b1.x), h[t][2 * ip + 1] + (ip ? b1.w : b1.y), hvh[t][ip], hvl[t][ip]);
+    else split16_two(gelu_erf(h[t][2 * ip] + (ip ? b1.z : b1.x)), gelu_erf(h[t][2 * ip + 1] + (ip ? b1.w : b1.y)), hvh[t][ip], hvl[t][ip]);
   };
   auto write_block = [&]() __attribute__((always_inline)) {
-    __syncthreads();                   // every wave has left run2 of the previous block
+    if (!(TB_EXP & 8)) __syncthreads();                   // every wave has left run2 of the previous block
 #pragma unroll
     for (int t = 0; t < RT; ++t)
     {
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
       *reinterpret_cast<U2*>(w) = U2{hvh[t][0], hvh[t][1]};
       *reinterpret_cast<U2*>(w + 16) = U2{hvl[t][0], hvl[t][1]};
     }
-    __syncthreads();
+    if (!(TB_EXP & 8)) __syncthreads();
   };
 
   run1();
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if constexpr (NB == 2) { if (c + 1 < 4) frags(ha, HS, c + 1, x[(c + 1) & 1]); }
-      else frags(ha, HS, c, x[0]);
+      else if (!(TB_EXP & 32) || c == 0) frags(ha, HS, c, x[0]);
       mma_item(2 * c, x[c & (NB - 1)], y0);
 #pragma unroll
       for (int e = (2 * c) * PER; e < (2 * c + 1) * PER; ++e)
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(512, RT <= 3 ? 4 : 2) void ffn_strip_x3_kernel(FfnA
 #pragma unroll
   for (int j = 0; j < RT * 2; ++j) {
     const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
-    if (m0 + row < p.M) st4(p.Y + (size_t)(m0 + row) * 256 + c4 * 4, ld4(Xs + row * XS + c4 * 4));
+    if (m0 + row < p.M && (!(TB_EXP & 4) || row == 0)) st4(p.Y + (size_t)(m0 + row) * 256 + c4 * 4, ld4(Xs + row * XS + c4 * 4));
   }
 }
 

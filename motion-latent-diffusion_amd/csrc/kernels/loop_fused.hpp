@@ -75,7 +75,8 @@ struct LoopArgs {
 };
 
 #ifndef LF_EXP
-#define LF_EXP 0          // tools/loopbench experiments (measurement only, 0 in the library)
+#define LF_EXP 0          // tools/loopbench experiments (measurement builds with WRONG results; 0 in the library): 1 / 4 = linear1 / linear2 re-use stale A
+                          // fragments (no LDS reads), 2 = no barrier per hidden block, 8 = the weight ring is never refreshed
 #endif
 constexpr int kLfXs = 264;                                // LDS row stride (words), = 8 mod 16: conflict-free fragment reads (strip.hpp)
 constexpr int kLfHs = 136;                                // ... of a 128-wide block of the hidden activation
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   F4 ring[kLoopRing][2];
   auto gload = [&](int slot) __attribute__((always_inline)) {
     const float* s = p.stream + goff;
-    ring[slot][0] = ld4(s);
+    ring[slot][0] = ld4(s);            // default cache policy: the CUs of an XCD re-read the same items from its L2 (`nt` loads: 19.0 -> 35.8 ms, r04)
     ring[slot][1] = ld4(s + 4);
     goff += (unsigned)kLoopItemFloats;
 #if !defined(MLDHIP_SIM)
@@ -461,15 +462,11 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   const float* xa = Xs + r * kLfXs + gs4;          // A fragments of the layer input
   const float* aa = As + r * kLfXs + gs4;          // ... of the attention output / the hidden-activation blocks
 
-#if !defined(MLDHIP_SIM)
-  if (LF_EXP & 32) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
-  if (LF_EXP & 64) { if (wave & 1) __builtin_amdgcn_s_setprio(1); }
-#endif
   if constexpr (DBG == 5) tph = clock_pinned();
   for (int step = 0; step < p.n; ++step) {
     goff = (unsigned)tid * 8u + (unsigned)(kLoopRing * kLoopItemFloats);
-    float x[2][3][4];                              // norm2 output of the current layer at this lane's positions
     for (int l = 0; l < p.L; ++l) {
+      float x[2][3][4];                            // norm2 output of this layer at this lane's positions (dies inside the layer: the next one reads Xs)
       const float* sm = prm + pbuf * kLfPrmFloats;        // this layer's small parameters (LDS)
       // ================= self-attention: two heads at a time (cross_attention.py:265-266; nn.MultiheadAttention, 4 heads of 64)
       for (int hp = 0; hp < 2; ++hp) {
@@ -717,42 +714,43 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
           put(Xs, kLfXs, 128, x[1]);
           __syncthreads();
         }
+      } else {
+      // ================= behind the last layer: end of the step: encoder.norm on the latent token (mld_denoiser.py:206), CFG (mld.py:339-342), DDIM eta = 0
+      {
+        ln_part1(x, 1);
+        __syncthreads();
+        ln_part2(x, 1, sm_fin, sm_fin + 256);
+        const float sat = p.ddim[step * 4], s1mat = p.ddim[step * 4 + 1], sap = p.ddim[step * 4 + 2], s1map = p.ddim[step * 4 + 3];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          float ec[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ec[i] = wave_xor(x[cb][0][i], 8);     // CFG row c + 8 lives in lane + 8 (same g)
+          if (r < 8) {
+            float* lp = lats + r * 256 + cb * 128 + cq0;
+            const F4 xt = ld4(lp);
+            const float xtv[4] = {xt.x, xt.y, xt.z, xt.w};
+            float nv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float eu = x[cb][0][i];
+              const float eps = eu + p.guidance * (ec[i] - eu);
+              const float x0 = (xtv[i] - s1mat * eps) / sat;
+              nv[i] = sap * x0 + s1map * eps;
+            }
+            st4(lp, F4{nv[0], nv[1], nv[2], nv[3]});
+          }
+        }
+        __syncthreads();
+        if (step + 1 < p.n) {
+          assemble(step + 1);
+          __syncthreads();
+        }
+        stamp(6);
+      }
       }
       stamp(5);
       pbuf ^= 1;
-    }
-    // ================= end of the step: encoder.norm on the latent token (mld_denoiser.py:206), CFG (mld.py:339-342), DDIM eta = 0
-    {
-      ln_part1(x, 1);
-      __syncthreads();
-      ln_part2(x, 1, sm_fin, sm_fin + 256);
-      const float sat = p.ddim[step * 4], s1mat = p.ddim[step * 4 + 1], sap = p.ddim[step * 4 + 2], s1map = p.ddim[step * 4 + 3];
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        float ec[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ec[i] = wave_xor(x[cb][0][i], 8);     // CFG row c + 8 lives in lane + 8 (same g)
-        if (r < 8) {
-          float* lp = lats + r * 256 + cb * 128 + cq0;
-          const F4 xt = ld4(lp);
-          const float xtv[4] = {xt.x, xt.y, xt.z, xt.w};
-          float nv[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float eu = x[cb][0][i];
-            const float eps = eu + p.guidance * (ec[i] - eu);
-            const float x0 = (xtv[i] - s1mat * eps) / sat;
-            nv[i] = sap * x0 + s1map * eps;
-          }
-          st4(lp, F4{nv[0], nv[1], nv[2], nv[3]});
-        }
-      }
-      __syncthreads();
-      if (step + 1 < p.n) {
-        assemble(step + 1);
-        __syncthreads();
-      }
-      stamp(6);
     }
   }
   {
