@@ -28,6 +28,9 @@ struct StripGemmArgs {
   const float* g2 = nullptr; const float* b2 = nullptr;
 };
 
+#ifndef SB_EXP
+#define SB_EXP 0          // tools/loopbench/strip_bench.hip experiments (measurement only, 0 in the library)
+#endif
 template <int RT, int NSEG, bool STAGE>
 constexpr int strip_gemm_lds_bytes() { return (NSEG * RT * 16 * kFsXs + (STAGE ? RT * 16 * kFsHs : 0) + 2 * 8 * RT * 16 + RT * 16) * 4; }
 
@@ -83,13 +86,14 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
   auto mma_item = [&](int j, const F4 (&x)[RT][2], f32x4 (&acc)[RT]) __attribute__((always_inline)) {
     const int slot = j % RING;
     const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
+    if (SB_EXP & 8) { acc[0][0] += ring[slot][0].x + ring[slot][1].w + x[0][0].x; gload(slot); sched_fence(); return; }
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][1]), wh, acc[t]);
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][0]), wl, acc[t]);
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = mfma_x3_16x16x32(__builtin_bit_cast(U4, x[t][0]), wh, acc[t]);
-    gload(slot);
+    if (!(SB_EXP & 4)) gload(slot);
     sched_fence();
   };
 
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
       const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;
-      const F4 v = ld4_hint<NT>(src + (size_t)m * 256 + c4 * 4);
+      const F4 v = (SB_EXP & 1) ? F4{0.01f * c4, 0.5f, -0.25f, 0.001f * row} : ld4_hint<NT>(src + (size_t)m * 256 + c4 * 4);
       unsigned h0, l0, h1, l1;
       split16_pair(v.x, v.y, h0, l0);
       split16_pair(v.z, v.w, h1, l1);
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
 #pragma unroll
           for (int j = 0; j < RT; ++j) {
             const int idx = tid + j * 512, row = idx >> 5, c4 = idx & 31;
-            if (m0 + row < p.M) st4_hint<NT>(p.Y + (size_t)(m0 + row) * p.ldy + pr * 256 + cb * 128 + c4 * 4, ld4(St + row * HS + c4 * 4));
+            if (m0 + row < p.M && (!(SB_EXP & 2) || row == 0)) st4_hint<NT>(p.Y + (size_t)(m0 + row) * p.ldy + pr * 256 + cb * 128 + c4 * 4, ld4(St + row * HS + c4 * 4));
           }
         }
       } else {
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
 #pragma unroll
         for (int j = 0; j < RT * 2; ++j) {
           const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
-          if (m0 + row < p.M) st4_hint<NT>(p.Y + (size_t)(m0 + row) * p.ldy + c4 * 4, ld4(Xs + row * XS + c4 * 4));
+          if (m0 + row < p.M && (!(SB_EXP & 2) || row == 0)) st4_hint<NT>(p.Y + (size_t)(m0 + row) * p.ldy + c4 * 4, ld4(Xs + row * XS + c4 * 4));
         }
       }
     } else {
