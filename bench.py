@@ -738,6 +738,10 @@ def main():
             peak = X3_PEAK_TF if x3 else FP32_MFMA_PEAK_TF
             roof.update({"kernel": "den_loop_kernel (kernels/loop_fused.hpp): the whole 50-step reverse loop of the call, one launch",
                          "achieved": round(flop_loop_call / use_us * 1e3, 2), "peak": round(peak, 1), "frac": round(flop_loop_call / use_us * 1e3 / peak, 4),
+                         "workgroups": (PB + 7) // 8, "cus": 256, "occupancy": round(min(1.0, (PB + 7) // 8 / 256.0), 3),
+                         "frac_on_occupied_cus": round(flop_loop_call / use_us * 1e3 / peak / min(1.0, (PB + 7) // 8 / 256.0), 4),
+                         "occupancy_note": "a workgroup owns 8 motions (48 token rows = three full 16-row MFMA tiles); the kernel's run time is flat in the batch, so a call "
+                                           "below 2 048 motions leaves CUs without a workgroup -- fewer motions per workgroup would not remove a row tile",
                          "gflop_per_launch": round(flop_loop_call, 1), "avg_us_rocprof_dispatch": round(avg_us, 1) if avg_us else None,
                          "avg_us_hip_events_loop_only_call": round(loop_ms * 1e3, 1) if loop_ms else None,
                          "clock": "hip_events on the launch stream, loop-only calls (include the condition-row GEMM and the latent copies)" if loop_ms else "rocprofv3 dispatch average",
