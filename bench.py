@@ -798,9 +798,9 @@ def main():
                 for _ in range(3):
                     t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
                 sweep[str(c_)] = {"motions_per_call": BATCH * c_, "ms_per_call": round(min(ts) * 1e3, 3), "value": round(BATCH * c_ / min(ts), 1),
-                                  "loop_workgroups": (BATCH * c_ + 7) // 8 if BATCH * c_ >= 320 else None}
+                                  "loop_workgroups": (BATCH * c_ + 7) // 8 if BATCH * c_ >= 192 else None}
             out["requests_per_call_sweep"] = {"unit": "motions/s", "note": "one call at a time, best of 3; loop_workgroups = workgroups of the persistent loop "
-                                              "(None: the call is below its 320-motion threshold and runs the column-split / latency kernels)", "shapes": sweep}
+                                              "(None: the call is below its 192-motion threshold and runs the latency kernels)", "shapes": sweep}
             # ---- BASELINE config 3 (512 prompts over 8 ranks) as seen by ONE rank: its share is one bs-64 batch (world 8) or all 512 (world 1)
             rs512 = reqs_all[:8]
             eng.sample_many(rs512, stream.cuda_stream)

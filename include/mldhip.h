@@ -146,10 +146,10 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     (kernels/strip.hpp: a few hundred motions per call), 3 = the sample-major persistent loop
  *                     (kernels/loop_fused.hpp: ONE launch for all steps of the call, a workgroup per 8 motions, weights streamed in
  *                     consumption order; built for latent_dim 256 / ff_size 1024 / 4 heads in the F32 and F16X3 modes -- refused
- *                     elsewhere).  Its run time does not depend on the batch up to 8 x #CUs = 2 048 motions, so it wins from ~1 000
- *                     motions per call up.
- *   "fused_min_batch" auto picks the persistent loop from this many motions per call up; 0 (default) = by operand format: 320 on
- *                     split-f16 MFMAs (27 ms per call whatever the batch), 1 280 on exact-fp32 MFMAs (77 ms)
+ *                     elsewhere).  Its run time does not depend on the batch up to 8 x #CUs = 2 048 motions.
+ *   "fused_min_batch" auto picks the persistent loop from this many motions per call up; 0 (default) = by operand format, from the measured
+ *                     crossover table (tools/ab_crossover.py, profiles/r04_loop_crossover.json): 192 on split-f16 MFMAs (19 ms per call
+ *                     whatever the batch; the split-f16 latency kernels take 19.0 ms at 192 motions), 1 280 on exact-fp32 MFMAs (73 ms)
  *   "fused_x3"        F16X3 mode: 1 (default) = the persistent loop multiplies on split-f16 MFMAs (row-swizzled operand images, 4 weight
  *                     items in flight per lane: the settled forms of round 3's "fused_swz" / "fused_ring" knobs), 0 = on exact-fp32 MFMAs
  *   "fused_dbg"       5 = the F16X3 persistent loop with per-phase cycle counters of the first 64 workgroups (same arithmetic, same
@@ -174,8 +174,9 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     on split-f16 MFMAs reading the pre-split weight image, 0 = on exact-fp32 MFMAs
  *   "strip_gemm"      F16X3 / FP8 modes, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:
  *                     1 (default) = row-strip kernels with register-direct weights (kernels/gemm_strip_x3.hpp), 0 = staged tiles
- *   "strip_min_rows"  auto picks the throughput kernels when the reverse loop has >= this many token rows
- *                     (6 x batch; default 768 = 128 motions)
+ *   "strip_min_rows"  auto picks the column-split throughput kernels when the reverse loop has >= this many token rows (6 x batch; default
+ *                     768 = 128 motions) -- in the modes whose latency kernels run fp32 / bf16 / fp8; in the F16X3 mode the split-f16
+ *                     latency kernels serve every call below the persistent loop's threshold (15.2 vs 18.4 ms at 128 motions)
  *   "strip_wide"      throughput kernels: 32 x 128 tiles for the wide GEMMs: 0 = auto (N >= 512), 1 = never, 2 = whenever N % 128 == 0
  *   "strip_waves"     throughput kernels: waves per workgroup of the 32 x 128 tiles, 4 or 8 (default 8)
  *   "strip_ffn2_split" throughput kernels: K slices (raw slabs) of the FFN2 GEMM, 1 or 2 (default 2)

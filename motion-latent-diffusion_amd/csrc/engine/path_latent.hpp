@@ -127,8 +127,19 @@ struct DenView {
   int ffn_slabs, skip_slabs;   // raw partial slabs FFN2 / the skip linear leave behind
 };
 
+// Which family runs the reverse loop of a call is a measured table (tools/ab_crossover.py -> profiles/r04_loop_crossover.json; ms per loop-only
+// call of B motions, MI355X):          B =    64    128    192    256    320    640  | exact fp32:  256    640   1 024  1 280  1 536
+//   latency kernels (tile32.hpp)           11.1   15.2   19.0   21.0     --     --  |             27.2     --     --     --     --
+//   column-split throughput (strip.hpp)    18.3   18.4   23.2   25.4   26.3   40.7  |             25.4   40.5   59.9   74.4   87.1
+//   persistent loop (loop_fused.hpp)       19.8   19.5   19.3   19.2   19.1   18.9  |             73.0   73.2   73.5   73.7   73.8
+// Split-f16 mode: the latency kernels (split-f16 MFMAs under "tile_x3") up to 191 motions, the persistent loop from 192 -- the
+// column-split family, whose loop arithmetic is fp32 in that mode, never wins there.  Exact fp32: latency kernels below 128 motions
+// ("strip_min_rows" 768), column-split up to 1 279, persistent loop from 1 280.
 bool use_strip(const E* e, int rows) {
-  return e->loop_kernel == 2 || (e->loop_kernel == 0 && rows >= e->strip_min_rows);
+  if (e->loop_kernel == 2) return true;
+  if (e->loop_kernel != 0) return false;
+  if (latency_prec(e) == PREC_BF16X3 && rows < 6 * 256) return false;      // split-f16 latency kernels beat the fp32 column-split ones wherever both run
+  return rows >= e->strip_min_rows;
 }
 
 DenView den_view(E* e, int R) {
@@ -237,9 +248,9 @@ bool fused_built(const E* e) {
   return !is_novae(e) && e->cfg.latent_dim == 256 && e->cfg.ff_size == 1024 && e->cfg.num_heads == 4 && loop_prec(e) == PREC_F32;
 }
 bool use_fused(const E* e, int B) {
-  // auto: the persistent loop takes the same time for any batch up to 8 x #CUs motions -- 29 ms on split-f16 MFMAs, 77 ms on exact-fp32
-  // ones (r03) -- the column-split throughput kernels 30 ms at 320 motions, 65 ms at 1 024, 120 ms at 2 048: cross-over by operand format
-  const int auto_min = e->fused_min_batch > 0 ? e->fused_min_batch : (fused_split(e) ? 320 : 1280);
+  // auto: the persistent loop takes the same time for any batch up to 8 x #CUs motions -- 19 ms on split-f16 MFMAs, 73 ms on exact-fp32
+  // ones (r04) -- see the measured table at use_strip above: cross-over by operand format
+  const int auto_min = e->fused_min_batch > 0 ? e->fused_min_batch : (fused_split(e) ? 192 : 1280);
   return e->loop_ips > 0 && (e->loop_kernel == 3 || (e->loop_kernel == 0 && B >= auto_min));
 }
 

@@ -71,7 +71,7 @@ class DataParallelSampler:
     never shared by two calls at once).  Results are identical either way.
 
     coalesce: how many consecutive chunks go into ONE engine call (``MLD.sample_many`` -> ``mldhip_sample_many``: one chain over
-    coalesce x batch_size motions; from 320 motions per call the split-f16 engine runs the reverse loop as one persistent launch, a
+    coalesce x batch_size motions; from 192 motions per call the split-f16 engine runs the reverse loop as one persistent launch, a
     workgroup per 8 motions, whose run time does not depend on the batch up to 2 048 motions).  ``None`` (default) = automatic:
     as many chunks of this rank's shard as the engine's capacity holds, ``min(chunks, engine.max_batch // batch_size)`` -- BASELINE
     config 3 (512 prompts) on ONE rank is one 512-motion call instead of eight latency-kernel calls when the engine was configured
@@ -121,10 +121,21 @@ class DataParallelSampler:
 
         can_overlap = (torch.cuda.is_available() and getattr(m, "fused", False)
                        and getattr(m, "condition", None) == "text" and not novae)         # latent text-to-motion only
-        coalesce = self.pick_coalesce(len(chunks)) if can_overlap else 1
+        can_coalesce_action = torch.cuda.is_available() and getattr(m, "fused", False) and action and hasattr(m, "sample_many_action")
+        coalesce = self.pick_coalesce(len(chunks)) if (can_overlap or can_coalesce_action) else 1
         self.last_coalesce = coalesce
         overlap = can_overlap and (self.in_flight > 1 or coalesce > 1)
         out = []
+        if can_coalesce_action and coalesce > 1:
+            # action model: `coalesce` chunks per engine call (MLD.sample_many_action -> mldhip_sample_many)
+            for g0 in range(0, len(chunks), coalesce):
+                grp = chunks[g0:g0 + coalesce]
+                reqs = [([int(a) for a in actions[s:e]], [int(x) for x in lengths[s:e]]) for s, e in grp]
+                lats = [noise(s, e, ln) for (s, e), (_, ln) in zip(grp, reqs)] if init_latents is not None else None
+                for (feats, _), (_, ln) in zip(m.sample_many_action(reqs, init_latents=lats, device=dev), reqs):
+                    f = feats.cpu()
+                    out.extend(f[k, :n] for k, n in enumerate(ln))
+            return list(range(lo, hi)), out
         if not overlap:
             for s, e in chunks:
                 ln = [int(x) for x in lengths[s:e]]

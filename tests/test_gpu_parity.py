@@ -433,6 +433,18 @@ def test_action_mld_module_surface_on_gpu(dev):
     ops = O.NumpyOps(np.float32)
     fr = O.sample_action(ops, O.to_backend(ops, sdd), O.to_backend(ops, sdv), acts, lat0, lengths)
     assert rs["m_rst"].is_cuda and np.abs(rs["m_rst"].cpu().numpy() - fr).max() < 1e-3
+    # several requests in ONE engine call (MLD.sample_many_action -> mldhip_sample_many) and the sampler's automatic requests per call:
+    # 5 labels in chunks of 2 on an engine that holds 8 motions -> all three chunks coalesced, the same features per label
+    outs = model.sample_many_action([(acts[:2], lengths[:2]), (acts[2:], lengths[2:])], init_latents=[_cuda(lat0[:2], dev), _cuda(lat0[2:], dev)])
+    got = torch.cat([torch.nn.functional.pad(f, (0, 0, 0, 60 - f.shape[1])) for f, _ in outs]).cpu().numpy()
+    for i, n in enumerate(lengths):
+        assert np.abs(got[i, :n] - fr[i, :n]).max() < 1e-3
+    from mld_hip.dp import DataParallelSampler
+    smp = DataParallelSampler(model, batch_size=2)
+    idx, feats = smp(actions=[int(a) for a in acts], lengths=lengths, init_latents=torch.from_numpy(lat0))
+    assert idx == list(range(5)) and smp.last_coalesce == 3
+    for i, n in enumerate(lengths):
+        assert feats[i].shape == (n, 150) and np.abs(feats[i].numpy() - fr[i, :n]).max() < 1e-3
     E.drop_engines()
 
 
