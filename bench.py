@@ -813,18 +813,29 @@ def main():
 
         cj = None
         if world == 1 and not a.no_cpu_baseline:
-            threads = min(32, os.cpu_count() or 1)          # MKL/OpenMP oversubscribes badly on a 256-thread host with these small GEMMs
-            info, cj = cpu_baseline(1234 + rank, threads)
+            # MKL/OpenMP oversubscribes badly on a 256-thread host with these small GEMMs: three thread counts, the best one is the baseline
+            # (VERDICT r3 weak #6c: 32 threads alone understated it); ~5 s of CPU work each
+            ncpu = os.cpu_count() or 1
+            tries = {}
+            info, cj = None, None
+            for th in sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
+                inf_, cj_ = cpu_baseline(1234 + rank, th)
+                if cj_ is None:
+                    continue
+                tries[str(th)] = round(inf_["motions_per_s"], 2)
+                if info is None or inf_["motions_per_s"] > info["motions_per_s"]:
+                    info, cj = inf_, cj_
+            threads = info["threads"] if info else min(32, ncpu)
             if cj is not None:
                 out["cpu_baseline"] = {"value": round(info["motions_per_s"], 2), "unit": "motions/s", "cores": info["threads"],
-                                       "kind": "port", "host_cpus": info["cores"],
-                                       "sample": "1 batch of 64 motions (T=196, 50 steps) through oracle.mld_oracle (torch-CPU backend), %.1f s" % info["seconds"],
+                                       "kind": "port", "host_cpus": info["cores"], "motions_per_s_by_threads": tries,
+                                       "sample": "1 batch of 64 motions (T=196, 50 steps) through oracle.mld_oracle (torch-CPU backend), %.1f s, best of the thread counts tried" % info["seconds"],
                                        "reference_modules_survey": {
                                            "value": 15.2, "unit": "motions/s", "cores": 8, "host": "survey sandbox, Xeon 2.1 GHz, MKL",
                                            "provenance": "SURVEY.md §8(d) probe: the reference's own MldDenoiser / MldVae modules + restated DDIM at B=64 "
                                                          "(4.2 s per batch); /root/reference cannot travel to the GPU box, so it is not re-timed here"}}
             else:
-                out["cpu_baseline"] = {"value": None, "unit": "motions/s", "cores": threads, "kind": "port", "sample": str(info)}
+                out["cpu_baseline"] = {"value": None, "unit": "motions/s", "cores": threads, "kind": "port", "sample": "the oracle child failed or timed out"}
             # the same array code on stock ATen kernels of the SAME GPU (SURVEY.md §7.2b "PyTorch-ROCm eager motions/s on the same GPU")
             info_g, jg = cpu_baseline(1234 + rank, threads, device="cuda", repeat=3)
             if jg is not None:

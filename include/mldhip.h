@@ -198,6 +198,8 @@ int mldhip_set_option(mldhip_handle* h, const char* name, int64_t value);
  *     reverse steps of the persistent loop and one denoiser call of the latency kernels at the first and last timestep; one
  *     decode of 4 x 64 frames) and compares: err = max|split - fp32| / max|fp32| (for the two loop steps: max|split - fp32| of the
  *     latents / max|latents - start noise| / (2 guidance_scale - 1), i.e. relative to the update the steps made, whatever the schedule).
+ *     Diffusion-only variant: one denoiser call on 4 CFG rows x 128 frames, reported as probe_err_decode / decode_split_ok (all of its
+ *     GEMMs and its frame-level attention follow that switch).
  *  2. FALLBACK: a stage whose err exceeds MLDHIP_PROBE_TOL (or is not finite) runs on the exact-fp32 kernels from then on --
  *     loop_split_ok = 0: reverse loop (persistent loop and latency kernels on v_mfma_f32_16x16x4_f32, ~3x slower);
  *     decode_split_ok = 0: decoder / encoder / diffusion-only GEMMs and attention.  Results then equal MLDHIP_PREC_F32's.

@@ -518,6 +518,25 @@ int range_probe(mldhip_handle* e, hipStream_t stream) {
     e->probe_err_decode = rel_err(ha, hb);
     e->split_decode_ok = e->probe_err_decode <= MLDHIP_PROBE_TOL;
   }
+  if (e->group_ready[0] && is_novae(e)) {
+    // ---- diffusion-only variant: one denoiser call (every GEMM and the frame-level attention run split in this mode) on 4 CFG rows x 128
+    //      frames (512 rows: above "gemm_small_m", so the staged split-f16 GEMMs are the ones that run)
+    const int R = 2 * std::min(2, e->cfg.max_batch), T = std::min(128, e->cfg.max_frames);
+    std::vector<float> hx((size_t)R * T * NF), ht((size_t)R * TD);
+    fill(hx, 1.0f); fill(ht, 0.5f);
+    std::vector<int32_t> lens(R, T);
+    lens[1] = std::max(1, T - 5); lens[R - 1] = std::max(1, T - 5);
+    Dev x, text, out;
+    if (x.up(hx) || text.up(ht) || out.make((size_t)R * T * NF)) return e->fail(MLDHIP_EHIP, "range probe: hipMalloc");
+    std::vector<float> ha, hb;
+    for (int split = 1; split >= 0; --split) {
+      e->split_decode_ok = split != 0;
+      if (int rc = mldhip_denoiser_forward_novae(e, x.p, e->timesteps[0], text.p, lens.data(), R, T, out.p, stream)) return rc;
+      if (down(out.p, (size_t)R * T * NF, split ? ha : hb)) return e->fail(MLDHIP_EHIP, "range probe: copy");
+    }
+    e->probe_err_decode = rel_err(ha, hb);
+    e->split_decode_ok = e->probe_err_decode <= MLDHIP_PROBE_TOL;
+  }
   e->phase = 0;
   return MLDHIP_OK;
 }

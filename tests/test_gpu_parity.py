@@ -915,6 +915,8 @@ def test_reduced_precision_modes_run_and_stay_sane(dev, golden_dir):
     e.load_tensor("mean", mean)
     e.load_tensor("std", std)
     e.finalize()
+    ns = e.numeric_status()                             # the range probe covers this variant too (one denoiser call, split vs fp32 kernels)
+    assert ns["probed"] == 1 and ns["decode_split_ok"] == 1 and 0 <= ns["probe_err_decode"] <= _lib.PROBE_TOL, ns
     e.set_option("gemm_small_m", 0)                     # 240 rows: drive the staged (precision-aware) GEMMs as at full size
     feats = torch.empty(3, 40, 263, device=dev)
     e.sample_novae(_cuda(gn["text_emb"], dev), _cuda(gn["init_latents"], dev), lens, _cuda(gn["step_noise"], dev), 0, feats, None)
