@@ -344,13 +344,11 @@ int build_ffn_streams(Ctx& c) {
   e->final_stream = nullptr;
   if (e->ffn_streams) { (void)hipFree(e->ffn_streams); e->ffn_streams = nullptr; }
   const bool split = e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE || e->cfg.precision == MLDHIP_PREC_FP8_DENOISER;
-  if (!split) return 0;
-  const bool novae512 = is_novae(e) && e->cfg.latent_dim == 512 && e->group_ready[0];      // K = 512 GEMMs of the trans_dec denoiser (path_novae.hpp)
-  if (!novae512 && (is_novae(e) || e->cfg.latent_dim != 256 || e->cfg.ff_size != 1024)) return 0;
+  if (!split || is_novae(e) || e->cfg.latent_dim != 256 || e->cfg.ff_size != 1024) return 0;
   std::vector<std::pair<const float*, const float*>> layers;
   if (e->group_ready[1]) for (auto& L : e->dec) layers.push_back({L.l1_w, L.l2_w});
   if (e->group_ready[3]) for (auto& L : e->venc) layers.push_back({L.l1_w, L.l2_w});
-  if (layers.empty() && !novae512) return 0;
+  if (layers.empty()) return 0;
   std::vector<LoopItem> items;
   auto push = [&](const float* w, int ld, int row0, int k0) { items.push_back(LoopItem{(long long)(w - e->arena) + (long long)row0 * ld + k0, ld, 0}); };
   for (auto& lw : layers) {
@@ -371,18 +369,11 @@ int build_ffn_streams(Ctx& c) {
           for (int cb = 0; cb < 2; ++cb) push(w, K, (2 * pr + cb) * 128, sg * 256 + kc * 32);
   };
   const int nbv = (e->cfg.num_layers - 1) / 2;
-  if (novae512) {
-    const int D = 512;
-    for (auto& L : e->ndec) {
-      gstream(L.in_w, 3 * D, D); gstream(L.out_w, D, D); gstream(L.cin_w, D, D); gstream(L.cout_w, D, D);
-      if (e->cfg.ff_size % 256 == 0) gstream(L.l1_w, e->cfg.ff_size, D);
-    }
-  }
-  if (!novae512 && e->group_ready[1]) {
+  if (e->group_ready[1]) {
     for (auto& L : e->dec) { gstream(L.in_w, 768, 256); gstream(L.out_w, 256, 256); }
     if (!is_actor(e)) for (int i = 0; i < nbv; ++i) gstream(P(e, "vae.decoder.linear_blocks." + std::to_string(i) + ".weight"), 256, 512);
   }
-  if (!novae512 && e->group_ready[3]) {
+  if (e->group_ready[3]) {
     for (auto& L : e->venc) { gstream(L.in_w, 768, 256); gstream(L.out_w, 256, 256); }
     if (!is_actor(e)) for (int i = 0; i < nbv; ++i) gstream(P(e, "vae.encoder.linear_blocks." + std::to_string(i) + ".weight"), 256, 512);
   }
@@ -392,7 +383,7 @@ int build_ffn_streams(Ctx& c) {
   e->final_stream = nullptr;
   const size_t final_first = items.size();
   const int NFv = e->cfg.nfeats;
-  if (!novae512 && e->group_ready[1] && !is_actor(e) && NFv > 256 && NFv <= kFsXs) {
+  if (e->group_ready[1] && !is_actor(e) && NFv > 256 && NFv <= kFsXs) {
     const float* wf = P(e, "vae.final_layer.weight");
     for (int kc = 0; kc < 8; ++kc)
       for (int blk = 0; blk < 3; ++blk) {
@@ -505,25 +496,6 @@ void dec_attention(Ctx& c, int B, int T, const int32_t* lens = nullptr, int shar
 int strip_rows_rt(const E* e, int M) {
   if (e->ffn_strip == 4 || e->ffn_strip == 6) return e->ffn_strip;
   return (M + 63) / 64 <= 512 ? 4 : 6;
-}
-
-// The K = 512 GEMMs of the diffusion-only variant (trans_dec denoiser, d = 512: in-projection N = 1536, the three N = 512 projections,
-// linear1 N = 1024 with GELU) on the row-strip kernel: a 48-row strip of the 512-wide rows is two K segments of one row (A2 = A + 256,
-// row pitch 512), the output leaves through the staging tile.  Replaces the staged 64 x 256 tiles of gemm.hpp for those shapes
-// (mld_denoiser.py:208-221, cross_attention.py:195-233); K = 1024 (linear2) and the 263-wide edges stay on the staged family.
-bool strip_gemm_k512(Ctx& c, const GemmArgs& g) {
-  E* e = c.e;
-  if (!e->strip_gemm || staged_prec(e) != PREC_BF16X3 || e->trace_on || g.M <= e->small_m) return false;
-  if (g.K1 != 512 || g.lda != 512 || g.K2 != 0 || g.N % 256 || (g.act != ACT_NONE && g.act != ACT_GELU) || g.relu_in || g.lens || g.res || g.skip_lens) return false;
-  auto it = e->gemm_stream_of.find(g.W);
-  if (it == e->gemm_stream_of.end()) return false;
-  StripGemmArgs a;
-  a.A = g.A; a.A2 = g.A + 256; a.lda = 512; a.W = it->second; a.bias = g.bias; a.Y = g.Y; a.ldy = g.ldy; a.M = g.M; a.N = g.N;
-  a.act = g.act == ACT_GELU ? 1 : 0;
-  MLD_LAUNCH((strip_gemm_x3_kernel<3, 2, false, true, true>), dim3((g.M + 47) / 48), dim3(512), (strip_gemm_lds_bytes<3, 2, true>()), c.stream, a);
-  count(c);
-  check_launch(c, "strip_gemm_k512");
-  return true;
 }
 
 bool strip_gemm(Ctx& c, const GemmArgs& g, bool ln) {

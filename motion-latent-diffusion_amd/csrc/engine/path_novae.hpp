@@ -62,20 +62,20 @@ void novae_denoiser_body(Ctx& c, int R, int T, const float* tkv, long long tkv_s
   check_launch(c, "add_pe_mod");
   for (int l = 0; l < e->cfg.num_layers && !c.rc; ++l) {
     const DecLayerP& L = e->ndec[l];
-    { const GemmArgs q = lin_args(e->X0, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D); if (!strip_gemm_k512(c, q)) gemm(c, q); }
+    gemm(c, lin_args(e->X0, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
     novae_self_attention(c, R, T);
-    { const GemmArgs o = lin_args(e->AO, D, D, L.out_w, L.out_b, e->Ha, D, M, D); if (!strip_gemm_k512(c, o)) gemm(c, o); }
+    gemm(c, lin_args(e->AO, D, D, L.out_w, L.out_b, e->Ha, D, M, D));
     novae_ln(c, e->Ha, e->X0, L.n1_w, L.n1_b, e->H1, M);
-    { const GemmArgs q = lin_args(e->H1, D, D, L.cin_w, L.cin_b, e->Hb, D, M, D); if (!strip_gemm_k512(c, q)) gemm(c, q); }      // cross-attention queries
+    gemm(c, lin_args(e->H1, D, D, L.cin_w, L.cin_b, e->Hb, D, M, D));                    // cross-attention queries
     MLD_LAUNCH((cross2_kernel<512, 128>), dim3((M + 3) / 4), dim3(256), 0, c.stream, (const float*)e->Hb, tkv + (size_t)l * tkv_stride,
                (const float*)(e->XKV + (size_t)l * 2 * e->cfg.max_batch * 2 * D), e->AO, M, T);
     count(c);
     check_launch(c, "cross2");
-    { const GemmArgs o = lin_args(e->AO, D, D, L.cout_w, L.cout_b, e->Ha, D, M, D); if (!strip_gemm_k512(c, o)) gemm(c, o); }
+    gemm(c, lin_args(e->AO, D, D, L.cout_w, L.cout_b, e->Ha, D, M, D));
     novae_ln(c, e->Ha, e->H1, L.n2_w, L.n2_b, e->X0, M);
     GemmArgs f1 = lin_args(e->X0, D, D, L.l1_w, L.l1_b, e->FF, F, M, F);
     f1.act = ACT_GELU;
-    if (!strip_gemm_k512(c, f1)) gemm(c, f1);
+    gemm(c, f1);
     gemm(c, lin_args(e->FF, F, F, L.l2_w, L.l2_b, e->Ha, D, M, D));
     novae_ln(c, e->Ha, e->X0, L.n3_w, L.n3_b, e->X0, M);       // in place: a wave reads its whole row before writing it
   }

@@ -14,10 +14,8 @@
 namespace mld {
 
 struct StripGemmArgs {
-  const float* A = nullptr;          // [M][lda] first K segment (256 columns)
-  const float* A2 = nullptr;         // [M][lda] second K segment (skip concat; or A + 256 of a 512-wide row: the diffusion-only variant) or NULL
-  int lda = 256;                     // row pitch of A / A2 in floats
-  int act = 0;                       // 1: erf-GELU on the output (ACT_GELU; the non-LN forms)
+  const float* A = nullptr;          // [M][256] first K segment
+  const float* A2 = nullptr;         // [M][256] second K segment (skip concat) or NULL
   const float* W = nullptr;          // fragment-ordered stream of the weight (N / 256 pairs x NSEG x 8 chunks x 2 items)
   const float* bias = nullptr;       // [N]
   float* Y = nullptr; int ldy = 0;
@@ -110,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
       const int idx = tid + j * 512, row = idx >> 6, c4 = idx & 63;
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;
-      const F4 v = (SB_EXP & 1) ? F4{0.01f * c4, 0.5f, -0.25f, 0.001f * row} : ld4_hint<NT>(src + (size_t)m * p.lda + c4 * 4);
+      const F4 v = (SB_EXP & 1) ? F4{0.01f * c4, 0.5f, -0.25f, 0.001f * row} : ld4_hint<NT>(src + (size_t)m * 256 + c4 * 4);
       unsigned h0, l0, h1, l1;
       split16_pair(v.x, v.y, h0, l0);
       split16_pair(v.z, v.w, h1, l1);
@@ -146,10 +144,7 @@ __global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) 
 #pragma unroll
           for (int t = 0; t < RT; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float v = cb == 0 ? acc0[t][i] + bi0 : acc1[t][i] + bi1;
-              St[(t * 16 + g * 4 + i) * HS + col0] = p.act == 1 ? gelu_erf(v) : v;
-            }
+            for (int i = 0; i < 4; ++i) St[(t * 16 + g * 4 + i) * HS + col0] = (cb == 0 ? acc0[t][i] + bi0 : acc1[t][i] + bi1);
           __syncthreads();
 #pragma unroll
           for (int j = 0; j < RT; ++j) {

@@ -204,7 +204,6 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<6, 1, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<6, 1, true>()));
   (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 1, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 1, true>()));
   (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 2, false>()));
-  (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<3, 2, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<3, 2, true>()));
   (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<6, 1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<6, 1, false>()));
   (void)hipFuncSetAttribute((const void*)strip_gemm_x3_kernel<4, 1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_gemm_lds_bytes<4, 1, false>()));
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<6>());
