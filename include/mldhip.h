@@ -174,6 +174,10 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     on split-f16 MFMAs reading the pre-split weight image, 0 = on exact-fp32 MFMAs
  *   "strip_gemm"      F16X3 / FP8 modes, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:
  *                     1 (default) = row-strip kernels with register-direct weights (kernels/gemm_strip_x3.hpp), 0 = staged tiles
+ *   "gemm_pipe"       F16X3 mode, diffusion-only variant (latent width 512): 1 (default) = its K >= 512 GEMMs at >= 2 048 rows run on the
+ *                     software-pipelined 128 x 256 tile (kernels/gemm_pipe.hpp: fragments of chunk c + 1 are read while chunk c is
+ *                     multiplied, one barrier per 32-wide K chunk; same products in the same order as the 64 x 128 staged tile,
+ *                     results identical to the bit), 2 = at any row count (tests), 0 = the 64 x 128 staged tile of kernels/gemm.hpp
  *   "strip_min_rows"  auto picks the column-split throughput kernels when the reverse loop has >= this many token rows (6 x batch; default
  *                     768 = 128 motions) -- in the modes whose latency kernels run fp32 / bf16 / fp8; in the F16X3 mode the split-f16
  *                     latency kernels serve every call below the persistent loop's threshold (15.2 vs 18.4 ms at 128 motions)

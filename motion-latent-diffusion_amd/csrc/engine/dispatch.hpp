@@ -87,13 +87,27 @@ void use_split_weights(const E* e, GemmArgs& a, int prec) {
   }
 }
 
+// The MFMA-bound GEMMs of the diffusion-only variant (d = 512: K in {512, 1024}, N in {512, 1024, 1536}, M = 25 088 rows at the BASELINE
+// shape) on the software-pipelined 128 x 256 tile (kernels/gemm_pipe.hpp; option "gemm_pipe"): split-f16 operands, W from the pre-split
+// image, one K segment, N a multiple of the tile width, no per-row masks.  Everything else keeps the 64 x 128 tile.
+bool use_gemm_pipe(const E* e, const GemmArgs& a, int prec, int nz) {
+  const int K = a.K1 + a.K2;
+  return e->gemm_pipe && e->cfg.vae_arch == MLDHIP_VAE_NONE && prec == PREC_BF16X3 && a.w_split && nz == 1 && a.K2 == 0 && (K == 512 || K == 1024) &&
+         a.N % 256 == 0 && (e->gemm_pipe == 2 || a.M >= e->gemm_pipe_min_rows) && !a.lens && !a.skip_lens && !a.relu_in && !e->trace_on && (a.lda & 3) == 0 && (a.ldy & 3) == 0;
+}
+
 void gemm(Ctx& c, const GemmArgs& a_, int nz = 1) {
   GemmArgs a = a_;
   const int K = a.K1 + a.K2;
   const bool small = a.M <= c.e->small_m || (K != 256 && K != 384 && K != 512 && K != 1024);
   const int prec = K == 384 ? PREC_F32 : staged_prec(c.e);     // K = 384 (padded 263-wide features): fp32 tile only
   if (!small) use_split_weights(c.e, a, prec);
-  if (small) {
+  if (!small && use_gemm_pipe(c.e, a, prec, nz)) {
+    const dim3 grid(gemm_pipe_grid<2, 4, 4, 4>(a.M, a.N));
+    constexpr int lds = gemm_pipe_lds_bytes<2, 4, 4, 4>();
+    if (K == 512) { MLD_LAUNCH((gemm_pipe_x3_kernel<2, 4, 4, 4, 16, 2>), grid, dim3(512), lds, c.stream, a); }
+    else { MLD_LAUNCH((gemm_pipe_x3_kernel<2, 4, 4, 4, 32, 2>), grid, dim3(512), lds, c.stream, a); }
+  } else if (small) {
     dim3 grid((a.M + 15) / 16, (a.N + 63) / 64, nz);
     MLD_LAUNCH((gemm_kernel<1, 4, 1, 1, false>), grid, dim3(256), 0, c.stream, a);
   } else {

@@ -127,6 +127,8 @@ struct mldhip_engine {
   int dec_l0_once = 1;       // "dec_l0_once": decoder layer 0 projects its input -- the positional rows, the same for every sample -- once per call ([T] rows instead of [B T])
   int tile_x3 = 1;           // "tile_x3": split-f16 mode runs the latency kernels (tile32.hpp) on split-f16 MFMAs too (0: exact fp32)
   int strip_gemm = 1;        // "strip_gemm": split modes, decoder / encoder in-projection, out-projection (+ LayerNorms) and skip linears on the row-strip kernels (kernels/gemm_strip_x3.hpp); 0 = the staged 64 x 128 / 64 x 256 tiles
+  int gemm_pipe = 1;         // "gemm_pipe": diffusion-only variant, split modes: the K >= 512 GEMMs on the software-pipelined 128 x 256 tile (kernels/gemm_pipe.hpp): 1 = launches of >= 2 048 rows, 2 = always (tests); 0 = the 64 x 128 staged tile
+  int gemm_pipe_min_rows = 2048;   // (not an option) row count from which the big tile is used: below it its 128-row tiles leave most CUs without a workgroup
   int strip_ffn2_split = 2;  // "strip_ffn2_split": K slices (= raw slabs) of FFN2 on the throughput kernels: 1 or 2
 
   // ---- numeric contract of the split-f16 mode (mldhip_numeric_status; include/mldhip.h "Range contract")

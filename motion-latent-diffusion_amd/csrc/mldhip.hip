@@ -32,6 +32,7 @@
 #include "kernels/attention.hpp"
 #include "kernels/elementwise.hpp"
 #include "kernels/gemm.hpp"
+#include "kernels/gemm_pipe.hpp"
 #include "kernels/novae.hpp"
 #include "kernels/rt.hpp"
 #include "kernels/tile32.hpp"
@@ -213,6 +214,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)final_strip_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, final_strip_lds_bytes());
   (void)hipFuncSetAttribute((const void*)attn_flash_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFlashLdsBytes);
   (void)hipFuncSetAttribute((const void*)attn_decode_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_x3_lds_bytes<4>());
+  (void)hipFuncSetAttribute((const void*)gemm_pipe_x3_kernel<2, 4, 4, 4, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (gemm_pipe_lds_bytes<2, 4, 4, 4>()));
+  (void)hipFuncSetAttribute((const void*)gemm_pipe_x3_kernel<2, 4, 4, 4, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (gemm_pipe_lds_bytes<2, 4, 4, 4>()));
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
@@ -353,6 +356,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "tile_x3") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "tile_x3 must be 0 or 1");
     e->tile_x3 = (int)value;
+  } else if (n == "gemm_pipe") {
+    if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "gemm_pipe must be 0 (off), 1 (auto: launches of >= 2 048 rows) or 2 (always)");
+    e->gemm_pipe = (int)value;
   } else if (n == "strip_gemm") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "strip_gemm must be 0 or 1");
     e->strip_gemm = (int)value;
