@@ -78,6 +78,13 @@ struct LoopArgs {
 #define LF_EXP 0          // tools/loopbench experiments (measurement builds with WRONG results; 0 in the library): 1 / 4 = linear1 / linear2 re-use stale A
                           // fragments (no LDS reads), 2 = no barrier per hidden block, 8 = the weight ring is never refreshed
 #endif
+#ifndef LF_RING
+#define LF_RING 8         // weight items in flight per lane (the stream carries 8 look-ahead items behind a step: 4 or 8; tools/loopbench A/B)
+#endif
+#ifndef LF_PIN
+#define LF_PIN 2          // tools/loopbench A/B: 0 = no placement pins, 1 = the accumulators of EVERY item are pinned behind its matrix instructions
+                          // (pin_acc below), 2 (the library) = only in the skip linears, where the matrix instructions sank
+#endif
 constexpr int kLfXs = 264;                                // LDS row stride (words), = 8 mod 16: conflict-free fragment reads (strip.hpp)
 constexpr int kLfHs = 136;                                // ... of a 128-wide block of the hidden activation
 constexpr int kLfXFloats = 48 * kLfXs, kLfHFloats = 48 * kLfHs, kLfAFloats = 2 * kLfHFloats;     // As: the attention output [48][264], or two hidden blocks
@@ -124,7 +131,9 @@ __global__ __launch_bounds__(512) void pack_loop_stream_kernel(const float* __re
 // 2 r + (g ^ (r >> 2)) mod 16 is still a permutation inside each of the instruction's four lane groups; tests/test_lds_layout.py).
 template <bool X3, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
-  constexpr int kLoopRing = 4;      // items in flight per lane (r03: 8 spills ring slots around the epilogues and loses, 33.1 vs 29.3 ms)
+  constexpr int kLoopRing = LF_RING;      // items in flight per lane.  (r03: 8 spilled ring slots around the epilogues at the 256-register cap and lost, 33.1 vs
+                                          // 29.3 ms; with the skip linears pinned -- pin_acc: 194 registers, no scratch -- 8 wins: 19.07 / 18.65 ms at 1 280 motions for
+                                          // no pins + ring 4 / pins + ring 8, 25.25 / 24.99 ms at 2 048, profiles/r04_loop_experiments.json)
   constexpr bool SWZ = X3;          // split images are always row-swizzled (r03c: 27.15 -> 26.75 ms; r04a: LDS bank-conflict cycles 1.43e9 -> 0.59e9 per launch)
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
@@ -180,7 +189,19 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   // attention scores) are four in-lane terms and two lane shuffles over g instead of sixteen-lane reductions per element, a softmax
   // is worked out by 4 lanes per row instead of 16, and a row's elements reach an operand image as one 8-byte store per plane instead
   // of eight 2-byte ones (r03 phase counters, plain layout: attention 4.2 ms, the two LayerNorm phases 6.8 ms of the loop's 29.8).
-  auto mma_item = [&](int j, const F4 (&x)[3][2], f32x4 (&acc)[3]) __attribute__((always_inline)) {
+  // hipcc linearises a basic block with a register-pressure list scheduler BEFORE the machine scheduler sees the fences: matrix
+  // instructions have no chain and may sink below the (chained) loads of several later items -- in the skip linears they did: the A
+  // fragments and ring slots of five chunks were live at once and spilled (rounds 3-4: 176-216 B of scratch per lane at 256 registers, every
+  // reload draining the in-order memory counter).  An empty asm volatile that "rewrites" the accumulators is chained like the fences: the
+  // item's matrix instructions stay in front of it.  Pinned skip linears: 194 registers, NO scratch.  (Pinning every item is level; pinning
+  // the nine GELU slices of mma_item_sliced into their slots -- hipcc collects them behind one matrix instruction -- gives the intended
+  // 1 MFMA : 4 VALU interleave in the machine code and is 2 % SLOWER: the feed-forward phase is not an issue-order effect.)
+  auto pin_acc = [](f32x4 (&a)[3]) __attribute__((always_inline)) {
+#if !defined(MLDHIP_SIM)
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]));
+#endif
+  };
+  auto mma_item = [&](int j, const F4 (&x)[3][2], f32x4 (&acc)[3], bool pin = false) __attribute__((always_inline)) {
     const int slot = j % kLoopRing;
     if constexpr (DBG == 2) {
       acc[0][0] += ring[slot][0].x + ring[slot][1].w + x[0][0].x;
@@ -211,6 +232,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[t] = mfma_f32_16x16x4(y1.w, x[t][1].w, acc[t]);
     }
+    if ((LF_PIN & 1) || ((LF_PIN & 2) && pin)) pin_acc(acc);
     if constexpr (DBG != 1 && !(LF_EXP & 8)) gload(slot);
     sched_fence();
   };
@@ -257,14 +279,14 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) { x[t][0] = ld4(a0 + t * ts + 32 * c); x[t][1] = ld4(a0 + t * ts + 32 * c + 16); }
   };
-  auto run2 = [&](const float* a0, f32x4 (&acc0)[3], f32x4 (&acc1)[3]) __attribute__((always_inline)) {
+  auto run2 = [&](const float* a0, f32x4 (&acc0)[3], f32x4 (&acc1)[3], bool pin = false) __attribute__((always_inline)) {
     F4 x[2][3][2];
     afrag(a0, 16 * kLfXs, 0, x[0]);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       if (c + 1 < 8) afrag(a0, 16 * kLfXs, c + 1, x[(c + 1) & 1]);
-      mma_item(2 * c, x[c & 1], acc0);
-      mma_item(2 * c + 1, x[c & 1], acc1);
+      mma_item(2 * c, x[c & 1], acc0, pin);
+      mma_item(2 * c + 1, x[c & 1], acc1, pin);
     }
   };
   auto run3 = [&](const float* a0, f32x4 (&acc0)[3], f32x4 (&acc1)[3], f32x4 (&acc2)[3]) __attribute__((always_inline)) {
@@ -568,6 +590,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
             auto epi = [&](int k) __attribute__((always_inline)) {
               if (c >= 6 || DBG == 4) return;                          // DBG 4 (measurement build): no feed-forward epilogue at all
               const int t = c >> 1, i0 = (c & 1) * 2;
+
               constexpr bool kGelu = DBG != 3;                         // DBG 3 (measurement build): identity for GELU
               if (k == 0) {
                 u0 = cur[t][i0] + (i0 ? b1.z : b1.x);
@@ -677,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
           const int si = l - nb;
           f32x4 z0[3], z1[3];
           zero3(z0); zero3(z1);
-          run2(xa, z0, z1);
+          run2(xa, z0, z1, true);
           stamp(9);
           __syncthreads();                               // everybody is done reading x
           const float* sk = p.skip + (size_t)(blockIdx.x * nb + (nb - 1 - si)) * (48 * 256);
@@ -699,7 +722,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
           }
           __syncthreads();
           stamp(10);
-          run2(xa, z0, z1);
+          run2(xa, z0, z1, true);
           stamp(11);
           const F4 sb0 = ld4(sm + kLsLayer + cq0), sb1 = ld4(sm + kLsLayer + 128 + cq0);
           const float sb0v[4] = {sb0.x, sb0.y, sb0.z, sb0.w}, sb1v[4] = {sb1.x, sb1.y, sb1.z, sb1.w};

@@ -28,10 +28,24 @@ def test_persistent_loop_code(rep):
     k = one(rep, "den_loop_kernel<true, 0>")
     assert k["flat"] == 0                      # DESIGN.md point 34: an opaque POINTER turned the ring into flat loads (+8 %)
     assert k["mfma"] == 1224 and k["ds_write_b16"] == 0
-    assert k["scratch"] <= 224 and k["vgpr"] == 256
+    # round 4: the skip linears' accumulators are pinned behind their matrix instructions (loop_fused.hpp pin_acc) -- the A fragments / ring
+    # slots of five chunks are no longer live at once: no scratch at all (rounds 3-4: 176-216 B per lane at the 256-register cap), 8-deep ring
+    assert k["scratch"] == 0 and k["vgpr"] <= 232
+    assert one(rep, "den_loop_kernel<false, 0>")["scratch"] == 0
     assert k["ds_bpermute"] <= 8               # round 4: row statistics on v_permlane16/32_swap (the 8 left are the once-per-step CFG row exchange, xor 8)
     assert one(rep, "den_loop_kernel<false, 0>")["flat"] == 0
     assert not [n for n in rep if "den_loop_kernel" in n and n.split("<")[1].split(">")[0].split(",")[1].strip() in ("1", "2", "3", "4")]   # measurement builds live in tools/loopbench
+
+
+def test_pipelined_gemm_tile_code(rep):
+    """kernels/gemm_pipe.hpp: 16 / 32 K chunks x 48 matrix instructions per wave, no scratch, and -- what the placement pins are for --
+    the global prefetch ring is never drained inside the chunk loop (a `s_waitcnt vmcnt(0)` there = the split of a staged row floated up
+    to its load)."""
+    for kcs in (16, 32):
+        k = one(rep, f"gemm_pipe_x3_kernel<2, 4, 4, 4, {kcs}, 2>")
+        assert k["mfma"] == kcs * 48 and k["scratch"] == 0 and k["flat"] == 0 and k["vgpr"] <= 240, k
+        assert k["vmcnt0"] <= 3, k                 # prologue (two chunks) only
+        assert k["barriers"] == kcs + 2, k         # one per chunk (none in front of chunk 0), prologue, two around the output tile
 
 
 def test_key_blocked_attention_reads_v_through_the_transpose_read(rep):
