@@ -186,7 +186,8 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "strip_ffn2_split" throughput kernels: K slices (raw slabs) of the FFN2 GEMM, 1 or 2 (default 2)
  *   "flash_attn"      split-f16 modes, frame-level self-attention of the decoder / encoder: key-blocked online-softmax kernel with
  *                     two workgroups per CU (kernels/attention.hpp attn_flash_x3_kernel): 0 = never, 1 = auto (default: calls
- *                     with >= 512 (sample, head) pairs), 2 = always
+ *                     with >= 512 (sample, head) pairs), 2 = always.  The diffusion-only variant (head dim 128) has its own form of
+ *                     the kernel (attn_flash128_x3_kernel, one workgroup per CU) under the same rule
  *   "gemm_small_m"    row count up to which one-off GEMMs use the register-direct 16x64 shape (default 256; tests set 0
  *                     to drive the LDS-staged kernels at simulator-sized shapes) */
 int mldhip_set_option(mldhip_handle* h, const char* name, int64_t value);

@@ -19,6 +19,13 @@ void novae_self_attention(Ctx& c, int R, int T) {
   const int H = e->cfg.num_heads, nkt = pick_nkt(T), nqt = (T + 15) / 16;
   dim3 grid(R * H, (nqt + 7) / 8), block(512);
   const int* nolens = nullptr;    // the reference passes no key-padding mask to the trans_dec denoiser (mld_denoiser.py:215)
+  if (staged_prec(e) == PREC_BF16X3 && T <= 256 && (e->flash_attn == 2 || (e->flash_attn == 1 && R * H >= 512)) && e->cfg.latent_dim == H * 128) {
+    // key-blocked form (attention.hpp attn_flash128_x3_kernel): one workgroup per (sample, head), K / V in blocks of 32 keys
+    MLD_LAUNCH(attn_flash128_x3_kernel, dim3(R * H), dim3(512), kFlash128LdsBytes, c.stream, (const float*)e->QKV, e->AO, nolens, T, H);
+    count(c);
+    check_launch(c, "attn_flash128_x3");
+    return;
+  }
   if (staged_prec(e) != PREC_F32) {   // GEMMs on bf16 MFMAs: the attention runs split-bf16 too
     switch (nkt) {
       case 4: MLD_LAUNCH((attn_seq_x3_kernel<4, 128>), grid, block, (attn_seq_x3_lds_bytes<4, 128>()), c.stream, (const float*)e->QKV, e->AO, nolens, T, H); break;

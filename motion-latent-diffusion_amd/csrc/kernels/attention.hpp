@@ -558,4 +558,205 @@ __global__ __launch_bounds__(512, 4) void attn_flash_x3_kernel(const float* __re
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// The key-blocked kernel for head dim 128 (the diffusion-only variant's trans_dec denoiser: 4 heads x 128, T = 196, no key-padding
+// mask: mld_denoiser.py:208-221, cross_attention.py:332-333).  Same algorithm, operand layouts and lane maps as attn_flash_x3_kernel --
+// blocks of 32 keys double buffered in LDS, a wave works on its two query tiles (w, w + 8) per block so every K / V fragment feeds two
+// tiles, lazy reference point, V through the transpose read -- at twice the row width: 4 contraction chunks for Q K^T, 8 output dim
+// tiles, 72-word rows (= 8 mod 16), 36.9 KB per stage.  Two query tiles x (8 + 8) fragments + 64 output accumulators per lane need the
+// 256-register budget: one workgroup per CU, two waves per SIMD (with ONE tile per wave the fragment reads per matrix instruction
+// double and LDS, not the matrix pipe, is the bound).  Replaces attn_seq_x3_kernel (novae.hpp: K, then V, through one LDS buffer,
+// 141 us per launch = 71 TFLOP/s at the BASELINE shape) when T <= 256.  lens == nullptr: every key counts.
+constexpr int kFlash128KStride = 72;      // words per K / V row of a block: 128 halves = 64 words + 8 pad
+constexpr int kFlash128StageWords = 4 * 32 * kFlash128KStride;        // K high / low, V high / low
+constexpr int kFlash128LdsBytes = 2 * kFlash128StageWords * 4;        // 73 728 B
+
+__global__ __launch_bounds__(512, 2) void attn_flash128_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                               const int* __restrict__ lens, int T, int H) {
+  constexpr int HD = 128, KST = kFlash128KStride, NW = 8, NCH = HD / 32, NDT = HD / 16;
+#if defined(MLDHIP_SIM)
+  unsigned* smem = reinterpret_cast<unsigned*>(hipsim::blk().dyn_smem.data());
+#else
+  extern __shared__ __attribute__((aligned(16))) unsigned smem_flash128[];
+  unsigned* smem = smem_flash128;
+#endif
+  const int D = H * HD;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  int len = T;
+  if (lens) len = lens[b] < T ? lens[b] : T;
+  const int nkt = (len + 15) >> 4, nkb = (nkt + 1) >> 1, nqt = (T + 15) >> 4;
+  const float* base = qkv + (long long)b * T * 3 * D + h * HD;
+
+  // ---- staging: thread t owns dims 4 (t & 31) .. + 3 of keys (t >> 5) and 16 + (t >> 5) of the block, K and V
+  const int skey = tid >> 5, c4 = tid & 31;
+  F4 kreg[2], vreg[2];
+  auto kvload = [&](int kb) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int key = kb * 32 + u * 16 + skey;
+      const int kc = key < len ? key : len - 1;
+      const float* p = base + (long long)kc * 3 * D + c4 * 4;
+      kreg[u] = ld4(p + D);
+      vreg[u] = ld4(p + 2 * D);
+    }
+  };
+  auto kvstore = [&](int kb) {
+    unsigned* Kh = smem + (kb & 1) * kFlash128StageWords;
+    unsigned* Kl = Kh + 32 * KST;
+    unsigned* Vh = Kl + 32 * KST;
+    unsigned* Vl = Vh + 32 * KST;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = u * 16 + skey;
+      const float m = kb * 32 + row < len ? 1.f : 0.f;     // keys past the length: zero operands (their scores are masked as well)
+      unsigned h0, l0, h1, l1;
+      split16_pair(kreg[u].x * m, kreg[u].y * m, h0, l0);
+      split16_pair(kreg[u].z * m, kreg[u].w * m, h1, l1);
+      *reinterpret_cast<U2*>(Kh + row * KST + c4 * 2) = U2{h0, h1};
+      *reinterpret_cast<U2*>(Kl + row * KST + c4 * 2) = U2{l0, l1};
+      split16_pair(vreg[u].x * m, vreg[u].y * m, h0, l0);
+      split16_pair(vreg[u].z * m, vreg[u].w * m, h1, l1);
+      *reinterpret_cast<U2*>(Vh + row * KST + c4 * 2) = U2{h0, h1};
+      *reinterpret_cast<U2*>(Vl + row * KST + c4 * 2) = U2{l0, l1};
+    }
+  };
+  kvload(0);
+
+  // ---- this wave's query tiles: fragments of Q (pre-scaled by 1/sqrt(128) x log2(e), split hi / lo), running statistics, accumulators
+  bool live[2];
+  U4 qh[2][NCH], ql[2][NCH];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int qt = wave + NW * t;
+    live[t] = qt < nqt;
+    int qrow = qt * 16 + r;
+    qrow = qrow < T ? qrow : T - 1;
+    const float* qp = base + (long long)qrow * 3 * D + g * 8;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const F4 t0 = ld4(qp + c * 32), t1 = ld4(qp + c * 32 + 4);
+      constexpr float qs = 0.08838834764831845f * 1.44269504088896340736f;     // 1/sqrt(128) x log2(e)
+      const float x[8] = {t0.x * qs, t0.y * qs, t0.z * qs, t0.w * qs, t1.x * qs, t1.y * qs, t1.z * qs, t1.w * qs};
+      split_hi_lo_x8(x, qh[t][c], ql[t][c]);
+    }
+  }
+  const int nt = live[1] ? 2 : 1;
+  float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+  f32x4 oacc[2][NDT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) oacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  kvstore(0);
+  if (nkb > 1) kvload(1);
+  __syncthreads();
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    const unsigned* Kh = smem + (kb & 1) * kFlash128StageWords;
+    const unsigned* Kl = Kh + 32 * KST;
+    const unsigned* Vh = Kl + 32 * KST;
+    const unsigned* Vl = Vh + 32 * KST;
+    if (live[0]) {                                // waves without a query tile only stage (wave-uniform branch)
+      f32x4 s[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) s[t][k2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const U4 kh = *reinterpret_cast<const U4*>(Kh + (k2 * 16 + r) * KST + c * 16 + g * 4);
+          const U4 kl = *reinterpret_cast<const U4*>(Kl + (k2 * 16 + r) * KST + c * 16 + g * 4);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            if (t < nt) {
+              s[t][k2] = mfma_x3_16x16x32(kl, qh[t][c], s[t][k2]);
+              s[t][k2] = mfma_x3_16x16x32(kh, ql[t][c], s[t][k2]);
+              s[t][k2] = mfma_x3_16x16x32(kh, qh[t][c], s[t][k2]);
+            }
+          }
+        }
+      U4 ph[2], pl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t >= nt) continue;
+        if (kb * 32 + 32 > len) {                 // the block that crosses the length: keys past it get -inf (wave-uniform test)
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[t][k2][i] = kb * 32 + k2 * 16 + g * 4 + i < len ? s[t][k2][i] : -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3])),
+                         fmaxf(fmaxf(s[t][1][0], s[t][1][1]), fmaxf(s[t][1][2], s[t][1][3])));
+        mx = max_groups(mx);                       // finite: key 32 kb < len
+        if (wave_any(mx > mrun[t] + 8.0f)) {       // lazy reference point (attn_flash_x3_kernel); first block: mrun = -inf
+          const float mnew = fmaxf(mrun[t], mx);
+          const float alpha = fast_exp2(mrun[t] - mnew);
+          lrun[t] *= alpha;
+          mrun[t] = mnew;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float a = wave_bcast(alpha, g * 4 + i);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) oacc[t][dt][i] *= a;
+          }
+        }
+        float psum = 0.f;
+        float pf[8];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float e = fast_exp2(s[t][k2][i] - mrun[t]);
+            pf[k2 * 4 + i] = e;
+            psum += e;
+          }
+        lrun[t] += sum_groups(psum);
+        split_hi_lo_x8_unit(pf, ph[t], pl[t]);
+      }
+      // O += P V_blk through the transpose read: lane (r, g) supplies key 4 g + (r >> 2) of a 16-key tile, dims 16 dt + 4 (r & 3) .. + 3
+      // (rows 72 = 8 mod 64 words apart: the eight rows of a 32-lane half cover all 64 banks once)
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int tro = (g * 4 + (r >> 2)) * KST + dt * 8 + (r & 3) * 2;
+        const U2 a0 = lds_read_tr16_b64(Vh + tro), a1 = lds_read_tr16_b64(Vh + tro + 16 * KST);
+        const U2 b0 = lds_read_tr16_b64(Vl + tro), b1 = lds_read_tr16_b64(Vl + tro + 16 * KST);
+        const U4 vhh = U4{a0.x, a0.y, a1.x, a1.y}, vll = U4{b0.x, b0.y, b1.x, b1.y};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if (t < nt) {
+            oacc[t][dt] = mfma_x3_16x16x32(pl[t], vhh, oacc[t][dt]);
+            oacc[t][dt] = mfma_x3_16x16x32(ph[t], vll, oacc[t][dt]);
+            oacc[t][dt] = mfma_x3_16x16x32(ph[t], vhh, oacc[t][dt]);
+          }
+        }
+      }
+    }
+    if (kb + 1 < nkb) {
+      kvstore(kb + 1);
+      if (kb + 2 < nkb) kvload(kb + 2);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (!live[t]) continue;
+    const int qt = wave + NW * t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float inv = 1.0f / wave_bcast(lrun[t], g * 4 + i);
+      const int q = qt * 16 + g * 4 + i;
+      if (q < T) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[(long long)(b * T + q) * D + h * HD + dt * 16 + r] = oacc[t][dt][i] * inv;
+      }
+    }
+  }
+}
+
 }  // namespace mld

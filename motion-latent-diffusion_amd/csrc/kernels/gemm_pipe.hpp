@@ -206,7 +206,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_pipe_x3_kernel(GemmArgs p
     const int nb = (c + 1) & 1, fb = c & 1;          // buffer of chunk c + 1 (read) / of chunk c, free from here on (written: chunk c + 2)
     const bool more = c + 1 < KCS && !(GP_EXP & 1), stage = c + 2 < KCS && !(GP_EXP & 2), fetch = c + 2 + RD < KCS && !(GP_EXP & 4);
     F4 (&sg)[NLD] = st[(c + 2) % RD];
-    if (c > 0 && !(GP_EXP & 16)) __syncthreads();                       // chunk c + 1 is complete in LDS; everybody's fragment reads of chunk c are done
+    // chunk c + 1 is complete in LDS and everybody's fragment reads of chunk c are done (__syncthreads waits for the issuing wave's LDS reads
+    // first).  Also in front of iteration 0: its first slot overwrites buffer 0 while a slower wave could still be reading its fragments of
+    // chunk 0 behind the prologue's barrier -- a race that showed as run-to-run differences of 1e-2 on the joints of a 20-step sample (r04).
+    if (!(GP_EXP & 16)) __syncthreads();
     auto slot = [&](int k) __attribute__((always_inline)) {
       if (stage) {
         float* dst = smem + fb * ROWS * kGemmLdsStride;

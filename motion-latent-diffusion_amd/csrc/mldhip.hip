@@ -213,6 +213,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<3>());
   (void)hipFuncSetAttribute((const void*)final_strip_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, final_strip_lds_bytes());
   (void)hipFuncSetAttribute((const void*)attn_flash_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFlashLdsBytes);
+  (void)hipFuncSetAttribute((const void*)attn_flash128_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFlash128LdsBytes);
   (void)hipFuncSetAttribute((const void*)attn_decode_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_x3_lds_bytes<4>());
   (void)hipFuncSetAttribute((const void*)gemm_pipe_x3_kernel<2, 4, 4, 4, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (gemm_pipe_lds_bytes<2, 4, 4, 4>()));
   (void)hipFuncSetAttribute((const void*)gemm_pipe_x3_kernel<2, 4, 4, 4, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (gemm_pipe_lds_bytes<2, 4, 4, 4>()));

@@ -927,6 +927,44 @@ def test_reduced_precision_modes_run_and_stay_sane(dev, golden_dir):
     e.close()
 
 
+def test_novae_split_f16_full_shape_kernels_vs_reference_golden(dev, golden_dir):
+    """precision = F16X3 at config 4's full CFG shape (R = 128, T = 196: M = 25 088 rows, 512 (sample, head) pairs) -- the shape at which the
+    software-pipelined 128 x 256 GEMM tile ("gemm_pipe", kernels/gemm_pipe.hpp) and the head-dim-128 key-blocked attention ("flash_attn",
+    attn_flash128_x3_kernel) are what runs: one denoiser call against the reference module's fixture for every combination; the two GEMM
+    tiles take the same products in the same order (identical to the bit, three calls each: a race between workgroup phases would show
+    here), the two attention kernels sum in another order (close, not equal)."""
+    gf = _gold(golden_dir, "novae_denoiser_full.npz")
+    b64 = syn.make_batch(64)
+    xf = syn._rng(12, "nvfull").standard_normal((64, 196, 263)).astype(np.float32)
+    x, text, lens = _cuda(np.concatenate([xf, xf]), dev), _cuda(b64.text_emb, dev), gf["lengths"].tolist() * 2
+    e = _lib.Engine(device=0, max_batch=64, max_frames=196, num_inference_steps=10, precision=1, **NOVAE_CFG)
+    e.load_state_dict(syn.make_novae_denoiser_state_dict(), "denoiser.")
+    mean, std = syn.make_mean_std()
+    e.load_tensor("mean", mean)
+    e.load_tensor("std", std)
+    e.finalize()
+    assert e.numeric_status()["decode_split_ok"] == 1
+    outs = {}
+    for pipe, flash in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        e.set_option("gemm_pipe", pipe)
+        e.set_option("flash_attn", flash)
+        runs = []
+        for _ in range(3):
+            out = torch.empty(128, 196, 263, device=dev)
+            e.denoiser_forward_novae(x, 500, text, lens, 196, out)
+            torch.cuda.synchronize()
+            runs.append(out)
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), (pipe, flash)
+        outs[(pipe, flash)] = runs[0]
+        err = float(np.abs(runs[0].cpu().numpy()[::16, ::7] - gf["out_t500_sub"]).max())
+        print("diffusion-only denoiser, split-f16, gemm_pipe %d flash_attn %d: err vs the reference fixture %.3e" % (pipe, flash, err))
+        assert err < 3e-4
+    assert torch.equal(outs[(1, 1)], outs[(0, 1)]) and torch.equal(outs[(1, 0)], outs[(0, 0)])
+    d = float((outs[(1, 1)] - outs[(1, 0)]).abs().max())
+    assert 0 < d < 1e-4, d
+    e.close()
+
+
 def test_key_blocked_attention_matches_whole_kv_attention_on_gpu(dev, golden_dir):
     """precision = BF16X3_DECODE: attn_flash_x3_kernel ("flash_attn" = 2; auto picks it from 512 (sample, head) pairs up) vs
     attn_decode_x3_kernel (= 0) on the benchmarked shape, full-length and ragged: joints within 5e-5 of each other (summation

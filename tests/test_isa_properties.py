@@ -45,7 +45,7 @@ def test_pipelined_gemm_tile_code(rep):
         k = one(rep, f"gemm_pipe_x3_kernel<2, 4, 4, 4, {kcs}, 2>")
         assert k["mfma"] == kcs * 48 and k["scratch"] == 0 and k["flat"] == 0 and k["vgpr"] <= 240, k
         assert k["vmcnt0"] <= 3, k                 # prologue (two chunks) only
-        assert k["barriers"] == kcs + 2, k         # one per chunk (none in front of chunk 0), prologue, two around the output tile
+        assert k["barriers"] == kcs + 3, k         # one per chunk, prologue, two around the output tile
 
 
 def test_key_blocked_attention_reads_v_through_the_transpose_read(rep):

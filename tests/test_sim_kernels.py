@@ -571,6 +571,16 @@ def test_novae_split_bf16_gemms_and_attention_sim(now):
     out2 = np.zeros((R, T, 263), np.float32)
     e.denoiser_forward_novae(x, 999, te, lens, T, out2)
     assert np.array_equal(out, out2)
+    # "flash_attn" = 2: the head-dim-128 form of the key-blocked attention (attention.hpp attn_flash128_x3_kernel: 32-key blocks double buffered,
+    # online softmax with the lazy reference point, V through the transpose read, 4 contraction chunks / 8 output dim tiles) instead of
+    # attn_seq_x3_kernel; T = 37 -> two key blocks, the second one crossing the sequence end.  Another summation order: close, not equal.
+    e.set_option("flash_attn", 2)
+    out3 = np.zeros((R, T, 263), np.float32)
+    e.denoiser_forward_novae(x, 999, te, lens, T, out3)
+    err3 = np.abs(out3 - O.denoiser_forward_novae(ops, bd, x, 999, te, lens)).max()
+    d3 = np.abs(out3 - out).max()
+    print("novae x3 denoiser err with the key-blocked attention", err3, "difference to the two-phase kernel", d3)
+    assert 1e-7 < err3 < 3e-4 and 0 < d3 < 2e-4
     e.close()
 
 
