@@ -93,7 +93,8 @@ void use_split_weights(const E* e, GemmArgs& a, int prec) {
 bool use_gemm_pipe(const E* e, const GemmArgs& a, int prec, int nz) {
   const int K = a.K1 + a.K2;
   return e->gemm_pipe && e->cfg.vae_arch == MLDHIP_VAE_NONE && prec == PREC_BF16X3 && a.w_split && nz == 1 && a.K2 == 0 && (K == 512 || K == 1024) &&
-         a.N % 256 == 0 && (e->gemm_pipe == 2 || a.M >= e->gemm_pipe_min_rows) && !a.lens && !a.skip_lens && !a.relu_in && !e->trace_on && (a.lda & 3) == 0 && (a.ldy & 3) == 0;
+         a.N % 256 == 0 && (e->gemm_pipe == 2 || a.M >= e->gemm_pipe_min_rows) && !a.lens && !a.skip_lens && !a.relu_in && !e->trace_on && (a.lda & 3) == 0 && (a.ldy & 3) == 0 &&
+         ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.Y) | reinterpret_cast<uintptr_t>(a.bias)) & 15) == 0;   // 16-byte row pieces, bias quads, tile stores
 }
 
 void gemm(Ctx& c, const GemmArgs& a_, int nz = 1) {
