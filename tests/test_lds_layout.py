@@ -128,3 +128,33 @@ def test_row_swizzled_operand_images_of_the_persistent_loop():
         for c in range(8 if name == "kLfXs" else 4):
             for half in (0, 16):
                 assert lds_cycles_b128_lane(stride, lambda r, g: (g ^ (r >> 2)) << 2, c * 32 + half) == 4
+
+
+def test_pipelined_gemm_tile_map_and_lds_rows():
+    """gemm_pipe.hpp: (a) the XCD-aware 1-D grid -- id lands on XCD id % 8; XCD x walks row tiles x, x + 8, ... and inside a row tile all
+    column tiles back to back -- visits every (row tile, column tile) exactly once, the padded workgroups fall outside, and the column
+    tiles of a row panel are consecutive dispatches of ONE XCD; (b) its fragment reads (ds_read_b128 at word 4 g of row r, 40-word rows,
+    high plane at + 0, low plane at + 16) are conflict free, as are the head-dim-128 attention's (72-word rows, four chunks)."""
+    src = open(os.path.join(CSRC, "gemm_pipe.hpp")).read()
+    assert "blockIdx.x & 7" in src and "(kk / nt) * 8 + xcd" in src and "kk % nt" in src
+    for mt, nt in ((196, 2), (196, 6), (196, 4), (1, 6), (9, 2), (16, 1)):
+        grid = (mt + 7) // 8 * 8 * nt
+        seen = {}
+        for wg in range(grid):
+            xcd, kk = wg & 7, wg >> 3
+            tm, tn = (kk // nt) * 8 + xcd, kk % nt
+            if tm < mt:
+                assert (tm, tn) not in seen
+                seen[(tm, tn)] = wg
+        assert len(seen) == mt * nt
+        for tm in range(mt):
+            ids = [seen[(tm, tn)] for tn in range(nt)]
+            assert len({i & 7 for i in ids}) == 1 and [i >> 3 for i in ids] == list(range(ids[0] >> 3, (ids[0] >> 3) + nt))
+    stride = constant("gemm.hpp", "kGemmLdsStride")
+    assert stride % 16 == 8
+    for plane in (0, 16):
+        assert lds_cycles_b128_lane(stride, lambda r, g: g * 4, plane) == 4
+    kst = constant("attention.hpp", "kFlash128KStride")
+    assert kst % 16 == 8
+    for c in range(4):
+        assert lds_cycles_b128_lane(kst, lambda r, g: g * 4, c * 16) == 4
