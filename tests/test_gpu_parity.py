@@ -557,6 +557,38 @@ def test_novae_mld_module_surface_on_gpu(dev, golden_dir):
     E.drop_engines()
 
 
+def test_novae_data_parallel_sampler_with_batches_in_flight(dev):
+    """DataParallelSampler(in_flight=2) on the diffusion-only variant: chunks on two rotating streams (two workspaces of one handle) give
+    the SAME motions as the serial loop -- start noise and the DDPM scheduler's per-step draws are pinned per prompt, chunks share one
+    Tmax (the trans_dec denoiser attends over the padded batch)."""
+    from mld_hip import config as C
+    from mld_hip import engine as E
+    from mld_hip.datamodule import HipDataModule
+    from mld_hip.dp import DataParallelSampler
+    from mld_hip.mld import MLD
+    from mld_hip.text_encoder import SyntheticTextEncoder
+
+    E.drop_engines()
+    steps = 5                              # (a divisor of the 1000 training steps)
+    cfg = C.load_config(os.path.join(C.CONFIG_DIR, "config_novae_humanml3d.yaml"), overrides={"model.scheduler.num_inference_timesteps": steps})
+    E.configure("novae", max_batch=4, max_frames=48, max_in_flight=2)
+    model = MLD(cfg, HipDataModule(cfg), text_encoder=SyntheticTextEncoder()).to(dev).eval()
+    model.denoiser.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_novae_denoiser_state_dict().items()}, strict=True)
+    n = 14
+    texts = [f"prompt number {i}" for i in range(n)]
+    lengths = [48 if i % 4 == 0 else 20 + 3 * (i % 7) for i in range(n)]          # every chunk of 4 holds a 48-frame motion: equal Tmax
+    g = torch.Generator().manual_seed(11)
+    lat0 = torch.randn(n, 48, 263, generator=g)
+    sn = torch.randn(steps, n, 48, 263, generator=g)
+    idx1, serial = DataParallelSampler(model, batch_size=4, in_flight=1)(texts, lengths, init_latents=lat0, step_noise=sn)
+    idx2, flight = DataParallelSampler(model, batch_size=4, in_flight=2)(texts, lengths, init_latents=lat0, step_noise=sn)
+    assert idx1 == idx2 == list(range(n)) and len(serial) == len(flight) == n
+    for a, b, ln in zip(serial, flight, lengths):
+        assert a.shape == b.shape == (ln, 22, 3) and bool(torch.isfinite(b).all()) and torch.equal(a, b)
+    E.configure("novae", max_batch=64, max_frames=196, max_in_flight=1)
+    E.drop_engines()
+
+
 def test_graph_replay_is_independent_of_caller_buffers(eng, dev):
     """Fresh input/output tensors on every call (what MLD.forward does) must replay the same captured graph correctly."""
     b = syn.make_batch(5, [60, 33, 60, 41, 8])
