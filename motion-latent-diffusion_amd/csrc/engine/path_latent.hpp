@@ -841,6 +841,8 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
       e->phase = 2;
       joints_body(c, f, B, T, joints_out);
       count_nonfinite(c, joints_out, (long long)B * T * e->cfg.njoints * 3);
+    } else {
+      count_nonfinite(c, f, (long long)B * T * e->cfg.nfeats);      // feats-only call: the decoder's output is what the caller gets
     }
   }
   return c.rc;

@@ -145,10 +145,12 @@ int novae_steps(E* e, hipStream_t stream, int B, int T, int s0, int s1, const fl
 int novae_epilogue(E* e, hipStream_t stream, int B, int T, float* feats_out, float* joints_out) {
   Ctx c{e, stream};
   const long long nel = (long long)B * T * e->cfg.nfeats;
+  count_nonfinite(c, e->lat, nel);       // the diffusion-only variant's result IS the sampled motion (advisor r4: it was never counted)
   if (feats_out) HIP_TRY(e, hipMemcpyAsync(feats_out, e->lat, nel * sizeof(float), hipMemcpyDeviceToDevice, stream));   // "decode" = identity (mld.py:241-242)
   if (joints_out) {
     e->phase = 2;
     joints_body(c, e->lat, B, T, joints_out);
+    count_nonfinite(c, joints_out, (long long)B * T * e->cfg.njoints * 3);
   }
   return c.rc;
 }

@@ -203,6 +203,8 @@ class Engine:
     def set_option(self, name: str, value: int):
         """Per-handle tuning option (include/mldhip.h: loop_kernel, strip_min_rows, gemm_small_m)."""
         self._check(self.lib.mldhip_set_option(self._h, name.encode(), int(value)))
+        if name == "range_probe":      # the probe is part of finalize: the C side un-finalizes the handle (advisor r4: the next sample failed with ESTATE)
+            self._dirty = True
 
     def finalize(self, stream: int = 0):
         self._check(self.lib.mldhip_finalize_weights(self._h, stream))

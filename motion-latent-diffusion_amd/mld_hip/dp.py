@@ -75,17 +75,19 @@ class DataParallelSampler:
 
     coalesce: how many consecutive chunks go into ONE engine call (``MLD.sample_many`` -> ``mldhip_sample_many``: one chain over
     coalesce x batch_size motions; from 192 motions per call the split-f16 engine runs the reverse loop as one persistent launch, a
-    workgroup per 8 motions, whose run time does not depend on the batch up to 2 048 motions).  ``None`` (default) = automatic:
+    workgroup per 8 motions, whose run time does not depend on the batch up to 2 048 motions).  Default 1: one chunk per engine call,
+    the reference's own shape (``MLD.forward`` per batch) -- coalesced calls run other loop kernels and are tolerance-equal, not
+    bit-equal, to per-chunk calls, so the switch is the caller's (advisor r4).  ``"auto"`` (``None`` is accepted as a synonym):
     as many chunks of this rank's shard as the engine's capacity holds, ``min(chunks, engine.max_batch // batch_size)`` -- BASELINE
     config 3 (512 prompts) on ONE rank is one 512-motion call instead of eight latency-kernel calls when the engine was configured
     with ``max_batch >= 512``; on eight ranks every rank holds one bs-64 batch and there is nothing to coalesce (the literal
     ``MLD.forward`` shape).  An int forces that many (the engine refuses more motions than its ``max_batch``)."""
 
-    def __init__(self, model, batch_size: int = 64, in_flight: int = 1, coalesce=None):
+    def __init__(self, model, batch_size: int = 64, in_flight: int = 1, coalesce=1):
         self.model = model
         self.batch_size = batch_size
         self.in_flight = max(1, int(in_flight))
-        self.coalesce = None if coalesce is None else max(1, int(coalesce))
+        self.coalesce = None if (coalesce is None or coalesce == "auto") else max(1, int(coalesce))
 
     def pick_coalesce(self, nchunks: int) -> int:
         """The automatic rule: chunks per engine call from the shard size and the engine's capacity."""

@@ -1051,7 +1051,7 @@ def test_config3_shape_512_prompts_through_the_dp_sampler(dev):
     model.sample_many = lambda reqs, init_latents=None: orig_many(reqs, [noise(l) for _, l in reqs])
     idx1, one = DataParallelSampler(model, batch_size=64, in_flight=1, coalesce=1)(texts, lengths)
     idx4, many = DataParallelSampler(model, batch_size=64, in_flight=2, coalesce=4)(texts, lengths)
-    auto = DataParallelSampler(model, batch_size=64)             # coalesce=None: picked from the shard (8 chunks) and the engine (max_batch 256)
+    auto = DataParallelSampler(model, batch_size=64, coalesce="auto")             # picked from the shard (8 chunks) and the engine (max_batch 256)
     idxa, manya = auto(texts, lengths)
     assert auto.last_coalesce == 4
     assert idx1 == idx4 == idxa == list(range(n)) and len(one) == len(many) == len(manya) == n
