@@ -335,6 +335,58 @@ int build_loop_stream(Ctx& c) {
   return 0;
 }
 
+// ---- cluster loop (kernels/loop_cluster.hpp): one bs-64 request (up to 8 x kClMaxClusters motions) as ONE launch of 12-workgroup clusters
+bool use_cluster(const E* e, int B) {
+  if (!e->cl_stream || !fused_split(e) || e->cluster_failed || B > 8 * kClMaxClusters || B > e->cfg.max_batch) return false;
+  return e->loop_kernel == 4 || (e->loop_kernel == 0 && B <= e->cluster_max_batch);
+}
+
+// finalize-time: per column group and wave, the weight fragments (16 rows x 32 k, split-f16) in the order den_cluster_kernel consumes them;
+// needs the packed small parameters / DDIM table of build_loop_stream
+int build_cluster_stream(Ctx& c) {
+  E* e = c.e;
+  if (e->cl_stream) { (void)hipFree(e->cl_stream); e->cl_stream = nullptr; }
+  if (!fused_built(e) || !e->group_ready[0] || !e->loop_ips || e->cfg.precision != MLDHIP_PREC_BF16X3_DECODE) return 0;
+  const int L = e->cfg.num_layers, nb = (L - 1) / 2, F = e->cfg.ff_size;
+  std::vector<ClFrag> frags;
+  auto push = [&](const float* w, int ld, int row0, int k0) { frags.push_back(ClFrag{(long long)(w - e->arena) + (long long)row0 * ld + k0, ld, 0}); };
+  for (int hc = 0; hc < 4; ++hc)
+    for (int w = 0; w < 8; ++w) {
+      e->cl_wave_off[hc * 8 + w] = (unsigned)(frags.size() * kClFragFloats);
+      const size_t first = frags.size();
+      for (int l = 0; l < L; ++l) {
+        const EncLayerP& P_ = e->den[l];
+        for (int kc = 0; kc < 8; ++kc) {                                           // Ph1: waves 0-3 [Q, K] of head hc, waves 4-7 [V]
+          if (w < 4) { push(P_.in_w, 256, 64 * hc + 16 * w, 32 * kc); push(P_.in_w, 256, 256 + 64 * hc + 16 * w, 32 * kc); }
+          else push(P_.in_w, 256, 512 + 64 * hc + 16 * (w - 4), 32 * kc);
+        }
+        for (int kc = 0; kc < 8; ++kc)                                             // out-projection: columns 32 w + 16 j
+          for (int j = 0; j < 2; ++j) push(P_.out_w, 256, 32 * w + 16 * j, 32 * kc);
+        for (int kc = 0; kc < 8; ++kc)                                             // linear1: hidden columns 256 hc + 32 w + 16 j
+          for (int j = 0; j < 2; ++j) push(P_.l1_w, 256, 256 * hc + 32 * w + 16 * j, 32 * kc);
+        for (int kc = 0; kc < 16; ++kc) push(P_.l2_w, F, 64 * hc + 16 * (w & 3), 512 * (w >> 2) + 32 * kc);      // linear2: K half w >> 2
+        if (l >= nb && l + 1 < L) {
+          const float* ws = P(e, "denoiser.encoder.linear_blocks." + std::to_string(l - nb) + ".weight");
+          for (int kc = 0; kc < 8; ++kc) push(ws, 512, 64 * hc + 16 * (w & 3), 256 * (w >> 2) + 32 * kc);         // skip linear: x half / parked half
+        }
+      }
+      for (int j = 0; j < kClRing; ++j) frags.push_back(frags[first + j]);        // look-ahead across the end of a step
+    }
+  ClFrag* fdev = nullptr;
+  if (hipMalloc((void**)&e->cl_stream, frags.size() * (size_t)kClFragFloats * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&fdev, frags.size() * sizeof(ClFrag)) != hipSuccess)
+    return e->fail(MLDHIP_EHIP, "hipMalloc(cluster loop stream)");
+  hipError_t st = hipMemcpy(fdev, frags.data(), frags.size() * sizeof(ClFrag), hipMemcpyHostToDevice);
+  if (st == hipSuccess) {
+    MLD_LAUNCH(pack_cluster_frags_kernel, dim3((unsigned)frags.size()), dim3(64), 0, c.stream, (const float*)e->arena, (const ClFrag*)fdev, e->cl_stream);
+    check_launch(c, "pack_cluster_frags");
+    st = hipStreamSynchronize(c.stream);
+  }
+  (void)hipFree(fdev);
+  if (st != hipSuccess) return e->fail(MLDHIP_EHIP, "cluster loop stream: %s", hipGetErrorString(st));
+  return c.rc;
+}
+
 // finalize-time (split precision modes): linear1 / linear2 of every decoder / encoder layer in the item order of
 // kernels/ffn_strip.hpp -- run1(0), then [run1(hb), run2(hb - 1)] for hb = 1..7, then run2(7) -- as split-f16 fragment images
 int build_ffn_streams(Ctx& c) {
@@ -799,6 +851,33 @@ void launch_fused_loop(Ctx& c, const float* init_lat, int B, int n, float guidan
   check_launch(c, "den_loop");
 }
 
+// the whole reverse loop (or its first `n` steps) of up to 8 x kClMaxClusters motions as one launch of clusters (kernels/loop_cluster.hpp)
+void launch_cluster_loop(Ctx& c, const float* init_lat, int B, int n, float guidance) {
+  E* e = c.e;
+  ClusterArgs a;
+  a.stream = e->cl_stream;
+  for (int i = 0; i < 32; ++i) a.wave_off[i] = e->cl_wave_off[i];
+  a.small = e->loop_small; a.T1 = e->T1; a.TP = e->TP; a.init_lat = init_lat; a.lat = e->lat; a.park = e->cl_park; a.ddim = e->loop_ddim;
+  a.xbuf = e->cl_xbuf;
+  a.ncl = (B + 7) / 8;
+  a.flags = reinterpret_cast<unsigned*>(e->cl_flags);
+  a.status = a.flags + (size_t)std::min<size_t>(kClMaxClusters, (e->cfg.max_batch + 7) / 8) * kClFlagWords;
+  a.B = B; a.L = e->cfg.num_layers; a.n = n; a.guidance = guidance; a.init_sigma = 1.0f;
+#if defined(MLDHIP_SIM)
+  a.xslots = std::min(a.ncl, 8);          // the simulator creates a fiber per work-item of every block: no idle XCD slots
+#else
+  a.xslots = 8;                           // block b -> XCD b % 8 (observed placement): a cluster's members share a slot
+#endif
+  // every polled word is zero at the start of every call (Guideline 16 "Re-initialise every call"): a memset node in front of the launch
+  hipError_t st = hipMemsetAsync(a.flags, 0, ((size_t)(a.status - a.flags) + 16) * sizeof(unsigned), c.stream);
+  if (st != hipSuccess) { c.rc = e->fail(MLDHIP_EHIP, "cluster loop: memset: %s", hipGetErrorString(st)); return; }
+  const dim3 grid((unsigned)(a.xslots * kClMembers * ((a.ncl + a.xslots - 1) / a.xslots)));
+  if (e->cluster_wt) MLD_LAUNCH_CORESIDENT((den_cluster_kernel<true>), grid, dim3(512), kClLdsBytes, c.stream, a);
+  else MLD_LAUNCH_CORESIDENT((den_cluster_kernel<false>), grid, dim3(512), kClLdsBytes, c.stream, a);
+  count(c);
+  check_launch(c, "den_cluster");
+}
+
 // `text` == nullptr selects the action condition (labels_dev holds the 2B labels).
 int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* init_lat, int B, int T,
                    float* lat_out, float* feats_out, float* joints_out) {
@@ -810,7 +889,9 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
   e->phase = 0;
   if (text) text_projection(c, text, 2 * B, e->TP);
   else action_rows(c, 2 * B, B, e->TP);
-  if (use_fused(e, B)) {
+  if (use_cluster(e, B)) {
+    launch_cluster_loop(c, init_lat, B, n, guidance);
+  } else if (use_fused(e, B)) {
     launch_fused_loop(c, init_lat, B, n, guidance);
   } else {
     const DenView v = den_view(e, 2 * B);

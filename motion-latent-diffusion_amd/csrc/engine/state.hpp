@@ -74,6 +74,9 @@ struct mldhip_engine {
   float* loop_small = nullptr;    // ... its biases / LayerNorm parameters, packed; then the DDIM coefficients [n][4]
   float* loop_ddim = nullptr;
   int loop_ips = 0;               // weight items per reverse step (0: the variant is not built for this configuration)
+  float* cl_stream = nullptr;     // cluster loop (kernels/loop_cluster.hpp): per column group and wave, the split-f16 fragments in consumption order
+  unsigned cl_wave_off[32] = {0}; // ... float offset of (column group, wave)'s sequence
+  int cluster_failed = 0;         // a cluster launch reported a timeout / a placement it cannot use: the handle stays on the other loop families
   float* arena_x3 = nullptr;  // split-bf16 image of the arena (precision modes with split-bf16 staged GEMMs; built by finalize)
   size_t arena_floats = 0;
   std::vector<EncLayerP> den;      // execution order
@@ -103,6 +106,7 @@ struct mldhip_engine {
   // decode
   float *cv1, *cvec, *LNO, *feats_int, *joints_int, *zbuf;
   float* FS = nullptr;   // sample-major loop: parked skip activations [ceil(max_batch / 8)][nb][48][256]
+  float *cl_xbuf = nullptr, *cl_park = nullptr, *cl_flags = nullptr;   // cluster loop: exchange regions [clusters][kClXFloats], parked skip rows [workgroups][nb][16][256], flags [clusters][64] + status [16] (words)
   float *Po, *Pf, *Ps;   // denoiser split-K slabs: out-proj [1], FFN2 [4], skip-linear [2], each [6*max_batch][256]
   unsigned long long* trace_buf = nullptr;   // measurement only (mldhip_profile_trace)
   unsigned long long* trace_on = nullptr;    // non-null while a traced launch is being built
@@ -114,7 +118,9 @@ struct mldhip_engine {
   float* TP;             // text projection rows [2*max_batch][256] (+pe[2]), gathered per chain
   // per-handle options (mldhip_set_option)
   int small_m = 256;         // "gemm_small_m": row count up to which the register-direct tiny-GEMM shape is used
-  int loop_kernel = 0;       // "loop_kernel": 0 auto (by rows / motions), 1 latency kernels (tile32.hpp), 2 throughput kernels (strip.hpp), 3 sample-major persistent loop (loop_fused.hpp)
+  int loop_kernel = 0;       // "loop_kernel": 0 auto (by rows / motions), 1 latency kernels (tile32.hpp), 2 throughput kernels (strip.hpp), 3 sample-major persistent loop (loop_fused.hpp), 4 cluster loop (loop_cluster.hpp)
+  int cluster_max_batch = 128; // "cluster_max_batch": auto runs the cluster loop (split mode) for calls of up to this many motions (0: never); at most 8 x kClMaxClusters
+  int cluster_wt = 1;        // "cluster_wt": 1 = write-through (sc1) payload stores, valid for any placement; 0 = plain stores (clusters must sit on one XCD each: checked in the kernel)
   int fused_x3 = 1;          // "fused_x3": in the split precision mode the sample-major loop multiplies on split-f16 MFMAs (0: exact fp32 MFMAs)
   int fused_dbg = 0;         // "fused_dbg": 5 = the split-mode loop with its phase counters (same arithmetic, mldhip_profile_trace "den_loop_phases"); 0 = off
   int fused_min_batch = 0;   // "fused_min_batch": auto picks the sample-major loop from this many motions per call up; 0 = by operand format (320 split-f16, 1 280 fp32)

@@ -1,0 +1,625 @@
+// The reverse-diffusion loop of ONE bs-64 request (up to 128 motions) as one persistent launch of CLUSTERS: 12 workgroups per 8 motions.
+//
+// Why it exists.  The metric's literal configuration -- one MLD.forward of 64 prompts (mld.py:216-265,290-360) -- ran on
+// the launch-per-GEMM family (tile32.hpp): 2 052 dependent launches of ~5.5 us, 12.3 ms per batch.  The sample-major loop (loop_fused.hpp)
+// does not help there: 8 workgroups, each streaming all 30 MB of weights per step, take its flat 19 ms.  What was measured first
+// (tools/loopbench/sync_bench.hip, profiles/r05_sync_bench.json): a hand-off between workgroups INSIDE a launch -- payload stores, one flag per
+// producer, a relaxed poll, L1-bypassing loads -- costs 1.7 us with nothing to move and 2.7 / 3.6 / 3.1 us with 16 / 64 / 48 KB gathered per
+// workgroup, against 3.8 / 4.8 / 4.3 us for the same bodies as launches.  So the loop is cut where its all-to-all points are, but the pieces stay
+// in one launch:
+//
+//   cluster = 8 motions = 16 rows of the CFG batch x 3 tokens (the row order of loop_fused.hpp: row = 16 t + c, c < 8 unconditional).
+//   member (t, h), t = token 0..2, h = column group 0..3; per layer (cross_attention.py:259-272, forward_post):
+//     Ph1  [X of all 48 rows in LDS]  Q of (token t, head h), K and V of head h for all three tokens (3x redundant over t: the 3-token
+//          attention needs them), scores + softmax + P.V for its 16 rows                      -> publishes AO[16 rows][64 columns]
+//     E1   gather AO of its token from the four members (t, *)                                    16 KB
+//     Ph2  out-projection of its 16 rows, all 256 columns (4x redundant over h: LayerNorm needs whole rows) + residual + norm1 -> h1;
+//          linear1 + GELU for hidden columns [256 h, 256 h + 256)                              -> publishes H[16][256] as a split-f16 image
+//     E2   gather the hidden activation of its token from (t, *)                                  64 KB
+//     Ph3  linear2 for output columns [64 h, 64 h + 64), K = 1024                              -> publishes Y[16][64]
+//     E3   gather Y and h1 of ALL 48 rows from the twelve members, residual + norm2 -> next layer's X    96 KB
+//   (+ per skip connection, cross_attention.py:56-58: norm2 of its own rows only, Linear(cat[x, skip]) for its 16 rows x 64 columns with
+//   the two K halves on the two halves of the workgroup, and one more gather of all 48 rows.)  End of a step (encoder.norm, CFG, DDIM:
+//   mld_denoiser.py:206, mld.py:339-346) and the next step's token rows are worked out redundantly by every member: no exchange.
+//   31 exchanges per step for the 9-layer model instead of 41 launches.
+//
+// Weights: as in loop_fused.hpp a weight element is used by exactly one wave, so nothing is staged in LDS: `finalize` writes, per column group
+// and WAVE, the fragments that wave consumes in consumption order ([fragment][lane][8 words] split-f16: high halves of k = 8g .. 8g + 7 of
+// weight row 16 x + r, then the low halves) and every lane streams its 32 bytes per fragment through an 8-deep register ring.  ~1 MB per
+// layer and workgroup, ~3x the non-redundant share: at bs 64 the chip has the CUs (96 of 256) and the L2 bandwidth to spare, it is latency
+// it lacks.
+//
+// Hand-offs: cdna_hip_programming.md Guideline 16 form R1 -- write-through (sc1) payload stores, every storing wave drains its memory counter,
+// barrier, one lane stores the member's flag (relaxed, agent scope; value = epoch, never reset inside a call; zeroed by a memset node in front of
+// the launch), consumers poll the flags of the producers they need with one relaxed load per lane, then read with sc1 loads.  PLAIN payload
+// stores are 0.15-0.6 us per exchange cheaper but only visible to consumers behind the SAME L2: WT = false is used only when every member of
+// the cluster reports the same HW_REG_XCC_ID (checked in the kernel's first exchange; block b runs on XCD b % 8 in practice, not by contract).
+// Buffers are double buffered by the parity of the epoch; E3-type waits cover all twelve members even where fewer rows are read, which is what
+// keeps a fast member from overwriting a buffer a slow one still reads.  Every spin is bounded: a member that waits longer than
+// kClTimeoutTicks sets the call's status word, every member that sees it leaves, the latents are poisoned with NaN (counted by the range
+// contract's non-finite counter) and the engine falls back to the launch family for the handle.
+#pragma once
+#include "loop_fused.hpp"
+
+namespace mld {
+
+constexpr int kClMembers = 12, kClRing = 8, kClFragFloats = 512;
+constexpr int kClXs = 264, kClHs = 1032;                       // LDS row strides (words), = 8 mod 16: conflict-free fragment reads
+constexpr unsigned kClPlane = 2u * 48u * 256u;                 // one double-buffered [48][256] fp32 exchange tensor (floats)
+constexpr unsigned kClAO = 0, kClH1 = kClPlane, kClY = 2 * kClPlane, kClZ = 3 * kClPlane, kClH = 4 * kClPlane;
+constexpr unsigned kClXFloats = kClH + 2u * 48u * 1024u;       // exchange region of one cluster: 196 608 floats = 768 KB
+constexpr int kClFlagWords = 4 * 16;                           // flag kinds AO, H, Y, Z: 16 words (one 64-byte line) each
+enum : int { kFlagAO = 0, kFlagH = 1, kFlagY = 2, kFlagZ = 3 };
+constexpr int kClBigFloats = 16 * kClHs;                       // X of all 48 rows ([48][264] = 12 672 words) and the token's hidden activation ([16][1032]) in turn
+static_assert(kClBigFloats >= 48 * kClXs, "X and the hidden activation share one region");
+constexpr int kClAsFloats = 16 * kClXs;
+constexpr int kClScFloats = 3 * 16 * 4, kClRedFloats = 2 * 16 * 8, kClRed2Floats = 4 * 64 * 4, kClCtlFloats = 16;
+constexpr int kClLdsFloats = kClBigFloats + kClAsFloats + kLfLatFloats + 2 * kLfPrmFloats + kClScFloats + kClRedFloats + kClRed2Floats + kClCtlFloats;
+constexpr int kClLdsBytes = kClLdsFloats * 4;                  // 125 760 B: one workgroup per CU
+constexpr int kClMaxClusters = 16;                             // two clusters per XCD (32 CUs): 128 motions
+
+struct ClFrag { long long src; int ld; int pad; };            // element [row0][k0] of a weight (floats into the arena), row stride
+
+struct ClusterArgs {
+  const float* stream;        // per column group and wave: [fragments of a step + kClRing][64 lanes][8 words]
+  unsigned wave_off[32];      // [column group][wave]: float offset of that wave's fragment sequence
+  const float* small;         // loop_fused.hpp's packed small parameters (kLs*)
+  const float* T1;            // [n][256] time-token rows
+  const float* TP;            // [2B][256] condition-token rows, unconditional half first
+  const float* init_lat;      // [B][256]
+  float* lat;                 // [B][256]
+  float* park;                // [workgroup][nb][16][256] parked skip rows of the member's own token
+  const float* ddim;          // [n][4]
+  float* xbuf;                // [clusters][kClXFloats] exchange regions
+  unsigned* flags;            // [clusters][kClFlagWords], zeroed in front of the launch
+  unsigned* status;           // [0]: 0 ok, 1 a wait timed out, 2 plain stores requested but a cluster spans XCDs; [1]: census scratch
+  int B, L, n, ncl;
+  int xslots;                 // blocks per launch row: 8 on the GPU (block b runs on XCD b % 8: a cluster's members share the slot), min(clusters, 8) on the simulator
+  float guidance, init_sigma;
+};
+
+#if defined(MLDHIP_SIM)
+constexpr unsigned long long kClTimeoutTicks = 1ull << 26;     // poll iterations
+#else
+constexpr unsigned long long kClTimeoutTicks = 20000000ull;    // 100 MHz ticks: 200 ms
+#endif
+
+// finalize-time: one fragment = 16 weight rows x 32 k as the split-f16 operand pair of lane (r, g): high halves of W[row0 + r][k0 + 8g .. + 7], then the low halves
+__global__ __launch_bounds__(64) void pack_cluster_frags_kernel(const float* __restrict__ arena, const ClFrag* __restrict__ frags, float* __restrict__ out) {
+  const ClFrag f = frags[blockIdx.x];
+  const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+  const float* src = arena + f.src + (long long)r * f.ld + 8 * g;
+  const F4 a = ld4(src), b = ld4(src + 4);
+  U4 hi, lo;
+  split16_pair(a.x, a.y, hi.x, lo.x);
+  split16_pair(a.z, a.w, hi.y, lo.y);
+  split16_pair(b.x, b.y, hi.z, lo.z);
+  split16_pair(b.z, b.w, hi.w, lo.w);
+  float* dst = out + (long long)blockIdx.x * kClFragFloats + lane * 8;
+  *reinterpret_cast<U4*>(dst) = hi;
+  *reinterpret_cast<U4*>(dst + 4) = lo;
+}
+
+// grid = 12 xslots x ceil(clusters / xslots), xslots = 8: block b -> XCD slot x = b % 8, index i = b / 8 -> cluster x + 8 (i / 12), member i % 12.  block = 512.
+// WT: write-through payload stores (any placement).  WT = false: plain stores, the kernel refuses (status 2) if a cluster spans XCDs.
+template <bool WT>
+__global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
+#if defined(MLDHIP_SIM)
+  float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
+#else
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+#endif
+  float* Xs = smem;                              // [48][264] layer input, split image; later [16][1032]: the token's hidden activation
+  float* As = Xs + kClBigFloats;                 // [16][264] attention output, then norm1 output (own token), split image
+  float* lats = As + kClAsFloats;                // [8][256]
+  float* prm = lats + kLfLatFloats;              // [2][kLfPrmFloats]
+  float* sc = prm + 2 * kLfPrmFloats;            // [3 keys][16 rows][4 waves] partial attention scores
+  float* red = sc + kClScFloats;                 // [2 passes][16 rows][8 waves]
+  float* red2 = red + kClRedFloats;              // [4 waves][64 lanes][4] K-half partial tiles
+  unsigned* ctl = reinterpret_cast<unsigned*>(red2 + kClRed2Floats);
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int bx = (int)blockIdx.x % p.xslots, bi = (int)blockIdx.x / p.xslots;
+  const int cluster = bx + p.xslots * (bi / kClMembers), member = bi % kClMembers;
+  if (cluster >= p.ncl) return;
+  const int tk = member >> 2, hc = member & 3;   // token, column group (= head)
+  const int s0 = cluster * 8, nb = (p.L - 1) / 2;
+  const float* sm_fin = p.small + (long long)p.L * kLsLayer + nb * 256;
+  const XBuf xb = xbuf_make(p.xbuf + (size_t)cluster * kClXFloats, kClXFloats * 4u);
+  unsigned* flags = p.flags + (size_t)cluster * kClFlagWords;
+
+  // ---- waiting for members: wave 0, lane m polls member m's flag of `kind`; bounded; the verdict reaches everybody through LDS + barrier
+  auto wait_flags = [&](int kind, unsigned mask, unsigned epoch) -> bool {
+    if (wave == 0) {
+      const unsigned* f = flags + kind * 16 + (lane < kClMembers ? lane : 0);
+      const bool need = lane < kClMembers && ((mask >> lane) & 1u);
+      bool ok = true;
+#if defined(MLDHIP_SIM)
+      unsigned long long it = 0;
+#else
+      const unsigned long long ts = realtime_100mhz();
+      unsigned it = 0;
+#endif
+      for (;;) {
+        const bool ready = !need || flag_load(f) >= epoch;
+        if (!wave_any(!ready)) break;
+        spin_pause();
+#if defined(MLDHIP_SIM)
+        if (++it > kClTimeoutTicks) { ok = false; break; }
+#else
+        if ((++it & 63u) == 0u) {
+          const bool late = realtime_100mhz() - ts > kClTimeoutTicks;
+          if (wave_any(late || flag_load(p.status) != 0u)) { ok = false; break; }
+        }
+#endif
+      }
+      if (lane == 0) {
+        if (!ok) flag_store(p.status, 1u);
+        ctl[0] = ok ? 1u : 0u;
+      }
+    }
+    __syncthreads();
+    return ctl[0] != 0u;
+  };
+  auto publish = [&](int kind, unsigned epoch) __attribute__((always_inline)) {
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) flag_store(flags + kind * 16 + member, epoch);
+  };
+  auto give_up = [&]() {           // a wait failed: poison this cluster's latents (member 0), leave
+    if (member == 0) {
+      const int c = tid >> 6, c4 = tid & 63;
+      const float qnan = __builtin_nanf("");
+      if (s0 + c < p.B) st4(p.lat + (long long)(s0 + c) * 256 + c4 * 4, F4{qnan, qnan, qnan, qnan});
+    }
+  };
+
+  // ---- weight ring: this lane's two MFMA operands (32 bytes) of the wave's next kClRing fragments
+  const unsigned wbase = p.wave_off[hc * 8 + wave] + (unsigned)lane * 8u;
+  unsigned goff = wbase;
+  F4 ring[kClRing][2];
+  auto gload = [&](int slot) __attribute__((always_inline)) {
+    const float* s = p.stream + goff;
+    ring[slot][0] = ld4(s);
+    ring[slot][1] = ld4(s + 4);
+    goff += (unsigned)kClFragFloats;
+#if !defined(MLDHIP_SIM)
+    asm volatile("" : "+v"(goff));
+#endif
+  };
+  // three tokens against one fragment (loop_fused.hpp mma_item); one token against one fragment on two accumulators (cross terms / high x high)
+  auto mma3 = [&](int j, const F4 (&x)[3][2], f32x4 (&acc)[3]) __attribute__((always_inline)) {
+    const int slot = j % kClRing;
+    const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][1]), acc[t]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wl, __builtin_bit_cast(U4, x[t][0]), acc[t]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][0]), acc[t]);
+    gload(slot);
+    sched_fence();
+  };
+  auto mma1 = [&](int j, const F4 (&x)[2], f32x4& a0, f32x4& a1) __attribute__((always_inline)) {
+    const int slot = j % kClRing;
+    const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
+    a0 = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[1]), a0);
+    a1 = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[0]), a1);
+    a0 = mfma_x3_16x16x32(wl, __builtin_bit_cast(U4, x[0]), a0);
+    gload(slot);
+    sched_fence();
+  };
+  const int swz4 = ((r >> 2) & 3) << 2;                    // row swizzle of the operand images (loop_fused.hpp SWZ): XOR of the word offset's bits 2-3
+  const int gs4 = (g << 2) ^ swz4;                         // this lane's 16-byte group of a half chunk
+  auto frag = [&](const float* buf, int st, int row, int kc, F4 (&x)[2]) __attribute__((always_inline)) {
+    const float* a = buf + row * st + 32 * kc + gs4;
+    x[0] = ld4(a);
+    x[1] = ld4(a + 16);
+  };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- row-per-wave helpers (gathers, LayerNorm over whole rows, token assembly): lane l owns columns 4l .. 4l + 3 of a row
+  auto st_row = [&](float* buf, int st, int row, F4 v) __attribute__((always_inline)) {       // -> split image, swizzled by the row
+    unsigned h0, l0, h1, l1;
+    split16_two(v.x, v.y, h0, l0);
+    split16_two(v.z, v.w, h1, l1);
+    unsigned* d = reinterpret_cast<unsigned*>(buf) + row * st + ((((lane >> 3) << 5) + ((lane & 7) << 1)) ^ (((row >> 2) & 3) << 2));
+    *reinterpret_cast<U2*>(d) = U2{h0, h1};
+    *reinterpret_cast<U2*>(d + 16) = U2{l0, l1};
+  };
+  auto ln_rows = [&](F4 (&v)[6], int nr, const float* gamma, const float* beta) __attribute__((always_inline)) {
+    const F4 gm = ld4(gamma + lane * 4), bt = ld4(beta + lane * 4);
+    float s[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s[i] = i < nr ? (v[i].x + v[i].y) + (v[i].z + v[i].w) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) if (i < nr) s[i] = sum64(s[i]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (i < nr) {
+        const float mean = s[i] * (1.0f / 256.0f);
+        v[i] = F4{v[i].x - mean, v[i].y - mean, v[i].z - mean, v[i].w - mean};
+        s[i] = (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) if (i < nr) s[i] = sum64(s[i]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (i < nr) {
+        const float rs = rsqrtf(s[i] * (1.0f / 256.0f) + kLnEps);
+        v[i] = F4{v[i].x * rs * gm.x + bt.x, v[i].y * rs * gm.y + bt.y, v[i].z * rs * gm.z + bt.z, v[i].w * rs * gm.w + bt.w};
+      }
+    }
+  };
+  auto f4add = [](F4 a, F4 b) { return F4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; };
+
+  // token rows of a reverse step -> Xs (mld_denoiser.py:143-196): this wave's rows w + 8 i: token 0 = latent + pe[0] (both CFG halves of motion w),
+  // token 1 = the step's time row, token 2 = the condition rows (unconditional, conditional)
+  auto assemble = [&](int step) __attribute__((always_inline)) {
+    const float* pe0 = sm_fin + 512;
+    int sidx = s0 + wave;
+    sidx = sidx < p.B ? sidx : p.B - 1;
+    const F4 pe = ld4(pe0 + lane * 4), la = ld4(lats + wave * 256 + lane * 4), tt = ld4(p.T1 + (unsigned)step * 256u + lane * 4);
+    const F4 tu = ld4(p.TP + (unsigned)sidx * 256u + lane * 4), tc = ld4(p.TP + (unsigned)(p.B + sidx) * 256u + lane * 4);
+    const F4 x0 = f4add(la, pe);
+    st_row(Xs, kClXs, wave, x0);
+    st_row(Xs, kClXs, wave + 8, x0);
+    st_row(Xs, kClXs, 16 + wave, tt);
+    st_row(Xs, kClXs, 24 + wave, tt);
+    st_row(Xs, kClXs, 32 + wave, tu);
+    st_row(Xs, kClXs, 40 + wave, tc);
+  };
+  // a layer's small parameters (+ the bias of the skip linear behind it) -> LDS, double buffered (loop_fused.hpp prm_fetch / prm_store)
+  F4 pf0, pf1;
+  auto prm_fetch = [&](int layer) __attribute__((always_inline)) {
+    const float* src = p.small + (unsigned)layer * (unsigned)kLsLayer;
+    const int o0 = tid * 4, o1 = 2048 + o0;
+    pf0 = ld4(src + o0);
+    pf1 = o1 < kLsLayer ? ld4(src + o1) : F4{0.f, 0.f, 0.f, 0.f};
+    if (o1 >= kLsLayer && o1 < kLsLayer + 256) {
+      const int si = layer - nb;
+      if (si >= 0 && layer + 1 < p.L) pf1 = ld4(p.small + (unsigned)p.L * (unsigned)kLsLayer + (unsigned)si * 256u + (unsigned)(o1 - kLsLayer));
+    }
+  };
+  auto prm_store = [&](int buf) __attribute__((always_inline)) {
+    float* dst = prm + buf * kLfPrmFloats;
+    const int o0 = tid * 4, o1 = 2048 + o0;
+    st4(dst + o0, pf0);
+    if (o1 < kLfPrmFloats) st4(dst + o1, pf1);
+  };
+
+  // ---- prologue: latents, parameters of layer 0, the first step's rows, the ring; placement census when plain stores were asked for
+  {
+    const int c = tid >> 6, c4 = tid & 63;
+    int s = s0 + c;
+    s = s < p.B ? s : p.B - 1;
+    const F4 v = ld4(p.init_lat + (long long)s * 256 + c4 * 4);
+    st4(lats + c * 256 + c4 * 4, F4{v.x * p.init_sigma, v.y * p.init_sigma, v.z * p.init_sigma, v.w * p.init_sigma});
+  }
+  prm_fetch(0);
+  prm_store(0);
+  __syncthreads();
+  assemble(0);
+#pragma unroll
+  for (int j = 0; j < kClRing; ++j) gload(j);
+  if constexpr (!WT) {
+    // every member posts 1 + its XCC id as its Z flag (Z epochs start above 16: see below); a cluster that spans XCDs cannot use plain stores
+    if (tid == 0) flag_store(flags + kFlagZ * 16 + member, 1u + xcc_id());
+    if (!wait_flags(kFlagZ, 0xFFFu, 1u)) { give_up(); return; }
+    if (wave == 0) {
+      const unsigned mine = 1u + xcc_id();
+      const unsigned other = lane < kClMembers ? flag_load(flags + kFlagZ * 16 + lane) : mine;
+      if (wave_any(other != mine)) {
+        if (lane == 0) { flag_store(p.status, 2u); ctl[1] = 1u; }
+      } else if (lane == 0) ctl[1] = 0u;
+    }
+    __syncthreads();
+    if (ctl[1] != 0u) { give_up(); return; }
+  }
+  __syncthreads();
+  int pbuf = 0;
+  const unsigned wg = blockIdx.x;
+
+  for (int step = 0; step < p.n; ++step) {
+    goff = wbase + (unsigned)(kClRing * kClFragFloats);
+    for (int l = 0; l < p.L; ++l) {
+      const float* sm = prm + pbuf * kLfPrmFloats;
+      const unsigned epoch = (unsigned)(step * p.L + l) + 1u;
+      const unsigned par = epoch & 1u;
+      const unsigned own_mask = 0xFu << (4 * tk);
+      // ================= Ph1: Q (own token), K, V (all tokens) of head hc; 3-token attention for the 16 rows of token tk
+      if (wave < 4) {
+        f32x4 q0 = zero4, q1 = zero4, k[3] = {zero4, zero4, zero4};
+        F4 x[2][3][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) frag(Xs, kClXs, 16 * t + r, 0, x[0][t]);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+          if (kc + 1 < 8) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) frag(Xs, kClXs, 16 * t + r, kc + 1, x[(kc + 1) & 1][t]);
+          }
+          // the own token's fragments, selected without a dynamic register index
+          F4 xo[2];
+          xo[0] = tk == 0 ? x[kc & 1][0][0] : (tk == 1 ? x[kc & 1][1][0] : x[kc & 1][2][0]);
+          xo[1] = tk == 0 ? x[kc & 1][0][1] : (tk == 1 ? x[kc & 1][1][1] : x[kc & 1][2][1]);
+          mma1(2 * kc, xo, q0, q1);
+          mma3(2 * kc + 1, x[kc & 1], k);
+        }
+        const F4 bq = ld4(sm + kLsInB + hc * 64 + wave * 16 + g * 4), bk = ld4(sm + kLsInB + 256 + hc * 64 + wave * 16 + g * 4);
+        const float qv[4] = {q0[0] + q1[0] + bq.x, q0[1] + q1[1] + bq.y, q0[2] + q1[2] + bq.z, q0[3] + q1[3] + bq.w};
+        const float bkv[4] = {bk.x, bk.y, bk.z, bk.w};
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          float sp = (qv[0] * (k[u][0] + bkv[0]) + qv[1] * (k[u][1] + bkv[1])) + (qv[2] * (k[u][2] + bkv[2]) + qv[3] * (k[u][3] + bkv[3]));
+          sp = sum_groups(sp);
+          if (g == 0) sc[(u * 16 + r) * 4 + wave] = sp;
+        }
+        __syncthreads();
+      } else {
+        const int w4 = wave - 4;
+        f32x4 v[3] = {zero4, zero4, zero4};
+        F4 x[2][3][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) frag(Xs, kClXs, 16 * t + r, 0, x[0][t]);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+          if (kc + 1 < 8) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) frag(Xs, kClXs, 16 * t + r, kc + 1, x[(kc + 1) & 1][t]);
+          }
+          mma3(kc, x[kc & 1], v);
+        }
+        const F4 bv = ld4(sm + kLsInB + 512 + hc * 64 + w4 * 16 + g * 4);
+        const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+        __syncthreads();
+        float a[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const F4 e = ld4(sc + (u * 16 + r) * 4);
+          a[u] = ((e.x + e.y) + (e.z + e.w)) * (0.125f * 1.44269504088896340736f);      // 1 / sqrt(64), log2 domain
+        }
+        const float m = fmaxf(a[0], fmaxf(a[1], a[2]));
+        const float e0 = fast_exp2(a[0] - m), e1 = fast_exp2(a[1] - m), e2 = fast_exp2(a[2] - m);
+        const float inv = fast_rcp(e0 + e1 + e2);
+        const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (p0 * (v[0][i] + bvv[i]) + p1 * (v[1][i] + bvv[i])) + p2 * (v[2][i] + bvv[i]);
+        xbuf_st4<WT>(xb, (kClAO + par * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + w4 * 16 + g * 4)) * 4u, F4{o[0], o[1], o[2], o[3]});
+      }
+      publish(kFlagAO, epoch);
+      // ================= E1: attention output of the token from its four members -> As
+      if (!wait_flags(kFlagAO, own_mask, epoch)) { give_up(); return; }
+      {
+        const F4 a0 = xbuf_ld4(xb, (kClAO + par * 12288u + (unsigned)((16 * tk + wave) * 256 + lane * 4)) * 4u);
+        const F4 a1 = xbuf_ld4(xb, (kClAO + par * 12288u + (unsigned)((16 * tk + wave + 8) * 256 + lane * 4)) * 4u);
+        st_row(As, kClXs, wave, a0);
+        st_row(As, kClXs, wave + 8, a1);
+      }
+      __syncthreads();
+      // ================= Ph2: out-projection (all 256 columns: this wave 32 w .. + 31) + residual + norm1 -> h1; linear1 + GELU of hidden columns 256 hc + 32 w .. + 31
+      {
+        f32x4 a[2][2] = {{zero4, zero4}, {zero4, zero4}};
+        F4 x[2][2];
+        frag(As, kClXs, r, 0, x[0]);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+          if (kc + 1 < 8) frag(As, kClXs, r, kc + 1, x[(kc + 1) & 1]);
+          mma1(2 * kc, x[kc & 1], a[0][0], a[0][1]);
+          mma1(2 * kc + 1, x[kc & 1], a[1][0], a[1][1]);
+        }
+        float u[2][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const F4 ob = ld4(sm + kLsOutB + wave * 32 + j * 16 + g * 4);
+          const unsigned* wq = reinterpret_cast<const unsigned*>(Xs) + (16 * tk + r) * kClXs + wave * 32 + ((j * 8 + g * 2) ^ swz4);
+          const U2 h = *reinterpret_cast<const U2*>(wq), lo = *reinterpret_cast<const U2*>(wq + 16);
+          u[j][0] = (a[j][0][0] + a[j][1][0]) + ob.x + (f16_bits_value(h.x) + f16_bits_value(lo.x));
+          u[j][1] = (a[j][0][1] + a[j][1][1]) + ob.y + (f16_bits_value(h.x >> 16) + f16_bits_value(lo.x >> 16));
+          u[j][2] = (a[j][0][2] + a[j][1][2]) + ob.z + (f16_bits_value(h.y) + f16_bits_value(lo.y));
+          u[j][3] = (a[j][0][3] + a[j][1][3]) + ob.w + (f16_bits_value(h.y >> 16) + f16_bits_value(lo.y >> 16));
+          sum += (u[j][0] + u[j][1]) + (u[j][2] + u[j][3]);
+        }
+        sum = sum_groups(sum);
+        if (g == 0) red[r * 8 + wave] = sum;
+        __syncthreads();
+        {
+          const F4 ma = ld4(red + r * 8), mb = ld4(red + r * 8 + 4);
+          const float mean = (((ma.x + ma.y) + (ma.z + ma.w)) + ((mb.x + mb.y) + (mb.z + mb.w))) * (1.0f / 256.0f);
+          float sq = 0.f;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { u[j][i] -= mean; sq += u[j][i] * u[j][i]; }
+          sq = sum_groups(sq);
+          if (g == 0) red[128 + r * 8 + wave] = sq;
+        }
+        __syncthreads();
+        {
+          const F4 qa = ld4(red + 128 + r * 8), qb = ld4(red + 128 + r * 8 + 4);
+          const float rs = rsqrtf((((qa.x + qa.y) + (qa.z + qa.w)) + ((qb.x + qb.y) + (qb.z + qb.w))) * (1.0f / 256.0f) + kLnEps);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const F4 gm = ld4(sm + kLsN1W + wave * 32 + j * 16 + g * 4), bt = ld4(sm + kLsN1B + wave * 32 + j * 16 + g * 4);
+            u[j][0] = u[j][0] * rs * gm.x + bt.x; u[j][1] = u[j][1] * rs * gm.y + bt.y; u[j][2] = u[j][2] * rs * gm.z + bt.z; u[j][3] = u[j][3] * rs * gm.w + bt.w;
+            unsigned h0, l0, h1, l1;
+            split16_two(u[j][0], u[j][1], h0, l0);
+            split16_two(u[j][2], u[j][3], h1, l1);
+            unsigned* wq = reinterpret_cast<unsigned*>(As) + r * kClXs + wave * 32 + ((j * 8 + g * 2) ^ swz4);
+            *reinterpret_cast<U2*>(wq) = U2{h0, h1};
+            *reinterpret_cast<U2*>(wq + 16) = U2{l0, l1};
+            // norm1 output of the token for everybody's norm2 residual: the column quarter of this member (waves 2 hc, 2 hc + 1), the value the GEMMs see (high + low half)
+            if ((wave >> 1) == hc)
+              xbuf_st4<WT>(xb, (kClH1 + par * 12288u + (unsigned)((16 * tk + r) * 256 + wave * 32 + j * 16 + g * 4)) * 4u,
+                           F4{f16_bits_value(h0) + f16_bits_value(l0), f16_bits_value(h0 >> 16) + f16_bits_value(l0 >> 16), f16_bits_value(h1) + f16_bits_value(l1),
+                              f16_bits_value(h1 >> 16) + f16_bits_value(l1 >> 16)});
+          }
+        }
+        __syncthreads();
+        // linear1 + GELU
+        f32x4 h[2][2] = {{zero4, zero4}, {zero4, zero4}};
+        frag(As, kClXs, r, 0, x[0]);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+          if (kc + 1 < 8) frag(As, kClXs, r, kc + 1, x[(kc + 1) & 1]);
+          mma1(2 * kc, x[kc & 1], h[0][0], h[0][1]);
+          mma1(2 * kc + 1, x[kc & 1], h[1][0], h[1][1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const F4 b1 = ld4(sm + kLsL1B + hc * 256 + wave * 32 + j * 16 + g * 4);
+          const float v0 = gelu_erf((h[j][0][0] + h[j][1][0]) + b1.x), v1 = gelu_erf((h[j][0][1] + h[j][1][1]) + b1.y);
+          const float v2 = gelu_erf((h[j][0][2] + h[j][1][2]) + b1.z), v3 = gelu_erf((h[j][0][3] + h[j][1][3]) + b1.w);
+          unsigned h0, l0, h1, l1;
+          split16_two(v0, v1, h0, l0);
+          split16_two(v2, v3, h1, l1);
+          // the hidden activation travels as the (unswizzled) split image: row 16 tk + r, chunk 8 hc + w (32 hidden columns = 32 words), high words 8 j + 2 g, low + 16
+          const unsigned wo = (kClH + par * 49152u + (unsigned)((16 * tk + r) * 1024 + (8 * hc + wave) * 32 + j * 8 + g * 2)) * 4u;
+          xbuf_st2<WT>(xb, wo, U2{h0, h1});
+          xbuf_st2<WT>(xb, wo + 64u, U2{l0, l1});
+        }
+      }
+      publish(kFlagH, epoch);
+      // ================= E2: the token's hidden activation (64 KB image) from its four members -> Xs region as [16][1032]
+      if (!wait_flags(kFlagH, own_mask, epoch)) { give_up(); return; }
+      {
+        F4 hv[8];
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+          const int q = tid + 512 * k8;                 // 16-byte unit: row q >> 8, unit (q & 255) of the row's 1024 words
+          hv[k8] = xbuf_ld4(xb, (kClH + par * 49152u + (unsigned)(16 * tk) * 1024u) * 4u + (unsigned)q * 16u);
+        }
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+          const int q = tid + 512 * k8, row = q >> 8, un = q & 255;
+          st4(Xs + row * kClHs + (((un >> 2) << 4) + (((un & 3) ^ ((row >> 2) & 3)) << 2)), hv[k8]);
+        }
+      }
+      __syncthreads();
+      // ================= Ph3: linear2 for output columns 64 hc + 16 (w & 3) .. + 15, K half w >> 2; halves meet through LDS -> Y
+      {
+        f32x4 y0 = zero4, y1 = zero4;
+        const int kh = wave >> 2;
+        F4 x[2][2];
+        frag(Xs, kClHs, r, 16 * kh, x[0]);
+#pragma unroll
+        for (int kc = 0; kc < 16; ++kc) {
+          if (kc + 1 < 16) frag(Xs, kClHs, r, 16 * kh + kc + 1, x[(kc + 1) & 1]);
+          mma1(kc, x[kc & 1], y0, y1);
+        }
+        f32x4 y = y0 + y1;
+        if (wave >= 4) *reinterpret_cast<f32x4*>(red2 + ((wave - 4) * 64 + lane) * 4) = y;
+        __syncthreads();
+        if (wave < 4) {
+          y += *reinterpret_cast<const f32x4*>(red2 + (wave * 64 + lane) * 4);
+          const F4 b2 = ld4(sm + kLsL2B + hc * 64 + wave * 16 + g * 4);
+          xbuf_st4<WT>(xb, (kClY + par * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + wave * 16 + g * 4)) * 4u, F4{y[0] + b2.x, y[1] + b2.y, y[2] + b2.z, y[3] + b2.w});
+        }
+      }
+      publish(kFlagY, epoch);
+      // ================= E3 and what follows the layer
+      const bool last = l + 1 == p.L, skip_next = !last && l >= nb;
+      prm_fetch(last ? 0 : l + 1);
+      if (!wait_flags(kFlagY, 0xFFFu, epoch)) { give_up(); return; }      // all twelve even where fewer rows are read (buffer-reuse invariant)
+      if (!last && !skip_next) {
+        // x' = norm2(y + h1) for all 48 rows -> Xs; input blocks park their own token's rows for the skip connection (cross_attention.py:48-52)
+        F4 v[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const unsigned off = (unsigned)((wave + 8 * i) * 256 + lane * 4);
+          v[i] = f4add(xbuf_ld4(xb, (kClY + par * 12288u + off) * 4u), xbuf_ld4(xb, (kClH1 + par * 12288u + off) * 4u));
+        }
+        ln_rows(v, 6, sm + kLsN2W, sm + kLsN2B);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st_row(Xs, kClXs, wave + 8 * i, v[i]);
+        if (l < nb) {
+          float* pk = p.park + ((size_t)wg * nb + l) * (16 * 256);
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            if ((i >> 1) == tk) st4(pk + (unsigned)((wave + 8 * (i & 1)) * 256 + lane * 4), v[i]);
+        }
+        prm_store(pbuf ^ 1);
+        __syncthreads();
+      } else if (skip_next) {
+        // norm2 of the token's own rows, then x = Linear(cat[x', skip]) for these 16 rows x 64 columns: K half 0 (x') on waves 0-3, half 1 (the parked rows) on waves 4-7
+        const int si = l - nb;
+        F4 v[6];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned off = (unsigned)((16 * tk + wave + 8 * i) * 256 + lane * 4);
+          v[i] = f4add(xbuf_ld4(xb, (kClY + par * 12288u + off) * 4u), xbuf_ld4(xb, (kClH1 + par * 12288u + off) * 4u));
+        }
+        const float* pk = p.park + ((size_t)wg * nb + (nb - 1 - si)) * (16 * 256);
+        const F4 s0v = ld4(pk + (unsigned)(wave * 256 + lane * 4)), s1v = ld4(pk + (unsigned)((wave + 8) * 256 + lane * 4));
+        ln_rows(v, 2, sm + kLsN2W, sm + kLsN2B);
+        st_row(Xs, kClXs, 16 * tk + wave, v[0]);
+        st_row(Xs, kClXs, 16 * tk + wave + 8, v[1]);
+        st_row(As, kClXs, wave, s0v);
+        st_row(As, kClXs, wave + 8, s1v);
+        __syncthreads();
+        f32x4 z0 = zero4, z1 = zero4;
+        const float* abuf = wave < 4 ? Xs + 16 * tk * kClXs : As;
+        F4 x[2][2];
+        frag(abuf, kClXs, r, 0, x[0]);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+          if (kc + 1 < 8) frag(abuf, kClXs, r, kc + 1, x[(kc + 1) & 1]);
+          mma1(kc, x[kc & 1], z0, z1);
+        }
+        f32x4 z = z0 + z1;
+        if (wave >= 4) *reinterpret_cast<f32x4*>(red2 + ((wave - 4) * 64 + lane) * 4) = z;
+        __syncthreads();
+        const unsigned zepoch = 16u + (unsigned)(step * nb + si) + 1u, zpar = zepoch & 1u;
+        if (wave < 4) {
+          z += *reinterpret_cast<const f32x4*>(red2 + (wave * 64 + lane) * 4);
+          const F4 sb = ld4(sm + kLsLayer + hc * 64 + wave * 16 + g * 4);
+          xbuf_st4<WT>(xb, (kClZ + zpar * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + wave * 16 + g * 4)) * 4u, F4{z[0] + sb.x, z[1] + sb.y, z[2] + sb.z, z[3] + sb.w});
+        }
+        publish(kFlagZ, zepoch);
+        if (!wait_flags(kFlagZ, 0xFFFu, zepoch)) { give_up(); return; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = xbuf_ld4(xb, (kClZ + zpar * 12288u + (unsigned)((wave + 8 * i) * 256 + lane * 4)) * 4u);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st_row(Xs, kClXs, wave + 8 * i, v[i]);
+        prm_store(pbuf ^ 1);
+        __syncthreads();
+      } else {
+        // end of the step, every member for itself: norm2 + encoder.norm of the latent token's rows w (unconditional) and w + 8 (conditional) of motion w,
+        // CFG (mld.py:339-342), DDIM eta = 0 (mld.py:345-346), the next step's rows
+        F4 v[6];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned off = (unsigned)((wave + 8 * i) * 256 + lane * 4);
+          v[i] = f4add(xbuf_ld4(xb, (kClY + par * 12288u + off) * 4u), xbuf_ld4(xb, (kClH1 + par * 12288u + off) * 4u));
+        }
+        ln_rows(v, 2, sm + kLsN2W, sm + kLsN2B);
+        ln_rows(v, 2, sm_fin, sm_fin + 256);
+        const float sat = p.ddim[step * 4], s1mat = p.ddim[step * 4 + 1], sap = p.ddim[step * 4 + 2], s1map = p.ddim[step * 4 + 3];
+        float* lp = lats + wave * 256 + lane * 4;
+        const F4 xt = ld4(lp);
+        const float eu[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, ec[4] = {v[1].x, v[1].y, v[1].z, v[1].w}, xtv[4] = {xt.x, xt.y, xt.z, xt.w};
+        float nv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float eps = eu[i] + p.guidance * (ec[i] - eu[i]);
+          const float x0 = (xtv[i] - s1mat * eps) / sat;
+          nv[i] = sap * x0 + s1map * eps;
+        }
+        st4(lp, F4{nv[0], nv[1], nv[2], nv[3]});
+        prm_store(pbuf ^ 1);
+        if (step + 1 < p.n) assemble(step + 1);      // (reads this wave's own latent row only)
+        __syncthreads();
+      }
+      pbuf ^= 1;
+    }
+  }
+  if (member == 0) {
+    const int c = tid >> 6, c4 = tid & 63;
+    if (s0 + c < p.B) st4(p.lat + (long long)(s0 + c) * 256 + c4 * 4, ld4(lats + c * 256 + c4 * 4));
+  }
+}
+
+}  // namespace mld

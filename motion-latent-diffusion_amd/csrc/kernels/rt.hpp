@@ -10,10 +10,15 @@
 #include "hipsim.h"
 #define MLD_LAUNCH(kernel, grid, block, shmem, stream, ...) \
   hipsim::launch((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })
+// every workgroup of the grid resident at once (kernels whose workgroups hand data to each other: loop_cluster.hpp); on the GPU a plain
+// launch whose grid the caller sized to the chip
+#define MLD_LAUNCH_CORESIDENT(kernel, grid, block, shmem, stream, ...) \
+  hipsim::launch_coresident((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })
 #else
 #include <hip/hip_runtime.h>
 #define MLD_LAUNCH(kernel, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (stream), __VA_ARGS__)
+#define MLD_LAUNCH_CORESIDENT MLD_LAUNCH
 #endif
 
 #include <cstdint>
@@ -458,6 +463,40 @@ __device__ __forceinline__ unsigned long long clock_light() {
   return t;
 #endif
 }
+
+// ---- inter-workgroup hand-off inside one launch (kernels/loop_cluster.hpp; cdna_hip_programming.md Guideline 16, MI355X_MICROARCH.md
+// "Workgroup dispatch, XCD placement & inter-workgroup visibility").  A CU's vector L1 is never refreshed by another CU's stores and the
+// eight XCD L2s are not coherent with each other, so: payload stores are WRITE-THROUGH (sc1: valid for any placement) or plain (valid only
+// when producer and consumer share an XCD's L2 -- the kernel checks HW_REG_XCC_ID before it uses them), every storing wave drains its
+// memory counter, ONE lane publishes a flag with a relaxed agent-scope store, the consumer polls that word relaxed (sc1) and then reads the
+// payload with L1-bypassing (sc1) loads.  All shared data goes through ONE buffer descriptor (byte offsets): the cache-policy bits are an
+// immediate of the buffer instructions, which hipcc counts in its wait bookkeeping (inline-asm loads are invisible to it).
+// The simulator has no caches: plain accesses, and a spinning fiber yields.
+#if defined(MLDHIP_SIM)
+struct XBuf { unsigned char* base; };
+__device__ __forceinline__ XBuf xbuf_make(void* p, unsigned) { return XBuf{static_cast<unsigned char*>(p)}; }
+__device__ __forceinline__ F4 xbuf_ld4(const XBuf& b, unsigned off) { return *reinterpret_cast<const F4*>(b.base + off); }
+template <bool WT> __device__ __forceinline__ void xbuf_st4(const XBuf& b, unsigned off, F4 v) { *reinterpret_cast<F4*>(b.base + off) = v; }
+template <bool WT> __device__ __forceinline__ void xbuf_st2(const XBuf& b, unsigned off, U2 v) { *reinterpret_cast<U2*>(b.base + off) = v; }
+__device__ __forceinline__ unsigned flag_load(const unsigned* p) { return *reinterpret_cast<const volatile unsigned*>(p); }
+__device__ __forceinline__ void flag_store(unsigned* p, unsigned v) { *reinterpret_cast<volatile unsigned*>(p) = v; }
+__device__ __forceinline__ void spin_pause() { hipsim::yield(); }
+__device__ __forceinline__ void drain_stores() {}
+__device__ __forceinline__ unsigned xcc_id() { return 0u; }
+#else
+typedef __amdgpu_buffer_rsrc_t XBuf;
+__device__ __forceinline__ XBuf xbuf_make(void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000); }
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ F4 xbuf_ld4(const XBuf& b, unsigned off) { return __builtin_bit_cast(F4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, 16)); }      // aux 16 = sc1: L2-served
+template <bool WT> __device__ __forceinline__ void xbuf_st4(const XBuf& b, unsigned off, F4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), b, (int)off, 0, WT ? 16 : 0); }
+template <bool WT> __device__ __forceinline__ void xbuf_st2(const XBuf& b, unsigned off, U2 v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), b, (int)off, 0, WT ? 16 : 0); }
+__device__ __forceinline__ unsigned flag_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flag_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u; }      // HW_REG_XCC_ID bits 3:0
+#endif
 
 __device__ __forceinline__ unsigned long long realtime_100mhz() {
 #if defined(MLDHIP_SIM)

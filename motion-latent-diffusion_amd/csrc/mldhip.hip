@@ -38,6 +38,7 @@
 #include "kernels/tile32.hpp"
 #include "kernels/strip.hpp"
 #include "kernels/loop_fused.hpp"
+#include "kernels/loop_cluster.hpp"
 #include "kernels/ffn_strip.hpp"
 #include "kernels/gemm_strip_x3.hpp"
 #include "kernels/final_strip.hpp"
@@ -158,6 +159,11 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   want(&e->QKV, rows * 3 * D); want(&e->AO, rows * D); want(&e->FF, rows * F);
   want(&e->lat, Bm * D); want(&e->zbuf, Bm * D);
   want(&e->FS, (Bm + 7) / 8 * ((L - 1) / 2) * 48 * D);
+  {
+    // cluster loop (kernels/loop_cluster.hpp): at most kClMaxClusters clusters of 8 motions, 12 workgroups each, launched in rows of 8 XCD slots
+    const size_t ncl = D == 256 ? std::min<size_t>(kClMaxClusters, (Bm + 7) / 8) : 0, wgs = 8 * kClMembers * ((ncl + 7) / 8);
+    want(&e->cl_xbuf, ncl * kClXFloats); want(&e->cl_park, wgs * ((L - 1) / 2) * 16 * 256); want(&e->cl_flags, ncl ? ncl * kClFlagWords + 16 : 0);
+  }
   want(&e->Po, 6 * Bm * D); want(&e->Pf, 8 * 6 * Bm * D); want(&e->Ps, 2 * 6 * Bm * D); want(&e->TP, 2 * Bm * D);
   want(&e->T1, n * D); want(&e->temb0, n * TD); want(&e->tmid, n * D);
   want(&e->text_bias, D); want(&e->time_b2pe, D); want(&e->t1_one, D); want(&e->temb0_one, TD + D);
@@ -220,6 +226,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_cluster_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kClLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_cluster_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kClLdsBytes);
 #define MLD_T32_ATTR1(MT, NS, TR, PR) \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<MT, NS, TR, PR, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<MT, NS, TR, PR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
@@ -277,6 +285,7 @@ void mldhip_destroy(mldhip_handle* e) {
   if (e->ffn_streams) (void)hipFree(e->ffn_streams);
   if (e->loop_stream) (void)hipFree(e->loop_stream);
   if (e->loop_stream_x3) (void)hipFree(e->loop_stream_x3);
+  if (e->cl_stream) (void)hipFree(e->cl_stream);
   if (e->loop_small) (void)hipFree(e->loop_small);
   for (auto& x : e->ctxs) {
     if (x.ws) (void)hipFree(x.ws);
@@ -319,12 +328,20 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   if (!e || !name) return MLDHIP_EINVAL;
   const std::string n = name;
   if (n == "loop_kernel") {
-    if (value < 0 || value > 3) return e->fail(MLDHIP_EINVAL, "loop_kernel must be 0 (auto), 1 (latency), 2 (throughput) or 3 (sample-major persistent loop)");
+    if (value < 0 || value > 4) return e->fail(MLDHIP_EINVAL, "loop_kernel must be 0 (auto), 1 (latency), 2 (throughput), 3 (sample-major persistent loop) or 4 (cluster loop)");
     if (value == 3 && e->finalized && !e->loop_ips) return e->fail(MLDHIP_EINVAL, "loop_kernel 3: the sample-major loop is built for fp32 loop arithmetic, ff_size 1024, 4 heads");
+    if (value == 4 && e->finalized && !e->cl_stream) return e->fail(MLDHIP_EINVAL, "loop_kernel 4: the cluster loop is built for the split-f16 mode, latent_dim 256, ff_size 1024, 4 heads");
     e->loop_kernel = (int)value;
+    if (value == 4) e->cluster_failed = 0;
   } else if (n == "fused_x3") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "fused_x3 must be 0 or 1");
     e->fused_x3 = (int)value;
+  } else if (n == "cluster_max_batch") {
+    if (value < 0 || value > 8 * kClMaxClusters) return e->fail(MLDHIP_EINVAL, "cluster_max_batch must be 0 .. %d", 8 * kClMaxClusters);
+    e->cluster_max_batch = (int)value;
+  } else if (n == "cluster_wt") {
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "cluster_wt must be 0 (plain payload stores, one XCD per cluster) or 1 (write-through)");
+    e->cluster_wt = (int)value;
   } else if (n == "fused_dbg") {
     if (value != 0 && value != 5) return e->fail(MLDHIP_EINVAL, "fused_dbg must be 0 or 5 (phase counters; the builds with wrong results live in tools/loopbench only)");
     if (value == 5 && !e->trace_buf && hipMalloc((void**)&e->trace_buf, (size_t)512 * 8 * 8 * sizeof(uint64_t)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(trace)");
@@ -627,6 +644,7 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
     if (check_launch(c, "split_bf16_weights")) return c.rc;
   }
   if (int rc = build_loop_stream(c)) return rc;
+  if (int rc = build_cluster_stream(c)) return rc;
   if (int rc = build_ffn_streams(c)) return rc;
   for (int k = 0; k < (int)e->ctxs.size(); ++k) {       // the derived tables live in each context's workspace
   bind_context(e, k);
@@ -672,6 +690,8 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
 #endif
   bind_context(e, 0);
   e->next_ctx = 0;
+  if (e->loop_kernel == 4 && !e->cl_stream)
+    return e->fail(MLDHIP_EINVAL, "loop_kernel 4: the cluster loop is built for the split-f16 mode, latent_dim 256, ff_size 1024, 4 heads");
   if (e->loop_kernel == 3 && !e->loop_ips)      // (set before finalize: refused here, like mldhip_set_option refuses it afterwards)
     return e->fail(MLDHIP_EINVAL, "loop_kernel 3: the sample-major loop is built for fp32 / split-f16 loop arithmetic, latent_dim 256, ff_size 1024, 4 heads");
   e->finalized = true;

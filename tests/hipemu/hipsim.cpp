@@ -32,8 +32,10 @@ hipsim_switch:
 .size hipsim_switch,.-hipsim_switch
 )");
 
-static BlockState g_blk;
-BlockState& blk() { return g_blk; }
+static BlockState g_single;
+static BlockState* g_cur = &g_single;      // the block whose fiber is running (launch_coresident switches it per fiber)
+BlockState& blk() { return *g_cur; }
+#define g_blk (*g_cur)
 
 static const size_t kStack = 256 * 1024;
 static std::vector<char*> g_stacks;
@@ -186,6 +188,7 @@ static void init_fiber(Fiber& f) {
 }
 
 void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
+  g_cur = &g_single;
   BlockState& b = g_blk;
   int n = int(block.x * block.y * block.z);
   if (n <= 0 || n > 1024) { std::fprintf(stderr, "hipsim: bad block size %d\n", n); std::abort(); }
@@ -231,6 +234,57 @@ void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
         }
       }
   b.cur = nullptr;
+}
+
+// Every block of the grid alive at once (persistent kernels whose workgroups hand data to each other and spin on flags: kernels/loop_cluster.hpp).
+// One fiber per work-item of EVERY block; the sweep visits the blocks in turn.  A spinning fiber must call hipsim::yield() (rt.hpp spin_pause).
+// Kernels launched this way may not use static __shared__ (one host variable for all blocks): dynamic shared memory only.
+void launch_coresident(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
+  const int n = int(block.x * block.y * block.z), nb = int(grid.x * grid.y * grid.z);
+  if (n <= 0 || n > 1024 || nb <= 0 || nb > 64) { std::fprintf(stderr, "hipsim: bad co-resident launch (%d blocks of %d)\n", nb, n); std::abort(); }
+  static std::vector<char*> stacks;
+  while (stacks.size() < (size_t)n * nb) stacks.push_back(static_cast<char*>(std::malloc(kStack)));
+  std::vector<BlockState> bs(nb);
+  const int nw = (n + 63) / 64;
+  for (int k = 0; k < nb; ++k) {
+    BlockState& b = bs[k];
+    b.nthreads = n; b.bdim = block; b.gdim = grid; b.body = body;
+    b.fibers.assign(n, Fiber());
+    b.dyn_smem.assign(shmem + 16, 0);
+    b.bid = uint3_{unsigned(k) % grid.x, (unsigned(k) / grid.x) % grid.y, unsigned(k) / (grid.x * grid.y)};
+    b.alive = n; b.bar_count = 0; b.bar_gen = 0;
+    b.waves.assign(nw, WaveState());
+    for (int t = 0; t < n; ++t) {
+      Fiber& f = b.fibers[t];
+      f.stack = stacks[(size_t)k * n + t];
+      f.tid = uint3_{unsigned(t) % block.x, (unsigned(t) / block.x) % block.y, unsigned(t) / (block.x * block.y)};
+      f.lane = t & 63;
+      f.wave = t >> 6;
+      b.waves[f.wave].alive++;
+      init_fiber(f);
+    }
+  }
+  unsigned long spins = 0;
+  bool forward = true;
+  for (;;) {
+    int alive = 0;
+    for (int kk = 0; kk < nb; ++kk) {
+      BlockState& b = bs[forward ? kk : nb - 1 - kk];
+      if (b.alive <= 0) continue;
+      alive += b.alive;
+      for (int q = 0; q < n; ++q) {
+        Fiber& f = b.fibers[forward ? q : n - 1 - q];
+        if (f.done) continue;
+        g_cur = &b;
+        b.cur = &f;
+        hipsim_switch(&b.sched_sp, f.sp);
+      }
+    }
+    if (!alive) break;
+    forward = !forward;
+    if (++spins > 400000000ul) { std::fprintf(stderr, "hipsim: deadlock in a co-resident launch\n"); std::abort(); }
+  }
+  g_cur = &g_single;
 }
 
 }  // namespace hipsim

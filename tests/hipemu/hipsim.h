@@ -58,6 +58,7 @@ struct BlockState {
 BlockState& blk();
 void yield();
 void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body);
+void launch_coresident(dim3 grid, dim3 block, size_t shmem, std::function<void()> body);   // all blocks alive at once (inter-workgroup hand-offs)
 void sync_threads();
 
 // ---- wave-level rendezvous: every live lane of the wave must call the same op ----
