@@ -373,6 +373,8 @@ int build_cluster_stream(Ctx& c) {
       for (int j = 0; j < kClRing; ++j) frags.push_back(frags[first + j]);        // look-ahead across the end of a step
     }
   ClFrag* fdev = nullptr;
+  if (!e->cl_wave_off_dev && hipMalloc((void**)&e->cl_wave_off_dev, 32 * sizeof(unsigned)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(cluster loop offsets)");
+  if (hipMemcpy(e->cl_wave_off_dev, e->cl_wave_off, 32 * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) return e->fail(MLDHIP_EHIP, "cluster loop offsets");
   if (hipMalloc((void**)&e->cl_stream, frags.size() * (size_t)kClFragFloats * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&fdev, frags.size() * sizeof(ClFrag)) != hipSuccess)
     return e->fail(MLDHIP_EHIP, "hipMalloc(cluster loop stream)");
@@ -856,7 +858,7 @@ void launch_cluster_loop(Ctx& c, const float* init_lat, int B, int n, float guid
   E* e = c.e;
   ClusterArgs a;
   a.stream = e->cl_stream;
-  for (int i = 0; i < 32; ++i) a.wave_off[i] = e->cl_wave_off[i];
+  a.wave_off = e->cl_wave_off_dev;
   a.small = e->loop_small; a.T1 = e->T1; a.TP = e->TP; a.init_lat = init_lat; a.lat = e->lat; a.park = e->cl_park; a.ddim = e->loop_ddim;
   a.xbuf = e->cl_xbuf;
   a.ncl = (B + 7) / 8;

@@ -76,6 +76,7 @@ struct mldhip_engine {
   int loop_ips = 0;               // weight items per reverse step (0: the variant is not built for this configuration)
   float* cl_stream = nullptr;     // cluster loop (kernels/loop_cluster.hpp): per column group and wave, the split-f16 fragments in consumption order
   unsigned cl_wave_off[32] = {0}; // ... float offset of (column group, wave)'s sequence
+  unsigned* cl_wave_off_dev = nullptr;   // ... the same 32 words in device memory (kernel arguments stay small)
   int cluster_failed = 0;         // a cluster launch reported a timeout / a placement it cannot use: the handle stays on the other loop families
   float* arena_x3 = nullptr;  // split-bf16 image of the arena (precision modes with split-bf16 staged GEMMs; built by finalize)
   size_t arena_floats = 0;

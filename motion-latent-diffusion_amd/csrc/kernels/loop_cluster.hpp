@@ -43,7 +43,10 @@
 
 namespace mld {
 
-constexpr int kClMembers = 12, kClRing = 8, kClFragFloats = 512;
+#ifndef CL_RING
+#define CL_RING 4
+#endif
+constexpr int kClMembers = 12, kClRing = CL_RING, kClFragFloats = 512;
 constexpr int kClXs = 264, kClHs = 1032;                       // LDS row strides (words), = 8 mod 16: conflict-free fragment reads
 constexpr unsigned kClPlane = 2u * 48u * 256u;                 // one double-buffered [48][256] fp32 exchange tensor (floats)
 constexpr unsigned kClAO = 0, kClH1 = kClPlane, kClY = 2 * kClPlane, kClZ = 3 * kClPlane, kClH = 4 * kClPlane;
@@ -62,7 +65,7 @@ struct ClFrag { long long src; int ld; int pad; };            // element [row0][
 
 struct ClusterArgs {
   const float* stream;        // per column group and wave: [fragments of a step + kClRing][64 lanes][8 words]
-  unsigned wave_off[32];      // [column group][wave]: float offset of that wave's fragment sequence
+  const unsigned* wave_off;   // [column group][wave] (32 words in device memory): float offset of that wave's fragment sequence
   const float* small;         // loop_fused.hpp's packed small parameters (kLs*)
   const float* T1;            // [n][256] time-token rows
   const float* TP;            // [2B][256] condition-token rows, unconditional half first
@@ -74,6 +77,7 @@ struct ClusterArgs {
   unsigned* flags;            // [clusters][kClFlagWords], zeroed in front of the launch
   unsigned* status;           // [0]: 0 ok, 1 a wait timed out, 2 plain stores requested but a cluster spans XCDs; [1]: census scratch
   int B, L, n, ncl;
+  unsigned long long* trace = nullptr;   // CL_TRACE builds (tools/loopbench only): [workgroup][wave][16] shader cycles per phase, summed over steps and layers
   int xslots;                 // blocks per launch row: 8 on the GPU (block b runs on XCD b % 8: a cluster's members share the slot), min(clusters, 8) on the simulator
   float guidance, init_sigma;
 };
@@ -117,8 +121,28 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
   float* red = sc + kClScFloats;                 // [2 passes][16 rows][8 waves]
   float* red2 = red + kClRedFloats;              // [4 waves][64 lanes][4] K-half partial tiles
   unsigned* ctl = reinterpret_cast<unsigned*>(red2 + kClRed2Floats);
-  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int r = lane & 15, g = lane >> 4;
+  const int wave = wave_uniform((int)threadIdx.x >> 6);
+  unsigned goff = 0;                                       // this lane's running word offset into its wave's fragment stream
+  const int hc_ = (((int)blockIdx.x / p.xslots) % kClMembers) & 3;
+  int lane = (int)threadIdx.x & 63, tid = (int)threadIdx.x, r = lane & 15, g = lane >> 4;
+  int swz4 = ((r >> 2) & 3) << 2;                          // row swizzle of the operand images (loop_fused.hpp SWZ): XOR of the word offset's bits 2-3
+  int gs4 = (g << 2) ^ swz4;                               // this lane's 16-byte group of a half chunk
+  // Lane-dependent indices are laundered at the top of every phase: address arithmetic built on them is then redone where it is used instead of
+  // being hoisted out of the step / layer loops and held -- i.e. spilled -- across all phases (loop_fused.hpp `opaque`; the first build of this kernel:
+  // 256 registers + 544 B of scratch per lane, most of it loop-invariant addresses stored in the prologue)
+  auto fresh = [&]() __attribute__((always_inline)) {
+#if !defined(MLDHIP_SIM)
+    asm volatile("" : "+v"(lane));
+#endif
+#if defined(CL_EXP) && (CL_EXP & 1)
+    goff = p.wave_off[hc_ * 8 + wave] + (unsigned)lane * 8u;      // measurement build (WRONG results, tools/loopbench only): every phase re-reads the step's first fragments -- an L2-resident weight stream
+#endif
+    tid = wave * 64 + lane;
+    r = lane & 15;
+    g = lane >> 4;
+    swz4 = ((r >> 2) & 3) << 2;
+    gs4 = (g << 2) ^ swz4;
+  };
   const int bx = (int)blockIdx.x % p.xslots, bi = (int)blockIdx.x / p.xslots;
   const int cluster = bx + p.xslots * (bi / kClMembers), member = bi % kClMembers;
   if (cluster >= p.ncl) return;
@@ -128,6 +152,12 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
   const XBuf xb = xbuf_make(p.xbuf + (size_t)cluster * kClXFloats, kClXFloats * 4u);
   unsigned* flags = p.flags + (size_t)cluster * kClFlagWords;
 
+#ifdef CL_TRACE
+  unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tph = clock_light();
+#define CL_STAMP(k) do { const unsigned long long t_ = clock_light(); ph[k] += t_ - tph; tph = t_; } while (0)
+#else
+#define CL_STAMP(k) do { } while (0)
+#endif
   // ---- waiting for members: wave 0, lane m polls member m's flag of `kind`; bounded; the verdict reaches everybody through LDS + barrier
   auto wait_flags = [&](int kind, unsigned mask, unsigned epoch) -> bool {
     if (wave == 0) {
@@ -159,10 +189,17 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
       }
     }
     __syncthreads();
+#if defined(CL_SAFE) && !defined(MLDHIP_SIM)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     return ctl[0] != 0u;
   };
   auto publish = [&](int kind, unsigned epoch) __attribute__((always_inline)) {
     drain_stores();
+#if defined(CL_SAFE) && !defined(MLDHIP_SIM)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    drain_stores();
+#endif
     __syncthreads();
     if (tid == 0) flag_store(flags + kind * 16 + member, epoch);
   };
@@ -176,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
 
   // ---- weight ring: this lane's two MFMA operands (32 bytes) of the wave's next kClRing fragments
   const unsigned wbase = p.wave_off[hc * 8 + wave] + (unsigned)lane * 8u;
-  unsigned goff = wbase;
+  goff = wbase;
   F4 ring[kClRing][2];
   auto gload = [&](int slot) __attribute__((always_inline)) {
     const float* s = p.stream + goff;
@@ -209,8 +246,6 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
     gload(slot);
     sched_fence();
   };
-  const int swz4 = ((r >> 2) & 3) << 2;                    // row swizzle of the operand images (loop_fused.hpp SWZ): XOR of the word offset's bits 2-3
-  const int gs4 = (g << 2) ^ swz4;                         // this lane's 16-byte group of a half chunk
   auto frag = [&](const float* buf, int st, int row, int kc, F4 (&x)[2]) __attribute__((always_inline)) {
     const float* a = buf + row * st + 32 * kc + gs4;
     x[0] = ld4(a);
@@ -303,6 +338,22 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
   assemble(0);
 #pragma unroll
   for (int j = 0; j < kClRing; ++j) gload(j);
+#if defined(CL_HELLO)
+  {   // experiment: every member announces itself and waits for the other eleven before the first exchange (a late memset node would strand somebody here)
+    if (tid == 0) flag_store(flags + kFlagH * 16 + member, 0u);      // (value 0 would never satisfy a wait: use the Y line with epoch-less value below)
+    if (tid == 0) flag_store(flags + 3 * 16 + 13 + 0 * member, 0u);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(flags + kFlagZ * 16 + 14, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {
+      const unsigned long long ts = realtime_100mhz();
+      while (flag_load(flags + kFlagZ * 16 + 14) < (unsigned)kClMembers) {
+        spin_pause();
+        if (realtime_100mhz() - ts > kClTimeoutTicks) { if (lane == 0) flag_store(p.status, 3u); break; }
+      }
+    }
+    __syncthreads();
+  }
+#endif
   if constexpr (!WT) {
     // every member posts 1 + its XCC id as its Z flag (Z epochs start above 16: see below); a cluster that spans XCDs cannot use plain stores
     if (tid == 0) flag_store(flags + kFlagZ * 16 + member, 1u + xcc_id());
@@ -328,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
       const unsigned epoch = (unsigned)(step * p.L + l) + 1u;
       const unsigned par = epoch & 1u;
       const unsigned own_mask = 0xFu << (4 * tk);
+      fresh();
       // ================= Ph1: Q (own token), K, V (all tokens) of head hc; 3-token attention for the 16 rows of token tk
       if (wave < 4) {
         f32x4 q0 = zero4, q1 = zero4, k[3] = {zero4, zero4, zero4};
@@ -389,9 +441,13 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         for (int i = 0; i < 4; ++i) o[i] = (p0 * (v[0][i] + bvv[i]) + p1 * (v[1][i] + bvv[i])) + p2 * (v[2][i] + bvv[i]);
         xbuf_st4<WT>(xb, (kClAO + par * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + w4 * 16 + g * 4)) * 4u, F4{o[0], o[1], o[2], o[3]});
       }
+      CL_STAMP(0);
       publish(kFlagAO, epoch);
+      CL_STAMP(1);
+      fresh();
       // ================= E1: attention output of the token from its four members -> As
       if (!wait_flags(kFlagAO, own_mask, epoch)) { give_up(); return; }
+      CL_STAMP(2);
       {
         const F4 a0 = xbuf_ld4(xb, (kClAO + par * 12288u + (unsigned)((16 * tk + wave) * 256 + lane * 4)) * 4u);
         const F4 a1 = xbuf_ld4(xb, (kClAO + par * 12288u + (unsigned)((16 * tk + wave + 8) * 256 + lane * 4)) * 4u);
@@ -399,6 +455,8 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         st_row(As, kClXs, wave + 8, a1);
       }
       __syncthreads();
+      CL_STAMP(3);
+      fresh();
       // ================= Ph2: out-projection (all 256 columns: this wave 32 w .. + 31) + residual + norm1 -> h1; linear1 + GELU of hidden columns 256 hc + 32 w .. + 31
       {
         f32x4 a[2][2] = {{zero4, zero4}, {zero4, zero4}};
@@ -459,6 +517,8 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
           }
         }
         __syncthreads();
+        CL_STAMP(4);
+        fresh();
         // linear1 + GELU
         f32x4 h[2][2] = {{zero4, zero4}, {zero4, zero4}};
         frag(As, kClXs, r, 0, x[0]);
@@ -482,9 +542,13 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
           xbuf_st2<WT>(xb, wo + 64u, U2{l0, l1});
         }
       }
+      CL_STAMP(5);
       publish(kFlagH, epoch);
+      CL_STAMP(6);
+      fresh();
       // ================= E2: the token's hidden activation (64 KB image) from its four members -> Xs region as [16][1032]
       if (!wait_flags(kFlagH, own_mask, epoch)) { give_up(); return; }
+      CL_STAMP(7);
       {
         F4 hv[8];
 #pragma unroll
@@ -499,6 +563,8 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         }
       }
       __syncthreads();
+      CL_STAMP(8);
+      fresh();
       // ================= Ph3: linear2 for output columns 64 hc + 16 (w & 3) .. + 15, K half w >> 2; halves meet through LDS -> Y
       {
         f32x4 y0 = zero4, y1 = zero4;
@@ -519,11 +585,15 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
           xbuf_st4<WT>(xb, (kClY + par * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + wave * 16 + g * 4)) * 4u, F4{y[0] + b2.x, y[1] + b2.y, y[2] + b2.z, y[3] + b2.w});
         }
       }
+      CL_STAMP(9);
       publish(kFlagY, epoch);
+      CL_STAMP(10);
+      fresh();
       // ================= E3 and what follows the layer
       const bool last = l + 1 == p.L, skip_next = !last && l >= nb;
       prm_fetch(last ? 0 : l + 1);
-      if (!wait_flags(kFlagY, 0xFFFu, epoch)) { give_up(); return; }      // all twelve even where fewer rows are read (buffer-reuse invariant)
+      if (!wait_flags(kFlagY, 0xFFFu, epoch)) { give_up(); return; }
+      CL_STAMP(11);      // all twelve even where fewer rows are read (buffer-reuse invariant)
       if (!last && !skip_next) {
         // x' = norm2(y + h1) for all 48 rows -> Xs; input blocks park their own token's rows for the skip connection (cross_attention.py:48-52)
         F4 v[6];
@@ -560,6 +630,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         st_row(As, kClXs, wave, s0v);
         st_row(As, kClXs, wave + 8, s1v);
         __syncthreads();
+        fresh();
         f32x4 z0 = zero4, z1 = zero4;
         const float* abuf = wave < 4 ? Xs + 16 * tk * kClXs : As;
         F4 x[2][2];
@@ -579,6 +650,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
           xbuf_st4<WT>(xb, (kClZ + zpar * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + wave * 16 + g * 4)) * 4u, F4{z[0] + sb.x, z[1] + sb.y, z[2] + sb.z, z[3] + sb.w});
         }
         publish(kFlagZ, zepoch);
+        fresh();
         if (!wait_flags(kFlagZ, 0xFFFu, zepoch)) { give_up(); return; }
 #pragma unroll
         for (int i = 0; i < 6; ++i) v[i] = xbuf_ld4(xb, (kClZ + zpar * 12288u + (unsigned)((wave + 8 * i) * 256 + lane * 4)) * 4u);
@@ -613,12 +685,33 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         if (step + 1 < p.n) assemble(step + 1);      // (reads this wave's own latent row only)
         __syncthreads();
       }
+      CL_STAMP(12);
       pbuf ^= 1;
     }
   }
+#ifdef CL_TRACE
+  if (p.trace && lane == 0) {
+    unsigned long long* o = p.trace + ((size_t)blockIdx.x * 8 + wave) * 16;
+    for (int k = 0; k < 16; ++k) o[k] = ph[k];
+  }
+#endif
   if (member == 0) {
     const int c = tid >> 6, c4 = tid & 63;
     if (s0 + c < p.B) st4(p.lat + (long long)(s0 + c) * 256 + c4 * 4, ld4(lats + c * 256 + c4 * 4));
+  }
+  // Every polled word goes back to zero before the launch ends: a member that is past its last wait counts itself in word 12 of the Z line; the
+  // twelfth arrival polls nothing any more and neither does anybody else, so it clears the cluster's 64 words.  The memset node in front of the
+  // launch (Guideline 16 "Re-initialise every call") stays, but a replayed graph was seen to start the kernel on flags of the PREVIOUS call
+  // (epochs up to n L: every wait passes at once, latents off by 10) -- replays of one captured call after another; eager launches never.
+  __syncthreads();
+  if (tid == 0) {
+#if defined(MLDHIP_SIM)
+    const unsigned prev = flags[kFlagZ * 16 + 12]++;
+#else
+    const unsigned prev = __hip_atomic_fetch_add(flags + kFlagZ * 16 + 12, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    if (prev == (unsigned)kClMembers - 1u)
+      for (int i = 0; i < kClFlagWords; ++i) flag_store(flags + i, 0u);
   }
 }
 

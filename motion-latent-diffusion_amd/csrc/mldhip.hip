@@ -286,6 +286,7 @@ void mldhip_destroy(mldhip_handle* e) {
   if (e->loop_stream) (void)hipFree(e->loop_stream);
   if (e->loop_stream_x3) (void)hipFree(e->loop_stream_x3);
   if (e->cl_stream) (void)hipFree(e->cl_stream);
+  if (e->cl_wave_off_dev) (void)hipFree(e->cl_wave_off_dev);
   if (e->loop_small) (void)hipFree(e->loop_small);
   for (auto& x : e->ctxs) {
     if (x.ws) (void)hipFree(x.ws);
@@ -786,7 +787,11 @@ int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* acti
     HIP_TRY(e, hipMemcpyAsync(e->labels_dev + B, actions_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   }
 #if !defined(MLDHIP_SIM)
-  if (e->cfg.use_graph) {
+  // A call whose reverse loop is the cluster launch is issued eagerly: it is ~50 launches, all behind a 9 ms kernel the host enqueues under,
+  // so a graph buys nothing -- and REPLAYS of a captured full call (cluster loop + T = 196 decode) were measured to return latents off by 5-20
+  // where the first launch of the same executable graph and every eager launch are right (r05, tools/dbg_cluster.py --graph 1 --prelat 1;
+  // cause not found: DESIGN.md "cluster loop").
+  if (e->cfg.use_graph && !use_cluster(e, B)) {
     const size_t D = e->cfg.latent_dim, NF = e->cfg.nfeats;
     const bool want_j = joints_out_dev != nullptr, want_f = feats_out_dev != nullptr || want_j;
     if (text_emb_dev)
@@ -863,7 +868,7 @@ int sample_many_impl(mldhip_handle* e, const mldhip_request* rq, int nreq, hipSt
   const float* text = action ? nullptr : e->text_in;
   bool replayed = false;
 #if !defined(MLDHIP_SIM)
-  if (e->cfg.use_graph) {
+  if (e->cfg.use_graph && !use_cluster(e, Btot)) {
     hipGraphExec_t exec = nullptr;
     if (int rc = graph_for(e, GraphKey{Btot, T, want_f, want_j}, text != nullptr, &exec)) return rc;
     HIP_TRY(e, hipGraphLaunch(exec, stream));
@@ -1255,6 +1260,16 @@ int mldhip_profile_trace(mldhip_handle* e, const char* name, int32_t B, int32_t 
     HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream_));
     const int64_t n = std::min<int64_t>(cap_u64, 64 * 8 * 16);      // 16 counters per wave: two 8-value records
     HIP_TRY(e, hipMemcpy(out_host, e->trace_buf, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return (int)(n / 64);
+  }
+  if (std::string(name) == "den_cluster_xbuf") {
+    // the exchange region of cluster 0 as the last cluster-loop call left it (kernels/loop_cluster.hpp: AO, h1, Y, Z, H of the last two layers) + its flags:
+    // what tests compare between the simulator and the GPU
+    if (!e->cl_xbuf) return e->fail(MLDHIP_ESTATE, "no cluster loop on this handle");
+    HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream_));
+    const int64_t n = std::min<int64_t>(cap_u64, (int64_t)kClXFloats / 2);
+    const int cl = std::max(0, std::min<int>(B, (int)std::min<size_t>(kClMaxClusters, (e->cfg.max_batch + 7) / 8) - 1));      // B = cluster index here
+    HIP_TRY(e, hipMemcpy(out_host, e->cl_xbuf + (size_t)cl * kClXFloats, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return (int)(n / 64);
   }
   double fl = 0;

@@ -7,4 +7,4 @@ NAME=$1; shift
 mkdir -p build/lb
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -Wno-unused-function -I motion-latent-diffusion_amd/csrc/kernels \
   -DLB_NAME="\"$NAME\"" "$@" -Rpass-analysis=kernel-resource-usage -o build/lb/$NAME tools/loopbench/${LB_SRC:-loop_bench.hip} 2> build/lb/$NAME.ru || { tail -20 build/lb/$NAME.ru; exit 1; }
-grep -A12 -E "Function Name: _ZN3mld(15den_loop|19ffn_strip_x3|20strip_gemm_x3|20attn_flash_x3|11gemm_kernel|11gemm_big)" build/lb/$NAME.ru | grep -E "Function Name|VGPRs:|ScratchSize|SGPRs:" | sed 's/.*remark: *//' | paste - - - - 
+grep -A12 -E "Function Name: _ZN3mld(15den_loop|18den_cluster|19ffn_strip_x3|20strip_gemm_x3|20attn_flash_x3|11gemm_kernel|11gemm_big)" build/lb/$NAME.ru | grep -E "Function Name|VGPRs:|ScratchSize|SGPRs:" | sed 's/.*remark: *//' | paste - - - - 
