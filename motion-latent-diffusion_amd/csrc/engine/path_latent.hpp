@@ -360,8 +360,8 @@ int build_cluster_stream(Ctx& c) {
           if (w < 4) { push(P_.in_w, 256, 64 * hc + 16 * w, 32 * kc); push(P_.in_w, 256, 256 + 64 * hc + 16 * w, 32 * kc); }
           else push(P_.in_w, 256, 512 + 64 * hc + 16 * (w - 4), 32 * kc);
         }
-        for (int kc = 0; kc < 8; ++kc)                                             // out-projection: columns 32 w + 16 j
-          for (int j = 0; j < 2; ++j) push(P_.out_w, 256, 32 * w + 16 * j, 32 * kc);
+        for (int kc = 0; kc < 2; ++kc)                                             // out-projection, the head's K slice: columns 32 w + 16 j, k = 64 hc + 32 kc
+          for (int j = 0; j < 2; ++j) push(P_.out_w, 256, 32 * w + 16 * j, 64 * hc + 32 * kc);
         for (int kc = 0; kc < 8; ++kc)                                             // linear1: hidden columns 256 hc + 32 w + 16 j
           for (int j = 0; j < 2; ++j) push(P_.l1_w, 256, 256 * hc + 32 * w + 16 * j, 32 * kc);
         for (int kc = 0; kc < 16; ++kc) push(P_.l2_w, F, 64 * hc + 16 * (w & 3), 512 * (w >> 2) + 32 * kc);      // linear2: K half w >> 2

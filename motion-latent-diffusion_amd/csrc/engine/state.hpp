@@ -120,8 +120,12 @@ struct mldhip_engine {
   // per-handle options (mldhip_set_option)
   int small_m = 256;         // "gemm_small_m": row count up to which the register-direct tiny-GEMM shape is used
   int loop_kernel = 0;       // "loop_kernel": 0 auto (by rows / motions), 1 latency kernels (tile32.hpp), 2 throughput kernels (strip.hpp), 3 sample-major persistent loop (loop_fused.hpp), 4 cluster loop (loop_cluster.hpp)
+#if defined(MLDHIP_SIM)
+  int cluster_max_batch = 0;   // (the functional simulator's tests pick the loop family explicitly)
+#else
   int cluster_max_batch = 128; // "cluster_max_batch": auto runs the cluster loop (split mode) for calls of up to this many motions (0: never); at most 8 x kClMaxClusters
-  int cluster_wt = 1;        // "cluster_wt": 1 = write-through (sc1) payload stores, valid for any placement; 0 = plain stores (clusters must sit on one XCD each: checked in the kernel)
+#endif
+  int cluster_wt = 0;        // "cluster_wt": 0 (default) = a cluster whose twelve members report one XCC id stores its payloads plain (served by the shared L2; -3.5 % per call), any other cluster write-through; 1 = write-through (sc1) always
   int fused_x3 = 1;          // "fused_x3": in the split precision mode the sample-major loop multiplies on split-f16 MFMAs (0: exact fp32 MFMAs)
   int fused_dbg = 0;         // "fused_dbg": 5 = the split-mode loop with its phase counters (same arithmetic, mldhip_profile_trace "den_loop_phases"); 0 = off
   int fused_min_batch = 0;   // "fused_min_batch": auto picks the sample-major loop from this many motions per call up; 0 = by operand format (320 split-f16, 1 280 fp32)

@@ -49,8 +49,10 @@ namespace mld {
 constexpr int kClMembers = 12, kClRing = CL_RING, kClFragFloats = 512;
 constexpr int kClXs = 264, kClHs = 1032;                       // LDS row strides (words), = 8 mod 16: conflict-free fragment reads
 constexpr unsigned kClPlane = 2u * 48u * 256u;                 // one double-buffered [48][256] fp32 exchange tensor (floats)
-constexpr unsigned kClAO = 0, kClH1 = kClPlane, kClY = 2 * kClPlane, kClZ = 3 * kClPlane, kClH = 4 * kClPlane;
-constexpr unsigned kClXFloats = kClH + 2u * 48u * 1024u;       // exchange region of one cluster: 196 608 floats = 768 KB
+constexpr unsigned kClSlab = 2u * 12u * 16u * 256u;            // one double-buffered set of per-member partial slabs [3 tokens][4 members][16][256] (floats)
+constexpr unsigned kClH1 = 0, kClY = kClPlane, kClZ = 2 * kClPlane, kClH = 3 * kClPlane, kClPO = kClH + 2u * 48u * 1024u;
+constexpr unsigned kClXFloats = kClPO + kClSlab;               // exchange region of one cluster: 270 336 floats = 1 056 KB
+constexpr int kClAoS = 72;                                     // LDS row stride (words) of the head's attention output image [16][64 columns]
 constexpr int kClFlagWords = 4 * 16;                           // flag kinds AO, H, Y, Z: 16 words (one 64-byte line) each
 enum : int { kFlagAO = 0, kFlagH = 1, kFlagY = 2, kFlagZ = 3 };
 constexpr int kClBigFloats = 16 * kClHs;                       // X of all 48 rows ([48][264] = 12 672 words) and the token's hidden activation ([16][1032]) in turn
@@ -75,7 +77,7 @@ struct ClusterArgs {
   const float* ddim;          // [n][4]
   float* xbuf;                // [clusters][kClXFloats] exchange regions
   unsigned* flags;            // [clusters][kClFlagWords], zeroed in front of the launch
-  unsigned* status;           // [0]: 0 ok, 1 a wait timed out, 2 plain stores requested but a cluster spans XCDs; [1]: census scratch
+  unsigned* status;           // [0]: 0 ok, 1 a wait timed out; [1]: clusters that span XCDs (plain stores asked for, write-through used)
   int B, L, n, ncl;
   unsigned long long* trace = nullptr;   // CL_TRACE builds (tools/loopbench only): [workgroup][wave][16] shader cycles per phase, summed over steps and layers
   int xslots;                 // blocks per launch row: 8 on the GPU (block b runs on XCD b % 8: a cluster's members share the slot), min(clusters, 8) on the simulator
@@ -105,7 +107,8 @@ __global__ __launch_bounds__(64) void pack_cluster_frags_kernel(const float* __r
 }
 
 // grid = 12 xslots x ceil(clusters / xslots), xslots = 8: block b -> XCD slot x = b % 8, index i = b / 8 -> cluster x + 8 (i / 12), member i % 12.  block = 512.
-// WT: write-through payload stores (any placement).  WT = false: plain stores, the kernel refuses (status 2) if a cluster spans XCDs.
+// WT = true: write-through (sc1) payload stores whatever the placement.  WT = false: every cluster whose twelve members report the same XCC id stores its
+// payloads plain (served from the shared L2); a cluster that spans XCDs falls back to write-through by itself.
 template <bool WT>
 __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
 #if defined(MLDHIP_SIM)
@@ -225,7 +228,9 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
 #endif
   };
   // three tokens against one fragment (loop_fused.hpp mma_item); one token against one fragment on two accumulators (cross terms / high x high)
-  auto mma3 = [&](int j, const F4 (&x)[3][2], f32x4 (&acc)[3]) __attribute__((always_inline)) {
+  // (`more` = false for the last kClRing fragments in front of a publish: the ring is refilled BEHIND the flag store, under the wait -- a drain of the
+  // payload stores would otherwise wait for the look-ahead loads issued just before them: the memory counter is in order)
+  auto mma3 = [&](int j, const F4 (&x)[3][2], f32x4 (&acc)[3], bool more = true) __attribute__((always_inline)) {
     const int slot = j % kClRing;
     const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
 #pragma unroll
@@ -234,17 +239,21 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
     for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wl, __builtin_bit_cast(U4, x[t][0]), acc[t]);
 #pragma unroll
     for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][0]), acc[t]);
-    gload(slot);
+    if (more) gload(slot);
     sched_fence();
   };
-  auto mma1 = [&](int j, const F4 (&x)[2], f32x4& a0, f32x4& a1) __attribute__((always_inline)) {
+  auto mma1 = [&](int j, const F4 (&x)[2], f32x4& a0, f32x4& a1, bool more = true) __attribute__((always_inline)) {
     const int slot = j % kClRing;
     const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
     a0 = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[1]), a0);
     a1 = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[0]), a1);
     a0 = mfma_x3_16x16x32(wl, __builtin_bit_cast(U4, x[0]), a0);
-    gload(slot);
+    if (more) gload(slot);
     sched_fence();
+  };
+  auto refill = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < kClRing; ++j) gload(j);
   };
   auto frag = [&](const float* buf, int st, int row, int kc, F4 (&x)[2]) __attribute__((always_inline)) {
     const float* a = buf + row * st + 32 * kc + gs4;
@@ -252,6 +261,9 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
     x[1] = ld4(a + 16);
   };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  bool wt_ = true;                                         // payload stores write-through (set after the placement census)
+  auto xst4 = [&](unsigned off, F4 v) __attribute__((always_inline)) { if (wt_) xbuf_st4<true>(xb, off, v); else xbuf_st4<false>(xb, off, v); };
+  auto xst2 = [&](unsigned off, U2 v) __attribute__((always_inline)) { if (wt_) xbuf_st2<true>(xb, off, v); else xbuf_st2<false>(xb, off, v); };
 
   // ---- row-per-wave helpers (gathers, LayerNorm over whole rows, token assembly): lane l owns columns 4l .. 4l + 3 of a row
   auto st_row = [&](float* buf, int st, int row, F4 v) __attribute__((always_inline)) {       // -> split image, swizzled by the row
@@ -338,39 +350,29 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
   assemble(0);
 #pragma unroll
   for (int j = 0; j < kClRing; ++j) gload(j);
-#if defined(CL_HELLO)
-  {   // experiment: every member announces itself and waits for the other eleven before the first exchange (a late memset node would strand somebody here)
-    if (tid == 0) flag_store(flags + kFlagH * 16 + member, 0u);      // (value 0 would never satisfy a wait: use the Y line with epoch-less value below)
-    if (tid == 0) flag_store(flags + 3 * 16 + 13 + 0 * member, 0u);
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(flags + kFlagZ * 16 + 14, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wave == 0) {
-      const unsigned long long ts = realtime_100mhz();
-      while (flag_load(flags + kFlagZ * 16 + 14) < (unsigned)kClMembers) {
-        spin_pause();
-        if (realtime_100mhz() - ts > kClTimeoutTicks) { if (lane == 0) flag_store(p.status, 3u); break; }
-      }
-    }
-    __syncthreads();
-  }
-#endif
+  bool wt = true;
   if constexpr (!WT) {
-    // every member posts 1 + its XCC id as its Z flag (Z epochs start above 16: see below); a cluster that spans XCDs cannot use plain stores
+    // every member posts 1 + its XCC id as its Z flag (Z epochs start above 16: see below); a cluster that spans XCDs keeps the write-through stores
     if (tid == 0) flag_store(flags + kFlagZ * 16 + member, 1u + xcc_id());
     if (!wait_flags(kFlagZ, 0xFFFu, 1u)) { give_up(); return; }
     if (wave == 0) {
       const unsigned mine = 1u + xcc_id();
       const unsigned other = lane < kClMembers ? flag_load(flags + kFlagZ * 16 + lane) : mine;
-      if (wave_any(other != mine)) {
-        if (lane == 0) { flag_store(p.status, 2u); ctl[1] = 1u; }
-      } else if (lane == 0) ctl[1] = 0u;
+      const bool spans = wave_any(other != mine);
+      if (lane == 0) { ctl[1] = spans ? 1u : 0u; if (spans && member == 0) flag_store(p.status + 1, 1u); }
     }
     __syncthreads();
-    if (ctl[1] != 0u) { give_up(); return; }
+    wt = ctl[1] != 0u;
   }
+  wt_ = wt;
   __syncthreads();
   int pbuf = 0;
   const unsigned wg = blockIdx.x;
+  // linear2 output (+ bias, added by its producer) + residual of row `row`, this lane's 4 columns
+  auto y_row = [&](unsigned par, int row, const float*) __attribute__((always_inline)) {
+    const unsigned off = (unsigned)(row * 256 + lane * 4);
+    return f4add(xbuf_ld4(xb, (kClY + par * 12288u + off) * 4u), xbuf_ld4(xb, (kClH1 + par * 12288u + off) * 4u));
+  };
 
   for (int step = 0; step < p.n; ++step) {
     goff = wbase + (unsigned)(kClRing * kClFragFloats);
@@ -439,84 +441,77 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         float o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = (p0 * (v[0][i] + bvv[i]) + p1 * (v[1][i] + bvv[i])) + p2 * (v[2][i] + bvv[i]);
-        xbuf_st4<WT>(xb, (kClAO + par * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + w4 * 16 + g * 4)) * 4u, F4{o[0], o[1], o[2], o[3]});
+        // attention output of head hc, row r, head dims 16 w4 + 4 g .. + 3 -> split image [16][64] in the As region (chunk w4 >> 1 of two)
+        unsigned h0, l0, h1, l1;
+        split16_two(o[0], o[1], h0, l0);
+        split16_two(o[2], o[3], h1, l1);
+        unsigned* wq = reinterpret_cast<unsigned*>(As) + r * kClAoS + (w4 >> 1) * 32 + (((w4 & 1) * 8 + g * 2) ^ swz4);
+        *reinterpret_cast<U2*>(wq) = U2{h0, h1};
+        *reinterpret_cast<U2*>(wq + 16) = U2{l0, l1};
+      }
+      __syncthreads();
+      {
+        // out-projection, split over K by HEAD: this member multiplies its head's 64 attention dims into all 256 output columns (this wave: 32 w .. + 31) and
+        // publishes the raw partial; the four partials of a token are summed by everybody in E1 (one quarter of the weight bytes of a full out-projection per member)
+        f32x4 a[2][2] = {{zero4, zero4}, {zero4, zero4}};
+        F4 x[2][2];
+        frag(As, kClAoS, r, 0, x[0]);
+        frag(As, kClAoS, r, 1, x[1]);
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+          mma1(2 * kc, x[kc], a[0][0], a[0][1], false);      // (16 or 8 fragments consumed so far in this phase: the ring slot is the same)
+          mma1(2 * kc + 1, x[kc], a[1][0], a[1][1], false);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 pj = a[j][0] + a[j][1];
+          xst4((kClPO + par * 49152u + (unsigned)(((tk * 4 + hc) * 16 + r) * 256 + wave * 32 + j * 16 + g * 4)) * 4u, F4{pj[0], pj[1], pj[2], pj[3]});
+        }
       }
       CL_STAMP(0);
       publish(kFlagAO, epoch);
+      refill();
       CL_STAMP(1);
       fresh();
       // ================= E1: attention output of the token from its four members -> As
       if (!wait_flags(kFlagAO, own_mask, epoch)) { give_up(); return; }
       CL_STAMP(2);
       {
-        const F4 a0 = xbuf_ld4(xb, (kClAO + par * 12288u + (unsigned)((16 * tk + wave) * 256 + lane * 4)) * 4u);
-        const F4 a1 = xbuf_ld4(xb, (kClAO + par * 12288u + (unsigned)((16 * tk + wave + 8) * 256 + lane * 4)) * 4u);
-        st_row(As, kClXs, wave, a0);
-        st_row(As, kClXs, wave + 8, a1);
+        // rows w and w + 8 of the token: sum of the four partials (fixed order) + bias + residual (the layer input as the GEMMs saw it) -> norm1, in-wave
+        F4 v[6];
+        const F4 ob = ld4(sm + kLsOutB + lane * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = wave + 8 * i;
+          F4 acc4 = xbuf_ld4(xb, (kClPO + par * 49152u + (unsigned)(((tk * 4 + 0) * 16 + row) * 256 + lane * 4)) * 4u);
+#pragma unroll
+          for (int m = 1; m < 4; ++m) acc4 = f4add(acc4, xbuf_ld4(xb, (kClPO + par * 49152u + (unsigned)(((tk * 4 + m) * 16 + row) * 256 + lane * 4)) * 4u));
+          const unsigned* wq = reinterpret_cast<const unsigned*>(Xs) + (16 * tk + row) * kClXs + ((((lane >> 3) << 5) + ((lane & 7) << 1)) ^ (((row >> 2) & 3) << 2));
+          const U2 h = *reinterpret_cast<const U2*>(wq), lo = *reinterpret_cast<const U2*>(wq + 16);
+          v[i] = F4{acc4.x + ob.x + (f16_bits_value(h.x) + f16_bits_value(lo.x)), acc4.y + ob.y + (f16_bits_value(h.x >> 16) + f16_bits_value(lo.x >> 16)),
+                    acc4.z + ob.z + (f16_bits_value(h.y) + f16_bits_value(lo.y)), acc4.w + ob.w + (f16_bits_value(h.y >> 16) + f16_bits_value(lo.y >> 16))};
+        }
+        CL_STAMP(3);
+        ln_rows(v, 2, sm + kLsN1W, sm + kLsN1B);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = wave + 8 * i;
+          unsigned h0, l0, h1, l1;
+          split16_two(v[i].x, v[i].y, h0, l0);
+          split16_two(v[i].z, v[i].w, h1, l1);
+          unsigned* d = reinterpret_cast<unsigned*>(As) + row * kClXs + ((((lane >> 3) << 5) + ((lane & 7) << 1)) ^ (((row >> 2) & 3) << 2));
+          *reinterpret_cast<U2*>(d) = U2{h0, h1};
+          *reinterpret_cast<U2*>(d + 16) = U2{l0, l1};
+          // norm1 output of the token for everybody's norm2 residual: this member's column quarter (lanes 16 hc .. + 15), the value the GEMMs see (high + low half)
+          if ((lane >> 4) == hc)
+            xst4((kClH1 + par * 12288u + (unsigned)((16 * tk + row) * 256 + lane * 4)) * 4u,
+                 F4{f16_bits_value(h0) + f16_bits_value(l0), f16_bits_value(h0 >> 16) + f16_bits_value(l0 >> 16), f16_bits_value(h1) + f16_bits_value(l1),
+                    f16_bits_value(h1 >> 16) + f16_bits_value(l1 >> 16)});
+        }
       }
       __syncthreads();
-      CL_STAMP(3);
-      fresh();
-      // ================= Ph2: out-projection (all 256 columns: this wave 32 w .. + 31) + residual + norm1 -> h1; linear1 + GELU of hidden columns 256 hc + 32 w .. + 31
       {
-        f32x4 a[2][2] = {{zero4, zero4}, {zero4, zero4}};
         F4 x[2][2];
-        frag(As, kClXs, r, 0, x[0]);
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-          if (kc + 1 < 8) frag(As, kClXs, r, kc + 1, x[(kc + 1) & 1]);
-          mma1(2 * kc, x[kc & 1], a[0][0], a[0][1]);
-          mma1(2 * kc + 1, x[kc & 1], a[1][0], a[1][1]);
-        }
-        float u[2][4];
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const F4 ob = ld4(sm + kLsOutB + wave * 32 + j * 16 + g * 4);
-          const unsigned* wq = reinterpret_cast<const unsigned*>(Xs) + (16 * tk + r) * kClXs + wave * 32 + ((j * 8 + g * 2) ^ swz4);
-          const U2 h = *reinterpret_cast<const U2*>(wq), lo = *reinterpret_cast<const U2*>(wq + 16);
-          u[j][0] = (a[j][0][0] + a[j][1][0]) + ob.x + (f16_bits_value(h.x) + f16_bits_value(lo.x));
-          u[j][1] = (a[j][0][1] + a[j][1][1]) + ob.y + (f16_bits_value(h.x >> 16) + f16_bits_value(lo.x >> 16));
-          u[j][2] = (a[j][0][2] + a[j][1][2]) + ob.z + (f16_bits_value(h.y) + f16_bits_value(lo.y));
-          u[j][3] = (a[j][0][3] + a[j][1][3]) + ob.w + (f16_bits_value(h.y >> 16) + f16_bits_value(lo.y >> 16));
-          sum += (u[j][0] + u[j][1]) + (u[j][2] + u[j][3]);
-        }
-        sum = sum_groups(sum);
-        if (g == 0) red[r * 8 + wave] = sum;
-        __syncthreads();
-        {
-          const F4 ma = ld4(red + r * 8), mb = ld4(red + r * 8 + 4);
-          const float mean = (((ma.x + ma.y) + (ma.z + ma.w)) + ((mb.x + mb.y) + (mb.z + mb.w))) * (1.0f / 256.0f);
-          float sq = 0.f;
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { u[j][i] -= mean; sq += u[j][i] * u[j][i]; }
-          sq = sum_groups(sq);
-          if (g == 0) red[128 + r * 8 + wave] = sq;
-        }
-        __syncthreads();
-        {
-          const F4 qa = ld4(red + 128 + r * 8), qb = ld4(red + 128 + r * 8 + 4);
-          const float rs = rsqrtf((((qa.x + qa.y) + (qa.z + qa.w)) + ((qb.x + qb.y) + (qb.z + qb.w))) * (1.0f / 256.0f) + kLnEps);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const F4 gm = ld4(sm + kLsN1W + wave * 32 + j * 16 + g * 4), bt = ld4(sm + kLsN1B + wave * 32 + j * 16 + g * 4);
-            u[j][0] = u[j][0] * rs * gm.x + bt.x; u[j][1] = u[j][1] * rs * gm.y + bt.y; u[j][2] = u[j][2] * rs * gm.z + bt.z; u[j][3] = u[j][3] * rs * gm.w + bt.w;
-            unsigned h0, l0, h1, l1;
-            split16_two(u[j][0], u[j][1], h0, l0);
-            split16_two(u[j][2], u[j][3], h1, l1);
-            unsigned* wq = reinterpret_cast<unsigned*>(As) + r * kClXs + wave * 32 + ((j * 8 + g * 2) ^ swz4);
-            *reinterpret_cast<U2*>(wq) = U2{h0, h1};
-            *reinterpret_cast<U2*>(wq + 16) = U2{l0, l1};
-            // norm1 output of the token for everybody's norm2 residual: the column quarter of this member (waves 2 hc, 2 hc + 1), the value the GEMMs see (high + low half)
-            if ((wave >> 1) == hc)
-              xbuf_st4<WT>(xb, (kClH1 + par * 12288u + (unsigned)((16 * tk + r) * 256 + wave * 32 + j * 16 + g * 4)) * 4u,
-                           F4{f16_bits_value(h0) + f16_bits_value(l0), f16_bits_value(h0 >> 16) + f16_bits_value(l0 >> 16), f16_bits_value(h1) + f16_bits_value(l1),
-                              f16_bits_value(h1 >> 16) + f16_bits_value(l1 >> 16)});
-          }
-        }
-        __syncthreads();
         CL_STAMP(4);
         fresh();
         // linear1 + GELU
@@ -525,8 +520,8 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
 #pragma unroll
         for (int kc = 0; kc < 8; ++kc) {
           if (kc + 1 < 8) frag(As, kClXs, r, kc + 1, x[(kc + 1) & 1]);
-          mma1(2 * kc, x[kc & 1], h[0][0], h[0][1]);
-          mma1(2 * kc + 1, x[kc & 1], h[1][0], h[1][1]);
+          mma1(2 * kc, x[kc & 1], h[0][0], h[0][1], 2 * kc + kClRing < 16);
+          mma1(2 * kc + 1, x[kc & 1], h[1][0], h[1][1], 2 * kc + 1 + kClRing < 16);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -538,12 +533,13 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
           split16_two(v2, v3, h1, l1);
           // the hidden activation travels as the (unswizzled) split image: row 16 tk + r, chunk 8 hc + w (32 hidden columns = 32 words), high words 8 j + 2 g, low + 16
           const unsigned wo = (kClH + par * 49152u + (unsigned)((16 * tk + r) * 1024 + (8 * hc + wave) * 32 + j * 8 + g * 2)) * 4u;
-          xbuf_st2<WT>(xb, wo, U2{h0, h1});
-          xbuf_st2<WT>(xb, wo + 64u, U2{l0, l1});
+          xst2(wo, U2{h0, h1});
+          xst2(wo + 64u, U2{l0, l1});
         }
       }
       CL_STAMP(5);
       publish(kFlagH, epoch);
+      refill();
       CL_STAMP(6);
       fresh();
       // ================= E2: the token's hidden activation (64 KB image) from its four members -> Xs region as [16][1032]
@@ -574,19 +570,24 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
 #pragma unroll
         for (int kc = 0; kc < 16; ++kc) {
           if (kc + 1 < 16) frag(Xs, kClHs, r, 16 * kh + kc + 1, x[(kc + 1) & 1]);
-          mma1(kc, x[kc & 1], y0, y1);
+          mma1(kc, x[kc & 1], y0, y1, kc + kClRing < 16);
         }
         f32x4 y = y0 + y1;
+#ifdef CL_TRACE
+        asm volatile("" : "+v"(y));
+        CL_STAMP(15);
+#endif
         if (wave >= 4) *reinterpret_cast<f32x4*>(red2 + ((wave - 4) * 64 + lane) * 4) = y;
         __syncthreads();
         if (wave < 4) {
           y += *reinterpret_cast<const f32x4*>(red2 + (wave * 64 + lane) * 4);
           const F4 b2 = ld4(sm + kLsL2B + hc * 64 + wave * 16 + g * 4);
-          xbuf_st4<WT>(xb, (kClY + par * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + wave * 16 + g * 4)) * 4u, F4{y[0] + b2.x, y[1] + b2.y, y[2] + b2.z, y[3] + b2.w});
+          xst4((kClY + par * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + wave * 16 + g * 4)) * 4u, F4{y[0] + b2.x, y[1] + b2.y, y[2] + b2.z, y[3] + b2.w});
         }
       }
       CL_STAMP(9);
       publish(kFlagY, epoch);
+      refill();
       CL_STAMP(10);
       fresh();
       // ================= E3 and what follows the layer
@@ -598,10 +599,11 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         // x' = norm2(y + h1) for all 48 rows -> Xs; input blocks park their own token's rows for the skip connection (cross_attention.py:48-52)
         F4 v[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const unsigned off = (unsigned)((wave + 8 * i) * 256 + lane * 4);
-          v[i] = f4add(xbuf_ld4(xb, (kClY + par * 12288u + off) * 4u), xbuf_ld4(xb, (kClH1 + par * 12288u + off) * 4u));
-        }
+        for (int i = 0; i < 6; ++i) v[i] = y_row(par, wave + 8 * i, sm + kLsL2B);
+#ifdef CL_TRACE
+        asm volatile("" : "+v"(v[0].x), "+v"(v[5].w));
+        CL_STAMP(14);
+#endif
         ln_rows(v, 6, sm + kLsN2W, sm + kLsN2B);
 #pragma unroll
         for (int i = 0; i < 6; ++i) st_row(Xs, kClXs, wave + 8 * i, v[i]);
@@ -618,10 +620,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         const int si = l - nb;
         F4 v[6];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const unsigned off = (unsigned)((16 * tk + wave + 8 * i) * 256 + lane * 4);
-          v[i] = f4add(xbuf_ld4(xb, (kClY + par * 12288u + off) * 4u), xbuf_ld4(xb, (kClH1 + par * 12288u + off) * 4u));
-        }
+        for (int i = 0; i < 2; ++i) v[i] = y_row(par, 16 * tk + wave + 8 * i, sm + kLsL2B);
         const float* pk = p.park + ((size_t)wg * nb + (nb - 1 - si)) * (16 * 256);
         const F4 s0v = ld4(pk + (unsigned)(wave * 256 + lane * 4)), s1v = ld4(pk + (unsigned)((wave + 8) * 256 + lane * 4));
         ln_rows(v, 2, sm + kLsN2W, sm + kLsN2B);
@@ -638,7 +637,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
 #pragma unroll
         for (int kc = 0; kc < 8; ++kc) {
           if (kc + 1 < 8) frag(abuf, kClXs, r, kc + 1, x[(kc + 1) & 1]);
-          mma1(kc, x[kc & 1], z0, z1);
+          mma1(kc, x[kc & 1], z0, z1, kc + kClRing < 8);
         }
         f32x4 z = z0 + z1;
         if (wave >= 4) *reinterpret_cast<f32x4*>(red2 + ((wave - 4) * 64 + lane) * 4) = z;
@@ -647,9 +646,10 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         if (wave < 4) {
           z += *reinterpret_cast<const f32x4*>(red2 + (wave * 64 + lane) * 4);
           const F4 sb = ld4(sm + kLsLayer + hc * 64 + wave * 16 + g * 4);
-          xbuf_st4<WT>(xb, (kClZ + zpar * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + wave * 16 + g * 4)) * 4u, F4{z[0] + sb.x, z[1] + sb.y, z[2] + sb.z, z[3] + sb.w});
+          xst4((kClZ + zpar * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + wave * 16 + g * 4)) * 4u, F4{z[0] + sb.x, z[1] + sb.y, z[2] + sb.z, z[3] + sb.w});
         }
         publish(kFlagZ, zepoch);
+      refill();
         fresh();
         if (!wait_flags(kFlagZ, 0xFFFu, zepoch)) { give_up(); return; }
 #pragma unroll
@@ -663,10 +663,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         // CFG (mld.py:339-342), DDIM eta = 0 (mld.py:345-346), the next step's rows
         F4 v[6];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const unsigned off = (unsigned)((wave + 8 * i) * 256 + lane * 4);
-          v[i] = f4add(xbuf_ld4(xb, (kClY + par * 12288u + off) * 4u), xbuf_ld4(xb, (kClH1 + par * 12288u + off) * 4u));
-        }
+        for (int i = 0; i < 2; ++i) v[i] = y_row(par, wave + 8 * i, sm + kLsL2B);
         ln_rows(v, 2, sm + kLsN2W, sm + kLsN2B);
         ln_rows(v, 2, sm_fin, sm_fin + 256);
         const float sat = p.ddim[step * 4], s1mat = p.ddim[step * 4 + 1], sap = p.ddim[step * 4 + 2], s1map = p.ddim[step * 4 + 3];

@@ -341,7 +341,7 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value < 0 || value > 8 * kClMaxClusters) return e->fail(MLDHIP_EINVAL, "cluster_max_batch must be 0 .. %d", 8 * kClMaxClusters);
     e->cluster_max_batch = (int)value;
   } else if (n == "cluster_wt") {
-    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "cluster_wt must be 0 (plain payload stores, one XCD per cluster) or 1 (write-through)");
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "cluster_wt must be 0 (plain payload stores inside an XCD, write-through across) or 1 (write-through always)");
     e->cluster_wt = (int)value;
   } else if (n == "fused_dbg") {
     if (value != 0 && value != 5) return e->fail(MLDHIP_EINVAL, "fused_dbg must be 0 or 5 (phase counters; the builds with wrong results live in tools/loopbench only)");
@@ -518,6 +518,18 @@ int range_probe(mldhip_handle* e, hipStream_t stream) {
       const float amp = std::max(1.0f, 2.0f * guidance - 1.0f);
       const float eb = !finite ? std::numeric_limits<float>::infinity() : (m > 0.f ? d / m / amp : (d > 0.f ? std::numeric_limits<float>::infinity() : 0.f));
       worst = std::max(worst, eb);
+      // (c) the cluster loop (kernels/loop_cluster.hpp: split-f16 only, unclamped images like the persistent loop's) on the same two steps, against the exact-fp32 result `hb`
+      if (e->cl_stream) {
+        e->split_loop_ok = true;
+        std::vector<float> hc_;
+        launch_cluster_loop(c, sample.p, Bp, std::min(2, n), guidance);
+        if (c.rc) return c.rc;
+        if (down(e->lat, (size_t)Bp * D, hc_)) return e->fail(MLDHIP_EHIP, "range probe: copy");
+        float d2 = 0.f;
+        bool fin2 = true;
+        for (size_t i = 0; i < hc_.size(); ++i) { fin2 = fin2 && std::isfinite(hc_[i]); d2 = std::max(d2, std::fabs(hc_[i] - hb[i])); }
+        worst = std::max(worst, !fin2 ? std::numeric_limits<float>::infinity() : (m > 0.f ? d2 / m / amp : (d2 > 0.f ? std::numeric_limits<float>::infinity() : 0.f)));
+      }
     }
     e->probe_err_loop = worst;
     e->split_loop_ok = worst <= MLDHIP_PROBE_TOL;

@@ -440,7 +440,7 @@ def test_action_mld_module_surface_on_gpu(dev):
     for i, n in enumerate(lengths):
         assert np.abs(got[i, :n] - fr[i, :n]).max() < 1e-3
     from mld_hip.dp import DataParallelSampler
-    smp = DataParallelSampler(model, batch_size=2)
+    smp = DataParallelSampler(model, batch_size=2, coalesce="auto")
     idx, feats = smp(actions=[int(a) for a in acts], lengths=lengths, init_latents=torch.from_numpy(lat0))
     assert idx == list(range(5)) and smp.last_coalesce == 3
     for i, n in enumerate(lengths):

@@ -35,14 +35,14 @@ int main(int argc, char** argv) {
     if (hipMalloc((void**)out, nfl * sizeof(float)) != hipSuccess) return 1;
     return hipMemcpy(*out, h.data(), nfl * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
   };
-  // per (column group, wave): fragments per step as den_cluster_kernel consumes them (waves 0-3: 64 per layer, waves 4-7: 56; + 8 per skip linear)
+  // per (column group, wave): fragments per step as den_cluster_kernel consumes them (waves 0-3: 52 per layer, waves 4-7: 44; + 8 per skip linear)
   ClusterArgs a;
   size_t nfrag = 0;
   unsigned woff[32];
   for (int hc = 0; hc < 4; ++hc)
     for (int w = 0; w < 8; ++w) {
       woff[hc * 8 + w] = (unsigned)(nfrag * kClFragFloats);
-      nfrag += (size_t)L * (w < 4 ? 64 : 56) + (size_t)nb * 8 + kClRing;
+      nfrag += (size_t)L * (w < 4 ? 52 : 44) + (size_t)nb * 8 + kClRing;
     }
   unsigned* woff_dev;
   CK(hipMalloc((void**)&woff_dev, sizeof woff));
@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     size_t i = 0;
     for (int hc = 0; hc < 4; ++hc)
       for (int w = 0; w < 8; ++w) {
-        const size_t per = (size_t)L * (w < 4 ? 64 : 56) + (size_t)nb * 8, first = i;
+        const size_t per = (size_t)L * (w < 4 ? 52 : 44) + (size_t)nb * 8, first = i;
         for (size_t k = 0; k < per; ++k, ++i) fr[i] = ClFrag{(long long)i * 512, 32, 0};
         for (int k = 0; k < kClRing; ++k, ++i) fr[i] = fr[first + k];
       }
@@ -139,21 +139,21 @@ int main(int argc, char** argv) {
   {
     std::vector<unsigned long long> ht((size_t)grid * 8 * 16);
     CK(hipMemcpy(ht.data(), tr, ht.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    static const char* names[13] = {"ph1_qkv_attn", "publish_ao", "wait_e1", "gather_e1", "outproj_norm1", "linear1_gelu", "publish_h", "wait_e2", "gather_e2", "linear2", "publish_y", "wait_e3", "e3_body"};
+    static const char* names[16] = {"ph1_qkv_attn", "publish_ao", "wait_e1", "gather_e1", "norm1", "linear1_gelu", "publish_h", "wait_e2", "gather_e2", "linear2_reduce_store", "publish_y", "wait_e3", "e3_rest", "outproj_products", "e3_loads_normal_layers", "linear2_products"};
     for (int wv = 0; wv < 8; wv += 4) {
-      double tot = 0, sum[13] = {0};
+      double tot = 0, sum[16] = {0};
       int cnt = 0;
       for (int b = 0; b < grid; ++b) {
         const unsigned long long* o = ht.data() + ((size_t)b * 8 + wv) * 16;
         double tb = 0;
-        for (int k = 0; k < 13; ++k) tb += (double)o[k];
+        for (int k = 0; k < 16; ++k) tb += (double)o[k];
         if (tb == 0) continue;
         ++cnt;
-        for (int k = 0; k < 13; ++k) sum[k] += (double)o[k];
+        for (int k = 0; k < 16; ++k) sum[k] += (double)o[k];
         tot += tb;
       }
       printf("{\"trace_wave\": %d, \"workgroups\": %d, \"cycles_per_layer\": %.0f, \"share\": {", wv, cnt, tot / cnt / (n * L));
-      for (int k = 0; k < 13; ++k) printf("%s\"%s\": %.0f", k ? ", " : "", names[k], sum[k] / cnt / (n * L));
+      for (int k = 0; k < 16; ++k) printf("%s\"%s\": %.0f", k ? ", " : "", names[k], sum[k] / cnt / (n * L));
       printf("}}\n");
     }
   }
