@@ -183,6 +183,70 @@ def test_pipeline_bs64_vs_reference_golden(eng, dev, golden_dir):
     assert np.abs(joints.cpu().numpy()[:, ::4] - g["joints_every4"]).max() < 1e-3
 
 
+def test_cluster_loop_bs64_vs_reference_golden_and_launch_family(dev, golden_dir):
+    """The metric's literal configuration on the kernel built for it: ONE bs-64 request, T = 196, split-f16 mode -- the reverse loop is the cluster launch
+    (kernels/loop_cluster.hpp: 8 clusters of 12 workgroups, hand-offs inside the launch), picked automatically for calls of up to 128 motions.
+    Against the reference's own outputs (pipeline_b64 fixture: reference MldDenoiser / MldVae / recover_from_ric, mld.py:290-360) at the tolerances of
+    test_pipeline_bs64_vs_reference_golden, against the launch-per-GEMM family of the same engine (loop_kernel 1), and: repeated calls, calls straight
+    behind each other without a host sync (a full decode between two loops), write-through and plain payload stores -- all identical to the bit."""
+    g = _gold(golden_dir, "pipeline_b64.npz")
+    b = syn.make_batch(64)
+    e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=1)
+    _load(e)
+    ns = e.numeric_status()
+    assert ns["probed"] == 1 and ns["loop_split_ok"] == 1, ns          # the probe ran the cluster kernel too (mldhip.hip range_probe (c))
+    text, lat0 = _cuda(b.text_emb, dev), _cuda(b.init_latents, dev)
+    lat, feats, joints = torch.empty(64, 1, 256, device=dev), torch.empty(64, 196, 263, device=dev), torch.empty(64, 196, 22, 3, device=dev)
+    e.sample(text, lat0, b.lengths, lat, feats, joints)
+    torch.cuda.synchronize()
+    assert e.launch_counts()[0] == 2                                    # condition rows + ONE loop launch
+    l0, j0 = lat.clone(), joints.clone()
+    assert np.abs(l0.cpu().numpy() - g["latents"]).max() < 5e-3
+    assert np.abs(feats.cpu().numpy()[:, -1] - g["feats_frame_last"]).max() < 2e-4
+    assert np.abs(j0.cpu().numpy()[:, ::4] - g["joints_every4"]).max() < 1e-3
+    for _ in range(4):                                                  # back to back, no host sync in between
+        e.sample(text, lat0, b.lengths, lat, feats, joints)
+    torch.cuda.synchronize()
+    assert torch.equal(lat, l0) and torch.equal(joints, j0)
+    e.set_option("cluster_wt", 1)
+    e.sample(text, lat0, b.lengths, lat, None, joints)
+    torch.cuda.synchronize()
+    assert torch.equal(lat, l0) and torch.equal(joints, j0)
+    e.set_option("loop_kernel", 1)
+    e.sample(text, lat0, b.lengths, lat, None, joints)
+    torch.cuda.synchronize()
+    assert e.launch_counts()[0] > 2000
+    dl, dj = float((lat - l0).abs().max()), float((joints - j0).abs().max())
+    print("cluster loop vs launch family at bs 64: latents %.3e joints %.3e" % (dl, dj))
+    assert dl < 1e-3 and dj < 2e-4
+    assert e.numeric_status()["nonfinite_values"] == 0
+    e.close()
+
+
+@pytest.mark.parametrize("B", [11, 128])
+def test_cluster_loop_ragged_and_two_clusters_per_xcd_vs_oracle(dev, B):
+    """11 motions (two clusters, the second with three live motions) and 128 motions (16 clusters = two per XCD, 192 workgroups): latents of the cluster
+    launch against the CPU oracle (torch fp32) and against the launch family."""
+    b = syn.make_batch(B, [40] * B, seed=21)
+    e = _lib.Engine(device=0, max_batch=B, max_frames=40, precision=1)
+    _load(e)
+    text, lat0 = _cuda(b.text_emb, dev), _cuda(b.init_latents, dev)
+    lat = torch.empty(B, 1, 256, device=dev)
+    e.sample(text, lat0, b.lengths, lat)
+    torch.cuda.synchronize()
+    assert e.launch_counts()[0] == 2
+    ops = O.TorchOps("float32")
+    ref = np.asarray(O.diffusion_reverse(ops, O.to_backend(ops, syn.make_denoiser_state_dict()), ops.asarray(b.text_emb), ops.asarray(b.init_latents), 7.5, 50, 4))
+    err = float(np.abs(lat.cpu().numpy() - ref).max())
+    l0 = lat.clone()
+    e.set_option("loop_kernel", 1)
+    e.sample(text, lat0, b.lengths, lat)
+    torch.cuda.synchronize()
+    print("cluster loop, %d motions: latents vs oracle %.3e, vs launch family %.3e" % (B, err, float((lat - l0).abs().max())))
+    assert err < 5e-3 and float((lat - l0).abs().max()) < 1e-3
+    e.close()
+
+
 def test_graph_replay_is_bit_identical_and_matches_eager(eng, dev):
     b = syn.make_batch(8, "ragged", seed=99)
     B, T = 8, max(b.lengths)

@@ -726,6 +726,42 @@ def test_sample_major_persistent_loop_sim(prec):
     e.close()
 
 
+@pytest.mark.parametrize("wt", [0, 1])
+def test_cluster_loop_sim(wt):
+    """loop_kernel = 4 (kernels/loop_cluster.hpp): the reverse loop as ONE launch of clusters -- 12 workgroups (3 tokens x 4 column groups) per 8 motions
+    that hand partial products to each other inside the launch (flags + L1-bypassing loads; the simulator runs every block of the grid as fibers
+    side by side, hipsim::launch_coresident).  B = 11: two clusters, the second with 3 live motions; a 3-layer skip stack (one skip linear: the Z
+    exchange), 2 steps (the end-of-step path, the ring's wrap into the next step); plain payload stores with the placement census (cluster_wt 0) and
+    write-through ones (1); against the oracle and the latency family.  Launch count: condition rows + the loop."""
+    dims = syn.ModelDims(num_layers=3)
+    sdd, sdv = syn.make_denoiser_state_dict(dims=dims), syn.make_vae_state_dict(dims=dims)
+    e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=12, max_frames=8, num_inference_steps=2, num_layers=3, precision=1)
+    e.load_state_dict(sdd, "denoiser.")
+    e.load_state_dict(sdv, "vae.")
+    e.finalize()
+    b = syn.make_batch(11, [8, 5, 3, 8, 1, 7, 2, 6, 8, 4, 8], seed=9)
+    ops = O.NumpyOps(np.float32)
+    ref = np.asarray(O.diffusion_reverse(ops, O.to_backend(ops, sdd), b.text_emb, b.init_latents, 7.5, 2, 4))
+    e.set_option("loop_kernel", 1)
+    lat1 = np.zeros((11, 1, 256), np.float32)
+    e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat1)
+    e.set_option("loop_kernel", 4)
+    e.set_option("cluster_wt", wt)
+    for _ in range(2):                      # twice: every flag is back at zero when a call ends
+        lat = np.full((11, 1, 256), np.nan, np.float32)
+        e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
+        assert e.launch_counts()[0] == 2
+        assert np.abs(lat - ref).max() < 2e-4 and np.abs(lat - lat1).max() < 2e-4, wt
+    # the precision mode without split arithmetic has no cluster build: refused like loop_kernel 3 where that is not built
+    e.close()
+    e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=4, max_frames=8, num_inference_steps=2, num_layers=3, precision=0)
+    e.load_state_dict(sdd, "denoiser.")
+    e.finalize()
+    with pytest.raises(_lib.MldHipError):
+        e.set_option("loop_kernel", 4)
+    e.close()
+
+
 def test_sample_major_loop_is_refused_where_it_is_not_built_sim():
     """ff_size 512 has no sample-major build: loop_kernel = 3 is refused after finalize, auto never picks it."""
     dims = syn.ModelDims(num_layers=3, ff_size=512)
