@@ -141,12 +141,20 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  * decoder.norm + final_layer as one row-strip launch ("final_strip"), V through the gfx950 transpose read ("attn_tr"), streaming hints on
  * the in-projection's strips ("nt_hints"), pre-split weight images ("split_weights"); round 2's LDS-staged feed-forward kernel
  * ("fused_ffn", kernels/ffn_fused.hpp) is gone.  Names:
- *   "loop_kernel"     reverse loop of the latent models: 0 = auto (default: by motions per call), 1 = latency kernels
+ *   "loop_kernel"     reverse loop of the latent models: 0 = auto (default: by motions per call: F16X3 mode -- cluster loop up to
+ *                     "cluster_max_batch" motions, latency kernels up to 191, persistent loop from 192), 1 = latency kernels
  *                     (kernels/tile32.hpp: one request of <= ~128 motions, 41 launches per step), 2 = column-split throughput kernels
  *                     (kernels/strip.hpp: a few hundred motions per call), 3 = the sample-major persistent loop
  *                     (kernels/loop_fused.hpp: ONE launch for all steps of the call, a workgroup per 8 motions, weights streamed in
  *                     consumption order; built for latent_dim 256 / ff_size 1024 / 4 heads in the F32 and F16X3 modes -- refused
- *                     elsewhere).  Its run time does not depend on the batch up to 8 x #CUs = 2 048 motions.
+ *                     elsewhere).  Its run time does not depend on the batch up to 8 x #CUs = 2 048 motions.  4 = the cluster loop
+ *                     (kernels/loop_cluster.hpp, ABI 4 / round 5: ONE launch for all steps of ONE request of up to 128 motions -- 12 workgroups
+ *                     (3 tokens x 4 column groups) per 8 motions hand partial products to each other inside the launch; F16X3 mode, latent_dim 256 /
+ *                     ff_size 1024 / 4 heads, refused elsewhere; 7.9 ms per 50-step loop for 8 .. 128 motions against 11.2 / 15.2 ms of the latency
+ *                     kernels at 64 / 128).  Calls it serves are issued eagerly, not through a captured graph
+ *   "cluster_max_batch" auto runs the cluster loop for calls of up to this many motions (default 128 = two clusters per XCD; 0 = never)
+ *   "cluster_wt"      cluster loop, payload stores of the in-launch hand-offs: 0 (default) = plain where the twelve workgroups of a cluster report one
+ *                     XCC id (served by the shared L2), write-through (sc1) for a cluster that spans XCDs; 1 = write-through always (+3.5 % per call)
  *   "fused_min_batch" auto picks the persistent loop from this many motions per call up; 0 (default) = by operand format, from the measured
  *                     crossover table (tools/ab_crossover.py, profiles/r04_loop_crossover.json): 192 on split-f16 MFMAs (19 ms per call
  *                     whatever the batch; the split-f16 latency kernels take 19.0 ms at 192 motions), 1 280 on exact-fp32 MFMAs (73 ms)

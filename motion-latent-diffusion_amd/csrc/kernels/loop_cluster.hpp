@@ -10,13 +10,13 @@
 //
 //   cluster = 8 motions = 16 rows of the CFG batch x 3 tokens (the row order of loop_fused.hpp: row = 16 t + c, c < 8 unconditional).
 //   member (t, h), t = token 0..2, h = column group 0..3; per layer (cross_attention.py:259-272, forward_post):
-//     Ph1  [X of all 48 rows in LDS]  Q of (token t, head h), K and V of head h for all three tokens (3x redundant over t: the 3-token
-//          attention needs them), scores + softmax + P.V for its 16 rows                      -> publishes AO[16 rows][64 columns]
-//     E1   gather AO of its token from the four members (t, *)                                    16 KB
-//     Ph2  out-projection of its 16 rows, all 256 columns (4x redundant over h: LayerNorm needs whole rows) + residual + norm1 -> h1;
-//          linear1 + GELU for hidden columns [256 h, 256 h + 256)                              -> publishes H[16][256] as a split-f16 image
+//     Ph1  [X of all 48 rows in LDS]  Q of (token t, head h) and K of head h for all three tokens on waves 0-3, V of head h for all three tokens on
+//          waves 4-7 (3x redundant over t: the 3-token attention needs them), scores through LDS, softmax + P.V for its 16 rows; then the
+//          out-projection SPLIT OVER K BY HEAD: the head's 64 attention dims into all 256 output columns   -> publishes a partial [16][256]
+//     E1   the 4 partials of its token, summed in a fixed order + bias + residual -> norm1, one row per wave (in-wave statistics)   64 KB
+//     Ph2  linear1 + GELU for hidden columns [256 h, 256 h + 256)                              -> publishes H[16][256] as a split-f16 image
 //     E2   gather the hidden activation of its token from (t, *)                                  64 KB
-//     Ph3  linear2 for output columns [64 h, 64 h + 64), K = 1024                              -> publishes Y[16][64]
+//     Ph3  linear2 for output columns [64 h, 64 h + 64), K = 1024 (halves on the two halves of the workgroup)   -> publishes Y[16][64]
 //     E3   gather Y and h1 of ALL 48 rows from the twelve members, residual + norm2 -> next layer's X    96 KB
 //   (+ per skip connection, cross_attention.py:56-58: norm2 of its own rows only, Linear(cat[x, skip]) for its 16 rows x 64 columns with
 //   the two K halves on the two halves of the workgroup, and one more gather of all 48 rows.)  End of a step (encoder.norm, CFG, DDIM:
@@ -25,19 +25,20 @@
 //
 // Weights: as in loop_fused.hpp a weight element is used by exactly one wave, so nothing is staged in LDS: `finalize` writes, per column group
 // and WAVE, the fragments that wave consumes in consumption order ([fragment][lane][8 words] split-f16: high halves of k = 8g .. 8g + 7 of
-// weight row 16 x + r, then the low halves) and every lane streams its 32 bytes per fragment through an 8-deep register ring.  ~1 MB per
-// layer and workgroup, ~3x the non-redundant share: at bs 64 the chip has the CUs (96 of 256) and the L2 bandwidth to spare, it is latency
-// it lacks.
+// weight row 16 x + r, then the low halves) and every lane streams its 32 bytes per fragment through a 4-deep register ring (8 spills).  768 KB
+// per layer and workgroup, 3.2x the non-redundant share: at bs 64 the chip has the CUs (96 of 256) to spare; the phases that stream run at the
+// L2 -> CU fill rate (58 B/clk), the rest of a layer is hand-off latency (DESIGN.md 3a has the kernel's own phase stamps).
 //
 // Hand-offs: cdna_hip_programming.md Guideline 16 form R1 -- write-through (sc1) payload stores, every storing wave drains its memory counter,
 // barrier, one lane stores the member's flag (relaxed, agent scope; value = epoch, never reset inside a call; zeroed by a memset node in front of
 // the launch), consumers poll the flags of the producers they need with one relaxed load per lane, then read with sc1 loads.  PLAIN payload
 // stores are 0.15-0.6 us per exchange cheaper but only visible to consumers behind the SAME L2: WT = false is used only when every member of
-// the cluster reports the same HW_REG_XCC_ID (checked in the kernel's first exchange; block b runs on XCD b % 8 in practice, not by contract).
+// the cluster reports the same HW_REG_XCC_ID (checked in the kernel's first exchange; block b runs on XCD b % 8 in practice, not by contract); a
+// cluster that spans XCDs keeps the write-through stores by itself.
 // Buffers are double buffered by the parity of the epoch; E3-type waits cover all twelve members even where fewer rows are read, which is what
 // keeps a fast member from overwriting a buffer a slow one still reads.  Every spin is bounded: a member that waits longer than
 // kClTimeoutTicks sets the call's status word, every member that sees it leaves, the latents are poisoned with NaN (counted by the range
-// contract's non-finite counter) and the engine falls back to the launch family for the handle.
+// contract's non-finite counter).  The twelfth member to finish clears the cluster's flag line, so every polled word is zero when a call ends.
 #pragma once
 #include "loop_fused.hpp"
 
