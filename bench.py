@@ -212,28 +212,6 @@ def events_ms(stream, fn):
     return e0.elapsed_time(e1), r
 
 
-def time_kernel(eng, name, B, T, iters, stream):
-    """Back-to-back launch interval (ms) of one named kernel, HIP events on the stream it is launched on."""
-    eng.profile_kernel(name, B, T, 3, stream.cuda_stream)
-    ms, flops = events_ms(stream, lambda: eng.profile_kernel(name, B, T, iters, stream.cuda_stream))
-    return ms / iters, flops
-
-
-def chain_marginal_us(eng, name, B, T, iters, stream):
-    """In-chain cost of one den_* GEMM: HIP events around `iters` repetitions of the real dependent layer chain
-    (qkv -> outproj -> ffn1 -> ffn2) minus the same chain without `name` (different kernels follow each other, as in the graph)."""
-    full = ["den_qkv", "den_outproj", "den_ffn1", "den_ffn2"]
-
-    def run(seq):
-        def go():
-            for _ in range(iters):
-                for k in seq:
-                    eng.profile_kernel(k, B, T, 1, stream.cuda_stream)
-        go()
-        return events_ms(stream, go)[0] / iters * 1e3
-    return max(0.0, run(full) - run([k for k in full if k != name]))
-
-
 def rocprof_child_stats(precision, coalesce, extra=(), keep_env="MLD_BENCH_KEEP_ROCPROF", timeout=240):
     """rocprofv3 --kernel-trace --stats over a short single-stream run of THIS workload in a child process -> {kernel: (avg ns, calls, total ns)}."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"

@@ -160,7 +160,7 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     whatever the batch; the split-f16 latency kernels take 19.0 ms at 192 motions), 1 280 on exact-fp32 MFMAs (73 ms)
  *   "fused_x3"        F16X3 mode: 1 (default) = the persistent loop multiplies on split-f16 MFMAs (row-swizzled operand images, 4 weight
  *                     items in flight per lane: the settled forms of round 3's "fused_swz" / "fused_ring" knobs), 0 = on exact-fp32 MFMAs
- *   "fused_dbg"       5 = the F16X3 persistent loop with per-phase cycle counters of the first 64 workgroups (same arithmetic, same
+ *   "fused_dbg"       (hooks build only, include/mldhip_hooks.h; unknown to the production library) 5 = the F16X3 persistent loop with per-phase cycle counters of the first 64 workgroups (same arithmetic, same
  *                     results), read back with mldhip_profile_trace("den_loop_phases") (tools/trace_loop.py); 0 (default) = off.  The
  *                     measurement builds that compute WRONG results (no weight stream, no MFMAs, ...) are not in the library any
  *                     more: tools/loopbench builds them stand-alone
@@ -356,17 +356,8 @@ int mldhip_feats2joints(mldhip_handle* h, const float* feats_dev, int32_t B, int
 int mldhip_get_timesteps(mldhip_handle* h, int32_t* out_host, int32_t n);
 int mldhip_get_alphas_cumprod(mldhip_handle* h, float* out_host, int32_t n);
 
-/* Measurement hook (no reference counterpart): enqueue ONE named kernel of the path `iters` times on
- * `stream` at its production shape for batch B / Tmax T; writes its algorithmic FLOPs per launch.
- * names: den_{qkv,outproj,ffn1,ffn2,final}, dec_{qkv,attn,outproj_ln,ffn1,ffn2_ln}.  The caller times it with events on `stream`. */
-int mldhip_profile_kernel(mldhip_handle* h, const char* name, int32_t B, int32_t T, int32_t iters,
-                          double* flops_per_launch, void* stream);
-
-/* Measurement hook: one traced launch of a den_* kernel; writes 8 uint64 timestamps per wave (64 per
- * workgroup) to out_host: start, loads landed, LDS written, barrier passed, MFMAs done, stores drained
- * (shader clock) and start/end on the 100 MHz realtime counter.  Returns workgroup slots copied. */
-int mldhip_profile_trace(mldhip_handle* h, const char* name, int32_t B, int32_t T, uint64_t* out_host,
-                         int64_t cap_u64, void* stream);
+/* (The measurement hooks of rounds 1-4 -- mldhip_profile_kernel, mldhip_profile_trace, option "fused_dbg" -- are not part of this library any more:
+ * include/mldhip_hooks.h, built into libmldhip_hooks.so by `make hooks`.) */
 
 /* Per-phase kernel launch counts of the last sample() (denoise loop, decode, joints). */
 int mldhip_get_launch_counts(mldhip_handle* h, int32_t* out_host /*[3]*/);

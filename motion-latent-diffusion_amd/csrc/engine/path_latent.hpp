@@ -846,8 +846,11 @@ void launch_fused_loop(Ctx& c, const float* init_lat, int B, int n, float guidan
   a.lat = e->lat; a.skip = e->FS; a.ddim = e->loop_ddim; a.B = B; a.L = e->cfg.num_layers; a.n = n;
   a.guidance = guidance; a.init_sigma = 1.0f;
   const dim3 grid((B + 7) / 8);
+#if defined(MLDHIP_HOOKS)
   if (x3 && e->fused_dbg == 5) { a.trace = reinterpret_cast<unsigned long long*>(e->trace_buf); MLD_LAUNCH((den_loop_kernel<true, 5>), grid, dim3(512), kLoopLdsBytes, c.stream, a); }
-  else if (x3) MLD_LAUNCH((den_loop_kernel<true>), grid, dim3(512), kLoopLdsBytes, c.stream, a);
+  else
+#endif
+  if (x3) MLD_LAUNCH((den_loop_kernel<true>), grid, dim3(512), kLoopLdsBytes, c.stream, a);
   else MLD_LAUNCH((den_loop_kernel<false>), grid, dim3(512), kLoopLdsBytes, c.stream, a);
   count(c);
   check_launch(c, "den_loop");

@@ -16,6 +16,9 @@
 //
 // Reference call stack being replaced: mld/models/modeltype/mld.py:216-265,290-360.
 #include "../../include/mldhip.h"
+#if defined(MLDHIP_HOOKS)
+#include "../../include/mldhip_hooks.h"
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -225,7 +228,9 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)gemm_pipe_x3_kernel<2, 4, 4, 4, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (gemm_pipe_lds_bytes<2, 4, 4, 4>()));
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+#if defined(MLDHIP_HOOKS)
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
+#endif
   (void)hipFuncSetAttribute((const void*)den_cluster_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kClLdsBytes);
   (void)hipFuncSetAttribute((const void*)den_cluster_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kClLdsBytes);
 #define MLD_T32_ATTR1(MT, NS, TR, PR) \
@@ -343,10 +348,12 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "cluster_wt") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "cluster_wt must be 0 (plain payload stores inside an XCD, write-through across) or 1 (write-through always)");
     e->cluster_wt = (int)value;
+#if defined(MLDHIP_HOOKS)
   } else if (n == "fused_dbg") {
     if (value != 0 && value != 5) return e->fail(MLDHIP_EINVAL, "fused_dbg must be 0 or 5 (phase counters; the builds with wrong results live in tools/loopbench only)");
     if (value == 5 && !e->trace_buf && hipMalloc((void**)&e->trace_buf, (size_t)512 * 8 * 8 * sizeof(uint64_t)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(trace)");
     e->fused_dbg = (int)value;
+#endif
   } else if (n == "range_probe") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "range_probe must be 0 or 1");
     e->range_probe = (int)value;
@@ -1185,6 +1192,8 @@ int mldhip_feats2joints(mldhip_handle* e, const float* feats_dev, int32_t B, int
 }
 
 
+// Measurement hooks: only in the hooks build (make hooks -> libmldhip_hooks.so, include/mldhip_hooks.h); the production library exports the sampling surface only.
+#if defined(MLDHIP_HOOKS)
 int mldhip_profile_kernel(mldhip_handle* e, const char* name, int32_t B, int32_t T, int32_t iters, double* flops_per_launch,
                           void* stream_) {
   // Launches ONE kernel of the sampling path `iters` times back-to-back on `stream` at its production
@@ -1298,6 +1307,8 @@ int mldhip_profile_trace(mldhip_handle* e, const char* name, int32_t B, int32_t 
   HIP_TRY(e, hipMemcpy(out_host, e->trace_buf, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return (int)(n / 64);
 }
+
+#endif  // MLDHIP_HOOKS
 
 int mldhip_get_timesteps(mldhip_handle* e, int32_t* out, int32_t n) {
   if (!e || !out) return MLDHIP_EINVAL;

@@ -88,13 +88,26 @@ _SYMBOLS = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "mldhip_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mldhip_feats2joints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    "mldhip_profile_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
-    "mldhip_profile_trace": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.c_int64, C.c_void_p]),
     "mldhip_get_timesteps": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]),
     "mldhip_get_alphas_cumprod": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
     "mldhip_get_launch_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mldhip_last_error": (C.c_char_p, [C.c_void_p]),
 }
+
+
+# measurement hooks: include/mldhip_hooks.h, exported by libmldhip_hooks.so only (`make -C csrc hooks`); bound when the loaded library has them
+_HOOK_SYMBOLS = {
+    "mldhip_profile_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
+    "mldhip_profile_trace": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.c_int64, C.c_void_p]),
+}
+HOOKS_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmldhip_hooks.so")
+
+
+def hooks_library() -> C.CDLL:
+    """The hooks build of the engine (tools/ only): the production surface + mldhip_profile_kernel / mldhip_profile_trace / option "fused_dbg"."""
+    if not os.path.exists(HOOKS_LIB):
+        raise FileNotFoundError(f"{HOOKS_LIB} not found: build it with `make -C motion-latent-diffusion_amd/csrc hooks`")
+    return load_library(HOOKS_LIB)
 
 
 def exported_symbols() -> List[str]:
@@ -116,6 +129,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the library does not export the ABI
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in _HOOK_SYMBOLS.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     if lib.mldhip_abi_version() != ABI_VERSION:
         raise RuntimeError(f"ABI version mismatch: library {lib.mldhip_abi_version()}, binding {ABI_VERSION}")
     return lib
@@ -285,17 +303,23 @@ class Engine:
     def feats2joints(self, feats, B: int, T: int, joints_out, stream: int = 0):
         self._check(self.lib.mldhip_feats2joints(self._h, _ptr(feats), B, T, _ptr(joints_out), stream))
 
+    def _hook(self, name):
+        fn = getattr(self.lib, name, None)
+        if fn is None:
+            raise MldHipError(-3, f"{name} is a measurement hook: load the hooks build (mld_hip._lib.hooks_library(), `make -C csrc hooks`)")
+        return fn
+
     def profile_kernel(self, name: str, B: int, T: int, iters: int, stream: int = 0) -> float:
         """Enqueue one kernel `iters` times; returns its algorithmic FLOPs per launch."""
         fl = C.c_double(0.0)
-        self._check(self.lib.mldhip_profile_kernel(self._h, name.encode(), B, T, iters, C.byref(fl), stream))
+        self._check(self._hook("mldhip_profile_kernel")(self._h, name.encode(), B, T, iters, C.byref(fl), stream))
         return fl.value
 
     def profile_trace(self, name: str, B: int, T: int, stream: int = 0) -> np.ndarray:
         """[workgroups, 8 waves, 8] uint64 timestamps of one traced den_* launch (measurement only)."""
         cap = 512 * 64
         buf = (C.c_uint64 * cap)()
-        n = self._check(self.lib.mldhip_profile_trace(self._h, name.encode(), B, T, buf, cap, stream))
+        n = self._check(self._hook("mldhip_profile_trace")(self._h, name.encode(), B, T, buf, cap, stream))
         return np.ctypeslib.as_array(buf).reshape(-1, 8, 8)[:n].copy()
 
     def timesteps(self) -> np.ndarray:

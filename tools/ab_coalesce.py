@@ -30,7 +30,7 @@ def tk(eng, name, B, T, iters, stream):
 
 out = {}
 stream = torch.cuda.current_stream()
-big = _lib.Engine(device=0, max_batch=64 * NREQ, max_frames=196, max_in_flight=2)
+big = _lib.Engine(lib=_lib.hooks_library(), device=0, max_batch=64 * NREQ, max_frames=196, max_in_flight=2)
 load(big)
 reqs = []
 for i in range(2 * NREQ):
@@ -66,7 +66,7 @@ big.set_option("loop_kernel", 1)
 out["coalesced_latency_kernels"] = run_many(1, max(2, STEPS // 2))
 big.set_option("loop_kernel", 0)
 
-small = _lib.Engine(device=0, max_batch=64, max_frames=196, max_in_flight=4)
+small = _lib.Engine(lib=_lib.hooks_library(), device=0, max_batch=64, max_frames=196, max_in_flight=4)
 load(small)
 streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
 solo = [torch.empty(64, 196, 22, 3, device=dev) for _ in range(NREQ)]

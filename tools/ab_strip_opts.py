@@ -17,7 +17,7 @@ for i in range(NREQ * NFL):
     b = syn.make_batch(64, None, seed=1234 + i, max_len=196)
     reqs.append(dict(text_emb=torch.from_numpy(b.text_emb).to(dev), init_latents=torch.from_numpy(b.init_latents).to(dev), lengths=b.lengths,
                      joints_out=torch.empty(64, 196, 22, 3, device=dev)))
-eng = _lib.Engine(device=0, max_batch=64 * NREQ, max_frames=196, max_in_flight=NFL, precision=1)
+eng = _lib.Engine(lib=_lib.hooks_library(), device=0, max_batch=64 * NREQ, max_frames=196, max_in_flight=NFL, precision=1)
 eng.load_state_dict(sd); eng.finalize()
 streams = [torch.cuda.Stream(device=dev) for _ in range(NFL)]
 stream = torch.cuda.current_stream()

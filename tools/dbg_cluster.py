@@ -32,7 +32,7 @@ if a.sim:
     e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=a.B, max_frames=8, num_inference_steps=a.steps, num_layers=a.layers, precision=1)
 else:
     import torch
-    e = _lib.Engine(device=0, max_batch=a.B, max_frames=a.T, num_inference_steps=a.steps, num_layers=a.layers, precision=1, use_graph=a.graph)
+    e = _lib.Engine(lib=_lib.hooks_library(), device=0, max_batch=a.B, max_frames=a.T, num_inference_steps=a.steps, num_layers=a.layers, precision=1, use_graph=a.graph)
 e.load_state_dict(sdd, "denoiser."); e.load_state_dict(sdv, "vae.")
 mean, std = syn.make_mean_std()
 e.load_tensor("mean", mean); e.load_tensor("std", std)

@@ -9,7 +9,7 @@ from mld_hip import _lib, synthetic as syn
 B, T = int(os.environ.get("TRACE_B", "64")), 196
 out = {}
 for prec in [int(x) for x in os.environ.get("TRACE_PREC", "0,1").split(",")]:
-    eng = _lib.Engine(device=0, max_batch=B, max_frames=T, precision=prec)
+    eng = _lib.Engine(lib=_lib.hooks_library(), device=0, max_batch=B, max_frames=T, precision=prec)
     eng.load_state_dict(syn.make_denoiser_state_dict(), "denoiser."); eng.load_state_dict(syn.make_vae_state_dict(), "vae.")
     m, s = syn.make_mean_std(); eng.load_tensor("mean", m); eng.load_tensor("std", s); eng.finalize()
     b = syn.make_batch(B)

@@ -10,7 +10,7 @@ from mld_hip import _lib, synthetic as syn
 
 dev = torch.device("cuda:0")
 N = int(os.environ.get("AB_N", "2048"))
-eng = _lib.Engine(device=0, max_batch=N, max_frames=196, precision=1)
+eng = _lib.Engine(lib=_lib.hooks_library(), device=0, max_batch=N, max_frames=196, precision=1)
 eng.load_state_dict(syn.make_denoiser_state_dict(), "denoiser."); eng.load_state_dict(syn.make_vae_state_dict(), "vae.")
 m, s = syn.make_mean_std(); eng.load_tensor("mean", m); eng.load_tensor("std", s); eng.finalize()
 reqs = []

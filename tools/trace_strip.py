@@ -8,7 +8,7 @@ import numpy as np, torch
 from mld_hip import _lib, synthetic as syn
 
 B, T = int(os.environ.get("TRACE_B", "320")), 196
-eng = _lib.Engine(device=0, max_batch=B, max_frames=T, precision=1)
+eng = _lib.Engine(lib=_lib.hooks_library(), device=0, max_batch=B, max_frames=T, precision=1)
 eng.load_state_dict(syn.make_denoiser_state_dict(), "denoiser."); eng.load_state_dict(syn.make_vae_state_dict(), "vae.")
 m, s = syn.make_mean_std(); eng.load_tensor("mean", m); eng.load_tensor("std", s); eng.finalize()
 torch.cuda.synchronize()

@@ -8,7 +8,7 @@ from mld_hip import _lib, synthetic as syn
 
 B, T = 64, 196
 PREC = int(os.environ.get("TRACE_PREC", "1"))                  # 1 = split-f16 (the latency kernels on split-f16 MFMAs), 0 = exact fp32
-eng = _lib.Engine(device=0, max_batch=B, max_frames=T, precision=PREC)
+eng = _lib.Engine(lib=_lib.hooks_library(), device=0, max_batch=B, max_frames=T, precision=PREC)
 eng.load_state_dict(syn.make_denoiser_state_dict(), "denoiser."); eng.load_state_dict(syn.make_vae_state_dict(), "vae.")
 m, s = syn.make_mean_std(); eng.load_tensor("mean", m); eng.load_tensor("std", s); eng.finalize()
 b = syn.make_batch(B)
