@@ -20,6 +20,33 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def pack_range(n: int, rank: int, world: int, per_rank: int) -> Tuple[int, int]:
+    """"pack" sharding: ceil(n / per_rank) BUSY ranks take `per_rank` prompts each (the last one the remainder), the other ranks none -- fewer, bigger engine calls
+    (one coalesced call of a few hundred motions runs the persistent loop at a higher rate per GPU than bs-64 calls do on the launch family)."""
+    per_rank = max(1, int(per_rank))
+    lo = min(n, rank * per_rank)
+    return lo, min(n, lo + per_rank)
+
+
+def plan_shards(n: int, world: int, batch_size: int, max_batch: int, policy: str = "auto", single_batch_is_fast: bool = True) -> dict:
+    """How DataParallelSampler spreads n prompts over `world` ranks.  "spread": contiguous equal shards on every rank (the reference's own multi-GPU form,
+    scripts/fit_motion_parallel.sh; BASELINE config 3 = one bs-64 batch per rank).  "pack": as few ranks as hold the prompts at `max_batch` per rank.  "auto":
+    spread whenever a bs-64 call is served by the cluster loop (engine >= r05: 7.0 k motions/s per rank at bs 64, 8 ranks = 56 k, against 20.5 k for one rank
+    with all 512 prompts in one call) or the shards are not smaller than a coalesced call anyway; pack only when per-rank shards would be single small batches
+    on an engine without that path.  Returns {"policy", "busy_ranks", "prompts_per_busy_rank", "why"}."""
+    per_spread = -(-n // max(1, world))
+    if policy == "auto":
+        small = per_spread <= batch_size and world > 1
+        policy = "pack" if (small and not single_batch_is_fast and max_batch > batch_size) else "spread"
+        why = ("auto: shards of %d prompts per rank; a single batch %s the cluster loop" % (per_spread, "runs" if single_batch_is_fast else "does not run"))
+    else:
+        why = "forced"
+    if policy == "pack":
+        per = min(max(batch_size, max_batch), n)
+        return {"policy": "pack", "busy_ranks": min(world, -(-n // per)), "prompts_per_busy_rank": per, "why": why}
+    return {"policy": "spread", "busy_ranks": min(world, n), "prompts_per_busy_rank": per_spread, "why": why}
+
+
 def pack_state(tensors: Dict[str, np.ndarray]) -> Tuple[np.ndarray, List[Tuple[str, Tuple[int, ...], int]]]:
     """Flatten a name->array dict into one float32 blob + an index (name, shape, offset)."""
     index, off, parts = [], 0, []
@@ -83,7 +110,8 @@ class DataParallelSampler:
     with ``max_batch >= 512``; on eight ranks every rank holds one bs-64 batch and there is nothing to coalesce (the literal
     ``MLD.forward`` shape).  An int forces that many (the engine refuses more motions than its ``max_batch``)."""
 
-    def __init__(self, model, batch_size: int = 64, in_flight: int = 1, coalesce=1):
+    def __init__(self, model, batch_size: int = 64, in_flight: int = 1, coalesce=1, shard: str = "auto", verbose: bool = False):
+        self.shard, self.verbose, self.last_plan = shard, verbose, None     # shard: "auto" | "spread" | "pack" (plan_shards)
         self.model = model
         self.batch_size = batch_size
         self.in_flight = max(1, int(in_flight))
@@ -91,7 +119,7 @@ class DataParallelSampler:
 
     def pick_coalesce(self, nchunks: int) -> int:
         """The automatic rule: chunks per engine call from the shard size and the engine's capacity."""
-        if self.coalesce is not None:
+        if self.coalesce is not None and not (self.last_plan and self.last_plan["policy"] == "pack"):      # packed shards exist to be coalesced
             return self.coalesce
         try:
             cap = int(self.model._engine().cfg.max_batch) // self.batch_size
@@ -111,7 +139,19 @@ class DataParallelSampler:
             raise ValueError("DataParallelSampler needs %s and lengths of equal size" % ("actions" if action else "texts"))
         rank = dist.get_rank() if dist.is_initialized() else 0
         world = dist.get_world_size() if dist.is_initialized() else 1
-        lo, hi = shard_range(len(items), rank, world)
+        try:
+            eng = m._engine()
+            max_batch, prec = int(eng.cfg.max_batch), int(eng.cfg.precision)
+        except Exception:          # not a fused Hip* model
+            max_batch, prec = self.batch_size, 0
+        fast_single = prec == 1 and self.batch_size <= 128 and getattr(m, "vae_type", "") != "no"      # F16X3 engine: calls of <= 128 motions run the cluster loop
+        self.last_plan = plan_shards(len(items), world, self.batch_size, max_batch, self.shard, fast_single)
+        if self.verbose and rank == 0:
+            print("DataParallelSampler: %(policy)s over %(busy_ranks)d busy rank(s), %(prompts_per_busy_rank)d prompts each (%(why)s)" % self.last_plan, flush=True)
+        if self.last_plan["policy"] == "pack":
+            lo, hi = pack_range(len(items), rank, world, self.last_plan["prompts_per_busy_rank"])
+        else:
+            lo, hi = shard_range(len(items), rank, world)
         chunks = [(s, min(hi, s + self.batch_size)) for s in range(lo, hi, self.batch_size)]
         dev = next(m.parameters()).device
         novae = getattr(m, "vae_type", "") == "no"

@@ -20,6 +20,7 @@ def sampler_job(mode, out_path, n):
     """mode 'action' / 'novae': this rank's shard through mld_hip.MLD + DataParallelSampler (the drop-in surface), the
     weights from ONE packed broadcast, starting noise pinned per prompt; rank 0 saves what every rank produced."""
     import dp_models
+    mode, _, shard = mode.partition(":")          # "action:pack": the sampler packs the prompts onto as few ranks as hold them
     rank, world = dist.get_rank(), dist.get_world_size()
     template = dp_models.state_template(mode)
     src = template if rank == 0 else {k: np.full_like(v, np.nan) for k, v in template.items()}
@@ -27,7 +28,7 @@ def sampler_job(mode, out_path, n):
     model, close = dp_models.build(mode, {k: v.clone() for k, v in state.items()}, key=f"inject:dp_{mode}_{rank}")
     try:
         kw = dp_models.job(mode, n)
-        idx, motions = dp.DataParallelSampler(model, batch_size=2)(**kw)
+        idx, motions = dp.DataParallelSampler(model, batch_size=2, shard=shard or "auto", verbose=True)(**kw)
     finally:
         close()
     gathered = [None] * world

@@ -67,18 +67,21 @@ def test_two_rank_job_matches_single_process(tmp_path, world):
     eng.close()
 
 
-@pytest.mark.parametrize("mode,n", [("action", 3), ("novae", 3)])
+@pytest.mark.parametrize("mode,n", [("action", 3), ("novae", 3), ("action:pack", 3)])
 def test_two_rank_sampler_job_other_variants_match_single_process(tmp_path, mode, n):
     """BASELINE config 5 (action-to-motion, quoted on 2 GPUs) and config 4 through the drop-in surface: mld_hip.MLD +
     DataParallelSampler on two gloo ranks (each with its own engine, weights from the one broadcast, noise pinned per prompt)
     must give the motions of a single-process run of the same prompts -- a motion may not depend on the rank it lands on."""
     import dp_models
+    job_mode, mode = mode, mode.partition(":")[0]
     out = str(tmp_path / f"dp_{mode}.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29519" if mode == "action" else "29521", os.path.join(HERE, "dp_worker.py"), out, str(n), mode]
+           "--master-port", {"action": "29519", "novae": "29521"}.get(job_mode, "29523"), os.path.join(HERE, "dp_worker.py"), out, str(n), job_mode]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+    if job_mode.endswith(":pack"):               # rank 0 says which sharding it chose: one busy rank holds all three prompts, rank 1 gets an empty shard
+        assert "DataParallelSampler: pack over 1 busy rank(s)" in r.stdout, r.stdout[-800:]
     got = np.load(out)
     model, close = dp_models.build(mode, dp_models.state_template(mode), key=f"inject:dp_{mode}_single")
     try:
@@ -91,3 +94,18 @@ def test_two_rank_sampler_job_other_variants_match_single_process(tmp_path, mode
         want = np.asarray(ref[i])
         assert got[f"m_{i}"].shape == want.shape == (kw["lengths"][i], 150) if mode == "action" else (kw["lengths"][i], 22, 3)
         assert np.abs(got[f"m_{i}"] - want).max() < 2e-5
+
+
+def test_shard_planning_rules():
+    """plan_shards / pack_range (mld_hip/dp.py): BASELINE config 3 (512 prompts, 8 ranks, bs 64) is spread one batch per rank when a bs-64 call runs the cluster
+    loop, packed onto one rank (one 512-motion call) on an engine without that path; forced policies; packed ranges cover every prompt exactly once."""
+    assert dp.plan_shards(512, 8, 64, 64, "auto", True)["policy"] == "spread"
+    pk = dp.plan_shards(512, 8, 64, 512, "auto", False)
+    assert pk["policy"] == "pack" and pk["busy_ranks"] == 1 and pk["prompts_per_busy_rank"] == 512
+    assert dp.plan_shards(512, 8, 64, 512, "auto", True)["policy"] == "spread"          # the cluster loop makes bs-64 shards the better form
+    assert dp.plan_shards(4096, 8, 64, 512, "auto", False)["policy"] == "spread"        # shards of 512 are big calls anyway
+    p4 = dp.plan_shards(300, 4, 64, 128, "pack")
+    assert p4["busy_ranks"] == 3 and p4["prompts_per_busy_rank"] == 128
+    spans = [dp.pack_range(300, r, 4, 128) for r in range(4)]
+    assert spans == [(0, 128), (128, 256), (256, 300), (300, 300)]
+    assert [dp.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
