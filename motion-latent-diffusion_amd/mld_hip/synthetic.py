@@ -122,6 +122,33 @@ def make_denoiser_state_dict(seed: int = 0, dims: ModelDims = ModelDims(), condi
     return sd
 
 
+def trained_like(sd: Dict[str, np.ndarray], seed: int = 11) -> Dict[str, np.ndarray]:
+    """A SECOND weight family with the statistics trained transformers show and xavier-uniform initialisation does not (tolerances must
+    not be tuned to one distribution): LayerNorm gains ~ N(1, 0.3) (clipped to [0.15, 2.5]) and biases ~ N(0, 0.1); every weight matrix gets heavy-tailed ROWS
+    (a log-normal factor per output row, sigma 0.6, and one row in 64 another x 4); biases ~ N(0, 0.05) on top of what they were; the denoiser's final norm
+    (`encoder.norm.*`) shrinks its gain to ~0.3 so the predicted noise -- and with it the sampled latents -- is several times smaller than with the first family.
+    Same keys and shapes as its input; deterministic in (seed, key)."""
+    out: Dict[str, np.ndarray] = {}
+    for k, v in sd.items():
+        g = _rng(seed, "tl:" + k)
+        a = np.array(v, np.float32, copy=True)
+        is_norm = (".norm" in k or k.startswith("norm") or "norm." in k) and a.ndim == 1
+        if is_norm and k.endswith("weight"):
+            a = np.clip(g.normal(1.0, 0.3, a.shape), 0.15, 2.5).astype(np.float32)
+            if k.endswith("encoder.norm.weight"):
+                a *= 0.3
+        elif is_norm and k.endswith("bias"):
+            a = g.normal(0.0, 0.1, a.shape).astype(np.float32)
+        elif a.ndim == 2 and k.endswith("weight") and min(a.shape) >= 16:
+            row = np.exp(g.normal(0.0, 0.6, (a.shape[0], 1))).astype(np.float32)
+            row[g.random((a.shape[0], 1)) < 1.0 / 64.0] *= 4.0
+            a = a * row / np.float32(np.exp(0.18))          # keep the mean square of the matrix where it was (E exp(2 N(0, 0.6)) = e^0.72, x the outlier rows)
+        elif a.ndim == 1 and k.endswith("bias"):
+            a = a + g.normal(0.0, 0.05, a.shape).astype(np.float32)
+        out[k] = np.ascontiguousarray(a, np.float32)
+    return out
+
+
 def make_novae_denoiser_state_dict(seed: int = 4, dims: ModelDims = ModelDims(latent_dim=512)) -> Dict[str, np.ndarray]:
     """Synthetic ``MldDenoiser`` weights for the diffusion-only variant (VAE_TYPE 'no', arch trans_dec, text condition;
     mld_denoiser.py:50-53,57-68,114-131): pose_embd / pose_proj, 9 plain TransformerDecoderLayers + final norm."""

@@ -180,7 +180,7 @@ def test_pipeline_bs64_vs_reference_golden(eng, dev, golden_dir):
     lat, feats, joints, _ = _run_sample(eng, dev, b)
     assert np.abs(lat.cpu().numpy() - g["latents"]).max() < 5e-3
     assert np.abs(feats.cpu().numpy()[:, -1] - g["feats_frame_last"]).max() < 2e-4
-    assert np.abs(joints.cpu().numpy()[:, ::4] - g["joints_every4"]).max() < 1e-3
+    assert np.abs(joints.cpu().numpy() - g["joints"]).max() < 1e-3
 
 
 def test_cluster_loop_bs64_vs_reference_golden_and_launch_family(dev, golden_dir):
@@ -203,7 +203,7 @@ def test_cluster_loop_bs64_vs_reference_golden_and_launch_family(dev, golden_dir
     l0, j0 = lat.clone(), joints.clone()
     assert np.abs(l0.cpu().numpy() - g["latents"]).max() < 5e-3
     assert np.abs(feats.cpu().numpy()[:, -1] - g["feats_frame_last"]).max() < 2e-4
-    assert np.abs(j0.cpu().numpy()[:, ::4] - g["joints_every4"]).max() < 1e-3
+    assert np.abs(j0.cpu().numpy() - g["joints"]).max() < 1e-3
     for _ in range(4):                                                  # back to back, no host sync in between
         e.sample(text, lat0, b.lengths, lat, feats, joints)
     torch.cuda.synchronize()
@@ -220,6 +220,37 @@ def test_cluster_loop_bs64_vs_reference_golden_and_launch_family(dev, golden_dir
     print("cluster loop vs launch family at bs 64: latents %.3e joints %.3e" % (dl, dj))
     assert dl < 1e-3 and dj < 2e-4
     assert e.numeric_status()["nonfinite_values"] == 0
+    e.close()
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_second_weight_family_vs_reference_golden(dev, golden_dir, prec):
+    """A second family of weights (mld_hip.synthetic.trained_like: LayerNorm gains ~ N(1, 0.3), heavy-tailed weight rows, a small final gain) against the REFERENCE
+    modules' outputs on those weights (tests/golden/pipeline_b8_trainedlike.npz, oracle/make_golden_trainedlike.py; B = 8 ragged, every frame kept): exact-fp32
+    engine, and the split-f16 engine on the cluster loop and on the launch family.  The tolerances are the first family's; the range probe's verdict is checked."""
+    g = _gold(golden_dir, "pipeline_b8_trainedlike.npz")
+    lengths = [int(x) for x in g["lengths"]]
+    b = syn.make_batch(8, lengths, seed=4321, max_len=64)
+    e = _lib.Engine(device=0, max_batch=8, max_frames=64, precision=prec)
+    e.load_state_dict(syn.trained_like(syn.make_denoiser_state_dict()), "denoiser.")
+    e.load_state_dict(syn.trained_like(syn.make_vae_state_dict(), seed=12), "vae.")
+    mean, std = syn.make_mean_std()
+    e.load_tensor("mean", mean)
+    e.load_tensor("std", std)
+    e.finalize()
+    if prec == 1:
+        ns = e.numeric_status()
+        assert ns["probed"] == 1 and ns["loop_split_ok"] == 1 and ns["decode_split_ok"] == 1, ns
+    text, lat0 = _cuda(b.text_emb, dev), _cuda(b.init_latents, dev)
+    lat, feats, joints = torch.empty(8, 1, 256, device=dev), torch.empty(8, 64, 263, device=dev), torch.empty(8, 64, 22, 3, device=dev)
+    for lk in ((0, 1) if prec == 1 else (0,)):
+        e.set_option("loop_kernel", lk)
+        e.sample(text, lat0, b.lengths, lat, feats, joints)
+        torch.cuda.synchronize()
+        assert (e.launch_counts()[0] == 2) == (prec == 1 and lk == 0)
+        el, ef, ej = (float(np.abs(a.cpu().numpy() - g[k]).max()) for a, k in ((lat, "latents"), (feats, "feats"), (joints, "joints")))
+        print("second weight family, precision %d, loop_kernel %d: latents %.3e feats %.3e joints %.3e" % (prec, lk, el, ef, ej))
+        assert el < 5e-3 and ef < 1e-3 and ej < 1e-3
     e.close()
 
 
@@ -348,7 +379,7 @@ def test_split_f16_decode_mode_meets_the_joint_tolerance(dev, golden_dir):
         e.set_option("dec_tail", tail)
         lat, feats, joints, _ = _run_sample(e, dev, b)
         err_f = np.abs(feats.cpu().numpy()[:, -1] - g["feats_frame_last"]).max()
-        err_j = np.abs(joints.cpu().numpy()[:, ::4] - g["joints_every4"]).max()
+        err_j = np.abs(joints.cpu().numpy() - g["joints"]).max()
         print("f16x3 decode (strip_gemm %d, ffn_strip %d): feats err %.3e joints err %.3e" % (sg, fs, err_f, err_j))
         assert err_f < 1e-4 and err_j < 5e-4
         f3 = torch.full((3, 100, 263), float("nan"), device=dev)
@@ -901,7 +932,7 @@ def test_sample_many_coalesced_requests_vs_reference_golden(dev, golden_dir, ora
     q = reqs[0]
     assert np.abs(q["latents_out"].cpu().numpy() - g["latents"]).max() < 5e-3
     assert np.abs(q["feats_out"].cpu().numpy()[:, -1] - g["feats_frame_last"]).max() < 2e-4
-    assert np.abs(q["joints_out"].cpu().numpy()[:, ::4] - g["joints_every4"]).max() < 1e-3
+    assert np.abs(q["joints_out"].cpu().numpy() - g["joints"]).max() < 1e-3
     for b, q in zip(batches[1:], reqs[1:]):
         B, T = len(b.lengths), max(b.lengths)
         lat, feats, joints = torch.empty(B, 1, 256, device=dev), torch.empty(B, T, 263, device=dev), torch.empty(B, T, 22, 3, device=dev)
@@ -1092,7 +1123,7 @@ def test_key_blocked_attention_matches_whole_kv_attention_on_gpu(dev, golden_dir
         assert 0 < df < 5e-5 and dj < 1e-4
         for i, n in enumerate(b.lengths):
             assert torch.all(outs[name, 2][0][i, n:] == 0)
-    err = float(np.abs(outs["full", 2][1].cpu().numpy()[:, ::4] - g["joints_every4"]).max())
+    err = float(np.abs(outs["full", 2][1].cpu().numpy() - g["joints"]).max())
     print("key-blocked attention, joints vs reference golden: %.2e" % err)
     assert err < 1e-3
     e.close()
@@ -1188,11 +1219,12 @@ def test_headline_serving_shape_every_motion_within_tolerance(dev, golden_dir, N
                 worst = max(worst, float(d[i, :n].max()))
         report[mix + "_vs_exact_fp32_engine"] = worst
         assert worst < 8e-4, report
-        # direct checks against the reference fixture (request 0) / the CPU oracle: eight requests per length mix
-        for k in ((0, 2, 5, 7, 11, 13, 17, 19) if mix == "full" else (1, 3, 6, 9, 12, 15, 16, 18)):
+        # direct checks against the reference fixture (request 0, every frame) / the CPU oracle: EVERY request of the driver's 1 280-motion call (round 5: no
+        # HIP-vs-HIP majority any more), eight requests per length mix of the 2 048-motion call
+        for k in (range(NREQ) if NREQ == 20 else ((0, 2, 5, 7, 11, 13, 17, 19) if mix == "full" else (1, 3, 6, 9, 12, 15, 16, 18))):
             b, q = batches[k], reqs[k]
             if mix == "full" and k == 0:
-                e = float(np.abs(q["joints_out"].cpu().numpy()[:, ::4] - g["joints_every4"]).max())
+                e = float(np.abs(q["joints_out"].cpu().numpy() - g["joints"]).max())
                 assert np.abs(q["latents_out"].cpu().numpy() - g["latents"]).max() < 5e-3
             else:
                 jr = ops.to_numpy(O.sample(ops, bd, bv, ops.asarray(b.text_emb), ops.asarray(b.init_latents), b.lengths,

@@ -169,3 +169,23 @@ def test_novae_variant_matches_reference(golden_dir):
     sch.set_timesteps(1000)
     assert tab.shape == (1000, 5) and tab[0, 4] == 0.0 and np.all(tab[1:, 4] > 0)          # no noise at t = 0 only
     np.testing.assert_array_equal(np.array(sch.coeffs(500), np.float32), tab[500])
+
+
+def test_second_weight_family_matches_reference(golden_dir):
+    """The trained-like weight family (mld_hip.synthetic.trained_like: LayerNorm gains ~ N(1, 0.3), heavy-tailed weight rows, a small final gain) through the oracle
+    against the reference modules' outputs on the same weights (oracle/make_golden_trainedlike.py): one denoiser call and the full 50-step pipeline, B = 8 ragged,
+    nothing subsampled.  Tolerances are the first family's -- they are not tuned to one distribution."""
+    g = _load(golden_dir, "pipeline_b8_trainedlike.npz")
+    ops = O.TorchOps("float32")
+    sdd, sdv = syn.trained_like(syn.make_denoiser_state_dict()), syn.trained_like(syn.make_vae_state_dict(), seed=12)
+    bd, bv = O.to_backend(ops, sdd), O.to_backend(ops, sdv)
+    lengths = [int(x) for x in g["lengths"]]
+    b = syn.make_batch(8, lengths, seed=4321, max_len=64)
+    mean, std = syn.make_mean_std()
+    x = np.concatenate([b.init_latents] * 2)
+    d0 = np.asarray(O.denoiser_forward(ops, bd, ops.asarray(x), 981, ops.asarray(b.text_emb)))
+    assert np.abs(d0 - g["denoiser_t981"]).max() < 1e-4
+    j, f, lat = O.sample(ops, bd, bv, ops.asarray(b.text_emb), ops.asarray(b.init_latents), lengths, mean, std, return_intermediates=True)
+    assert np.abs(np.asarray(lat) - g["latents"]).max() < 5e-3
+    assert np.abs(np.asarray(f) - g["feats"]).max() < 2e-4
+    assert np.abs(np.asarray(j) - g["joints"]).max() < 1e-3
