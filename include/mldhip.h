@@ -165,7 +165,9 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     measurement builds that compute WRONG results (no weight stream, no MFMAs, ...) are not in the library any
  *                     more: tools/loopbench builds them stand-alone
  *   "range_probe"     F16X3 mode: 1 (default) = mldhip_finalize_weights runs the range probe of the "Range contract" below, 0 = skips it
- *                     (the split kernels are used unconditionally).  Setting it un-finalizes the handle
+ *                     (the split kernels are used unconditionally), 2 = as 1, and the first text-conditioned mldhip_sample after finalize
+ *                     repeats the reverse-loop part on the first 8 motions of ITS batch (the caller's embeddings and start noise) before
+ *                     it samples: the verdict then covers a real prompt batch, not only the seeded one.  Setting it un-finalizes the handle
  *   "ffn_strip"       F16X3 / FP8 modes, decoder / encoder layers: strip height of the register-direct kernels (kernels/ffn_strip.hpp,
  *                     kernels/gemm_strip_x3.hpp): 1 (default) = by launch size -- more than 512 strips of 64 rows: 96-row strips for the
  *                     GEMMs, 48-row strips at two workgroups per CU for the feed-forward block; else 64 rows (one bs-64 request: 196

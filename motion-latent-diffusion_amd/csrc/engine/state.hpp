@@ -148,6 +148,7 @@ struct mldhip_engine {
 #else
   int range_probe = 1;       // "range_probe": finalize compares the split-f16 kernels with the exact-fp32 ones on a probe batch and falls back per stage
 #endif
+  bool probe_first_call = false; // "range_probe" 2: the next text-conditioned mldhip_sample runs the reverse-loop probe on its own batch first
   bool split_loop_ok = true;     // false: the reverse loop runs on exact-fp32 MFMAs although the handle was created in the split mode
   bool split_decode_ok = true;   // false: decoder / encoder / diffusion-only GEMMs and attention run on exact-fp32 MFMAs
   float probe_err_loop = -1.f, probe_err_decode = -1.f;   // probe results (max-abs difference / max-abs reference); -1: not probed

@@ -997,3 +997,23 @@ def test_range_probe_keeps_or_replaces_the_split_kernels_sim():
         else:
             assert s0["probed"] == 0 and s0["loop_split_ok"] == 1
             assert s1["nonfinite_values"] > 0, (worst, s1)              # inf -> NaN inside the split kernels, counted at run time
+    # "range_probe" 2: weights that pass the seeded probe, a FIRST BATCH that does not (text embeddings x 3e5: the condition rows leave the half range) -- the
+    # first mldhip_sample repeats the loop probe on its own batch, moves the loop to the exact-fp32 kernels and then agrees with the oracle
+    sdd, sdv = syn.make_denoiser_state_dict(dims=dims), syn.make_vae_state_dict(dims=dims)
+    e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=8, max_frames=8, num_inference_steps=2, num_layers=3, precision=1)
+    e.load_state_dict(sdd, "denoiser."); e.load_state_dict(sdv, "vae.")
+    e.load_tensor("mean", mean); e.load_tensor("std", std)
+    e.set_option("range_probe", 2)
+    e.finalize()
+    s0 = e.numeric_status()
+    assert s0["probed"] == 1 and s0["loop_split_ok"] == 1, s0
+    wild = (b.text_emb * np.float32(3e5)).astype(np.float32)
+    jr = np.asarray(O.sample(ops, O.to_backend(ops, sdd), O.to_backend(ops, sdv), wild, b.init_latents, b.lengths, mean, std, steps=2))
+    e.set_option("loop_kernel", 1)
+    joints = np.full((3, 8, 22, 3), np.nan, np.float32)
+    e.sample(wild, b.init_latents, b.lengths, joints_out=joints)
+    s1 = e.numeric_status()
+    err = max(float(np.nan_to_num(np.abs(joints[i, :n] - jr[i, :n]), nan=np.inf).max()) for i, n in enumerate(b.lengths))
+    e.close()
+    assert s1["loop_split_ok"] == 0 and s1["probe_err_loop"] > _lib.PROBE_TOL, s1
+    assert err < 1e-3 and s1["nonfinite_values"] == 0, (err, s1)
