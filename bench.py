@@ -274,9 +274,11 @@ def bench_a2m(local, dev, warmup, steps, streams, B=256, T=60):
     _, den15, _ = algorithmic_gflop(B, T, L=15, NF=150)
     _, _, dec6 = algorithmic_gflop(B, T, L=6, NF=150)
     gflop = den15 * STEPS_DDIM + dec6 - (6 - 1) / 2 * 2.0 * B * T * 512 * 256 / 1e9   # ActorVae has no skip linears
-    modes = {}
+    modes, rejected = {}, {}
     nfl = len(streams)          # the caller's streams: their hardware-queue placement is already known to be good (DESIGN.md §3 point 15)
     for prec in ("f32", "f16x3", "bf16", "fp8_denoiser"):
+        keep = prec in ("f32", "f16x3")      # bf16 / fp8 e4m3 fail every stated tolerance on these weights AND are slower than split-f16: reported under
+                                             # `rejected_modes` (one bs-256 call at a time, with their error), not in the table of modes
         eng = _lib.Engine(device=local, max_batch=B, max_frames=T, condition=_lib.COND_ACTION, nclasses=12, vae_arch=_lib.VAE_ACTOR,
                           vae_num_layers=6, num_layers=15, nfeats=150, max_in_flight=nfl, precision=PRECISIONS[prec])
         eng.load_state_dict(sdd, "denoiser.")
@@ -298,6 +300,11 @@ def bench_a2m(local, dev, warmup, steps, streams, B=256, T=60):
         modes[prec]["peak_note"] = "fp32 MFMA peak (the reverse loop, 90 % of this workload's FLOPs, runs exact fp32 on the column-split kernels at this batch)" \
             if prec in ("f32", "f16x3") else "dense 16-bit / fp8-at-bf16-rate MFMA peak of the loop GEMMs' operand format"
         eng.close()
+        if not keep:
+            rejected[prec] = dict(modes.pop(prec), why="latents off by %.2g on |x| ~ 73 against the reference fixture (tolerance 5e-3): no parity claim; slower than f16x3 as well "
+                                                       "(its GEMMs run on the round-2 column-split kernels, split-f16 on the persistent loop); the conclusion is about THESE random-init weights "
+                                                       "under CFG 7.5 x 50 steps (profiles/r03_precision_ab.json), not about the format on trained weights" % err)
+            continue
         # the engine-side way to keep the GPU full (no reliance on how streams land on hardware queues): four bs-256 requests in ONE
         # mldhip_sample_many call -- 1 024 motions: the f32 / f16x3 modes then run the sample-major persistent loop (15 layers)
         try:
@@ -334,7 +341,7 @@ def bench_a2m(local, dev, warmup, steps, streams, B=256, T=60):
                         "`value_4_requests_per_call`: four requests in ONE mldhip_sample_many call (1 024 motions)" % (nfl, nfl),
             "unit": "motions/s", "algorithmic_gflop_per_batch": round(gflop, 1),
             "latents_absmax": float(np.abs(gold["latents"]).max()), "reference_vs_oracle_floor_latents": float(gold["oracle_diff_latents"]),
-            "modes": modes}
+            "modes": modes, "rejected_modes": rejected}
 
 
 def bench_text_encoder(dev, n_texts=2 * BATCH, iters=10):
