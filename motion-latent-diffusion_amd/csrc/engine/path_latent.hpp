@@ -873,9 +873,14 @@ void launch_cluster_loop(Ctx& c, const float* init_lat, int B, int n, float guid
 #else
   a.xslots = 8;                           // block b -> XCD b % 8 (observed placement): a cluster's members share a slot
 #endif
-  // every polled word is zero at the start of every call (Guideline 16 "Re-initialise every call"): a memset node in front of the launch
-  hipError_t st = hipMemsetAsync(a.flags, 0, ((size_t)(a.status - a.flags) + 16) * sizeof(unsigned), c.stream);
-  if (st != hipSuccess) { c.rc = e->fail(MLDHIP_EHIP, "cluster loop: memset: %s", hipGetErrorString(st)); return; }
+  // every polled word is zero at the start of every call (Guideline 16 "Re-initialise every call")
+  const int words = (int)(a.status - a.flags) + 16;
+  if (e->cluster_clear_memset) {
+    hipError_t st = hipMemsetAsync(a.flags, 0, (size_t)words * sizeof(unsigned), c.stream);
+    if (st != hipSuccess) { c.rc = e->fail(MLDHIP_EHIP, "cluster loop: memset: %s", hipGetErrorString(st)); return; }
+  } else {
+    MLD_LAUNCH(clear_cluster_flags_kernel, dim3(1), dim3(256), 0, c.stream, a.flags, words);
+  }
   const dim3 grid((unsigned)(a.xslots * kClMembers * ((a.ncl + a.xslots - 1) / a.xslots)));
   if (e->cluster_wt) MLD_LAUNCH_CORESIDENT((den_cluster_kernel<true>), grid, dim3(512), kClLdsBytes, c.stream, a);
   else MLD_LAUNCH_CORESIDENT((den_cluster_kernel<false>), grid, dim3(512), kClLdsBytes, c.stream, a);

@@ -77,6 +77,8 @@ struct mldhip_engine {
   float* cl_stream = nullptr;     // cluster loop (kernels/loop_cluster.hpp): per column group and wave, the split-f16 fragments in consumption order
   unsigned cl_wave_off[32] = {0}; // ... float offset of (column group, wave)'s sequence
   unsigned* cl_wave_off_dev = nullptr;   // ... the same 32 words in device memory (kernel arguments stay small)
+  bool cluster_clear_memset = false;   // flags of the cluster loop cleared by hipMemsetAsync instead of clear_cluster_flags_kernel ("cluster_graph" 2)
+  bool cluster_graph = true;      // "cluster_graph" (hooks build only): 0 = calls served by the cluster loop are issued eagerly, 2 = graphs + memset-node clear (reproduces the r05 replay fault)
   int cluster_failed = 0;         // a cluster launch reported a timeout / a placement it cannot use: the handle stays on the other loop families
   float* arena_x3 = nullptr;  // split-bf16 image of the arena (precision modes with split-bf16 staged GEMMs; built by finalize)
   size_t arena_floats = 0;

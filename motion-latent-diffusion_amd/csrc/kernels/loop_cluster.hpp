@@ -107,6 +107,11 @@ __global__ __launch_bounds__(64) void pack_cluster_frags_kernel(const float* __r
   *reinterpret_cast<U4*>(dst + 4) = lo;
 }
 
+// every polled word zero at the start of a call (Guideline 16 "Re-initialise every call"): a kernel of the call's own stream, not a memset node
+__global__ __launch_bounds__(256) void clear_cluster_flags_kernel(unsigned* __restrict__ flags, int words) {
+  for (int i = threadIdx.x; i < words; i += 256) flag_store(flags + i, 0u);
+}
+
 // grid = 12 xslots x ceil(clusters / xslots), xslots = 8: block b -> XCD slot x = b % 8, index i = b / 8 -> cluster x + 8 (i / 12), member i % 12.  block = 512.
 // WT = true: write-through (sc1) payload stores whatever the placement.  WT = false: every cluster whose twelve members report the same XCC id stores its
 // payloads plain (served from the shared L2); a cluster that spans XCDs falls back to write-through by itself.

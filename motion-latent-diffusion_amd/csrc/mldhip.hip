@@ -349,6 +349,8 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "cluster_wt must be 0 (plain payload stores inside an XCD, write-through across) or 1 (write-through always)");
     e->cluster_wt = (int)value;
 #if defined(MLDHIP_HOOKS)
+  } else if (n == "cluster_graph") {
+    e->cluster_graph = value != 0; e->cluster_clear_memset = value == 2;     // hooks build only: 0 eager issue, 1 (default) graphs, 2 graphs with the flags cleared by a memset node (the r05 replay fault; tools/dbg_cluster.py)
   } else if (n == "fused_dbg") {
     if (value != 0 && value != 5) return e->fail(MLDHIP_EINVAL, "fused_dbg must be 0 or 5 (phase counters; the builds with wrong results live in tools/loopbench only)");
     if (value == 5 && !e->trace_buf && hipMalloc((void**)&e->trace_buf, (size_t)512 * 8 * 8 * sizeof(uint64_t)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(trace)");
@@ -826,11 +828,9 @@ int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* acti
     HIP_TRY(e, hipMemcpyAsync(e->labels_dev + B, actions_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   }
 #if !defined(MLDHIP_SIM)
-  // A call whose reverse loop is the cluster launch is issued eagerly: it is ~50 launches, all behind a 9 ms kernel the host enqueues under,
-  // so a graph buys nothing -- and REPLAYS of a captured full call (cluster loop + T = 196 decode) were measured to return latents off by 5-20
-  // where the first launch of the same executable graph and every eager launch are right (r05, tools/dbg_cluster.py --graph 1 --prelat 1;
-  // cause not found: DESIGN.md "cluster loop").
-  if (e->cfg.use_graph && !use_cluster(e, B)) {
+  // Calls served by the cluster loop replay a captured graph like the rest; its flags are cleared by a kernel, not a memset node: replays of
+  // a hipMemsetAsync node in front of den_cluster_kernel left address-like words in the tail of the buffer on this runtime (r05).
+  if (e->cfg.use_graph && (!use_cluster(e, B) || e->cluster_graph)) {    // cluster_graph: true outside the hooks build
     const size_t D = e->cfg.latent_dim, NF = e->cfg.nfeats;
     const bool want_j = joints_out_dev != nullptr, want_f = feats_out_dev != nullptr || want_j;
     if (text_emb_dev)
@@ -907,7 +907,7 @@ int sample_many_impl(mldhip_handle* e, const mldhip_request* rq, int nreq, hipSt
   const float* text = action ? nullptr : e->text_in;
   bool replayed = false;
 #if !defined(MLDHIP_SIM)
-  if (e->cfg.use_graph && !use_cluster(e, Btot)) {
+  if (e->cfg.use_graph && (!use_cluster(e, Btot) || e->cluster_graph)) {
     hipGraphExec_t exec = nullptr;
     if (int rc = graph_for(e, GraphKey{Btot, T, want_f, want_j}, text != nullptr, &exec)) return rc;
     HIP_TRY(e, hipGraphLaunch(exec, stream));
@@ -1302,6 +1302,15 @@ int mldhip_profile_trace(mldhip_handle* e, const char* name, int32_t B, int32_t 
     const int64_t n = std::min<int64_t>(cap_u64, 64 * 8 * 16);      // 16 counters per wave: two 8-value records
     HIP_TRY(e, hipMemcpy(out_host, e->trace_buf, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return (int)(n / 64);
+  }
+  if (std::string(name) == "den_cluster_status") {
+    // the cluster loop's status words of the last call: [0] timeout flag, [1] clusters that span XCDs, then per workgroup (first 256) its XCC id + 1 (debug builds of the kernel)
+    if (!e->cl_flags) return e->fail(MLDHIP_ESTATE, "no cluster loop on this handle");
+    HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream_));
+    const size_t ncl = std::min<size_t>(kClMaxClusters, (e->cfg.max_batch + 7) / 8);
+    const int64_t n = std::min<int64_t>(cap_u64, 8);
+    HIP_TRY(e, hipMemcpy(out_host, reinterpret_cast<unsigned*>(e->cl_flags) + ncl * kClFlagWords, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 1;
   }
   if (std::string(name) == "den_cluster_xbuf") {
     // the exchange region of cluster 0 as the last cluster-loop call left it (kernels/loop_cluster.hpp: AO, h1, Y, Z, H of the last two layers) + its flags:

@@ -58,6 +58,8 @@ else:
     e.sample(te, x0, b.lengths, lat1)
 e.set_option("loop_kernel", 4)
 e.set_option("cluster_wt", a.wt)
+if not a.sim and a.graph:
+    e.set_option("cluster_graph", a.graph)
 jj = None
 if a.full and not a.sim:
     jj = torch.zeros(a.B, a.T, 22, 3, device=dev)
@@ -81,7 +83,10 @@ for rep in range(a.repeat):
         pc = np.abs(d).reshape(a.B, -1).max(1).reshape(-1, 8).max(1)
         pm = np.abs(d).reshape(a.B, -1).max(1)
         print("   bad motions", np.nonzero(pm > 1e-3)[0].tolist(), "bad columns of the worst motion", np.nonzero(np.abs(d).reshape(a.B, -1)[int(pm.argmax())] > 1e-3)[0].tolist()[:40])
-        print("call", rep, "max abs", float(np.abs(d).max()), "per cluster", np.array2string(pc, precision=2), flush=True)
+        stb = (C.c_uint64 * 8)()
+        e.lib.mldhip_profile_trace(e._h, b"den_cluster_status", 0, 8, stb, 8, 0)
+        st32 = np.frombuffer(stb, dtype=np.uint32)
+        print("call", rep, "max abs", float(np.abs(d).max()), "per cluster", np.array2string(pc, precision=2), "status", st32[:4].tolist(), flush=True)
         dumps = []
         for cl in range(a.B // 8 if a.dump else 0):
             bufc = (C.c_uint64 * (196608 // 2))()
