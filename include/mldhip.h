@@ -155,6 +155,8 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "cluster_max_batch" auto runs the cluster loop for calls of up to this many motions (default 128 = two clusters per XCD; 0 = never)
  *   "cluster_wt"      cluster loop, payload stores of the in-launch hand-offs: 0 (default) = plain where the twelve workgroups of a cluster report one
  *                     XCC id (served by the shared L2), write-through (sc1) for a cluster that spans XCDs; 1 = write-through always (+3.5 % per call)
+ *   "cluster_groups"  cluster loop, column groups per token: 0 (default) = 8 (24 workgroups per cluster: the feed-forward block on twice the CUs) for calls
+ *                     of up to 64 motions -- every cluster still has an XCD's 32 CUs to itself -- and 4 (12 workgroups) above; 4 / 8 = forced (8 only up to 64)
  *   "fused_min_batch" auto picks the persistent loop from this many motions per call up; 0 (default) = by operand format, from the measured
  *                     crossover table (tools/ab_crossover.py, profiles/r04_loop_crossover.json): 192 on split-f16 MFMAs (19 ms per call
  *                     whatever the batch; the split-f16 latency kernels take 19.0 ms at 192 motions), 1 280 on exact-fp32 MFMAs (73 ms)

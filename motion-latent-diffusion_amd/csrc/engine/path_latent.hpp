@@ -341,6 +341,14 @@ bool use_cluster(const E* e, int B) {
   return e->loop_kernel == 4 || (e->loop_kernel == 0 && B <= e->cluster_max_batch);
 }
 
+// column groups per token of a cluster call: 8 (24 workgroups per cluster: the feed-forward block on twice the CUs) while every cluster still has an XCD's 32 CUs
+// to itself (up to 8 clusters = 64 motions), 4 (12 workgroups) above; option "cluster_groups" 4 / 8 forces one (8 only where it fits)
+int cluster_groups(const E* e, int B) {
+  const bool fits8 = (B + 7) / 8 <= 8;
+  if (e->cluster_groups == 4 || !fits8) return 4;
+  return 8;
+}
+
 // finalize-time: per column group and wave, the weight fragments (16 rows x 32 k, split-f16) in the order den_cluster_kernel consumes them;
 // needs the packed small parameters / DDIM table of build_loop_stream
 int build_cluster_stream(Ctx& c) {
@@ -372,9 +380,33 @@ int build_cluster_stream(Ctx& c) {
       }
       for (int j = 0; j < kClRing; ++j) frags.push_back(frags[first + j]);        // look-ahead across the end of a step
     }
+  // the wide form (den_cluster_kernel<.., 8>): 8 column groups; groups 0-3 are the heads (the same Ph1 sequence), every group holds an eighth of the feed-forward block
+  for (int hc = 0; hc < 8; ++hc)
+    for (int w = 0; w < 8; ++w) {
+      e->cl_wave_off[32 + hc * 8 + w] = (unsigned)(frags.size() * kClFragFloats);
+      const size_t first = frags.size();
+      for (int l = 0; l < L; ++l) {
+        const EncLayerP& P_ = e->den[l];
+        if (hc < 4) {
+          for (int kc = 0; kc < 8; ++kc) {
+            if (w < 4) { push(P_.in_w, 256, 64 * hc + 16 * w, 32 * kc); push(P_.in_w, 256, 256 + 64 * hc + 16 * w, 32 * kc); }
+            else push(P_.in_w, 256, 512 + 64 * hc + 16 * (w - 4), 32 * kc);
+          }
+          for (int kc = 0; kc < 2; ++kc)
+            for (int j = 0; j < 2; ++j) push(P_.out_w, 256, 32 * w + 16 * j, 64 * hc + 32 * kc);
+        }
+        for (int kc = 0; kc < 8; ++kc) push(P_.l1_w, 256, 128 * hc + 16 * w, 32 * kc);                           // linear1: hidden columns 128 hc + 16 w
+        for (int kc = 0; kc < 8; ++kc) push(P_.l2_w, F, 32 * hc + 16 * (w & 1), 256 * (w >> 1) + 32 * kc);        // linear2: tile w & 1, K quarter w >> 1
+        if (l >= nb && l + 1 < L) {
+          const float* ws = P(e, "denoiser.encoder.linear_blocks." + std::to_string(l - nb) + ".weight");
+          for (int kc = 0; kc < 4; ++kc) push(ws, 512, 32 * hc + 16 * (w & 1), 128 * (w >> 1) + 32 * kc);         // skip linear: K quarter w >> 1 (0, 1: x; 2, 3: parked)
+        }
+      }
+      for (int j = 0; j < kClRing; ++j) frags.push_back(frags[first + j]);
+    }
   ClFrag* fdev = nullptr;
-  if (!e->cl_wave_off_dev && hipMalloc((void**)&e->cl_wave_off_dev, 32 * sizeof(unsigned)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(cluster loop offsets)");
-  if (hipMemcpy(e->cl_wave_off_dev, e->cl_wave_off, 32 * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) return e->fail(MLDHIP_EHIP, "cluster loop offsets");
+  if (!e->cl_wave_off_dev && hipMalloc((void**)&e->cl_wave_off_dev, 96 * sizeof(unsigned)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(cluster loop offsets)");
+  if (hipMemcpy(e->cl_wave_off_dev, e->cl_wave_off, 96 * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) return e->fail(MLDHIP_EHIP, "cluster loop offsets");
   if (hipMalloc((void**)&e->cl_stream, frags.size() * (size_t)kClFragFloats * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&fdev, frags.size() * sizeof(ClFrag)) != hipSuccess)
     return e->fail(MLDHIP_EHIP, "hipMalloc(cluster loop stream)");
@@ -860,8 +892,9 @@ void launch_fused_loop(Ctx& c, const float* init_lat, int B, int n, float guidan
 void launch_cluster_loop(Ctx& c, const float* init_lat, int B, int n, float guidance) {
   E* e = c.e;
   ClusterArgs a;
+  const int cg = cluster_groups(e, B), members = 3 * cg;
   a.stream = e->cl_stream;
-  a.wave_off = e->cl_wave_off_dev;
+  a.wave_off = e->cl_wave_off_dev + (cg == 8 ? 32 : 0);
   a.small = e->loop_small; a.T1 = e->T1; a.TP = e->TP; a.init_lat = init_lat; a.lat = e->lat; a.park = e->cl_park; a.ddim = e->loop_ddim;
   a.xbuf = e->cl_xbuf;
   a.ncl = (B + 7) / 8;
@@ -881,9 +914,14 @@ void launch_cluster_loop(Ctx& c, const float* init_lat, int B, int n, float guid
   } else {
     MLD_LAUNCH(clear_cluster_flags_kernel, dim3(1), dim3(256), 0, c.stream, a.flags, words);
   }
-  const dim3 grid((unsigned)(a.xslots * kClMembers * ((a.ncl + a.xslots - 1) / a.xslots)));
-  if (e->cluster_wt) MLD_LAUNCH_CORESIDENT((den_cluster_kernel<true>), grid, dim3(512), kClLdsBytes, c.stream, a);
-  else MLD_LAUNCH_CORESIDENT((den_cluster_kernel<false>), grid, dim3(512), kClLdsBytes, c.stream, a);
+  const dim3 grid((unsigned)(a.xslots * members * ((a.ncl + a.xslots - 1) / a.xslots)));
+  if (cg == 8) {
+    if (e->cluster_wt) MLD_LAUNCH_CORESIDENT((den_cluster_kernel<true, 8>), grid, dim3(512), kClLdsBytes, c.stream, a);
+    else MLD_LAUNCH_CORESIDENT((den_cluster_kernel<false, 8>), grid, dim3(512), kClLdsBytes, c.stream, a);
+  } else {
+    if (e->cluster_wt) MLD_LAUNCH_CORESIDENT((den_cluster_kernel<true, 4>), grid, dim3(512), kClLdsBytes, c.stream, a);
+    else MLD_LAUNCH_CORESIDENT((den_cluster_kernel<false, 4>), grid, dim3(512), kClLdsBytes, c.stream, a);
+  }
   count(c);
   check_launch(c, "den_cluster");
 }

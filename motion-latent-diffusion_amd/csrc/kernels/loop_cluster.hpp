@@ -47,19 +47,19 @@ namespace mld {
 #ifndef CL_RING
 #define CL_RING 4
 #endif
-constexpr int kClMembers = 12, kClRing = CL_RING, kClFragFloats = 512;
+constexpr int kClMembers = 12, kClMembersMax = 24, kClRing = CL_RING, kClFragFloats = 512;   // members: 3 tokens x 4 column groups (x 8: the wide form)
 constexpr int kClXs = 264, kClHs = 1032;                       // LDS row strides (words), = 8 mod 16: conflict-free fragment reads
 constexpr unsigned kClPlane = 2u * 48u * 256u;                 // one double-buffered [48][256] fp32 exchange tensor (floats)
 constexpr unsigned kClSlab = 2u * 12u * 16u * 256u;            // one double-buffered set of per-member partial slabs [3 tokens][4 members][16][256] (floats)
 constexpr unsigned kClH1 = 0, kClY = kClPlane, kClZ = 2 * kClPlane, kClH = 3 * kClPlane, kClPO = kClH + 2u * 48u * 1024u;
 constexpr unsigned kClXFloats = kClPO + kClSlab;               // exchange region of one cluster: 270 336 floats = 1 056 KB
 constexpr int kClAoS = 72;                                     // LDS row stride (words) of the head's attention output image [16][64 columns]
-constexpr int kClFlagWords = 4 * 16;                           // flag kinds AO, H, Y, Z: 16 words (one 64-byte line) each
+constexpr int kClFlagLine = 32, kClFlagWords = 4 * kClFlagLine; // flag kinds AO, H, Y, Z: 32 words (one 128-byte line) each; word 28 of the Z line counts finished members
 enum : int { kFlagAO = 0, kFlagH = 1, kFlagY = 2, kFlagZ = 3 };
 constexpr int kClBigFloats = 16 * kClHs;                       // X of all 48 rows ([48][264] = 12 672 words) and the token's hidden activation ([16][1032]) in turn
 static_assert(kClBigFloats >= 48 * kClXs, "X and the hidden activation share one region");
 constexpr int kClAsFloats = 16 * kClXs;
-constexpr int kClScFloats = 3 * 16 * 4, kClRedFloats = 2 * 16 * 8, kClRed2Floats = 4 * 64 * 4, kClCtlFloats = 16;
+constexpr int kClScFloats = 3 * 16 * 4, kClRedFloats = 2 * 16 * 8, kClRed2Floats = 6 * 64 * 4, kClCtlFloats = 16;
 constexpr int kClLdsFloats = kClBigFloats + kClAsFloats + kLfLatFloats + 2 * kLfPrmFloats + kClScFloats + kClRedFloats + kClRed2Floats + kClCtlFloats;
 constexpr int kClLdsBytes = kClLdsFloats * 4;                  // 125 760 B: one workgroup per CU
 constexpr int kClMaxClusters = 16;                             // two clusters per XCD (32 CUs): 128 motions
@@ -68,7 +68,7 @@ struct ClFrag { long long src; int ld; int pad; };            // element [row0][
 
 struct ClusterArgs {
   const float* stream;        // per column group and wave: [fragments of a step + kClRing][64 lanes][8 words]
-  const unsigned* wave_off;   // [column group][wave] (32 words in device memory): float offset of that wave's fragment sequence
+  const unsigned* wave_off;   // [column group][wave] (32 or 64 words in device memory): float offset of that wave's fragment sequence
   const float* small;         // loop_fused.hpp's packed small parameters (kLs*)
   const float* T1;            // [n][256] time-token rows
   const float* TP;            // [2B][256] condition-token rows, unconditional half first
@@ -115,8 +115,12 @@ __global__ __launch_bounds__(256) void clear_cluster_flags_kernel(unsigned* __re
 // grid = 12 xslots x ceil(clusters / xslots), xslots = 8: block b -> XCD slot x = b % 8, index i = b / 8 -> cluster x + 8 (i / 12), member i % 12.  block = 512.
 // WT = true: write-through (sc1) payload stores whatever the placement.  WT = false: every cluster whose twelve members report the same XCC id stores its
 // payloads plain (served from the shared L2); a cluster that spans XCDs falls back to write-through by itself.
-template <bool WT>
+// CG = column groups per token: 4 (12 members: every member is a head) or 8 (24 members, calls of up to 8 clusters: the feed-forward block on twice the CUs --
+// members (t, h < 4) are the heads and do everything, members (t, h >= 4) skip Ph1 and enter at E1; linear1 = 128 hidden columns per member, linear2 and the
+// skip linear = 32 output columns per member with K on four wave pairs).
+template <bool WT, int CG>
 __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
+  constexpr int kM = 3 * CG;
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
 #else
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
   unsigned* ctl = reinterpret_cast<unsigned*>(red2 + kClRed2Floats);
   const int wave = wave_uniform((int)threadIdx.x >> 6);
   unsigned goff = 0;                                       // this lane's running word offset into its wave's fragment stream
-  const int hc_ = (((int)blockIdx.x / p.xslots) % kClMembers) & 3;
+  [[maybe_unused]] const int hc_ = (((int)blockIdx.x / p.xslots) % kM) % CG;
   int lane = (int)threadIdx.x & 63, tid = (int)threadIdx.x, r = lane & 15, g = lane >> 4;
   int swz4 = ((r >> 2) & 3) << 2;                          // row swizzle of the operand images (loop_fused.hpp SWZ): XOR of the word offset's bits 2-3
   int gs4 = (g << 2) ^ swz4;                               // this lane's 16-byte group of a half chunk
@@ -153,9 +157,11 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
     gs4 = (g << 2) ^ swz4;
   };
   const int bx = (int)blockIdx.x % p.xslots, bi = (int)blockIdx.x / p.xslots;
-  const int cluster = bx + p.xslots * (bi / kClMembers), member = bi % kClMembers;
+  const int cluster = bx + p.xslots * (bi / kM), member = bi % kM;
   if (cluster >= p.ncl) return;
-  const int tk = member >> 2, hc = member & 3;   // token, column group (= head)
+  const int tk = member / CG, hc = member % CG;  // token, column group (a head when < 4)
+  const bool att = hc < 4;
+  constexpr unsigned all_mask = (1u << kM) - 1u;
   const int s0 = cluster * 8, nb = (p.L - 1) / 2;
   const float* sm_fin = p.small + (long long)p.L * kLsLayer + nb * 256;
   const XBuf xb = xbuf_make(p.xbuf + (size_t)cluster * kClXFloats, kClXFloats * 4u);
@@ -170,8 +176,8 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
   // ---- waiting for members: wave 0, lane m polls member m's flag of `kind`; bounded; the verdict reaches everybody through LDS + barrier
   auto wait_flags = [&](int kind, unsigned mask, unsigned epoch) -> bool {
     if (wave == 0) {
-      const unsigned* f = flags + kind * 16 + (lane < kClMembers ? lane : 0);
-      const bool need = lane < kClMembers && ((mask >> lane) & 1u);
+      const unsigned* f = flags + kind * kClFlagLine + (lane < kM ? lane : 0);
+      const bool need = lane < kM && ((mask >> lane) & 1u);
       bool ok = true;
 #if defined(MLDHIP_SIM)
       unsigned long long it = 0;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
     drain_stores();
 #endif
     __syncthreads();
-    if (tid == 0) flag_store(flags + kind * 16 + member, epoch);
+    if (tid == 0) flag_store(flags + kind * kClFlagLine + member, epoch);
   };
   auto give_up = [&]() {           // a wait failed: poison this cluster's latents (member 0), leave
     if (member == 0) {
@@ -359,11 +365,11 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
   bool wt = true;
   if constexpr (!WT) {
     // every member posts 1 + its XCC id as its Z flag (Z epochs start above 16: see below); a cluster that spans XCDs keeps the write-through stores
-    if (tid == 0) flag_store(flags + kFlagZ * 16 + member, 1u + xcc_id());
-    if (!wait_flags(kFlagZ, 0xFFFu, 1u)) { give_up(); return; }
+    if (tid == 0) flag_store(flags + kFlagZ * kClFlagLine + member, 1u + xcc_id());
+    if (!wait_flags(kFlagZ, all_mask, 1u)) { give_up(); return; }
     if (wave == 0) {
       const unsigned mine = 1u + xcc_id();
-      const unsigned other = lane < kClMembers ? flag_load(flags + kFlagZ * 16 + lane) : mine;
+      const unsigned other = lane < kM ? flag_load(flags + kFlagZ * kClFlagLine + lane) : mine;
       const bool spans = wave_any(other != mine);
       if (lane == 0) { ctl[1] = spans ? 1u : 0u; if (spans && member == 0) flag_store(p.status + 1, 1u); }
     }
@@ -386,9 +392,10 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
       const float* sm = prm + pbuf * kLfPrmFloats;
       const unsigned epoch = (unsigned)(step * p.L + l) + 1u;
       const unsigned par = epoch & 1u;
-      const unsigned own_mask = 0xFu << (4 * tk);
+      const unsigned own_mask = ((1u << CG) - 1u) << (CG * tk), ao_mask = 0xFu << (CG * tk);
       fresh();
       // ================= Ph1: Q (own token), K, V (all tokens) of head hc; 3-token attention for the 16 rows of token tk
+      if (att) {
       if (wave < 4) {
         f32x4 q0 = zero4, q1 = zero4, k[3] = {zero4, zero4, zero4};
         F4 x[2][3][2];
@@ -477,10 +484,11 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
       CL_STAMP(0);
       publish(kFlagAO, epoch);
       refill();
+      }
       CL_STAMP(1);
       fresh();
       // ================= E1: attention output of the token from its four members -> As
-      if (!wait_flags(kFlagAO, own_mask, epoch)) { give_up(); return; }
+      if (!wait_flags(kFlagAO, ao_mask, epoch)) { give_up(); return; }
       CL_STAMP(2);
       {
         // rows w and w + 8 of the token: sum of the four partials (fixed order) + bias + residual (the layer input as the GEMMs saw it) -> norm1, in-wave
@@ -521,6 +529,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         CL_STAMP(4);
         fresh();
         // linear1 + GELU
+        if constexpr (CG == 4) {
         f32x4 h[2][2] = {{zero4, zero4}, {zero4, zero4}};
         frag(As, kClXs, r, 0, x[0]);
 #pragma unroll
@@ -541,6 +550,26 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
           const unsigned wo = (kClH + par * 49152u + (unsigned)((16 * tk + r) * 1024 + (8 * hc + wave) * 32 + j * 8 + g * 2)) * 4u;
           xst2(wo, U2{h0, h1});
           xst2(wo + 64u, U2{l0, l1});
+        }
+        } else {
+        // hidden columns 128 hc + 16 w .. + 15: one tile per wave, 8 fragments
+        f32x4 ha = zero4, hb = zero4;
+        frag(As, kClXs, r, 0, x[0]);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+          if (kc + 1 < 8) frag(As, kClXs, r, kc + 1, x[(kc + 1) & 1]);
+          mma1(kc, x[kc & 1], ha, hb, kc + kClRing < 8);
+        }
+        const F4 b1 = ld4(sm + kLsL1B + hc * 128 + wave * 16 + g * 4);
+        const float v0 = gelu_erf((ha[0] + hb[0]) + b1.x), v1 = gelu_erf((ha[1] + hb[1]) + b1.y);
+        const float v2 = gelu_erf((ha[2] + hb[2]) + b1.z), v3 = gelu_erf((ha[3] + hb[3]) + b1.w);
+        unsigned h0, l0, h1, l1;
+        split16_two(v0, v1, h0, l0);
+        split16_two(v2, v3, h1, l1);
+        // same image: chunk 4 hc + (w >> 1), tile w & 1 of the chunk
+        const unsigned wo = (kClH + par * 49152u + (unsigned)((16 * tk + r) * 1024 + (4 * hc + (wave >> 1)) * 32 + (wave & 1) * 8 + g * 2)) * 4u;
+        xst2(wo, U2{h0, h1});
+        xst2(wo + 64u, U2{l0, l1});
         }
       }
       CL_STAMP(5);
@@ -568,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
       CL_STAMP(8);
       fresh();
       // ================= Ph3: linear2 for output columns 64 hc + 16 (w & 3) .. + 15, K half w >> 2; halves meet through LDS -> Y
-      {
+      if constexpr (CG == 4) {
         f32x4 y0 = zero4, y1 = zero4;
         const int kh = wave >> 2;
         F4 x[2][2];
@@ -590,6 +619,30 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
           const F4 b2 = ld4(sm + kLsL2B + hc * 64 + wave * 16 + g * 4);
           xst4((kClY + par * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + wave * 16 + g * 4)) * 4u, F4{y[0] + b2.x, y[1] + b2.y, y[2] + b2.z, y[3] + b2.w});
         }
+      } else {
+        // output columns 32 hc + 16 (w & 1) .. + 15, K quarter w >> 1 (8 fragments); the quarters meet through LDS in a fixed order
+        f32x4 y0 = zero4, y1 = zero4;
+        const int tile = wave & 1, kq = wave >> 1;
+        F4 x[2][2];
+        frag(Xs, kClHs, r, 8 * kq, x[0]);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+          if (kc + 1 < 8) frag(Xs, kClHs, r, 8 * kq + kc + 1, x[(kc + 1) & 1]);
+          mma1(kc, x[kc & 1], y0, y1, kc + kClRing < 8);
+        }
+        f32x4 y = y0 + y1;
+#ifdef CL_TRACE
+        asm volatile("" : "+v"(y));
+        CL_STAMP(15);
+#endif
+        if (kq) *reinterpret_cast<f32x4*>(red2 + (((kq - 1) * 2 + tile) * 64 + lane) * 4) = y;
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) y += *reinterpret_cast<const f32x4*>(red2 + ((q * 2 + tile) * 64 + lane) * 4);
+          const F4 b2 = ld4(sm + kLsL2B + hc * 32 + tile * 16 + g * 4);
+          xst4((kClY + par * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 32 + tile * 16 + g * 4)) * 4u, F4{y[0] + b2.x, y[1] + b2.y, y[2] + b2.z, y[3] + b2.w});
+        }
       }
       CL_STAMP(9);
       publish(kFlagY, epoch);
@@ -599,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
       // ================= E3 and what follows the layer
       const bool last = l + 1 == p.L, skip_next = !last && l >= nb;
       prm_fetch(last ? 0 : l + 1);
-      if (!wait_flags(kFlagY, 0xFFFu, epoch)) { give_up(); return; }
+      if (!wait_flags(kFlagY, all_mask, epoch)) { give_up(); return; }
       CL_STAMP(11);      // all twelve even where fewer rows are read (buffer-reuse invariant)
       if (!last && !skip_next) {
         // x' = norm2(y + h1) for all 48 rows -> Xs; input blocks park their own token's rows for the skip connection (cross_attention.py:48-52)
@@ -637,6 +690,8 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         __syncthreads();
         fresh();
         f32x4 z0 = zero4, z1 = zero4;
+        const unsigned zepoch = 16u + (unsigned)(step * nb + si) + 1u, zpar = zepoch & 1u;
+        if constexpr (CG == 4) {
         const float* abuf = wave < 4 ? Xs + 16 * tk * kClXs : As;
         F4 x[2][2];
         frag(abuf, kClXs, r, 0, x[0]);
@@ -648,16 +703,36 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         f32x4 z = z0 + z1;
         if (wave >= 4) *reinterpret_cast<f32x4*>(red2 + ((wave - 4) * 64 + lane) * 4) = z;
         __syncthreads();
-        const unsigned zepoch = 16u + (unsigned)(step * nb + si) + 1u, zpar = zepoch & 1u;
         if (wave < 4) {
           z += *reinterpret_cast<const f32x4*>(red2 + (wave * 64 + lane) * 4);
           const F4 sb = ld4(sm + kLsLayer + hc * 64 + wave * 16 + g * 4);
           xst4((kClZ + zpar * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + wave * 16 + g * 4)) * 4u, F4{z[0] + sb.x, z[1] + sb.y, z[2] + sb.z, z[3] + sb.w});
         }
+        } else {
+        // 32 columns per member: tile w & 1, K quarter w >> 1 of the 512 (quarters 0, 1: x', 2, 3: the parked rows), 4 fragments
+        const int tile = wave & 1, kq = wave >> 1;
+        const float* abuf = kq < 2 ? Xs + 16 * tk * kClXs : As;
+        F4 x[2][2];
+        frag(abuf, kClXs, r, 4 * (kq & 1), x[0]);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          if (kc + 1 < 4) frag(abuf, kClXs, r, 4 * (kq & 1) + kc + 1, x[(kc + 1) & 1]);
+          mma1(kc, x[kc & 1], z0, z1, kc + kClRing < 4);
+        }
+        f32x4 z = z0 + z1;
+        if (kq) *reinterpret_cast<f32x4*>(red2 + (((kq - 1) * 2 + tile) * 64 + lane) * 4) = z;
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) z += *reinterpret_cast<const f32x4*>(red2 + ((q * 2 + tile) * 64 + lane) * 4);
+          const F4 sb = ld4(sm + kLsLayer + hc * 32 + tile * 16 + g * 4);
+          xst4((kClZ + zpar * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 32 + tile * 16 + g * 4)) * 4u, F4{z[0] + sb.x, z[1] + sb.y, z[2] + sb.z, z[3] + sb.w});
+        }
+        }
         publish(kFlagZ, zepoch);
       refill();
         fresh();
-        if (!wait_flags(kFlagZ, 0xFFFu, zepoch)) { give_up(); return; }
+        if (!wait_flags(kFlagZ, all_mask, zepoch)) { give_up(); return; }
 #pragma unroll
         for (int i = 0; i < 6; ++i) v[i] = xbuf_ld4(xb, (kClZ + zpar * 12288u + (unsigned)((wave + 8 * i) * 256 + lane * 4)) * 4u);
 #pragma unroll
@@ -702,18 +777,17 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
     const int c = tid >> 6, c4 = tid & 63;
     if (s0 + c < p.B) st4(p.lat + (long long)(s0 + c) * 256 + c4 * 4, ld4(lats + c * 256 + c4 * 4));
   }
-  // Every polled word goes back to zero before the launch ends: a member that is past its last wait counts itself in word 12 of the Z line; the
-  // twelfth arrival polls nothing any more and neither does anybody else, so it clears the cluster's 64 words.  The memset node in front of the
-  // launch (Guideline 16 "Re-initialise every call") stays, but a replayed graph was seen to start the kernel on flags of the PREVIOUS call
-  // (epochs up to n L: every wait passes at once, latents off by 10) -- replays of one captured call after another; eager launches never.
+  // Every polled word goes back to zero before the launch ends: a member that is past its last wait counts itself in word 28 of the Z line; the
+  // last arrival polls nothing any more and neither does anybody else, so it clears the cluster's flag words.  clear_cluster_flags_kernel in front of
+  // the launch (Guideline 16 "Re-initialise every call") does it again.
   __syncthreads();
   if (tid == 0) {
 #if defined(MLDHIP_SIM)
-    const unsigned prev = flags[kFlagZ * 16 + 12]++;
+    const unsigned prev = flags[kFlagZ * kClFlagLine + 28]++;
 #else
-    const unsigned prev = __hip_atomic_fetch_add(flags + kFlagZ * 16 + 12, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = __hip_atomic_fetch_add(flags + kFlagZ * kClFlagLine + 28, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-    if (prev == (unsigned)kClMembers - 1u)
+    if (prev == (unsigned)kM - 1u)
       for (int i = 0; i < kClFlagWords; ++i) flag_store(flags + i, 0u);
   }
 }

@@ -164,7 +164,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   want(&e->FS, (Bm + 7) / 8 * ((L - 1) / 2) * 48 * D);
   {
     // cluster loop (kernels/loop_cluster.hpp): at most kClMaxClusters clusters of 8 motions, 12 workgroups each, launched in rows of 8 XCD slots
-    const size_t ncl = D == 256 ? std::min<size_t>(kClMaxClusters, (Bm + 7) / 8) : 0, wgs = 8 * kClMembers * ((ncl + 7) / 8);
+    const size_t ncl = D == 256 ? std::min<size_t>(kClMaxClusters, (Bm + 7) / 8) : 0, wgs = std::max<size_t>(8 * kClMembers * ((ncl + 7) / 8), 8 * kClMembersMax);
     want(&e->cl_xbuf, ncl * kClXFloats); want(&e->cl_park, wgs * ((L - 1) / 2) * 16 * 256); want(&e->cl_flags, ncl ? ncl * kClFlagWords + 16 : 0);
   }
   want(&e->Po, 6 * Bm * D); want(&e->Pf, 8 * 6 * Bm * D); want(&e->Ps, 2 * 6 * Bm * D); want(&e->TP, 2 * Bm * D);
@@ -231,8 +231,10 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
 #if defined(MLDHIP_HOOKS)
   (void)hipFuncSetAttribute((const void*)den_loop_kernel<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kLoopLdsBytes);
 #endif
-  (void)hipFuncSetAttribute((const void*)den_cluster_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kClLdsBytes);
-  (void)hipFuncSetAttribute((const void*)den_cluster_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kClLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_cluster_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kClLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_cluster_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kClLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_cluster_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kClLdsBytes);
+  (void)hipFuncSetAttribute((const void*)den_cluster_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kClLdsBytes);
 #define MLD_T32_ATTR1(MT, NS, TR, PR) \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<MT, NS, TR, PR, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes); \
   (void)hipFuncSetAttribute((const void*)gemm_tile32_kernel<MT, NS, TR, PR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kT32LdsBytes);
@@ -348,6 +350,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "cluster_wt") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "cluster_wt must be 0 (plain payload stores inside an XCD, write-through across) or 1 (write-through always)");
     e->cluster_wt = (int)value;
+  } else if (n == "cluster_groups") {
+    if (value != 0 && value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "cluster_groups must be 0 (auto: 8 up to 64 motions, 4 above), 4 or 8");
+    e->cluster_groups = (int)value;
 #if defined(MLDHIP_HOOKS)
   } else if (n == "cluster_graph") {
     e->cluster_graph = value != 0; e->cluster_clear_memset = value == 2;     // hooks build only: 0 eager issue, 1 (default) graphs, 2 graphs with the flags cleared by a memset node (the r05 replay fault; tools/dbg_cluster.py)

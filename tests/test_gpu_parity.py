@@ -185,7 +185,7 @@ def test_pipeline_bs64_vs_reference_golden(eng, dev, golden_dir):
 
 def test_cluster_loop_bs64_vs_reference_golden_and_launch_family(dev, golden_dir):
     """The metric's literal configuration on the kernel built for it: ONE bs-64 request, T = 196, split-f16 mode -- the reverse loop is the cluster launch
-    (kernels/loop_cluster.hpp: 8 clusters of 12 workgroups, hand-offs inside the launch), picked automatically for calls of up to 128 motions.
+    (kernels/loop_cluster.hpp: 8 clusters of 24 workgroups -- 8 column groups per token up to 64 motions --, hand-offs inside the launch), picked automatically for calls of up to 128 motions.
     Against the reference's own outputs (pipeline_b64 fixture: reference MldDenoiser / MldVae / recover_from_ric, mld.py:290-360) at the tolerances of
     test_pipeline_bs64_vs_reference_golden, against the launch-per-GEMM family of the same engine (loop_kernel 1), and: repeated calls, calls straight
     behind each other without a host sync (a full decode between two loops), write-through and plain payload stores -- all identical to the bit."""
@@ -212,6 +212,19 @@ def test_cluster_loop_bs64_vs_reference_golden_and_launch_family(dev, golden_dir
     e.sample(text, lat0, b.lengths, lat, None, joints)
     torch.cuda.synchronize()
     assert torch.equal(lat, l0) and torch.equal(joints, j0)
+    # the 12-workgroup form (what calls of more than 64 motions run on) on the same batch: another summation order in linear2 / the skip linear, same tolerances
+    e.set_option("cluster_groups", 4)
+    for wt in (0, 1):
+        e.set_option("cluster_wt", wt)
+        for _ in range(2):
+            e.sample(text, lat0, b.lengths, lat, None, joints)
+        torch.cuda.synchronize()
+        if wt == 0:
+            l4, j4 = lat.clone(), joints.clone()
+        assert torch.equal(lat, l4) and torch.equal(joints, j4)
+    assert np.abs(l4.cpu().numpy() - g["latents"]).max() < 5e-3 and np.abs(j4.cpu().numpy() - g["joints"]).max() < 1e-3
+    print("cluster loop, 8 vs 4 column groups at bs 64: latents %.3e joints %.3e" % (float((l4 - l0).abs().max()), float((j4 - j0).abs().max())))
+    assert float((l4 - l0).abs().max()) < 1e-3
     e.set_option("loop_kernel", 1)
     e.sample(text, lat0, b.lengths, lat, None, joints)
     torch.cuda.synchronize()

@@ -726,9 +726,10 @@ def test_sample_major_persistent_loop_sim(prec):
     e.close()
 
 
-@pytest.mark.parametrize("wt", [0, 1])
-def test_cluster_loop_sim(wt):
-    """loop_kernel = 4 (kernels/loop_cluster.hpp): the reverse loop as ONE launch of clusters -- 12 workgroups (3 tokens x 4 column groups) per 8 motions
+@pytest.mark.parametrize("wt,groups", [(0, 4), (1, 4), (0, 8)])
+def test_cluster_loop_sim(wt, groups):
+    """loop_kernel = 4 (kernels/loop_cluster.hpp): the reverse loop as ONE launch of clusters -- 12 workgroups (3 tokens x 4 column groups) per 8 motions,
+    or 24 (x 8 column groups: option cluster_groups 8, the default up to 64 motions; the members without a head enter each layer at E1) --
     that hand partial products to each other inside the launch (flags + L1-bypassing loads; the simulator runs every block of the grid as fibers
     side by side, hipsim::launch_coresident).  B = 11: two clusters, the second with 3 live motions; a 3-layer skip stack (one skip linear: the Z
     exchange), 2 steps (the end-of-step path, the ring's wrap into the next step); plain payload stores with the placement census (cluster_wt 0) and
@@ -747,11 +748,12 @@ def test_cluster_loop_sim(wt):
     e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat1)
     e.set_option("loop_kernel", 4)
     e.set_option("cluster_wt", wt)
+    e.set_option("cluster_groups", groups)
     for _ in range(2):                      # twice: every flag is back at zero when a call ends
         lat = np.full((11, 1, 256), np.nan, np.float32)
         e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
         assert e.launch_counts()[0] == 2
-        assert np.abs(lat - ref).max() < 2e-4 and np.abs(lat - lat1).max() < 2e-4, wt
+        assert np.abs(lat - ref).max() < 2e-4 and np.abs(lat - lat1).max() < 2e-4, (wt, groups)
     # the precision mode without split arithmetic has no cluster build: refused like loop_kernel 3 where that is not built
     e.close()
     e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=4, max_frames=8, num_inference_steps=2, num_layers=3, precision=0)

@@ -14,6 +14,9 @@
 #ifndef CB_WT
 #define CB_WT true
 #endif
+#ifndef CB_CG
+#define CB_CG 4
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 using namespace mld;
@@ -35,14 +38,19 @@ int main(int argc, char** argv) {
     if (hipMalloc((void**)out, nfl * sizeof(float)) != hipSuccess) return 1;
     return hipMemcpy(*out, h.data(), nfl * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
   };
-  // per (column group, wave): fragments per step as den_cluster_kernel consumes them (waves 0-3: 52 per layer, waves 4-7: 44; + 8 per skip linear)
+  // per (column group, wave): fragments per step as den_cluster_kernel consumes them (4 groups: waves 0-3 52 per layer, waves 4-7 44, + 8 per skip linear;
+  // 8 groups: 20 / 12 in Ph1 for groups 0-3, 16 in the feed-forward block, + 4 per skip linear)
   ClusterArgs a;
   size_t nfrag = 0;
-  unsigned woff[32];
-  for (int hc = 0; hc < 4; ++hc)
+  unsigned woff[CB_CG * 8];
+  auto per_step = [&](int hc, int w) {
+    if (CB_CG == 4) return (size_t)L * (w < 4 ? 52 : 44) + (size_t)nb * 8;
+    return (size_t)L * ((hc < 4 ? (w < 4 ? 20 : 12) : 0) + 16) + (size_t)nb * 4;
+  };
+  for (int hc = 0; hc < CB_CG; ++hc)
     for (int w = 0; w < 8; ++w) {
       woff[hc * 8 + w] = (unsigned)(nfrag * kClFragFloats);
-      nfrag += (size_t)L * (w < 4 ? 52 : 44) + (size_t)nb * 8 + kClRing;
+      nfrag += per_step(hc, w) + kClRing;
     }
   unsigned* woff_dev;
   CK(hipMalloc((void**)&woff_dev, sizeof woff));
@@ -55,9 +63,9 @@ int main(int argc, char** argv) {
   {
     std::vector<ClFrag> fr(nfrag);
     size_t i = 0;
-    for (int hc = 0; hc < 4; ++hc)
+    for (int hc = 0; hc < CB_CG; ++hc)
       for (int w = 0; w < 8; ++w) {
-        const size_t per = (size_t)L * (w < 4 ? 52 : 44) + (size_t)nb * 8, first = i;
+        const size_t per = per_step(hc, w), first = i;
         for (size_t k = 0; k < per; ++k, ++i) fr[i] = ClFrag{(long long)i * 512, 32, 0};
         for (int k = 0; k < kClRing; ++k, ++i) fr[i] = fr[first + k];
       }
@@ -78,7 +86,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(small, h.data(), small_floats * sizeof(float), hipMemcpyHostToDevice));
   }
   if (dev((size_t)n * 256, 1.f, 0.f, &T1) || dev((size_t)2 * B * 256, 1.f, 0.f, &TP) || dev((size_t)B * 256, 1.f, 0.f, &init)) return 1;
-  const int grid = 8 * kClMembers * ((ncl + 7) / 8);
+  const int grid = 8 * 3 * CB_CG * ((ncl + 7) / 8);
   CK(hipMalloc((void**)&lat, (size_t)B * 256 * sizeof(float)));
   CK(hipMalloc((void**)&park, (size_t)grid * nb * 16 * 256 * sizeof(float)));
   CK(hipMalloc((void**)&xbuf, (size_t)ncl * kClXFloats * sizeof(float)));
@@ -91,7 +99,7 @@ int main(int argc, char** argv) {
   }
   a.stream = stream; a.small = small; a.T1 = T1; a.TP = TP; a.init_lat = init; a.lat = lat; a.park = park; a.ddim = ddim; a.xbuf = xbuf;
   a.flags = flags; a.status = flags + (size_t)ncl * kClFlagWords; a.B = B; a.L = L; a.n = n; a.ncl = ncl; a.xslots = 8; a.guidance = 7.5f; a.init_sigma = 1.f;
-  CK(hipFuncSetAttribute((const void*)den_cluster_kernel<CB_WT>, hipFuncAttributeMaxDynamicSharedMemorySize, kClLdsBytes));
+  CK(hipFuncSetAttribute((const void*)den_cluster_kernel<CB_WT, CB_CG>, hipFuncAttributeMaxDynamicSharedMemorySize, kClLdsBytes));
 #ifdef CL_TRACE
   unsigned long long* tr;
   CK(hipMalloc((void**)&tr, (size_t)grid * 8 * 16 * sizeof(unsigned long long)));
@@ -108,9 +116,9 @@ int main(int argc, char** argv) {
   std::vector<double> sums;
   for (int it = 0; it < reps + 1; ++it) {
     if (dirty) hipLaunchKernelGGL(dirty_kernel, dim3(2048), dim3(256), 0, 0, dirty, dirty_floats, (float)it);
-    CK(hipMemsetAsync(flags, 0, ((size_t)ncl * kClFlagWords + 16) * sizeof(unsigned), 0));
+    hipLaunchKernelGGL(clear_cluster_flags_kernel, dim3(1), dim3(256), 0, 0, flags, (int)(ncl * kClFlagWords + 16));
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(den_cluster_kernel<CB_WT>, dim3(grid), dim3(512), kClLdsBytes, 0, a);
+    hipLaunchKernelGGL((den_cluster_kernel<CB_WT, CB_CG>), dim3(grid), dim3(512), kClLdsBytes, 0, a);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     CK(hipGetLastError());
@@ -158,7 +166,7 @@ int main(int argc, char** argv) {
     }
   }
 #endif
-  printf("{\"name\": \"%s\", \"motions\": %d, \"clusters\": %d, \"workgroups\": %d, \"steps\": %d, \"write_through\": %d, \"ms_min\": %.3f, \"ms_median\": %.3f, \"us_per_layer\": %.2f, \"status\": %u, \"latents_checksum\": %.6f}\n",
-         LB_NAME, B, ncl, grid, n, (int)CB_WT, ms.front(), ms[ms.size() / 2], ms[ms.size() / 2] * 1000.0 / (n * L), st[0], cs);
+  printf("{\"name\": \"%s\", \"motions\": %d, \"clusters\": %d, \"workgroups\": %d, \"steps\": %d, \"column_groups\": %d, \"write_through\": %d, \"ms_min\": %.3f, \"ms_median\": %.3f, \"us_per_layer\": %.2f, \"status\": %u, \"latents_checksum\": %.6f}\n",
+         LB_NAME, B, ncl, grid, n, CB_CG, (int)CB_WT, ms.front(), ms[ms.size() / 2], ms[ms.size() / 2] * 1000.0 / (n * L), st[0], cs);
   return 0;
 }
