@@ -380,10 +380,17 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
   __syncthreads();
   int pbuf = 0;
   const unsigned wg = blockIdx.x;
-  // linear2 output (+ bias, added by its producer) + residual of row `row`, this lane's 4 columns
+  // linear2 output + bias + residual (both added by its producer) of row `row`, this lane's 4 columns
   auto y_row = [&](unsigned par, int row, const float*) __attribute__((always_inline)) {
-    const unsigned off = (unsigned)(row * 256 + lane * 4);
-    return f4add(xbuf_ld4(xb, (kClY + par * 12288u + off) * 4u), xbuf_ld4(xb, (kClH1 + par * 12288u + off) * 4u));
+    return xbuf_ld4(xb, (kClY + par * 12288u + (unsigned)(row * 256 + lane * 4)) * 4u);
+  };
+  // norm1 output of the own token, row r, columns c0 .. c0 + 3 as the GEMMs saw it (high + low half of the As image): the residual of norm2
+  auto h1_res = [&](int c0) __attribute__((always_inline)) {
+    const int l4 = c0 >> 2;
+    const unsigned* wq = reinterpret_cast<const unsigned*>(As) + r * kClXs + ((((l4 >> 3) << 5) + ((l4 & 7) << 1)) ^ swz4);
+    const U2 h = *reinterpret_cast<const U2*>(wq), lo = *reinterpret_cast<const U2*>(wq + 16);
+    return F4{f16_bits_value(h.x) + f16_bits_value(lo.x), f16_bits_value(h.x >> 16) + f16_bits_value(lo.x >> 16),
+              f16_bits_value(h.y) + f16_bits_value(lo.y), f16_bits_value(h.y >> 16) + f16_bits_value(lo.y >> 16)};
   };
 
   for (int step = 0; step < p.n; ++step) {
@@ -516,11 +523,6 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
           unsigned* d = reinterpret_cast<unsigned*>(As) + row * kClXs + ((((lane >> 3) << 5) + ((lane & 7) << 1)) ^ (((row >> 2) & 3) << 2));
           *reinterpret_cast<U2*>(d) = U2{h0, h1};
           *reinterpret_cast<U2*>(d + 16) = U2{l0, l1};
-          // norm1 output of the token for everybody's norm2 residual: this member's column quarter (lanes 16 hc .. + 15), the value the GEMMs see (high + low half)
-          if ((lane >> 4) == hc)
-            xst4((kClH1 + par * 12288u + (unsigned)((16 * tk + row) * 256 + lane * 4)) * 4u,
-                 F4{f16_bits_value(h0) + f16_bits_value(l0), f16_bits_value(h0 >> 16) + f16_bits_value(l0 >> 16), f16_bits_value(h1) + f16_bits_value(l1),
-                    f16_bits_value(h1 >> 16) + f16_bits_value(l1 >> 16)});
         }
       }
       __syncthreads();
@@ -616,8 +618,9 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         __syncthreads();
         if (wave < 4) {
           y += *reinterpret_cast<const f32x4*>(red2 + (wave * 64 + lane) * 4);
-          const F4 b2 = ld4(sm + kLsL2B + hc * 64 + wave * 16 + g * 4);
-          xst4((kClY + par * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + wave * 16 + g * 4)) * 4u, F4{y[0] + b2.x, y[1] + b2.y, y[2] + b2.z, y[3] + b2.w});
+          const F4 b2 = ld4(sm + kLsL2B + hc * 64 + wave * 16 + g * 4), rs = h1_res(hc * 64 + wave * 16 + g * 4);
+          xst4((kClY + par * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 64 + wave * 16 + g * 4)) * 4u,
+               F4{(y[0] + b2.x) + rs.x, (y[1] + b2.y) + rs.y, (y[2] + b2.z) + rs.z, (y[3] + b2.w) + rs.w});
         }
       } else {
         // output columns 32 hc + 16 (w & 1) .. + 15, K quarter w >> 1 (8 fragments); the quarters meet through LDS in a fixed order
@@ -640,8 +643,9 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         if (wave < 2) {
 #pragma unroll
           for (int q = 0; q < 3; ++q) y += *reinterpret_cast<const f32x4*>(red2 + ((q * 2 + tile) * 64 + lane) * 4);
-          const F4 b2 = ld4(sm + kLsL2B + hc * 32 + tile * 16 + g * 4);
-          xst4((kClY + par * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 32 + tile * 16 + g * 4)) * 4u, F4{y[0] + b2.x, y[1] + b2.y, y[2] + b2.z, y[3] + b2.w});
+          const F4 b2 = ld4(sm + kLsL2B + hc * 32 + tile * 16 + g * 4), rs = h1_res(hc * 32 + tile * 16 + g * 4);
+          xst4((kClY + par * 12288u + (unsigned)((16 * tk + r) * 256 + hc * 32 + tile * 16 + g * 4)) * 4u,
+               F4{(y[0] + b2.x) + rs.x, (y[1] + b2.y) + rs.y, (y[2] + b2.z) + rs.z, (y[3] + b2.w) + rs.w});
         }
       }
       CL_STAMP(9);
