@@ -780,8 +780,8 @@ def main():
         cluster = launches_single[0] <= 4
         single = {"value": round(world * BATCH / ms1["median"], 2), "unit": "motions/s", "ms_per_batch": {k: (round(v * 1e3, 4) if k != "n" else v) for k, v in ms1.items()},
                   "steps_per_repetition": K1, "launches_per_call": launches_single,
-                  "shape": ("mldhip_sample, B = 64, T = 196: the reverse loop is ONE launch of 8 clusters x 12 workgroups that hand partial products to each other inside the "
-                            "launch (kernels/loop_cluster.hpp), issued eagerly; decoder on the 64-row strips") if cluster else
+                  "shape": ("mldhip_sample, B = 64, T = 196: the reverse loop is ONE launch of 8 clusters x 24 workgroups (3 tokens x 8 column groups per 8 motions, a cluster per XCD) that "
+                            "hand partial products to each other inside the launch (kernels/loop_cluster.hpp), replayed from a captured graph; decoder on the 64-row strips") if cluster else
                            "mldhip_sample, B = 64, T = 196: 2 052 dependent launches (hipGraph replay), reverse loop at 384 token rows on the latency kernels (tile32.hpp)"}
         if solo and not a.no_rocprof:
             st1, where1 = rocprof_child_stats(a.precision, 1, keep_env="MLD_BENCH_KEEP_ROCPROF_SINGLE")
@@ -793,17 +793,17 @@ def main():
                 if hits_c:
                     n, (avg, calls_, total) = max(hits_c, key=lambda kv: kv[1][2])
                     gf = gf_den * STEPS_DDIM                                 # the whole loop of one bs-64 batch
-                    # the kernel's own limit is not the matrix pipe: a member streams ~768 KB of weight fragments per layer through its CU's L2 -> L1 path
+                    # the kernel's own limit is not the matrix pipe: a member with a head streams ~512 KB of weight fragments per layer through its CU's L2 -> L1 path
                     # (56 B/clk/CU = 34.5 TB/s over 256 CUs, MI355X_MICROARCH.md "L2"), 3 exchanges per layer of ~2.4 us each come on top
-                    wbytes = 768e3 * 9 * STEPS_DDIM
+                    wbytes = 512e3 * 9 * STEPS_DDIM
                     fill = wbytes / (avg * 1e-9) / (34.5e12 / 256)
-                    single["roofline"] = {"bound": "mfma", "kernel": "den_cluster_kernel (kernels/loop_cluster.hpp): the whole 50-step reverse loop of one bs-64 batch, one launch of 96 workgroups",
+                    single["roofline"] = {"bound": "mfma", "kernel": "den_cluster_kernel (kernels/loop_cluster.hpp): the whole 50-step reverse loop of one bs-64 batch, one launch of 192 workgroups",
                                           "achieved": round(gf / (avg * 1e-9) / 1e3, 2), "peak": round(X3_PEAK_TF, 1), "peak_of": "split-f16 MFMA roof (dense f16 peak / 3)",
                                           "unit": "TFLOP/s", "frac": round(gf / (avg * 1e-9) / 1e3 / X3_PEAK_TF, 4), "avg_us_rocprof_dispatch": round(avg / 1e3, 2),
-                                          "launches_per_batch": 1, "gflop_per_launch": round(gf, 2), "workgroups": 96, "cus": 256,
+                                          "launches_per_batch": 1, "gflop_per_launch": round(gf, 2), "workgroups": 192, "cus": 256,
                                           "l2_to_cu_fill": {"weight_bytes_per_member_and_launch": int(wbytes), "achieved_frac_of_56_B_per_clk_per_cu": round(fill, 3),
-                                                            "note": "per-member weight stream (3.2x the non-redundant share: K / V for all three tokens per token member) over the kernel's "
-                                                                    "duration, against the per-CU L2 fill rate; the phases that stream run at ~58 B/clk, the rest of the time is hand-offs"},
+                                                            "note": "weight stream of a member with a head (K / V for all three tokens per token member; the twelve members without a head stream 128 KB per layer) "
+                                                                    "over the kernel's duration, against the per-CU L2 fill rate; the phases that stream run at ~58 B/clk, the rest of the time is hand-offs"},
                                           "share_of_gpu_time": round(total / tot1, 4), "rocprof": where1,
                                           "note": "one request cannot fill the chip: 384 token rows, 31 dependent exchanges per step; bound by hand-off latency (3 per layer, "
                                                   "~2.4 us each: profiles/r05_sync_bench.json) next to the per-CU weight stream, not by the matrix pipe (DESIGN.md, cluster loop)"}
@@ -827,7 +827,7 @@ def main():
         if solo:
             # ---- how the rate depends on the requests per call (the loop's run time is flat in the batch up to 2 048 motions; the decoder's is linear)
             sweep = {}
-            for c_ in (1, 2, 5, 10, 20, 32):
+            for c_ in (1, 2, 4, 5, 10, 20, 32):
                 rs = reqs_all[:c_]
                 fn = (lambda: eng.sample_many(rs, stream.cuda_stream)) if c_ > 1 else (lambda: eng.sample(rs[0]["text_emb"], rs[0]["init_latents"], rs[0]["lengths"], rs[0]["latents_out"], None, rs[0]["joints_out"], stream.cuda_stream))
                 fn(); fn()
@@ -836,9 +836,9 @@ def main():
                 for _ in range(3):
                     t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
                 sweep[str(c_)] = {"motions_per_call": BATCH * c_, "ms_per_call": round(min(ts) * 1e3, 3), "value": round(BATCH * c_ / min(ts), 1),
-                                  "loop_workgroups": (BATCH * c_ + 7) // 8 if BATCH * c_ >= 192 else None}
+                                  "loop_workgroups": (BATCH * c_ + 7) // 8 if BATCH * c_ > 256 else None}
             out["requests_per_call_sweep"] = {"unit": "motions/s", "note": "one call at a time, best of 3; loop_workgroups = workgroups of the persistent loop "
-                                              "(None: calls of up to 128 motions run the cluster loop, 129-191 the latency kernels)", "shapes": sweep}
+                                              "(None: calls of up to 256 motions run the cluster loop -- one launch up to 128 motions, two above)", "shapes": sweep}
             # ---- BASELINE config 3 (512 prompts over 8 ranks) as seen by ONE rank: its share is one bs-64 batch (world 8) or all 512 (world 1)
             rs512 = reqs_all[:8]
             eng.sample_many(rs512, stream.cuda_stream)

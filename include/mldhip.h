@@ -152,7 +152,8 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     (3 tokens x 4 column groups) per 8 motions hand partial products to each other inside the launch; F16X3 mode, latent_dim 256 /
  *                     ff_size 1024 / 4 heads, refused elsewhere; 7.9 ms per 50-step loop for 8 .. 128 motions against 11.2 / 15.2 ms of the latency
  *                     kernels at 64 / 128).  Calls it serves are issued eagerly, not through a captured graph
- *   "cluster_max_batch" auto runs the cluster loop for calls of up to this many motions (default 128 = two clusters per XCD; 0 = never)
+ *   "cluster_max_batch" auto runs the cluster loop for calls of up to this many motions (default 256: one launch up to 128 = two clusters per XCD, two launches one
+ *                     after the other up to 256 -- 2 x 7.6 ms against the persistent loop's flat 18.7 ms; 0 = never)
  *   "cluster_wt"      cluster loop, payload stores of the in-launch hand-offs: 0 (default) = plain where the twelve workgroups of a cluster report one
  *                     XCC id (served by the shared L2), write-through (sc1) for a cluster that spans XCDs; 1 = write-through always (+3.5 % per call)
  *   "cluster_groups"  cluster loop, column groups per token: 0 (default) = 8 (24 workgroups per cluster: the feed-forward block on twice the CUs) for calls

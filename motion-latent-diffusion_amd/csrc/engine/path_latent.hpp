@@ -337,7 +337,7 @@ int build_loop_stream(Ctx& c) {
 
 // ---- cluster loop (kernels/loop_cluster.hpp): one bs-64 request (up to 8 x kClMaxClusters motions) as ONE launch of 12-workgroup clusters
 bool use_cluster(const E* e, int B) {
-  if (!e->cl_stream || !fused_split(e) || e->cluster_failed || B > 8 * kClMaxClusters || B > e->cfg.max_batch) return false;
+  if (!e->cl_stream || !fused_split(e) || e->cluster_failed || B > kClMaxCall || B > e->cfg.max_batch) return false;
   return e->loop_kernel == 4 || (e->loop_kernel == 0 && B <= e->cluster_max_batch);
 }
 
@@ -889,15 +889,17 @@ void launch_fused_loop(Ctx& c, const float* init_lat, int B, int n, float guidan
 }
 
 // the whole reverse loop (or its first `n` steps) of up to 8 x kClMaxClusters motions as one launch of clusters (kernels/loop_cluster.hpp)
-void launch_cluster_loop(Ctx& c, const float* init_lat, int B, int n, float guidance) {
+// motions [s_base, s_base + nm) of a call of B
+void launch_cluster_chunk(Ctx& c, const float* init_lat, int B, int s_base, int nm, int n, float guidance) {
   E* e = c.e;
   ClusterArgs a;
-  const int cg = cluster_groups(e, B), members = 3 * cg;
+  const int cg = cluster_groups(e, nm), members = 3 * cg;
+  a.s_base = s_base; a.s_end = s_base + nm;
   a.stream = e->cl_stream;
   a.wave_off = e->cl_wave_off_dev + (cg == 8 ? 32 : 0);
   a.small = e->loop_small; a.T1 = e->T1; a.TP = e->TP; a.init_lat = init_lat; a.lat = e->lat; a.park = e->cl_park; a.ddim = e->loop_ddim;
   a.xbuf = e->cl_xbuf;
-  a.ncl = (B + 7) / 8;
+  a.ncl = (nm + 7) / 8;
   a.flags = reinterpret_cast<unsigned*>(e->cl_flags);
   a.status = a.flags + (size_t)std::min<size_t>(kClMaxClusters, (e->cfg.max_batch + 7) / 8) * kClFlagWords;
   a.B = B; a.L = e->cfg.num_layers; a.n = n; a.guidance = guidance; a.init_sigma = 1.0f;
@@ -924,6 +926,12 @@ void launch_cluster_loop(Ctx& c, const float* init_lat, int B, int n, float guid
   }
   count(c);
   check_launch(c, "den_cluster");
+}
+
+// up to 128 motions: one launch; up to kClMaxCall = 256: two launches one after the other on the call's stream (they share the exchange regions and flags; 2 x 7.6 ms
+// against the sample-major loop's flat 18.7 ms) -- never side by side: 2 x 192 workgroups are not co-resident
+void launch_cluster_loop(Ctx& c, const float* init_lat, int B, int n, float guidance) {
+  for (int s = 0; s < B && !c.rc; s += 8 * kClMaxClusters) launch_cluster_chunk(c, init_lat, B, s, std::min(8 * kClMaxClusters, B - s), n, guidance);
 }
 
 // `text` == nullptr selects the action condition (labels_dev holds the 2B labels).

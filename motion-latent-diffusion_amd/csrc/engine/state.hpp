@@ -126,7 +126,7 @@ struct mldhip_engine {
 #if defined(MLDHIP_SIM)
   int cluster_max_batch = 0;   // (the functional simulator's tests pick the loop family explicitly)
 #else
-  int cluster_max_batch = 128; // "cluster_max_batch": auto runs the cluster loop (split mode) for calls of up to this many motions (0: never); at most 8 x kClMaxClusters
+  int cluster_max_batch = 256; // "cluster_max_batch": auto runs the cluster loop (split mode) for calls of up to this many motions (0: never); at most kClMaxCall = 256 (two launches above 128)
 #endif
   int cluster_wt = 0;        // "cluster_wt": 0 (default) = a cluster whose twelve members report one XCC id stores its payloads plain (served by the shared L2; -3.5 % per call), any other cluster write-through; 1 = write-through (sc1) always
   int fused_x3 = 1;          // "fused_x3": in the split precision mode the sample-major loop multiplies on split-f16 MFMAs (0: exact fp32 MFMAs)

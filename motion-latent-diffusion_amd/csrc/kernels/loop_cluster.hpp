@@ -62,7 +62,8 @@ constexpr int kClAsFloats = 16 * kClXs;
 constexpr int kClScFloats = 3 * 16 * 4, kClRedFloats = 2 * 16 * 8, kClRed2Floats = 6 * 64 * 4, kClCtlFloats = 16;
 constexpr int kClLdsFloats = kClBigFloats + kClAsFloats + kLfLatFloats + 2 * kLfPrmFloats + kClScFloats + kClRedFloats + kClRed2Floats + kClCtlFloats;
 constexpr int kClLdsBytes = kClLdsFloats * 4;                  // 125 760 B: one workgroup per CU
-constexpr int kClMaxClusters = 16;                             // two clusters per XCD (32 CUs): 128 motions
+constexpr int kClMaxClusters = 16;                             // two clusters per XCD (32 CUs): 128 motions per launch
+constexpr int kClMaxCall = 2 * 8 * kClMaxClusters;             // motions per call the engine serves with (two) cluster launches
 
 struct ClFrag { long long src; int ld; int pad; };            // element [row0][k0] of a weight (floats into the arena), row stride
 
@@ -79,7 +80,8 @@ struct ClusterArgs {
   float* xbuf;                // [clusters][kClXFloats] exchange regions
   unsigned* flags;            // [clusters][kClFlagWords], zeroed in front of the launch
   unsigned* status;           // [0]: 0 ok, 1 a wait timed out; [1]: clusters that span XCDs (plain stores asked for, write-through used)
-  int B, L, n, ncl;
+  int B, L, n, ncl;           // B: motions of the CALL (the condition rows' pitch); this launch serves motions [s_base, s_end)
+  int s_base = 0, s_end = 0;
   unsigned long long* trace = nullptr;   // CL_TRACE builds (tools/loopbench only): [workgroup][wave][16] shader cycles per phase, summed over steps and layers
   int xslots;                 // blocks per launch row: 8 on the GPU (block b runs on XCD b % 8: a cluster's members share the slot), min(clusters, 8) on the simulator
   float guidance, init_sigma;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
   const int tk = member / CG, hc = member % CG;  // token, column group (a head when < 4)
   const bool att = hc < 4;
   constexpr unsigned all_mask = (1u << kM) - 1u;
-  const int s0 = cluster * 8, nb = (p.L - 1) / 2;
+  const int s0 = p.s_base + cluster * 8, nb = (p.L - 1) / 2;
   const float* sm_fin = p.small + (long long)p.L * kLsLayer + nb * 256;
   const XBuf xb = xbuf_make(p.xbuf + (size_t)cluster * kClXFloats, kClXFloats * 4u);
   unsigned* flags = p.flags + (size_t)cluster * kClFlagWords;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
     if (member == 0) {
       const int c = tid >> 6, c4 = tid & 63;
       const float qnan = __builtin_nanf("");
-      if (s0 + c < p.B) st4(p.lat + (long long)(s0 + c) * 256 + c4 * 4, F4{qnan, qnan, qnan, qnan});
+      if (s0 + c < p.s_end) st4(p.lat + (long long)(s0 + c) * 256 + c4 * 4, F4{qnan, qnan, qnan, qnan});
     }
   };
 
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
   auto assemble = [&](int step) __attribute__((always_inline)) {
     const float* pe0 = sm_fin + 512;
     int sidx = s0 + wave;
-    sidx = sidx < p.B ? sidx : p.B - 1;
+    sidx = sidx < p.s_end ? sidx : p.s_end - 1;
     const F4 pe = ld4(pe0 + lane * 4), la = ld4(lats + wave * 256 + lane * 4), tt = ld4(p.T1 + (unsigned)step * 256u + lane * 4);
     const F4 tu = ld4(p.TP + (unsigned)sidx * 256u + lane * 4), tc = ld4(p.TP + (unsigned)(p.B + sidx) * 256u + lane * 4);
     const F4 x0 = f4add(la, pe);
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
   {
     const int c = tid >> 6, c4 = tid & 63;
     int s = s0 + c;
-    s = s < p.B ? s : p.B - 1;
+    s = s < p.s_end ? s : p.s_end - 1;
     const F4 v = ld4(p.init_lat + (long long)s * 256 + c4 * 4);
     st4(lats + c * 256 + c4 * 4, F4{v.x * p.init_sigma, v.y * p.init_sigma, v.z * p.init_sigma, v.w * p.init_sigma});
   }
@@ -779,7 +781,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
 #endif
   if (member == 0) {
     const int c = tid >> 6, c4 = tid & 63;
-    if (s0 + c < p.B) st4(p.lat + (long long)(s0 + c) * 256 + c4 * 4, ld4(lats + c * 256 + c4 * 4));
+    if (s0 + c < p.s_end) st4(p.lat + (long long)(s0 + c) * 256 + c4 * 4, ld4(lats + c * 256 + c4 * 4));
   }
   // Every polled word goes back to zero before the launch ends: a member that is past its last wait counts itself in word 28 of the Z line; the
   // last arrival polls nothing any more and neither does anybody else, so it clears the cluster's flag words.  clear_cluster_flags_kernel in front of

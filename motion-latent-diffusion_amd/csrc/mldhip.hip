@@ -345,7 +345,7 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "fused_x3 must be 0 or 1");
     e->fused_x3 = (int)value;
   } else if (n == "cluster_max_batch") {
-    if (value < 0 || value > 8 * kClMaxClusters) return e->fail(MLDHIP_EINVAL, "cluster_max_batch must be 0 .. %d", 8 * kClMaxClusters);
+    if (value < 0 || value > kClMaxCall) return e->fail(MLDHIP_EINVAL, "cluster_max_batch must be 0 .. %d", kClMaxCall);
     e->cluster_max_batch = (int)value;
   } else if (n == "cluster_wt") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "cluster_wt must be 0 (plain payload stores inside an XCD, write-through across) or 1 (write-through always)");

@@ -267,10 +267,11 @@ def test_second_weight_family_vs_reference_golden(dev, golden_dir, prec):
     e.close()
 
 
-@pytest.mark.parametrize("B", [11, 128])
+@pytest.mark.parametrize("B", [11, 128, 197])
 def test_cluster_loop_ragged_and_two_clusters_per_xcd_vs_oracle(dev, B):
-    """11 motions (two clusters, the second with three live motions) and 128 motions (16 clusters = two per XCD, 192 workgroups): latents of the cluster
-    launch against the CPU oracle (torch fp32) and against the launch family."""
+    """11 motions (two clusters, the second with three live motions), 128 motions (16 clusters = two per XCD, 192 workgroups) and 197 motions (two launches
+    one after the other: 128 on 12-workgroup clusters + 69 ragged, sharing the exchange regions): latents of the cluster launch(es) against the CPU oracle
+    (torch fp32) and against the launch family."""
     b = syn.make_batch(B, [40] * B, seed=21)
     e = _lib.Engine(device=0, max_batch=B, max_frames=40, precision=1)
     _load(e)
@@ -278,7 +279,7 @@ def test_cluster_loop_ragged_and_two_clusters_per_xcd_vs_oracle(dev, B):
     lat = torch.empty(B, 1, 256, device=dev)
     e.sample(text, lat0, b.lengths, lat)
     torch.cuda.synchronize()
-    assert e.launch_counts()[0] == 2
+    assert e.launch_counts()[0] == (2 if B <= 128 else 3)
     ops = O.TorchOps("float32")
     ref = np.asarray(O.diffusion_reverse(ops, O.to_backend(ops, syn.make_denoiser_state_dict()), ops.asarray(b.text_emb), ops.asarray(b.init_latents), 7.5, 50, 4))
     err = float(np.abs(lat.cpu().numpy() - ref).max())
