@@ -76,8 +76,10 @@ struct LoopArgs {
 
 #ifndef LF_EXP
 #define LF_EXP 0          // tools/loopbench experiments (measurement builds with WRONG results; 0 in the library): 1 / 4 = linear1 / linear2 re-use stale A
-                          // fragments (no LDS reads), 2 = no barrier per hidden block, 8 = the weight ring is never refreshed
+                          // fragments (no LDS reads), 2 = no barrier per hidden block, 8 = the weight ring is never refreshed, 16 = matrix instructions and
+                          // fragment reads of TWO row tiles per item instead of three (the matrix work of a 5-motion workgroup: VERDICT r4 item 3's upper bound)
 #endif
+constexpr int kLfMmaTiles = (LF_EXP & 16) ? 2 : 3;
 #ifndef LF_RING
 #define LF_RING 8         // weight items in flight per lane (the stream carries 8 look-ahead items behind a step: 4 or 8; tools/loopbench A/B)
 #endif
@@ -208,11 +210,11 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     } else if constexpr (X3) {
       const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][1]), acc[t]);
+      for (int t = 0; t < kLfMmaTiles; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][1]), acc[t]);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wl, __builtin_bit_cast(U4, x[t][0]), acc[t]);
+      for (int t = 0; t < kLfMmaTiles; ++t) acc[t] = mfma_x3_16x16x32(wl, __builtin_bit_cast(U4, x[t][0]), acc[t]);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][0]), acc[t]);
+      for (int t = 0; t < kLfMmaTiles; ++t) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][0]), acc[t]);
     } else {
       const F4 y0 = ring[slot][0], y1 = ring[slot][1];
 #pragma unroll
@@ -251,11 +253,11 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
     } else if constexpr (X3) {
       const U4 wh = __builtin_bit_cast(U4, ring[slot][0]), wl = __builtin_bit_cast(U4, ring[slot][1]);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) { acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][1]), acc[t]); epi(t); sched_fence(); }
+      for (int t = 0; t < 3; ++t) { if (t < kLfMmaTiles) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][1]), acc[t]); epi(t); sched_fence(); }
 #pragma unroll
-      for (int t = 0; t < 3; ++t) { acc[t] = mfma_x3_16x16x32(wl, __builtin_bit_cast(U4, x[t][0]), acc[t]); epi(3 + t); sched_fence(); }
+      for (int t = 0; t < 3; ++t) { if (t < kLfMmaTiles) acc[t] = mfma_x3_16x16x32(wl, __builtin_bit_cast(U4, x[t][0]), acc[t]); epi(3 + t); sched_fence(); }
 #pragma unroll
-      for (int t = 0; t < 3; ++t) { acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][0]), acc[t]); epi(6 + t); sched_fence(); }
+      for (int t = 0; t < 3; ++t) { if (t < kLfMmaTiles) acc[t] = mfma_x3_16x16x32(wh, __builtin_bit_cast(U4, x[t][0]), acc[t]); epi(6 + t); sched_fence(); }
     } else {
       const F4 y0 = ring[slot][0], y1 = ring[slot][1];
       const float yv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void den_loop_kernel(LoopArgs p) {
   // (the A fragments of chunk c + 1 are requested before chunk c is multiplied: the fence in mma_item keeps that order)
   auto afrag = [&](const float* a0, int ts, int c, F4 (&x)[3][2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) { x[t][0] = ld4(a0 + t * ts + 32 * c); x[t][1] = ld4(a0 + t * ts + 32 * c + 16); }
+    for (int t = 0; t < kLfMmaTiles; ++t) { x[t][0] = ld4(a0 + t * ts + 32 * c); x[t][1] = ld4(a0 + t * ts + 32 * c + 16); }
   };
   auto run2 = [&](const float* a0, f32x4 (&acc0)[3], f32x4 (&acc1)[3], bool pin = false) __attribute__((always_inline)) {
     F4 x[2][3][2];

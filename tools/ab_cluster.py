@@ -31,7 +31,8 @@ def main():
         te, x0 = torch.from_numpy(bb.text_emb).to(dev), torch.from_numpy(bb.init_latents).to(dev)
         variants = [("f32_launches", 0, {"loop_kernel": 1}), ("x3_launches", 1, {"loop_kernel": 1}), ("x3_persistent", 1, {"loop_kernel": 3}),
                     ("x3_cluster_wt", 1, {"loop_kernel": 4, "cluster_wt": 1}), ("x3_cluster_plain", 1, {"loop_kernel": 4, "cluster_wt": 0}),
-                    ("x3_cluster_4groups", 1, {"loop_kernel": 4, "cluster_wt": 0, "cluster_groups": 4})]
+                    ("x3_cluster_4groups", 1, {"loop_kernel": 4, "cluster_wt": 0, "cluster_groups": 4}),
+                    ("x3_cluster_tail48", 1, {"loop_kernel": 4, "cluster_wt": 0, "ffn_strip": 3})]
         if a.variants:
             variants = [v for v in variants if v[0] in a.variants.split(",") or v[0] == "f32_launches"]
         engines = {}
