@@ -2,6 +2,7 @@
 // Part of libmldhip's single translation unit (included by ../mldhip.hip, in this order: state, params, dispatch,
 // path_latent, path_novae).  Internal linkage throughout (anonymous namespace) except the handle type itself.
 #pragma once
+#include <mutex>
 
 namespace {
 
@@ -46,6 +47,36 @@ struct CtxUse {
     x.used = true;
 #endif
   }
+};
+
+// Two cluster launches (kernels/loop_cluster.hpp) must never be dispatched side by side: each would keep its resident workgroups spinning on members that the other
+// one's workgroups keep off the CUs (2 x 192 workgroups, 256 CUs) until the 200 ms timeout fails both.  One lane per device and process: a call served by the cluster loop waits
+// for the previous such call of ANY handle or stream (the whole call: its event sits behind the decode) and leaves its own event behind; the lane's mutex is held while the
+// call is enqueued, so wait / record pairs of host threads do not interleave.  Other kernels beside a cluster launch only delay it (they end); other PROCESSES on the
+// same GPU are outside the lane's reach (include/mldhip.h "cluster loop").
+struct ClusterLane {
+#if !defined(MLDHIP_SIM)
+  struct Slot { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool used = false; };
+  static Slot& slot(int dev) { static Slot s[16]; return s[dev & 15]; }
+  Slot* s = nullptr;
+  hipStream_t stream;
+  ClusterLane(E* e, hipStream_t st, bool on) : stream(st) {
+    if (!on) return;
+    s = &slot(e->device);
+    s->mu.lock();
+    if (!s->ev && hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { s->ev = nullptr; return; }
+    if (s->used && s->last != stream) (void)hipStreamWaitEvent(stream, s->ev, 0);
+  }
+  ~ClusterLane() {
+    if (!s) return;
+    if (s->ev && hipEventRecord(s->ev, stream) == hipSuccess) { s->last = stream; s->used = true; }
+    s->mu.unlock();
+  }
+#else
+  ClusterLane(E*, hipStream_t, bool) {}
+#endif
+  ClusterLane(const ClusterLane&) = delete;
+  ClusterLane& operator=(const ClusterLane&) = delete;
 };
 
 // Selects the engine's device for the duration of one C-ABI call and restores the caller's current device on exit

@@ -349,6 +349,22 @@ int cluster_groups(const E* e, int B) {
   return 8;
 }
 
+// sticky status word [2] of any workspace context: a cluster launch of this handle ran into its wait bound since the last look (synchronous: call it behind a sync); clears it
+bool cluster_timed_out(E* e) {
+  if (!e->cl_flags) return false;
+  const size_t words = (size_t)std::min<size_t>(kClMaxClusters, (e->cfg.max_batch + 7) / 8) * kClFlagWords;
+  size_t off = 0;
+  bool found = false, hit = false;
+  for (auto& cv : e->carve) if (cv.first == &e->cl_flags) { off = cv.second; found = true; }
+  if (!found) return false;
+  for (auto& x : e->ctxs) {
+    unsigned st = 0;
+    unsigned* w = x.ws ? reinterpret_cast<unsigned*>(x.ws + off) + words + 2 : nullptr;
+    if (w && hipMemcpy(&st, w, sizeof st, hipMemcpyDeviceToHost) == hipSuccess && st != 0u) { hit = true; (void)hipMemset(w, 0, sizeof st); }
+  }
+  return hit;
+}
+
 // finalize-time: per column group and wave, the weight fragments (16 rows x 32 k, split-f16) in the order den_cluster_kernel consumes them;
 // needs the packed small parameters / DDIM table of build_loop_stream
 int build_cluster_stream(Ctx& c) {
@@ -909,7 +925,7 @@ void launch_cluster_chunk(Ctx& c, const float* init_lat, int B, int s_base, int 
   a.xslots = 8;                           // block b -> XCD b % 8 (observed placement): a cluster's members share a slot
 #endif
   // every polled word is zero at the start of every call (Guideline 16 "Re-initialise every call")
-  const int words = (int)(a.status - a.flags) + 16;
+  const int words = (int)(a.status - a.flags) + 2;        // the flags and the two per-launch status words (status[2] is sticky: cluster_timed_out)
   if (e->cluster_clear_memset) {
     hipError_t st = hipMemsetAsync(a.flags, 0, (size_t)words * sizeof(unsigned), c.stream);
     if (st != hipSuccess) { c.rc = e->fail(MLDHIP_EHIP, "cluster loop: memset: %s", hipGetErrorString(st)); return; }

@@ -43,9 +43,12 @@ constexpr int strip_gemm_lds_bytes() { return (NSEG * RT * 16 * kFsXs + (STAGE ?
 // (Round 3 also carried a run-time-selectable ring depth and separate load / store hint bits; round 4 keeps the measured forms only: 8 items in
 // flight per lane -- 4 in the LayerNorm form, whose epilogue needs the registers -- and the hinted build for the N = 768 in-projection.)
 template <int RT, int NSEG, bool LN, bool STAGE, bool NT = false>
-__global__ __launch_bounds__(512, 2) void strip_gemm_x3_kernel(StripGemmArgs p) {
+__global__ __launch_bounds__(512, (RT * NSEG <= 4 && RT <= 3 ? 4 : 2)) void strip_gemm_x3_kernel(StripGemmArgs p) {      // RT <= 3: 80 KB of LDS and 128 registers -- two workgroups per CU
   static_assert(!(LN && (NSEG != 1 || STAGE)), "the LayerNorm form is the N = 256, K = 256 out-projection");
-  constexpr int RING = LN ? 4 : 8;      // weight items in flight per lane
+#ifndef SB_RING3
+#define SB_RING3 4        // items in flight per lane of the 48-row form (128 registers: 8 spill 40 B)
+#endif
+  constexpr int RING = LN ? 4 : (RT <= 3 ? SB_RING3 : 8);   // (RT <= 3 with one K segment, RT = 2 with two: the forms at four waves per SIMD)      // weight items in flight per lane
   constexpr int BM = RT * 16, XS = kFsXs, HS = kFsHs;
 #if defined(MLDHIP_SIM)
   float* smem = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());

@@ -79,7 +79,7 @@ struct ClusterArgs {
   const float* ddim;          // [n][4]
   float* xbuf;                // [clusters][kClXFloats] exchange regions
   unsigned* flags;            // [clusters][kClFlagWords], zeroed in front of the launch
-  unsigned* status;           // [0]: 0 ok, 1 a wait timed out; [1]: clusters that span XCDs (plain stores asked for, write-through used)
+  unsigned* status;           // [0]: 0 ok, 1 a wait timed out; [1]: clusters that span XCDs (plain stores asked for, write-through used); both cleared per launch.  [2]: a wait timed out in SOME launch since the host last looked (sticky)
   int B, L, n, ncl;           // B: motions of the CALL (the condition rows' pitch); this launch serves motions [s_base, s_end)
   int s_base = 0, s_end = 0;
   unsigned long long* trace = nullptr;   // CL_TRACE builds (tools/loopbench only): [workgroup][wave][16] shader cycles per phase, summed over steps and layers
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
 #endif
       }
       if (lane == 0) {
-        if (!ok) flag_store(p.status, 1u);
+        if (!ok) { flag_store(p.status, 1u); flag_store(p.status + 2, 1u); }      // [2] is sticky: cleared by the host once it has acted on it
         ctl[0] = ok ? 1u : 0u;
       }
     }

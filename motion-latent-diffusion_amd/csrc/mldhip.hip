@@ -354,6 +354,8 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value != 0 && value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "cluster_groups must be 0 (auto: 8 up to 64 motions, 4 above), 4 or 8");
     e->cluster_groups = (int)value;
 #if defined(MLDHIP_HOOKS)
+  } else if (n == "cluster_lane") {
+    e->cluster_lane = value != 0;       // hooks build only: 0 = cluster calls of different streams are NOT ordered behind each other (reproduces the co-residency starvation: tools/two_streams.py)
   } else if (n == "cluster_graph") {
     e->cluster_graph = value != 0; e->cluster_clear_memset = value == 2;     // hooks build only: 0 eager issue, 1 (default) graphs, 2 graphs with the flags cleared by a memset node (the r05 replay fault; tools/dbg_cluster.py)
   } else if (n == "fused_dbg") {
@@ -546,13 +548,21 @@ int range_probe(mldhip_handle* e, hipStream_t stream, const float* user_text = n
       if (e->cl_stream) {
         e->split_loop_ok = true;
         std::vector<float> hc_;
-        launch_cluster_loop(c, sample.p, Bp, std::min(2, n), guidance);
+        {
+          ClusterLane lane(e, c.stream, true);
+          launch_cluster_loop(c, sample.p, Bp, std::min(2, n), guidance);
+        }
         if (c.rc) return c.rc;
         if (down(e->lat, (size_t)Bp * D, hc_)) return e->fail(MLDHIP_EHIP, "range probe: copy");
-        float d2 = 0.f;
-        bool fin2 = true;
-        for (size_t i = 0; i < hc_.size(); ++i) { fin2 = fin2 && std::isfinite(hc_[i]); d2 = std::max(d2, std::fabs(hc_[i] - hb[i])); }
-        worst = std::max(worst, !fin2 ? std::numeric_limits<float>::infinity() : (m > 0.f ? d2 / m / amp : (d2 > 0.f ? std::numeric_limits<float>::infinity() : 0.f)));
+        if (cluster_timed_out(e)) {
+          // the device did not keep the launch's workgroups resident together (a wait ran into its 200 ms bound): not an arithmetic verdict -- the handle leaves the cluster loop
+          e->cluster_failed = 1;
+        } else {
+          float d2 = 0.f;
+          bool fin2 = true;
+          for (size_t i = 0; i < hc_.size(); ++i) { fin2 = fin2 && std::isfinite(hc_[i]); d2 = std::max(d2, std::fabs(hc_[i] - hb[i])); }
+          worst = std::max(worst, !fin2 ? std::numeric_limits<float>::infinity() : (m > 0.f ? d2 / m / amp : (d2 > 0.f ? std::numeric_limits<float>::infinity() : 0.f)));
+        }
       }
     }
     if (user) worst = std::max(worst, e->probe_err_loop);          // the verdict covers the seeded batch AND the caller's
@@ -751,6 +761,18 @@ int mldhip_numeric_status(mldhip_handle* e, mldhip_numeric_info* out) {
   unsigned n = 0;
   HIP_TRY(e, hipMemcpy(&n, e->nonfinite, sizeof n, hipMemcpyDeviceToHost));
   HIP_TRY(e, hipMemset(e->nonfinite, 0, sizeof n));
+  // a cluster launch that ran into its wait bound poisoned its latents (counted above) and left its status word set: the handle stays off the cluster loop from here on
+  // (the captured graphs that hold it are dropped); mldhip_set_option("loop_kernel", 4) re-arms it
+  if (!e->cluster_failed && cluster_timed_out(e)) {
+    e->cluster_failed = 1;
+#if !defined(MLDHIP_SIM)
+    for (auto& x : e->ctxs) {
+      for (auto& kv : x.graphs) (void)hipGraphExecDestroy(kv.second);
+      x.graphs.clear();
+      x.graph_lru.clear();
+    }
+#endif
+  }
   out->probed = e->probe_err_loop >= 0.f || e->probe_err_decode >= 0.f;
   out->loop_split_ok = e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE && e->split_loop_ok;
   out->decode_split_ok = e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE && e->split_decode_ok;
@@ -823,6 +845,7 @@ int sample_impl(mldhip_handle* e, const float* text_emb_dev, const int32_t* acti
   }
   CtxUse use(e, stream);                                  // picks + binds a workspace context (see WsContext)
   if (use.rc) return use.rc;
+  ClusterLane lane(e, stream, e->cluster_lane && use_cluster(e, B));         // cluster launches never side by side (engine/params.hpp)
   HIP_TRY(e, hipMemcpyAsync(e->lens_dev, lengths_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   if (actions_host) {
     for (int i = 0; i < B; ++i)
@@ -886,6 +909,7 @@ int sample_many_impl(mldhip_handle* e, const mldhip_request* rq, int nreq, hipSt
     return e->fail(MLDHIP_ESTATE, "mldhip_sample_many needs denoiser.*, vae.decoder.* (and mean/std for joints) loaded");
   CtxUse use(e, stream);
   if (use.rc) return use.rc;
+  ClusterLane lane(e, stream, e->cluster_lane && use_cluster(e, Btot));
   const size_t D = e->cfg.latent_dim, NF = e->cfg.nfeats, TD = e->cfg.text_dim, NJ = (size_t)e->cfg.njoints * 3;
   HIP_TRY(e, hipMemcpyAsync(e->lens_dev, lens.data(), (size_t)Btot * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   if (action) {

@@ -9,6 +9,7 @@ Tolerances (fp32 arithmetic both sides, different summation orders):
   joints                                   1e-3   (the north-star tolerance)
 """
 import os
+import time
 
 import numpy as np
 import pytest
@@ -233,6 +234,34 @@ def test_cluster_loop_bs64_vs_reference_golden_and_launch_family(dev, golden_dir
     print("cluster loop vs launch family at bs 64: latents %.3e joints %.3e" % (dl, dj))
     assert dl < 1e-3 and dj < 2e-4
     assert e.numeric_status()["nonfinite_values"] == 0
+    e.close()
+
+
+def test_cluster_calls_in_flight_on_two_streams_never_run_side_by_side(dev):
+    """Two cluster launches dispatched side by side would starve each other of CUs (2 x 192 workgroups spinning on members that are not resident) until the
+    200 ms wait bound fails both.  The engine keeps one lane per device (engine/params.hpp ClusterLane): six bs-64 calls alternating on two streams of a handle
+    with two workspaces must return exactly what the same calls return one after another, with no non-finite value and no timeout."""
+    b = syn.make_batch(64, [60] * 64, seed=5)
+    e = _lib.Engine(device=0, max_batch=64, max_frames=60, precision=1, max_in_flight=2)
+    _load(e)
+    text, lat0 = _cuda(b.text_emb, dev), _cuda(b.init_latents, dev)
+    ref_l, ref_j = torch.empty(64, 1, 256, device=dev), torch.empty(64, 60, 22, 3, device=dev)
+    e.sample(text, lat0, b.lengths, ref_l, None, ref_j)
+    torch.cuda.synchronize()
+    assert e.launch_counts()[0] == 2
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    outs = [(torch.full((64, 1, 256), float("nan"), device=dev), torch.full((64, 60, 22, 3), float("nan"), device=dev)) for _ in range(6)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i, (l, j) in enumerate(outs):
+        e.sample(text, lat0, b.lengths, l, None, j, streams[i & 1].cuda_stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for l, j in outs:
+        assert torch.equal(l, ref_l) and torch.equal(j, ref_j)
+    ns = e.numeric_status()
+    assert ns["nonfinite_values"] == 0 and ns["loop_split_ok"] == 1, ns
+    assert dt < 0.15, dt                         # six calls of ~8 ms; a starved pair would sit in its 200 ms wait bound
     e.close()
 
 

@@ -11,8 +11,11 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 using namespace mld;
 #ifdef SB_SKIP
-#define SB_VARIANT 4, 2, false, false
-constexpr int kRT = 4, kNSEG = 2, kN = 256; constexpr bool kStage = false;
+#ifndef SB_SKIP_RT
+#define SB_SKIP_RT 4
+#endif
+#define SB_VARIANT SB_SKIP_RT, 2, false, false
+constexpr int kRT = SB_SKIP_RT, kNSEG = 2, kN = 256; constexpr bool kStage = false;
 #else
 #ifndef SB_VARIANT
 #define SB_VARIANT 6, 1, false, true, true
