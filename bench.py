@@ -453,12 +453,13 @@ def bench_novae(local, dev, full, streams, B=64, T=196):
             "peaks": "f32: fp32 MFMA 157.3 TF; f16x3: dense 16-bit MFMA peak / 3 (three MFMAs per product) = 833 TF; bf16: 2500 TF"}
 
 
-PMC_FILE = os.path.join(REPO, "profiles", "r04_pmc_traffic.json")
+PMC_FILE = next((f for f in (os.path.join(REPO, "profiles", "r05_pmc_traffic.json"), os.path.join(REPO, "profiles", "r04_pmc_traffic.json")) if os.path.exists(f)),
+                os.path.join(REPO, "profiles", "r05_pmc_traffic.json"))
 
 
 def pmc_summary(coalesce, loop_code_hash):
-    """The PMC summary (tools/gpu_pmc.sh: separate rocprofv3 --pmc passes) of THIS call shape: profiles/r04_pmc_traffic.json holds one
-    entry per requests-per-call it was collected at (20 = the driver's `--steps 20`, 32 = the chip-filling call).  Refused when it was
+    """The PMC summary (tools/gpu_pmc.sh: separate rocprofv3 --pmc passes) of THIS call shape: profiles/r05_pmc_traffic.json holds one
+    entry per requests-per-call it was collected at (1 = one bs-64 request: the cluster loop, 20 = the driver's `--steps 20`, 32 = the chip-filling call).  Refused when it was
     collected on other machine code of the loop kernel AND on other sources."""
     try:
         pmc = json.load(open(PMC_FILE))
@@ -807,6 +808,11 @@ def main():
                                           "share_of_gpu_time": round(total / tot1, 4), "rocprof": where1,
                                           "note": "one request cannot fill the chip: 384 token rows, 31 dependent exchanges per step; bound by hand-off latency (3 per layer, "
                                                   "~2.4 us each: profiles/r05_sync_bench.json) next to the per-CU weight stream, not by the matrix pipe (DESIGN.md, cluster loop)"}
+                    ccode = kernel_code_hash(mangled_part(n))
+                    pmc1, note1 = pmc_summary(1, ccode)
+                    single["roofline"]["traffic"] = pmc1["kernels"]["den_cluster"]["traffic_bytes_per_launch"] if pmc1 and "den_cluster" in pmc1.get("kernels", {}) else None
+                    single["roofline"]["traffic_source"], single["roofline"]["kernel_code_hash"] = note1, ccode
+                    single["roofline"]["algorithmic_bytes_per_launch"] = int(STEPS_DDIM * 30.4e6 + BATCH * 3 * 1024 * 2)     # every weight once per step (the 8 XCDs' L2s each fetch their copy: x8 at most)
                 elif hits:
                     n, (avg, calls_, total) = max(hits, key=lambda kv: kv[1][1])
                     gf = 2.0 * 384 * 256 * 1024 / 1e9

@@ -3,12 +3,12 @@
 # PMC_SHAPES (default "20 32") requests per mldhip_sample_many call -- 20 = the driver's `bench.py --steps 20`, 32 = the chip-filling call.
 # Per shape: FETCH_SIZE and WRITE_SIZE per kernel, then the SQ counters that say where the time goes.  Writes ONE summary,
 # gpurun_out/<TAG>_pmc_traffic.json = {"shapes": {"20": {...}, "32": {...}}}, each entry stamped with the hash of the engine sources AND of the
-# loop kernel's machine code it ran on (bench.py refuses an entry that matches neither).  Copy it to profiles/r04_pmc_traffic.json.
+# loop kernel's machine code it ran on (bench.py refuses an entry that matches neither; shape 1 = ONE bs-64 request: the cluster loop).  Copy it to profiles/r05_pmc_traffic.json.
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-TAG=${1:-r04}
-SHAPES=${PMC_SHAPES:-"20 32"}
+TAG=${1:-r05}
+SHAPES=${PMC_SHAPES:-"1 20 32"}
 PASSES=("FETCH_SIZE" "WRITE_SIZE")
 [ "${PMC_TRAFFIC_ONLY:-0}" = 1 ] || PASSES+=("SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE")
 for COAL in $SHAPES; do
@@ -24,7 +24,7 @@ import csv, glob, collections, json, os, sys
 sys.path.insert(0, os.getcwd())
 import bench
 tag, shapes = sys.argv[1], sys.argv[2:]
-NAMES = {"den_loop": "den_loop_kernel", "dec_ffn": "ffn_strip_x3_kernel", "dec_qkv": "strip_gemm_x3_kernel<6, 1, false, true",
+NAMES = {"den_loop": "den_loop_kernel", "den_cluster": "den_cluster_kernel", "dec_ffn": "ffn_strip_x3_kernel", "dec_qkv": "strip_gemm_x3_kernel<6, 1, false, true",
          "dec_skip": "strip_gemm_x3_kernel<4, 2, false, false", "dec_attn": "attn_flash_x3_kernel", "dec_final": "final_strip_x3_kernel"}
 out = {"note": ("rocprofv3 --pmc, separate passes with --kernel-trace only, over bench.py --profile-child --coalesce N --steps 1 (one call of N bs-64 requests).  "
                 "FETCH/WRITE_SIZE are KB; fetch bytes = 2 x FETCH_SIZE x 1024 (gfx950 wide-read correction of MI355X_MICROARCH.md); weights and the working set of the loop "
@@ -58,8 +58,9 @@ for coal in shapes:
             s["lds_conflict_frac"] = round(s["SQ_LDS_BANK_CONFLICT"] / s["SQ_LDS_IDX_ACTIVE"], 4)
         if len(s) > 1:
             sq[short] = dict(kernel=k[:100], **s)
-    loop = next((k for k in agg if "den_loop_kernel" in k), None)
+    loop = next((k for k in agg if "den_loop_kernel" in k), None) or next((k for k in agg if "den_cluster_kernel" in k), None)
     out["shapes"][str(coal)] = {"source_hash": bench.source_hash(), "loop_kernel_code_hash": bench.kernel_code_hash(bench.mangled_part(loop)) if loop else None,
+                                "loop_kernel": loop[:80] if loop else None,
                                 "requests_per_call": int(coal), "kernels": traffic, "sq": sq}
 json.dump(out, open(f"gpurun_out/{tag}_pmc_traffic.json", "w"), indent=1)
 for coal, e in out["shapes"].items():
