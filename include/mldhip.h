@@ -142,16 +142,20 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  * the in-projection's strips ("nt_hints"), pre-split weight images ("split_weights"); round 2's LDS-staged feed-forward kernel
  * ("fused_ffn", kernels/ffn_fused.hpp) is gone.  Names:
  *   "loop_kernel"     reverse loop of the latent models: 0 = auto (default: by motions per call: F16X3 mode -- cluster loop up to
- *                     "cluster_max_batch" motions, latency kernels up to 191, persistent loop from 192), 1 = latency kernels
+ *                     "cluster_max_batch" = 256 motions, persistent loop above), 1 = latency kernels
  *                     (kernels/tile32.hpp: one request of <= ~128 motions, 41 launches per step), 2 = column-split throughput kernels
  *                     (kernels/strip.hpp: a few hundred motions per call), 3 = the sample-major persistent loop
  *                     (kernels/loop_fused.hpp: ONE launch for all steps of the call, a workgroup per 8 motions, weights streamed in
  *                     consumption order; built for latent_dim 256 / ff_size 1024 / 4 heads in the F32 and F16X3 modes -- refused
  *                     elsewhere).  Its run time does not depend on the batch up to 8 x #CUs = 2 048 motions.  4 = the cluster loop
- *                     (kernels/loop_cluster.hpp, ABI 4 / round 5: ONE launch for all steps of ONE request of up to 128 motions -- 12 workgroups
- *                     (3 tokens x 4 column groups) per 8 motions hand partial products to each other inside the launch; F16X3 mode, latent_dim 256 /
- *                     ff_size 1024 / 4 heads, refused elsewhere; 7.9 ms per 50-step loop for 8 .. 128 motions against 11.2 / 15.2 ms of the latency
- *                     kernels at 64 / 128).  Calls it serves are issued eagerly, not through a captured graph
+ *                     (kernels/loop_cluster.hpp, ABI 4 / round 5: ONE launch for all steps of ONE request of up to 128 motions -- 24 (up to 64 motions)
+ *                     or 12 workgroups per 8 motions (3 tokens x 8 / 4 column groups) hand partial products to each other inside the launch; F16X3 mode,
+ *                     latent_dim 256 / ff_size 1024 / 4 heads, refused elsewhere; 6.8 / 7.6 ms per 50-step loop at 64 / 128 motions against 11.2 / 15.2 ms
+ *                     of the latency kernels).  The launch needs its workgroups resident together: it is sized to the chip, every wait inside it is
+ *                     bounded (200 ms: the latents of the call are then NaN and counted, and the handle leaves the cluster loop at the next
+ *                     mldhip_numeric_status / at finalize's probe), and calls served by it on different streams of this PROCESS are ordered behind each
+ *                     other (one lane per device: two such launches side by side could starve each other of CUs).  Another process that fills the
+ *                     same GPU with long-running workgroups is outside that guard: set "cluster_max_batch" 0 there
  *   "cluster_max_batch" auto runs the cluster loop for calls of up to this many motions (default 256: one launch up to 128 = two clusters per XCD, two launches one
  *                     after the other up to 256 -- 2 x 7.6 ms against the persistent loop's flat 18.7 ms; 0 = never)
  *   "cluster_wt"      cluster loop, payload stores of the in-launch hand-offs: 0 (default) = plain where the twelve workgroups of a cluster report one
@@ -218,7 +222,8 @@ int mldhip_set_option(mldhip_handle* h, const char* name, int64_t value);
  * there is a guard, in three parts:
  *  1. PROBE (mldhip_finalize_weights, option "range_probe"): the handle runs its own split-f16 kernels and its exact-fp32
  *     kernels on one probe batch built from the loaded weights (8 motions, seeded unit-normal latents / condition rows: two
- *     reverse steps of the persistent loop and one denoiser call of the latency kernels at the first and last timestep; one
+ *     reverse steps of the persistent loop and of the cluster loop (its 24-workgroup form: the 12-workgroup form differs in the order of two
+ *     sums only) and one denoiser call of the latency kernels at the first and last timestep; one
  *     decode of 4 x 64 frames) and compares: err = max|split - fp32| / max|fp32| (for the two loop steps: max|split - fp32| of the
  *     latents / max|latents - start noise| / (2 guidance_scale - 1), i.e. relative to the update the steps made, whatever the schedule).
  *     Diffusion-only variant: one denoiser call on 4 CFG rows x 128 frames, reported as probe_err_decode / decode_split_ok (all of its
