@@ -545,7 +545,12 @@ int range_probe(mldhip_handle* e, hipStream_t stream, const float* user_text = n
       const float eb = !finite ? std::numeric_limits<float>::infinity() : (m > 0.f ? d / m / amp : (d > 0.f ? std::numeric_limits<float>::infinity() : 0.f));
       worst = std::max(worst, eb);
       // (c) the cluster loop (kernels/loop_cluster.hpp: split-f16 only, unclamped images like the persistent loop's) on the same two steps, against the exact-fp32 result `hb`
-      if (e->cl_stream) {
+#if defined(MLDHIP_SIM)
+      const bool probe_cluster = e->cl_stream && (e->loop_kernel == 4 || e->cluster_max_batch > 0);      // (the simulator's handles never pick it by themselves: 20 s per probe saved)
+#else
+      const bool probe_cluster = e->cl_stream != nullptr;
+#endif
+      if (probe_cluster) {
         e->split_loop_ok = true;
         std::vector<float> hc_;
         {

@@ -726,7 +726,7 @@ def test_sample_major_persistent_loop_sim(prec):
     e.close()
 
 
-@pytest.mark.parametrize("wt,groups", [(0, 4), (1, 4), (0, 8)])
+@pytest.mark.parametrize("wt,groups", [(0, 4), (1, 8)])
 def test_cluster_loop_sim(wt, groups):
     """loop_kernel = 4 (kernels/loop_cluster.hpp): the reverse loop as ONE launch of clusters -- 12 workgroups (3 tokens x 4 column groups) per 8 motions,
     or 24 (x 8 column groups: option cluster_groups 8, the default up to 64 motions; the members without a head enter each layer at E1) --
