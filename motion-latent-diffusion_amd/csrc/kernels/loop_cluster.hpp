@@ -1,4 +1,4 @@
-// The reverse-diffusion loop of ONE bs-64 request (up to 128 motions) as one persistent launch of CLUSTERS: 12 workgroups per 8 motions.
+// The reverse-diffusion loop of ONE bs-64 request (up to 128 motions per launch) as one persistent launch of CLUSTERS: 24 or 12 workgroups per 8 motions.
 //
 // Why it exists.  The metric's literal configuration -- one MLD.forward of 64 prompts (mld.py:216-265,290-360) -- ran on
 // the launch-per-GEMM family (tile32.hpp): 2 052 dependent launches of ~5.5 us, 12.3 ms per batch.  The sample-major loop (loop_fused.hpp)
@@ -9,36 +9,40 @@
 // in one launch:
 //
 //   cluster = 8 motions = 16 rows of the CFG batch x 3 tokens (the row order of loop_fused.hpp: row = 16 t + c, c < 8 unconditional).
-//   member (t, h), t = token 0..2, h = column group 0..3; per layer (cross_attention.py:259-272, forward_post):
+//   member (t, h), t = token 0..2, h = column group 0..CG-1 (CG = 4: every member is a head; CG = 8, calls of up to 64 motions: members h < 4 are the
+//   heads and do everything, members h >= 4 skip Ph1 and enter at E1); per layer (cross_attention.py:259-272, forward_post):
 //     Ph1  [X of all 48 rows in LDS]  Q of (token t, head h) and K of head h for all three tokens on waves 0-3, V of head h for all three tokens on
 //          waves 4-7 (3x redundant over t: the 3-token attention needs them), scores through LDS, softmax + P.V for its 16 rows; then the
 //          out-projection SPLIT OVER K BY HEAD: the head's 64 attention dims into all 256 output columns   -> publishes a partial [16][256]
 //     E1   the 4 partials of its token, summed in a fixed order + bias + residual -> norm1, one row per wave (in-wave statistics)   64 KB
-//     Ph2  linear1 + GELU for hidden columns [256 h, 256 h + 256)                              -> publishes H[16][256] as a split-f16 image
+//     Ph2  linear1 + GELU for hidden columns [1024 h / CG, + 1024 / CG)                      -> publishes its slice of H[16][1024] as a split-f16 image
 //     E2   gather the hidden activation of its token from (t, *)                                  64 KB
-//     Ph3  linear2 for output columns [64 h, 64 h + 64), K = 1024 (halves on the two halves of the workgroup)   -> publishes Y[16][64]
-//     E3   gather Y and h1 of ALL 48 rows from the twelve members, residual + norm2 -> next layer's X    96 KB
-//   (+ per skip connection, cross_attention.py:56-58: norm2 of its own rows only, Linear(cat[x, skip]) for its 16 rows x 64 columns with
-//   the two K halves on the two halves of the workgroup, and one more gather of all 48 rows.)  End of a step (encoder.norm, CFG, DDIM:
+//     Ph3  linear2 for output columns [256 h / CG, + 256 / CG), K = 1024 on two (CG 4) or four (CG 8) groups of waves that meet through LDS; + bias
+//          + the norm2 residual from its own norm1 image                                        -> publishes Y[16][256 / CG]
+//     E3   gather Y of ALL 48 rows from all members, norm2 -> next layer's X    48 KB
+//   (+ per skip connection, cross_attention.py:56-58: norm2 of its own rows only, Linear(cat[x, skip]) for its 16 rows x 256 / CG columns with
+//   K split like linear2's, and one more gather of all 48 rows.)  End of a step (encoder.norm, CFG, DDIM:
 //   mld_denoiser.py:206, mld.py:339-346) and the next step's token rows are worked out redundantly by every member: no exchange.
 //   31 exchanges per step for the 9-layer model instead of 41 launches.
 //
 // Weights: as in loop_fused.hpp a weight element is used by exactly one wave, so nothing is staged in LDS: `finalize` writes, per column group
 // and WAVE, the fragments that wave consumes in consumption order ([fragment][lane][8 words] split-f16: high halves of k = 8g .. 8g + 7 of
-// weight row 16 x + r, then the low halves) and every lane streams its 32 bytes per fragment through a 4-deep register ring (8 spills).  768 KB
-// per layer and workgroup, 3.2x the non-redundant share: at bs 64 the chip has the CUs (96 of 256) to spare; the phases that stream run at the
-// L2 -> CU fill rate (58 B/clk), the rest of a layer is hand-off latency (DESIGN.md 3a has the kernel's own phase stamps).
+// weight row 16 x + r, then the low halves) and every lane streams its 32 bytes per fragment through a 4-deep register ring (6 or 8 spill).  A head
+// member streams 512 KB (CG 8) / 768 KB (CG 4) per layer; the phases that stream run at the L2 -> CU fill rate (58 B/clk), the rest of a layer is
+// hand-off latency (DESIGN.md 3a has the kernel's own phase stamps).
 //
 // Hand-offs: cdna_hip_programming.md Guideline 16 form R1 -- write-through (sc1) payload stores, every storing wave drains its memory counter,
-// barrier, one lane stores the member's flag (relaxed, agent scope; value = epoch, never reset inside a call; zeroed by a memset node in front of
-// the launch), consumers poll the flags of the producers they need with one relaxed load per lane, then read with sc1 loads.  PLAIN payload
-// stores are 0.15-0.6 us per exchange cheaper but only visible to consumers behind the SAME L2: WT = false is used only when every member of
-// the cluster reports the same HW_REG_XCC_ID (checked in the kernel's first exchange; block b runs on XCD b % 8 in practice, not by contract); a
-// cluster that spans XCDs keeps the write-through stores by itself.
-// Buffers are double buffered by the parity of the epoch; E3-type waits cover all twelve members even where fewer rows are read, which is what
+// barrier, one lane stores the member's flag (relaxed, agent scope; value = epoch, never reset inside a call; zeroed by clear_cluster_flags_kernel in
+// front of the launch -- NOT by a memset node: DESIGN.md 3a), consumers poll the flags of the producers they need with one relaxed load per lane, then
+// read with sc1 loads.  PLAIN payload stores are 0.15-0.6 us per exchange cheaper but only visible to consumers behind the SAME L2: WT = false is
+// used only when every member of the cluster reports the same HW_REG_XCC_ID (checked in the kernel's first exchange; block b runs on XCD b % 8 in
+// practice, not by contract); a cluster that spans XCDs keeps the write-through stores by itself.
+// Buffers are double buffered by the parity of the epoch; E3-type waits cover ALL members even where fewer rows are read, which is what
 // keeps a fast member from overwriting a buffer a slow one still reads.  Every spin is bounded: a member that waits longer than
-// kClTimeoutTicks sets the call's status word, every member that sees it leaves, the latents are poisoned with NaN (counted by the range
-// contract's non-finite counter).  The twelfth member to finish clears the cluster's flag line, so every polled word is zero when a call ends.
+// kClTimeoutTicks sets the call's status words, every member that sees it leaves, the latents are poisoned with NaN (counted by the range
+// contract's non-finite counter) and the handle leaves the cluster loop (mldhip_numeric_status).  The last member to finish clears the cluster's flag
+// line, so every polled word is zero when a call ends.  The launch needs all its workgroups resident together: the engine sizes it to the chip and never
+// issues two of them side by side (engine/params.hpp ClusterLane).
 #pragma once
 #include "loop_fused.hpp"
 
@@ -206,17 +210,10 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
       }
     }
     __syncthreads();
-#if defined(CL_SAFE) && !defined(MLDHIP_SIM)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
     return ctl[0] != 0u;
   };
   auto publish = [&](int kind, unsigned epoch) __attribute__((always_inline)) {
     drain_stores();
-#if defined(CL_SAFE) && !defined(MLDHIP_SIM)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    drain_stores();
-#endif
     __syncthreads();
     if (tid == 0) flag_store(flags + kind * kClFlagLine + member, epoch);
   };
@@ -383,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
   int pbuf = 0;
   const unsigned wg = blockIdx.x;
   // linear2 output + bias + residual (both added by its producer) of row `row`, this lane's 4 columns
-  auto y_row = [&](unsigned par, int row, const float*) __attribute__((always_inline)) {
+  auto y_row = [&](unsigned par, int row) __attribute__((always_inline)) {
     return xbuf_ld4(xb, (kClY + par * 12288u + (unsigned)(row * 256 + lane * 4)) * 4u);
   };
   // norm1 output of the own token, row r, columns c0 .. c0 + 3 as the GEMMs saw it (high + low half of the As image): the residual of norm2
@@ -664,7 +661,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         // x' = norm2(y + h1) for all 48 rows -> Xs; input blocks park their own token's rows for the skip connection (cross_attention.py:48-52)
         F4 v[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v[i] = y_row(par, wave + 8 * i, sm + kLsL2B);
+        for (int i = 0; i < 6; ++i) v[i] = y_row(par, wave + 8 * i);
 #ifdef CL_TRACE
         asm volatile("" : "+v"(v[0].x), "+v"(v[5].w));
         CL_STAMP(14);
@@ -685,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         const int si = l - nb;
         F4 v[6];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) v[i] = y_row(par, 16 * tk + wave + 8 * i, sm + kLsL2B);
+        for (int i = 0; i < 2; ++i) v[i] = y_row(par, 16 * tk + wave + 8 * i);
         const float* pk = p.park + ((size_t)wg * nb + (nb - 1 - si)) * (16 * 256);
         const F4 s0v = ld4(pk + (unsigned)(wave * 256 + lane * 4)), s1v = ld4(pk + (unsigned)((wave + 8) * 256 + lane * 4));
         ln_rows(v, 2, sm + kLsN2W, sm + kLsN2B);
@@ -750,7 +747,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         // CFG (mld.py:339-342), DDIM eta = 0 (mld.py:345-346), the next step's rows
         F4 v[6];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) v[i] = y_row(par, wave + 8 * i, sm + kLsL2B);
+        for (int i = 0; i < 2; ++i) v[i] = y_row(par, wave + 8 * i);
         ln_rows(v, 2, sm + kLsN2W, sm + kLsN2B);
         ln_rows(v, 2, sm_fin, sm_fin + 256);
         const float sat = p.ddim[step * 4], s1mat = p.ddim[step * 4 + 1], sap = p.ddim[step * 4 + 2], s1map = p.ddim[step * 4 + 3];
