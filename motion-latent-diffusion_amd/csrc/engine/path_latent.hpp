@@ -336,15 +336,19 @@ int build_loop_stream(Ctx& c) {
 }
 
 // ---- cluster loop (kernels/loop_cluster.hpp): one bs-64 request (up to 8 x kClMaxClusters motions) as ONE launch of 12-workgroup clusters
+int cluster_groups(const E* e, int B);
 bool use_cluster(const E* e, int B) {
   if (!e->cl_stream || !fused_split(e) || e->cluster_failed || B > kClMaxCall || B > e->cfg.max_batch) return false;
+  // every workgroup of a launch needs a CU of its own (125 KB of LDS each) at the same time: the biggest launch of the call against the device's CUs
+  const int nm = std::min(B, 8 * kClMaxClusters);
+  if (3 * cluster_groups(e, nm) * ((nm + 7) / 8) > e->num_cus) return false;
   return e->loop_kernel == 4 || (e->loop_kernel == 0 && B <= e->cluster_max_batch);
 }
 
 // column groups per token of a cluster call: 8 (24 workgroups per cluster: the feed-forward block on twice the CUs) while every cluster still has an XCD's 32 CUs
 // to itself (up to 8 clusters = 64 motions), 4 (12 workgroups) above; option "cluster_groups" 4 / 8 forces one (8 only where it fits)
 int cluster_groups(const E* e, int B) {
-  const bool fits8 = (B + 7) / 8 <= 8;
+  const bool fits8 = (B + 7) / 8 <= 8 && 24 * ((B + 7) / 8) <= e->num_cus;
   if (e->cluster_groups == 4 || !fits8) return 4;
   return 8;
 }

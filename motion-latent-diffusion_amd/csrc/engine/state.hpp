@@ -81,6 +81,7 @@ struct mldhip_engine {
   bool cluster_lane = true;       // "cluster_lane" (hooks build only): 0 = no ordering between cluster calls of different streams (the starvation it prevents, on purpose)
   bool cluster_clear_memset = false;   // flags of the cluster loop cleared by hipMemsetAsync instead of clear_cluster_flags_kernel ("cluster_graph" 2)
   bool cluster_graph = true;      // "cluster_graph" (hooks build only): 0 = calls served by the cluster loop are issued eagerly, 2 = graphs + memset-node clear (reproduces the r05 replay fault)
+  int num_cus = 1 << 20;          // CUs of the device (a partitioned or masked device has fewer than 256): a cluster launch needs a CU per workgroup (simulator: no limit)
   int cluster_failed = 0;         // a cluster launch reported a timeout / a placement it cannot use: the handle stays on the other loop families
   float* arena_x3 = nullptr;  // split-bf16 image of the arena (precision modes with split-bf16 staged GEMMs; built by finalize)
   size_t arena_floats = 0;

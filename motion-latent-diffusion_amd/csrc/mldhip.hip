@@ -119,15 +119,22 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_last_error = "no HIP device visible (libmldhip has no CPU path)"; return MLDHIP_ENODEV; }
   if (device < 0 || device >= ndev) return bad("device index out of range");
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-    g_last_error = std::string("libmldhip is built for gfx950 only; device is ") + prop.gcnArchName;
-    return MLDHIP_ENODEV;
+  int num_cus = 0;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      g_last_error = std::string("libmldhip is built for gfx950 only; device is ") + prop.gcnArchName;
+      return MLDHIP_ENODEV;
+    }
+    num_cus = prop.multiProcessorCount;
   }
 #endif
   DeviceGuard dg(device);      // allocations below land on `device`; the caller's current device is restored on return
   auto* e = new mldhip_engine();
   e->cfg = *cfg;
   e->device = device;
+#if !defined(MLDHIP_SIM)
+  e->num_cus = num_cus;
+#endif
   declare_params(e);
   build_schedule(e);
   auto fail_create = [&](int code) { g_last_error = e->err; mldhip_destroy(e); return code; };
