@@ -167,6 +167,8 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     whatever the batch; the split-f16 latency kernels take 19.0 ms at 192 motions), 1 280 on exact-fp32 MFMAs (73 ms)
  *   "fused_x3"        F16X3 mode: 1 (default) = the persistent loop multiplies on split-f16 MFMAs (row-swizzled operand images, 4 weight
  *                     items in flight per lane: the settled forms of round 3's "fused_swz" / "fused_ring" knobs), 0 = on exact-fp32 MFMAs
+ *   "cluster_chunk"   (hooks build only) motions per cluster launch (default 128, a multiple of 8): lets the tests drive the several-launches path of calls above 128
+ *                     motions with a few motions
  *   "cluster_lane"    (hooks build only) 0 = calls served by the cluster loop on different streams are not ordered behind each other: two cluster launches side by side
  *                     starve each other of CUs until the 200 ms wait bound fails both (tools/two_streams.py shows it); 1 (default, and always in the production library):
  *                     one lane per device and process

@@ -340,7 +340,7 @@ int cluster_groups(const E* e, int B);
 bool use_cluster(const E* e, int B) {
   if (!e->cl_stream || !fused_split(e) || e->cluster_failed || B > kClMaxCall || B > e->cfg.max_batch) return false;
   // every workgroup of a launch needs a CU of its own (125 KB of LDS each) at the same time: the biggest launch of the call against the device's CUs
-  const int nm = std::min(B, 8 * kClMaxClusters);
+  const int nm = std::min(B, e->cluster_chunk);
   if (3 * cluster_groups(e, nm) * ((nm + 7) / 8) > e->num_cus) return false;
   return e->loop_kernel == 4 || (e->loop_kernel == 0 && B <= e->cluster_max_batch);
 }
@@ -951,7 +951,8 @@ void launch_cluster_chunk(Ctx& c, const float* init_lat, int B, int s_base, int 
 // up to 128 motions: one launch; up to kClMaxCall = 256: two launches one after the other on the call's stream (they share the exchange regions and flags; 2 x 7.6 ms
 // against the sample-major loop's flat 18.7 ms) -- never side by side: 2 x 192 workgroups are not co-resident
 void launch_cluster_loop(Ctx& c, const float* init_lat, int B, int n, float guidance) {
-  for (int s = 0; s < B && !c.rc; s += 8 * kClMaxClusters) launch_cluster_chunk(c, init_lat, B, s, std::min(8 * kClMaxClusters, B - s), n, guidance);
+  const int chunk = c.e->cluster_chunk;          // 128 (hooks / simulator builds: "cluster_chunk" makes the two-launch path testable on a few motions)
+  for (int s = 0; s < B && !c.rc; s += chunk) launch_cluster_chunk(c, init_lat, B, s, std::min(chunk, B - s), n, guidance);
 }
 
 // `text` == nullptr selects the action condition (labels_dev holds the 2B labels).

@@ -361,6 +361,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value != 0 && value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "cluster_groups must be 0 (auto: 8 up to 64 motions, 4 above), 4 or 8");
     e->cluster_groups = (int)value;
 #if defined(MLDHIP_HOOKS)
+  } else if (n == "cluster_chunk") {
+    if (value < 8 || value > 8 * kClMaxClusters || value % 8) return e->fail(MLDHIP_EINVAL, "cluster_chunk must be a multiple of 8 in 8 .. %d", 8 * kClMaxClusters);
+    e->cluster_chunk = (int)value;      // hooks build only: motions per cluster launch (tests of the several-launches path on a few motions)
   } else if (n == "cluster_lane") {
     e->cluster_lane = value != 0;       // hooks build only: 0 = cluster calls of different streams are NOT ordered behind each other (reproduces the co-residency starvation: tools/two_streams.py)
   } else if (n == "cluster_graph") {

@@ -754,6 +754,13 @@ def test_cluster_loop_sim(wt, groups):
         e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
         assert e.launch_counts()[0] == 2
         assert np.abs(lat - ref).max() < 2e-4 and np.abs(lat - lat1).max() < 2e-4, (wt, groups)
+    if groups == 8:
+        # calls above 128 motions run several launches one after the other on shared exchange regions (ClusterArgs s_base / s_end): here 8 + 3 motions
+        e.set_option("cluster_chunk", 8)
+        lat = np.full((11, 1, 256), np.nan, np.float32)
+        e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
+        assert e.launch_counts()[0] == 3
+        assert np.abs(lat - ref).max() < 2e-4 and np.abs(lat - lat1).max() < 2e-4
     # the precision mode without split arithmetic has no cluster build: refused like loop_kernel 3 where that is not built
     e.close()
     e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=4, max_frames=8, num_inference_steps=2, num_layers=3, precision=0)
