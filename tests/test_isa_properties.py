@@ -60,3 +60,16 @@ def test_row_strip_kernels_have_no_scratch_and_no_flat_accesses(rep):
         assert k["scratch"] == 0 and k["flat"] == 0, (part, k)
     assert one(rep, "final_strip_x3_kernel")["mfma"] == 8 * 3 * 3 * 3          # chunks x column blocks x row tiles x split products
     assert not [n for n in rep if "ffn_x3_kernel" in n]                        # round 2's LDS-staged feed-forward kernel is gone
+
+
+def test_cluster_loop_code(rep):
+    """kernels/loop_cluster.hpp: the first GPU build kept the loop-invariant addresses of every phase live (256 registers + 544 B of scratch per lane: 9.9 ms against
+    7.9); lane indices are laundered per phase since, and the ring stays at 4 fragments (6 / 8 spill).  Matrix instructions per wave and layer path: Ph1 96 (Q, K) or
+    72 (V) + 12 (out-projection partial), linear1 + linear2 48 + 48 (4 column groups) or 24 + 24 (8), skip linear 24 or 12."""
+    for wt in ("true", "false"):
+        k4, k8 = one(rep, f"den_cluster_kernel<{wt}, 4>"), one(rep, f"den_cluster_kernel<{wt}, 8>")
+        for k in (k4, k8):
+            assert k["scratch"] == 0 and k["vgpr_spills"] == 0 and k["flat"] == 0 and k["vgpr"] <= 200, k
+            assert k["ds_write_b16"] == 0
+        assert k4["mfma"] == 96 + 72 + 12 + 48 + 48 + 24 and k8["mfma"] == 96 + 72 + 12 + 24 + 24 + 12
+    assert one(rep, "clear_cluster_flags_kernel")["global_store"] == 1
