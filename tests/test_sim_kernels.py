@@ -771,6 +771,32 @@ def test_cluster_loop_sim(wt, groups):
     e.close()
 
 
+def test_cluster_loop_two_skip_levels_sim():
+    """A 5-layer skip stack (two input blocks, two skip connections): the cluster loop parks the rows of TWO levels and pops them in reverse order
+    (cross_attention.py:48-58: xs.append in the input blocks, xs.pop() in the output blocks) -- the 3-layer models of the other simulator tests have one
+    level only.  One ragged cluster (5 motions), one step, 24 workgroups; against the oracle and the launch family."""
+    dims = syn.ModelDims(num_layers=5)
+    sdd = syn.make_denoiser_state_dict(dims=dims)
+    e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=8, max_frames=8, num_inference_steps=1, num_layers=5, precision=1)
+    e.load_state_dict(sdd, "denoiser.")
+    e.load_state_dict(syn.make_vae_state_dict(dims=dims), "vae.")
+    e.finalize()
+    b = syn.make_batch(5, [8, 5, 3, 8, 1], seed=17)
+    ops = O.NumpyOps(np.float32)
+    ref = np.asarray(O.diffusion_reverse(ops, O.to_backend(ops, sdd), b.text_emb, b.init_latents, 7.5, 1, 4))
+    e.set_option("loop_kernel", 1)
+    lat1 = np.zeros((5, 1, 256), np.float32)
+    e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat1)
+    e.set_option("loop_kernel", 4)
+    for groups in (8, 4):
+        e.set_option("cluster_groups", groups)
+        lat = np.full((5, 1, 256), np.nan, np.float32)
+        e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
+        assert e.launch_counts()[0] == 2
+        assert np.abs(lat - ref).max() < 2e-4 and np.abs(lat - lat1).max() < 2e-4, groups
+    e.close()
+
+
 def test_sample_major_loop_is_refused_where_it_is_not_built_sim():
     """ff_size 512 has no sample-major build: loop_kernel = 3 is refused after finalize, auto never picks it."""
     dims = syn.ModelDims(num_layers=3, ff_size=512)
