@@ -167,6 +167,8 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     whatever the batch; the split-f16 latency kernels take 19.0 ms at 192 motions), 1 280 on exact-fp32 MFMAs (73 ms)
  *   "fused_x3"        F16X3 mode: 1 (default) = the persistent loop multiplies on split-f16 MFMAs (row-swizzled operand images, 4 weight
  *                     items in flight per lane: the settled forms of round 3's "fused_swz" / "fused_ring" knobs), 0 = on exact-fp32 MFMAs
+ *   "cluster_inject"  (hooks build only) fault injection: 1 + the index of a cluster member that never raises its first flag (the wait bound shrinks to 2 ms): the members
+ *                     waiting for it run into the bound, the call returns NaN latents (counted) and the handle leaves the cluster loop at the next mldhip_numeric_status; 0 = off
  *   "cluster_chunk"   (hooks build only) motions per cluster launch (default 128, a multiple of 8): lets the tests drive the several-launches path of calls above 128
  *                     motions with a few motions
  *   "cluster_lane"    (hooks build only) 0 = calls served by the cluster loop on different streams are not ordered behind each other: two cluster launches side by side

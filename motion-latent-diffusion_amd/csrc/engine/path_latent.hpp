@@ -915,6 +915,7 @@ void launch_cluster_chunk(Ctx& c, const float* init_lat, int B, int s_base, int 
   ClusterArgs a;
   const int cg = cluster_groups(e, nm), members = 3 * cg;
   a.s_base = s_base; a.s_end = s_base + nm;
+  a.timeout = e->cluster_timeout ? (unsigned)e->cluster_timeout : kClTimeoutTicks; a.mute = e->cluster_mute;
   a.stream = e->cl_stream;
   a.wave_off = e->cl_wave_off_dev + (cg == 8 ? 32 : 0);
   a.small = e->loop_small; a.T1 = e->T1; a.TP = e->TP; a.init_lat = init_lat; a.lat = e->lat; a.park = e->cl_park; a.ddim = e->loop_ddim;

@@ -78,6 +78,7 @@ struct mldhip_engine {
   unsigned cl_wave_off[96] = {0}; // ... float offset of (column group, wave)'s sequence: 32 words of the 4-group form, 64 of the 8-group form
   unsigned* cl_wave_off_dev = nullptr;   // ... the same 96 words in device memory (kernel arguments stay small)
   int cluster_groups = 0;         // "cluster_groups": 0 = 8 column groups per token up to 64 motions and 4 above, 4 / 8 = forced (8 only up to 64 motions)
+  int cluster_mute = -1, cluster_timeout = 0;   // "cluster_inject" (hooks build only): member that never raises its first flag, and the shortened wait bound that goes with it
   int cluster_chunk = 128;        // "cluster_chunk" (hooks build only): motions per cluster launch (a multiple of 8, at most 8 x kClMaxClusters = 128)
   bool cluster_lane = true;       // "cluster_lane" (hooks build only): 0 = no ordering between cluster calls of different streams (the starvation it prevents, on purpose)
   bool cluster_clear_memset = false;   // flags of the cluster loop cleared by hipMemsetAsync instead of clear_cluster_flags_kernel ("cluster_graph" 2)

@@ -86,15 +86,17 @@ struct ClusterArgs {
   unsigned* status;           // [0]: 0 ok, 1 a wait timed out; [1]: clusters that span XCDs (plain stores asked for, write-through used); both cleared per launch.  [2]: a wait timed out in SOME launch since the host last looked (sticky)
   int B, L, n, ncl;           // B: motions of the CALL (the condition rows' pitch); this launch serves motions [s_base, s_end)
   int s_base = 0, s_end = 0;
+  unsigned timeout = 0;       // wait bound: 100 MHz ticks (GPU) / poll iterations (simulator); kClTimeoutTicks unless a test shortens it
+  int mute = -1;              // hooks builds (fault injection, tests): this member never raises its first flag -- everybody who waits for it runs into the bound
   unsigned long long* trace = nullptr;   // CL_TRACE builds (tools/loopbench only): [workgroup][wave][16] shader cycles per phase, summed over steps and layers
   int xslots;                 // blocks per launch row: 8 on the GPU (block b runs on XCD b % 8: a cluster's members share the slot), min(clusters, 8) on the simulator
   float guidance, init_sigma;
 };
 
 #if defined(MLDHIP_SIM)
-constexpr unsigned long long kClTimeoutTicks = 1ull << 26;     // poll iterations
+constexpr unsigned kClTimeoutTicks = 1u << 26;                 // poll iterations
 #else
-constexpr unsigned long long kClTimeoutTicks = 20000000ull;    // 100 MHz ticks: 200 ms
+constexpr unsigned kClTimeoutTicks = 20000000u;                // 100 MHz ticks: 200 ms
 #endif
 
 // finalize-time: one fragment = 16 weight rows x 32 k as the split-f16 operand pair of lane (r, g): high halves of W[row0 + r][k0 + 8g .. + 7], then the low halves
@@ -196,10 +198,10 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         if (!wave_any(!ready)) break;
         spin_pause();
 #if defined(MLDHIP_SIM)
-        if (++it > kClTimeoutTicks) { ok = false; break; }
+        if (++it > p.timeout) { ok = false; break; }
 #else
         if ((++it & 63u) == 0u) {
-          const bool late = realtime_100mhz() - ts > kClTimeoutTicks;
+          const bool late = realtime_100mhz() - ts > p.timeout;
           if (wave_any(late || flag_load(p.status) != 0u)) { ok = false; break; }
         }
 #endif
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
   auto publish = [&](int kind, unsigned epoch) __attribute__((always_inline)) {
     drain_stores();
     __syncthreads();
-    if (tid == 0) flag_store(flags + kind * kClFlagLine + member, epoch);
+    if (tid == 0 && !(member == p.mute && epoch == 1u)) flag_store(flags + kind * kClFlagLine + member, epoch);
   };
   auto give_up = [&]() {           // a wait failed: poison this cluster's latents (member 0), leave
     if (member == 0) {

@@ -361,6 +361,16 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value != 0 && value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "cluster_groups must be 0 (auto: 8 up to 64 motions, 4 above), 4 or 8");
     e->cluster_groups = (int)value;
 #if defined(MLDHIP_HOOKS)
+  } else if (n == "cluster_inject") {
+    // hooks build only: fault injection for the tests of the bounded waits -- member value - 1 of every cluster never raises its first flag and the wait bound shrinks to
+    // 2 ms (GPU) / 1 500 polls (simulator); 0 = off
+    if (value < 0 || value > kClMembersMax) return e->fail(MLDHIP_EINVAL, "cluster_inject must be 0 (off) or 1 + a member index");
+    e->cluster_mute = (int)value - 1;
+#if defined(MLDHIP_SIM)
+    e->cluster_timeout = value ? 1500 : 0;
+#else
+    e->cluster_timeout = value ? 200000 : 0;
+#endif
   } else if (n == "cluster_chunk") {
     if (value < 8 || value > 8 * kClMaxClusters || value % 8) return e->fail(MLDHIP_EINVAL, "cluster_chunk must be a multiple of 8 in 8 .. %d", 8 * kClMaxClusters);
     e->cluster_chunk = (int)value;      // hooks build only: motions per cluster launch (tests of the several-launches path on a few motions)

@@ -265,6 +265,42 @@ def test_cluster_calls_in_flight_on_two_streams_never_run_side_by_side(dev):
     e.close()
 
 
+def test_cluster_loop_bounded_waits_and_fallback_on_gpu(dev):
+    """The bounded waits of the cluster launch on hardware (hooks build of the library, option "cluster_inject": one member of every cluster never raises its first
+    flag, wait bound 2 ms): the call returns instead of hanging, its latents are NaN and counted, mldhip_numeric_status takes the handle off the cluster loop, the
+    next call (launch family) equals the exact-fp32 engine within the split tolerance; loop_kernel 4 re-arms the cluster loop and the result is the usual one."""
+    if not os.path.exists(_lib.HOOKS_LIB):
+        pytest.skip("hooks build of the library not present (make -C motion-latent-diffusion_amd/csrc hooks)")
+    b = syn.make_batch(64, [40] * 64, seed=31)
+    e = _lib.Engine(lib=_lib.hooks_library(), device=0, max_batch=64, max_frames=40, precision=1)
+    _load(e)
+    text, lat0 = _cuda(b.text_emb, dev), _cuda(b.init_latents, dev)
+    lat = torch.zeros(64, 1, 256, device=dev)
+    e.sample(text, lat0, b.lengths, lat)
+    torch.cuda.synchronize()
+    good = lat.clone()
+    assert e.launch_counts()[0] == 2 and not torch.isnan(good).any()
+    e.set_option("cluster_inject", 1 + 2)                    # member (token 0, head 2) of every cluster
+    t0 = time.perf_counter()
+    e.sample(text, lat0, b.lengths, lat)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert dt < 2.0, dt                                      # graph capture + a 2 ms bound, not a hang
+    assert torch.isnan(lat).all()
+    ns = e.numeric_status()
+    assert ns["nonfinite_values"] == 64 * 256, ns
+    e.sample(text, lat0, b.lengths, lat)                     # the handle has left the cluster loop
+    torch.cuda.synchronize()
+    assert e.launch_counts()[0] > 2000 and float((lat - good).abs().max()) < 1e-3
+    e.set_option("cluster_inject", 0)
+    e.set_option("loop_kernel", 4)
+    e.sample(text, lat0, b.lengths, lat)
+    torch.cuda.synchronize()
+    assert e.launch_counts()[0] == 2 and torch.equal(lat, good)
+    assert e.numeric_status()["nonfinite_values"] == 0
+    e.close()
+
+
 @pytest.mark.parametrize("prec", [0, 1])
 def test_second_weight_family_vs_reference_golden(dev, golden_dir, prec):
     """A second family of weights (mld_hip.synthetic.trained_like: LayerNorm gains ~ N(1, 0.3), heavy-tailed weight rows, a small final gain) against the REFERENCE

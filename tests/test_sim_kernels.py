@@ -797,6 +797,36 @@ def test_cluster_loop_two_skip_levels_sim():
     e.close()
 
 
+def test_cluster_loop_bounded_waits_and_fallback_sim():
+    """Every wait inside the cluster launch is bounded.  Fault injection (hooks / simulator builds, option "cluster_inject"): one member never raises its first flag,
+    so its partners run into the (shortened) bound -- the call must come back (no hang) with its latents poisoned, the range contract's counter must see them, and
+    mldhip_numeric_status must take the handle off the cluster loop: the next call runs on another loop family and is right; loop_kernel 4 re-arms it."""
+    dims = syn.ModelDims(num_layers=3)
+    sdd = syn.make_denoiser_state_dict(dims=dims)
+    e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=8, max_frames=8, num_inference_steps=2, num_layers=3, precision=1)
+    e.load_state_dict(sdd, "denoiser.")
+    e.load_state_dict(syn.make_vae_state_dict(dims=dims), "vae.")
+    e.finalize()
+    b = syn.make_batch(8, [8] * 8, seed=23)
+    ops = O.NumpyOps(np.float32)
+    ref = np.asarray(O.diffusion_reverse(ops, O.to_backend(ops, sdd), b.text_emb, b.init_latents, 7.5, 2, 4))
+    e.set_option("loop_kernel", 4)
+    e.set_option("cluster_inject", 1 + 5)                    # member (token 0, column group 5): a member without a head
+    lat = np.zeros((8, 1, 256), np.float32)
+    e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
+    assert e.launch_counts()[0] == 2 and np.isnan(lat).all()
+    ns = e.numeric_status()
+    assert ns["nonfinite_values"] == 8 * 256, ns
+    e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)          # the handle has left the cluster loop
+    assert e.launch_counts()[0] > 2 and np.abs(lat - ref).max() < 2e-4
+    assert e.numeric_status()["nonfinite_values"] == 0
+    e.set_option("cluster_inject", 0)
+    e.set_option("loop_kernel", 4)                           # re-arms it
+    e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
+    assert e.launch_counts()[0] == 2 and np.abs(lat - ref).max() < 2e-4
+    e.close()
+
+
 def test_sample_major_loop_is_refused_where_it_is_not_built_sim():
     """ff_size 512 has no sample-major build: loop_kernel = 3 is refused after finalize, auto never picks it."""
     dims = syn.ModelDims(num_layers=3, ff_size=512)

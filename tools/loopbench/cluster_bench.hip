@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(ddim, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   a.stream = stream; a.small = small; a.T1 = T1; a.TP = TP; a.init_lat = init; a.lat = lat; a.park = park; a.ddim = ddim; a.xbuf = xbuf;
-  a.flags = flags; a.status = flags + (size_t)ncl * kClFlagWords; a.B = B; a.s_base = 0; a.s_end = B; a.L = L; a.n = n; a.ncl = ncl; a.xslots = 8; a.guidance = 7.5f; a.init_sigma = 1.f;
+  a.flags = flags; a.status = flags + (size_t)ncl * kClFlagWords; a.B = B; a.s_base = 0; a.s_end = B; a.timeout = kClTimeoutTicks; a.L = L; a.n = n; a.ncl = ncl; a.xslots = 8; a.guidance = 7.5f; a.init_sigma = 1.f;
   CK(hipFuncSetAttribute((const void*)den_cluster_kernel<CB_WT, CB_CG>, hipFuncAttributeMaxDynamicSharedMemorySize, kClLdsBytes));
 #ifdef CL_TRACE
   unsigned long long* tr;
