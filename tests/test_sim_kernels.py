@@ -797,7 +797,8 @@ def test_cluster_loop_two_skip_levels_sim():
     e.close()
 
 
-def test_cluster_loop_bounded_waits_and_fallback_sim():
+@pytest.mark.parametrize("groups", [8, 4])
+def test_cluster_loop_bounded_waits_and_fallback_sim(groups):
     """Every wait inside the cluster launch is bounded.  Fault injection (hooks / simulator builds, option "cluster_inject"): one member never raises its first flag,
     so its partners run into the (shortened) bound -- the call must come back (no hang) with its latents poisoned, the range contract's counter must see them, and
     mldhip_numeric_status must take the handle off the cluster loop: the next call runs on another loop family and is right; loop_kernel 4 re-arms it."""
@@ -811,7 +812,8 @@ def test_cluster_loop_bounded_waits_and_fallback_sim():
     ops = O.NumpyOps(np.float32)
     ref = np.asarray(O.diffusion_reverse(ops, O.to_backend(ops, sdd), b.text_emb, b.init_latents, 7.5, 2, 4))
     e.set_option("loop_kernel", 4)
-    e.set_option("cluster_inject", 1 + 5)                    # member (token 0, column group 5): a member without a head
+    e.set_option("cluster_groups", groups)                   # (4: the per-wave wait of the 12-workgroup form's E2 runs into the bound too)
+    e.set_option("cluster_inject", 1 + (5 if groups == 8 else 2))      # member (token 0, column group 5): a member without a head / (token 0, head 2)
     lat = np.zeros((8, 1, 256), np.float32)
     e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
     assert e.launch_counts()[0] == 2 and np.isnan(lat).all()
