@@ -13,8 +13,9 @@ them (default 32 = 2 048 motions) per call: ONE persistent launch runs the whole
 motions, kernels/loop_fused.hpp), then one decode.  Calls are issued one after another on ONE stream: no calls in flight, no
 stream / hardware-queue placement to get right (round 2's headline needed both).  The timed region (exactly K steps between
 barrier + synchronize pairs) is repeated --repeats times; `value` is the median repetition, min / max are carried.
-`single_batch` is the same K steps issued strictly one bs-64 batch after another on the latency kernels (the configuration
-BASELINE.json's metric names literally), with its own roofline.  Ranks are pure data parallel: weights are broadcast once
+`single_batch` / `value_single_batch` is the same K steps issued strictly one bs-64 batch after another (the configuration
+BASELINE.json's metric names literally; since round 5 the reverse loop of such a call is ONE launch of workgroup clusters,
+kernels/loop_cluster.hpp), with its own roofline from a second rocprofv3 child.  Ranks are pure data parallel: weights are broadcast once
 from rank 0 (one RCCL broadcast of the packed blob), every rank samples its own prompts, no data-path collective.  Rank 0
 prints ONE JSON line.
 
@@ -24,9 +25,9 @@ residuals / scheduler in fp32) -- it meets the <= 1e-3 joint tolerance with a 5x
 every motion of this call shape; the measured error is in `parity`).  Exact-fp32 MFMA and plain bf16 are reported as
 `alt_modes`, each with its measured error.
 
-roofline: the dominant kernel of the headline call by rocprofv3 time -- algorithmic FLOPs per launch / its average dispatch
-duration from a rocprofv3 --kernel-trace --stats child run of the same call shape (HIP events around loop-only calls on the
-launch stream are carried beside it).  The peak is the one that binds the kernel's arithmetic: split-f16 kernels issue
+roofline: the dominant kernel of the headline call by rocprofv3 time -- `achieved` / `frac` = algorithmic FLOPs per launch / its
+average dispatch duration from a rocprofv3 --kernel-trace --stats child run of the same call shape (the summary committed under
+profiles/); the live figure (HIP events around loop-only calls on the launch stream) is carried beside it as `frac_hip_events`.  The peak is the one that binds the kernel's arithmetic: split-f16 kernels issue
 three f16 MFMAs per algorithmic product, so their roof is the dense f16 MFMA peak / 3; exact-fp32 kernels: the fp32 MFMA peak.
 """
 import argparse
