@@ -31,7 +31,7 @@ def pack_range(n: int, rank: int, world: int, per_rank: int) -> Tuple[int, int]:
 def plan_shards(n: int, world: int, batch_size: int, max_batch: int, policy: str = "auto", single_batch_is_fast: bool = True) -> dict:
     """How DataParallelSampler spreads n prompts over `world` ranks.  "spread": contiguous equal shards on every rank (the reference's own multi-GPU form,
     scripts/fit_motion_parallel.sh; BASELINE config 3 = one bs-64 batch per rank).  "pack": as few ranks as hold the prompts at `max_batch` per rank.  "auto":
-    spread whenever a bs-64 call is served by the cluster loop (engine >= r05: 7.0 k motions/s per rank at bs 64, 8 ranks = 56 k, against 20.5 k for one rank
+    spread whenever a bs-64 call is served by the cluster loop (engine >= r05: 8.1 k motions/s per rank at bs 64, 8 ranks = 65 k, against 20.5 k for one rank
     with all 512 prompts in one call) or the shards are not smaller than a coalesced call anyway; pack only when per-rank shards would be single small batches
     on an engine without that path.  Returns {"policy", "busy_ranks", "prompts_per_busy_rank", "why"}."""
     per_spread = -(-n // max(1, world))
