@@ -780,7 +780,11 @@ def test_cluster_loop_two_skip_levels_sim():
     e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=8, max_frames=8, num_inference_steps=1, num_layers=5, precision=1)
     e.load_state_dict(sdd, "denoiser.")
     e.load_state_dict(syn.make_vae_state_dict(dims=dims), "vae.")
+    e.set_option("range_probe", 1)                           # finalize's probe runs the cluster loop too where the handle may pick it (probe (c), mldhip.hip)
+    e.set_option("cluster_max_batch", 8)
     e.finalize()
+    ns = e.numeric_status()
+    assert ns["probed"] == 1 and ns["loop_split_ok"] == 1 and 0.0 <= ns["probe_err_loop"] < _lib.PROBE_TOL, ns
     b = syn.make_batch(5, [8, 5, 3, 8, 1], seed=17)
     ops = O.NumpyOps(np.float32)
     ref = np.asarray(O.diffusion_reverse(ops, O.to_backend(ops, sdd), b.text_emb, b.init_latents, 7.5, 1, 4))
