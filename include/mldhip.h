@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MLDHIP_ABI_VERSION 4
+#define MLDHIP_ABI_VERSION 5
 
 enum {
   MLDHIP_OK = 0,
@@ -196,6 +196,11 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     zeros + the positional rows (mld_vae.py:216-222, actor_vae.py:221-222), the same for every sample, so Q, K, V of
  *                     layer 0 are computed for [T] rows and every (sample, head) attention workgroup reads them (exact: same numbers,
  *                     B times less work and no [B T][3 D] round trip through HBM for that layer); 0 = per sample like the other layers
+ *   "dec_half"        F16X3 mode, decoder self-attention block, OPT-IN: 0 (default) = fp32 Q | K | V and split x3 products
+ *                     (kernels/gemm_strip_x3.hpp, attention.hpp); 1 = in-projection on half rows x split weights, Q | K | V stored as halves
+ *                     (q pre-scaled), attention on plain half operands (kernels/dec_half.hpp) -- kept only if finalize's probe reads the form below
+ *                     MLDHIP_PROBE_TOL_HALF on the handle's own weights ("Range contract" below: it is NOT safe in general); 4 / 6 = 1 with
+ *                     64- / 96-row in-projection strips; 2 = 1 without the probe's veto (A/B tools)
  *   "tile_x3"         F16X3 mode: 1 (default) = the latency kernels of the reverse loop (kernels/tile32.hpp, one request at a time) multiply
  *                     on split-f16 MFMAs reading the pre-split weight image, 0 = on exact-fp32 MFMAs
  *   "strip_gemm"      F16X3 / FP8 modes, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:
@@ -218,7 +223,7 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     to drive the LDS-staged kernels at simulator-sized shapes) */
 int mldhip_set_option(mldhip_handle* h, const char* name, int64_t value);
 
-/* Range contract of MLDHIP_PREC_F16X3 (ABI 4).  A split operand x = hi + lo keeps 22 mantissa bits only while x sits inside the
+/* Range contract of MLDHIP_PREC_F16X3 (ABI 4; ABI 5 adds the decoder's half Q | K | V form).  A split operand x = hi + lo keeps 22 mantissa bits only while x sits inside the
  * half format's comfortable range: |x| > 65 504 has no high half (operands produced inside a kernel -- LayerNorm / GELU /
  * attention outputs -- are not clamped: they become inf, then NaN; weights and caller inputs saturate), and the low half of
  * |x| < 2^-3 is a half subnormal (absolute error <= 3e-8 -- harmless for an O(1) tensor, NOT for one that lives at 1e-4: a
@@ -244,8 +249,19 @@ int mldhip_set_option(mldhip_handle* h, const char* name, int64_t value);
  * LayerNorm gains x 2^+-10 read 1.4e-6 and stay split; weight matrices x 2^-12 read 1.2e-5 and fall back (joints 9e-5 off if forced to
  * stay split); a feed-forward layer whose hidden activation passes 65 504 reads 2.2e-3 / 5e-5 and falls back in both stages (joints 1e-2
  * off without the guard, finite: the conversions saturate before the matrix instructions see an inf).
+ * Round 6 (ABI 5): an OPT-IN cheaper form of the decoder's self-attention block inside this mode (option "dec_half", kernels/dec_half.hpp):
+ * in-projection with its input rows rounded to ONE half and the weights kept split (2 matrix instructions per product), Q | K | V stored as halves,
+ * Q K^T and P V on plain half operands.  The decode is not amplified by guidance x 50 steps, so the question was worth asking per GEMM class
+ * (tools/precision_attribution_decoder.py -> profiles/r06_decoder_precision.json): on the committed fixtures' latents (|z| ~ 75) the form costs
+ * <= 2e-5 on the joints; on unit-normal latents -- where the per-sample cross-attention vector no longer drowns the frame-to-frame signal -- 3.1e-4
+ * (first weight family) and 6.7e-4 .. 8.8e-4 (heavy-tailed second family: rounding Q and K alone costs 5.7e-4), and ANY rounded operand in the
+ * feed-forward block / out-projection / skip / final linears costs 1e-3 .. 4e-3 there.  So nothing in the decoder leaves 22-bit products by default;
+ * the half form exists for weights that pass the probe: same 4 x 64 frames on UNIT-normal latents, against the exact-fp32 decode of the same latents,
+ * bound MLDHIP_PROBE_TOL_HALF = 3e-5 (a decode error of e ends ~ 7.5 e x max|feats| on the joints: 2.5e-4 at most); above it, or with the option
+ * off, the block runs on fp32 Q | K | V and x3 products (decode_half_ok = 0).
  * The other modes: F32 has no such limits; BF16 / FP8 are reported-only modes whose errors bench.py prints. */
 #define MLDHIP_PROBE_TOL 6e-6f
+#define MLDHIP_PROBE_TOL_HALF 3e-5f
 typedef struct mldhip_numeric_info {
   int32_t struct_size;        /* sizeof(mldhip_numeric_info), set by the caller */
   int32_t probed;             /* 1: finalize ran the probe (F16X3 mode, "range_probe" 1) */
@@ -254,6 +270,8 @@ typedef struct mldhip_numeric_info {
   float probe_err_loop;       /* err of part 1 (-1: not probed) */
   float probe_err_decode;
   int64_t nonfinite_values;   /* non-finite latents / joints elements counted since the previous mldhip_numeric_status call */
+  int32_t decode_half_ok;     /* ABI 5.  1: the decoder's self-attention block runs on half Q | K | V ("dec_half"); 0: fp32 Q | K | V, x3 products */
+  float probe_err_decode_half; /* the probe's reading of that form (-1: not probed / option off) */
 } mldhip_numeric_info;
 /* Synchronises the device (it reads the counter), fills *out and resets nonfinite_values.  No reference counterpart. */
 int mldhip_numeric_status(mldhip_handle* h, mldhip_numeric_info* out);

@@ -669,6 +669,13 @@ void ffn_block(Ctx& c, const float* x, float* y, int M, const float* w1, const f
   gemm_ln(c, f2);
 }
 
+// The decoder's self-attention block on half Q | K | V (kernels/dec_half.hpp; option "dec_half", verdict of finalize's probe in dec_half_ok): split mode,
+// row-strip kernels on, D = 256 as 4 heads of 64, at most 16 query tiles per (sample, head)
+bool dec_half_on(const E* e, int T) {
+  return e->dec_half && (e->dec_half_ok || e->dec_half == 2) && staged_prec(e) == PREC_BF16X3 && e->strip_gemm && !e->trace_on && e->cfg.latent_dim == 256 &&
+         e->cfg.num_heads == 4 && T <= 256;
+}
+
 // pos_input: xin holds the time queries themselves (zeros + positional rows, init_queries_kernel): row t of EVERY sample is pe[t], so
 // the layer's Q, K, V depend on t only.  They are then projected once, for sample 0's T rows, and read by every (sample, head)
 // attention workgroup (which still applies its own sample's length mask): exact, and the [B T][3 D] tensor of that layer -- 1.23 GB
@@ -679,12 +686,37 @@ void dec_layer(Ctx& c, int l, const float* xin, float* xout, int B, int T, bool 
   const int D = e->cfg.latent_dim, M = B * T;
   auto ragged = [&](GemmArgs g) { g.skip_lens = e->lens_dev; g.skip_rpg = T; return g; };   // skip all-padding row tiles
   const bool once = pos_input && e->dec_l0_once && B > 1;
-  {
+  if (dec_half_on(e, T) && e->gemm_stream_of.count(L.in_w) && (once || M > e->small_m)) {
+    // the self-attention block on half Q | K | V (kernels/dec_half.hpp, "dec_half"): in-projection = half rows x split weights, output packed
+    // [row][768] halves with q pre-scaled; attention on plain half operands
+    unsigned* qh = reinterpret_cast<unsigned*>(e->QKV);
+    if (once) {
+      // one sample's T rows through the fp32 projection (a launch of a few microseconds), then converted; the halves sit behind the fp32 rows
+      // (B > 1: the buffer holds at least two samples' rows)
+      gemm(c, lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, T, 3 * D));
+      qh += (size_t)T * 3 * D;
+      MLD_LAUNCH(qkv_to_half_kernel, dim3((T * 96 + 255) / 256), dim3(256), 0, c.stream, (const float*)e->QKV, qh, T);
+      count(c);
+      check_launch(c, "qkv_to_half");
+    } else {
+      InprojHArgs a;
+      a.A = xin; a.W = e->gemm_stream_of[L.in_w]; a.bias = L.in_b; a.Y = qh; a.M = M; a.skip_lens = e->lens_dev; a.skip_rpg = T;
+      // 64-row strips, two workgroups per CU (69 KB of LDS, 128 registers): one workgroup's row loads / output stores run under the other's products
+      // ("dec_half" 6: 96-row strips, one per CU -- a third less weight traffic per row)
+      if (e->dec_half == 6) MLD_LAUNCH(strip_inproj_h_kernel<6>, dim3((M + 95) / 96), dim3(512), inproj_h_lds_bytes<6>(), c.stream, a);
+      else MLD_LAUNCH(strip_inproj_h_kernel<4>, dim3((M + 63) / 64), dim3(512), inproj_h_lds_bytes<4>(), c.stream, a);
+      count(c);
+      check_launch(c, "strip_inproj_h");
+    }
+    MLD_LAUNCH(attn_flash_h_kernel, dim3(B * e->cfg.num_heads), dim3(512), kFlashHLdsBytes, c.stream, (const unsigned*)qh, e->AO, (const int*)e->lens_dev, T, e->cfg.num_heads, once ? 1 : 0);
+    count(c);
+    check_launch(c, "attn_flash_h");
+  } else {
     // once: all T rows (no ragged skip: sample 0 may be shorter than the samples that read its rows)
     const GemmArgs q = once ? lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, T, 3 * D) : ragged(lin_args(xin, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
     if (!strip_gemm(c, q, false)) gemm(c, q);
+    dec_attention(c, B, T, nullptr, once ? 1 : 0);
   }
-  dec_attention(c, B, T, nullptr, once ? 1 : 0);
   // Chip-filling launches of the split modes: the rest of the layer in ONE launch (kernels/ffn_strip.hpp, TAIL form) -- the H1 tensor
   // between the out-projection kernel and the feed-forward kernel is not written and read back ("dec_tail", on by default)
   if (e->dec_tail && staged_prec(e) == PREC_BF16X3 && e->strip_gemm && (e->ffn_strip == 3 || (e->ffn_strip == 1 && strip_rows_rt(e, M) == 6)) &&

@@ -143,6 +143,7 @@ struct mldhip_engine {
   int ffn_strip = 1;         // "ffn_strip": register-direct decoder kernels (ffn_strip.hpp, gemm_strip_x3.hpp): 0 off, 1 auto strip height, 4 / 6 = 64 / 96 rows always
   int dec_tail = 1;          // "dec_tail": out-projection + norms + feed-forward block of a decoder layer as one launch (chip-filling launches, split modes)
   int dec_l0_once = 1;       // "dec_l0_once": decoder layer 0 projects its input -- the positional rows, the same for every sample -- once per call ([T] rows instead of [B T])
+  int dec_half = 0;          // "dec_half": OPT-IN (default 0 = fp32 Q | K | V and split x3 products: gemm_strip_x3.hpp, attention.hpp).  1 / 4 / 6: split mode, decoder self-attention block on half Q | K | V (kernels/dec_half.hpp): in-projection with half activation rows x split weights (2 matrix instructions per product), Q | K | V stored as halves, attention on plain half operands -- kept only where finalize's probe reads it below MLDHIP_PROBE_TOL_HALF on the handle's weights; 2 = without that veto (A/B tools).  Off by default because it is not safe in general: profiles/r06_decoder_precision.json (heavy-tailed weights on O(1) latents: 6.7e-4 .. 8.8e-4 on the joints)
   int tile_x3 = 1;           // "tile_x3": split-f16 mode runs the latency kernels (tile32.hpp) on split-f16 MFMAs too (0: exact fp32)
   int strip_gemm = 1;        // "strip_gemm": split modes, decoder / encoder in-projection, out-projection (+ LayerNorms) and skip linears on the row-strip kernels (kernels/gemm_strip_x3.hpp); 0 = the staged 64 x 128 / 64 x 256 tiles
   int gemm_pipe = 1;         // "gemm_pipe": diffusion-only variant, split modes: the K >= 512 GEMMs on the software-pipelined 128 x 256 tile (kernels/gemm_pipe.hpp): 1 = launches of >= 2 048 rows, 2 = always (tests); 0 = the 64 x 128 staged tile
@@ -158,6 +159,8 @@ struct mldhip_engine {
   bool probe_first_call = false; // "range_probe" 2: the next text-conditioned mldhip_sample runs the reverse-loop probe on its own batch first
   bool split_loop_ok = true;     // false: the reverse loop runs on exact-fp32 MFMAs although the handle was created in the split mode
   bool split_decode_ok = true;   // false: decoder / encoder / diffusion-only GEMMs and attention run on exact-fp32 MFMAs
+  bool dec_half_ok = true;       // false: the probe read the half-Q|K|V form of the decoder's self-attention block above MLDHIP_PROBE_TOL_HALF: the decoder keeps fp32 Q | K | V and x3 products
+  float probe_err_decode_half = -1.f;
   float probe_err_loop = -1.f, probe_err_decode = -1.f;   // probe results (max-abs difference / max-abs reference); -1: not probed
   unsigned* nonfinite = nullptr; // device counter: non-finite values seen in the latents / joints a sample call produced (sticky until read)
 

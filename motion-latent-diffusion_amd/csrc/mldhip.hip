@@ -45,6 +45,7 @@
 #include "kernels/ffn_strip.hpp"
 #include "kernels/gemm_strip_x3.hpp"
 #include "kernels/final_strip.hpp"
+#include "kernels/dec_half.hpp"
 
 using namespace mld;
 
@@ -229,6 +230,9 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)ffn_strip_x3_kernel<3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn_strip_lds_bytes<3>());
   (void)hipFuncSetAttribute((const void*)final_strip_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, final_strip_lds_bytes());
   (void)hipFuncSetAttribute((const void*)attn_flash_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFlashLdsBytes);
+  (void)hipFuncSetAttribute((const void*)attn_flash_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFlashHLdsBytes);
+  (void)hipFuncSetAttribute((const void*)strip_inproj_h_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, inproj_h_lds_bytes<4>());
+  (void)hipFuncSetAttribute((const void*)strip_inproj_h_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, inproj_h_lds_bytes<6>());
   (void)hipFuncSetAttribute((const void*)attn_flash128_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFlash128LdsBytes);
   (void)hipFuncSetAttribute((const void*)attn_decode_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_x3_lds_bytes<4>());
   (void)hipFuncSetAttribute((const void*)gemm_pipe_x3_kernel<2, 4, 4, 4, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (gemm_pipe_lds_bytes<2, 4, 4, 4>()));
@@ -408,6 +412,11 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "dec_l0_once") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "dec_l0_once must be 0 or 1");
     e->dec_l0_once = (int)value;
+  } else if (n == "dec_half") {
+    if (value < 0 || value > 6 || value == 3 || value == 5) return e->fail(MLDHIP_EINVAL, "dec_half must be 0 (fp32 Q|K|V, split x3 products), 1 (half Q|K|V; strip height by launch size), 4 or 6 (1 with 64- / 96-row in-projection strips always) or 2 (1, but never overruled by finalize's probe)");
+    // the probe's reading of the form is part of finalize: switching it on (with the veto in force) on a probed handle that has not read it asks for finalize again
+    if (value != 0 && value != 2 && e->finalized && e->range_probe && e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE && e->probe_err_decode >= 0.f && e->probe_err_decode_half < 0.f) e->finalized = false;
+    e->dec_half = (int)value;
   } else if (n == "tile_x3") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "tile_x3 must be 0 or 1");
     e->tile_x3 = (int)value;
@@ -617,24 +626,48 @@ int range_probe(mldhip_handle* e, hipStream_t stream, const float* user_text = n
     Dev z, feats;
     if (z.up(hz) || feats.make((size_t)B * T * NF)) return e->fail(MLDHIP_EHIP, "range probe: hipMalloc");
     std::vector<float> ha, hb;
+    auto run = [&](std::vector<float>& h) -> int {
+      CtxUse use(e, stream);
+      if (use.rc) return use.rc;
+      HIP_TRY(e, hipMemcpyAsync(e->lens_dev, lens.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+      Ctx c{e, stream};
+      e->phase = 1;
+      decode_body(c, z.p, B, T, feats.p);
+      if (c.rc) return c.rc;
+      if (down(feats.p, (size_t)B * T * NF, h)) return e->fail(MLDHIP_EHIP, "range probe: copy");
+      return 0;
+    };
+    const int dh = e->dec_half;
+    struct RestoreDH { mldhip_handle* e; int v; ~RestoreDH() { e->dec_half = v; } } restore_dh{e, dh};
+    e->split_decode_ok = false;                    // the exact-fp32 decode: the reference of every form below
+    if (int rc = run(hb)) return rc;
+    e->split_decode_ok = true;
     float worst = 0.f;
-    for (int form = 0; form < 2; ++form) {
+    for (int form = 0; form < 2; ++form) {         // fp32 Q | K | V, split x3 products: key-blocked and whole-K/V attention
+      e->dec_half = 0;
       e->flash_attn = form == 0 ? 2 : 0;
-      for (int split = 1; split >= 0; --split) {
-        e->split_decode_ok = split != 0;
-        CtxUse use(e, stream);
-        if (use.rc) return use.rc;
-        HIP_TRY(e, hipMemcpyAsync(e->lens_dev, lens.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        Ctx c{e, stream};
-        e->phase = 1;
-        decode_body(c, z.p, B, T, feats.p);
-        if (c.rc) return c.rc;
-        if (down(feats.p, (size_t)B * T * NF, split ? ha : hb)) return e->fail(MLDHIP_EHIP, "range probe: copy");
-      }
+      if (int rc = run(ha)) return rc;
       worst = std::max(worst, rel_err(ha, hb));
+    }
+    float half_err = -1.f;
+    if (dh) {
+      // the opt-in self-attention block on half Q | K | V (kernels/dec_half.hpp): its own bound, read on UNIT-normal latents -- with large latents the per-sample
+      // cross-attention vector drowns the frame-to-frame signal the self-attention carries and the form looks 10-30x better than it is (profiles/r06_decoder_precision.json)
+      std::vector<float> hz1((size_t)B * D);
+      fill(hz1, 1.0f);
+      HIP_TRY(e, hipMemcpy(z.p, hz1.data(), hz1.size() * sizeof(float), hipMemcpyHostToDevice));
+      e->dec_half = 0;
+      e->split_decode_ok = false;
+      if (int rc = run(hb)) return rc;
+      e->split_decode_ok = true;
+      e->dec_half = 2;
+      if (int rc = run(ha)) return rc;
+      half_err = rel_err(ha, hb);
     }
     e->probe_err_decode = worst;
     e->split_decode_ok = worst <= MLDHIP_PROBE_TOL;
+    e->probe_err_decode_half = half_err;
+    e->dec_half_ok = !dh || (half_err >= 0.f && half_err <= MLDHIP_PROBE_TOL_HALF);      // (option off: nothing to veto; switching it on later un-finalizes the handle, mldhip_set_option)
   }
   if (e->group_ready[0] && is_novae(e)) {
     // ---- diffusion-only variant: one denoiser call (every GEMM and the frame-level attention run split in this mode) on 4 CFG rows x 128
@@ -769,8 +802,8 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
   if (e->loop_kernel == 3 && !e->loop_ips)      // (set before finalize: refused here, like mldhip_set_option refuses it afterwards)
     return e->fail(MLDHIP_EINVAL, "loop_kernel 3: the sample-major loop is built for fp32 / split-f16 loop arithmetic, latent_dim 256, ff_size 1024, 4 heads");
   e->finalized = true;
-  e->split_loop_ok = e->split_decode_ok = true;
-  e->probe_err_loop = e->probe_err_decode = -1.f;
+  e->split_loop_ok = e->split_decode_ok = e->dec_half_ok = true;
+  e->probe_err_loop = e->probe_err_decode = e->probe_err_decode_half = -1.f;
   if (e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE && e->range_probe) {
     if (int rc = range_probe(e, stream)) { e->finalized = false; return rc; }
     e->probe_first_call = e->range_probe == 2;
@@ -804,6 +837,8 @@ int mldhip_numeric_status(mldhip_handle* e, mldhip_numeric_info* out) {
   out->probe_err_loop = e->probe_err_loop;
   out->probe_err_decode = e->probe_err_decode;
   out->nonfinite_values = (int64_t)n;
+  out->decode_half_ok = e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE && e->split_decode_ok && e->dec_half && (e->dec_half_ok || e->dec_half == 2);
+  out->probe_err_decode_half = e->probe_err_decode_half;
   return MLDHIP_OK;
 }
 

@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libmldhip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class MldHipError(RuntimeError):
@@ -47,10 +47,12 @@ class Request(C.Structure):
 class NumericInfo(C.Structure):
     """Mirror of ``mldhip_numeric_info`` (include/mldhip.h, "Range contract" of the split-f16 mode)."""
     _fields_ = [("struct_size", C.c_int32), ("probed", C.c_int32), ("loop_split_ok", C.c_int32), ("decode_split_ok", C.c_int32),
-                ("probe_err_loop", C.c_float), ("probe_err_decode", C.c_float), ("nonfinite_values", C.c_int64)]
+                ("probe_err_loop", C.c_float), ("probe_err_decode", C.c_float), ("nonfinite_values", C.c_int64),
+                ("decode_half_ok", C.c_int32), ("probe_err_decode_half", C.c_float)]
 
 
 PROBE_TOL = 6e-6                         # MLDHIP_PROBE_TOL
+PROBE_TOL_HALF = 3e-5                     # MLDHIP_PROBE_TOL_HALF
 COND_TEXT, COND_ACTION = 0, 1            # MLDHIP_COND_*
 VAE_MLD, VAE_ACTOR, VAE_NONE = 0, 1, 2   # MLDHIP_VAE_*
 ARCH_TRANS_ENC, ARCH_TRANS_DEC = 0, 1    # MLDHIP_ARCH_*

@@ -43,6 +43,11 @@ def plan_shards(n: int, world: int, batch_size: int, max_batch: int, policy: str
         why = "forced"
     if policy == "pack":
         per = min(max(batch_size, max_batch), n)
+        if -(-n // per) > world:
+            # more prompts than `world` calls of max_batch hold: every rank is busy and takes ceil(n / world) (its shard is chunked by batch_size and coalesced
+            # per engine call anyway) -- the packed ranges must cover EVERY prompt (advisor r5: n = 512, world = 1, max_batch = 64 used to cover 64)
+            per = -(-n // world)
+            why += "; more prompts than world x max_batch: ceil(n / world) per rank"
         return {"policy": "pack", "busy_ranks": min(world, -(-n // per)), "prompts_per_busy_rank": per, "why": why}
     return {"policy": "spread", "busy_ranks": min(world, n), "prompts_per_busy_rank": per_spread, "why": why}
 

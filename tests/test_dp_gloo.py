@@ -109,3 +109,11 @@ def test_shard_planning_rules():
     spans = [dp.pack_range(300, r, 4, 128) for r in range(4)]
     assert spans == [(0, 128), (128, 256), (256, 300), (300, 300)]
     assert [dp.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    # a forced "pack" never drops prompts (advisor r5): the union of the packed ranges is range(n) for every (n, world, max_batch), also when
+    # n > world x max_batch -- then every rank is busy with ceil(n / world)
+    for n, world, bs, mb in ((512, 1, 64, 64), (2048, 2, 64, 512), (300, 4, 64, 128), (7, 8, 64, 64), (1000, 3, 64, 256), (513, 8, 64, 64), (64, 8, 64, 2048)):
+        plan = dp.plan_shards(n, world, bs, mb, "pack")
+        spans = [dp.pack_range(n, r, world, plan["prompts_per_busy_rank"]) for r in range(world)]
+        covered = [i for lo, hi in spans for i in range(lo, hi)]
+        assert covered == list(range(n)), (n, world, mb, plan, spans)
+        assert sum(1 for lo, hi in spans if hi > lo) == plan["busy_ranks"], (plan, spans)

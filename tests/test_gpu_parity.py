@@ -470,6 +470,69 @@ def test_split_f16_decode_mode_meets_the_joint_tolerance(dev, golden_dir):
     e.close()
 
 
+def test_decoder_half_qkv_opt_in_form_probe_and_parity(dev, golden_dir):
+    """"dec_half" (kernels/dec_half.hpp; OFF by default): the decoder's self-attention block on half Q | K | V.  (a) the default handle does not run
+    it (decode_half_ok = 0, no reading); (b) switched on before finalize, the probe reads the form on unit-normal latents and keeps it exactly when the
+    reading is <= MLDHIP_PROBE_TOL_HALF (the documented rule), on both synthetic weight families; (c) forced ("dec_half" 2), the reference's own ragged
+    MldVae.decode fixture and the bs-64 pipeline fixture stay inside the feature / joint tolerances (|z| ~ 75: the easy case), and on unit-normal
+    latents -- the case the form is opt-in for -- the joints against the oracle are printed and held to the 1e-3 contract on the first family;
+    (d) the 96-row strip form gives the same features to rounding."""
+    sdd = syn.make_denoiser_state_dict()
+    mean, std = syn.make_mean_std()
+    g = _gold(golden_dir, "pipeline_b64.npz")
+    gd = _gold(golden_dir, "vae_decode_b3.npz")
+
+    def mk(sdv, dh):
+        e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=1)
+        e.load_state_dict(sdd, "denoiser."); e.load_state_dict(sdv, "vae."); e.load_tensor("mean", mean); e.load_tensor("std", std)
+        if dh:
+            e.set_option("dec_half", dh)
+        e.finalize()
+        return e
+    sdv1 = syn.make_vae_state_dict()
+    e0 = mk(sdv1, 0)
+    s0 = e0.numeric_status()
+    assert s0["decode_half_ok"] == 0 and s0["probe_err_decode_half"] == -1.0 and s0["decode_split_ok"] == 1, s0
+    e0.close()
+    for fam, sdv in (("family1", sdv1), ("family2", syn.trained_like(sdv1))):
+        e = mk(sdv, 1)
+        s = e.numeric_status()
+        print("dec_half probe", fam, {k: s[k] for k in ("decode_half_ok", "probe_err_decode_half", "probe_err_decode", "decode_split_ok")})
+        assert s["probe_err_decode_half"] > s["probe_err_decode"] >= 0 and s["decode_half_ok"] == (1 if s["probe_err_decode_half"] <= _lib.PROBE_TOL_HALF else 0), s
+        e.close()
+    e = mk(sdv1, 2)
+    assert e.numeric_status()["decode_half_ok"] == 1
+    f3 = torch.full((3, 100, 263), float("nan"), device=dev)
+    e.vae_decode(_cuda(gd["z"], dev), [int(x) for x in gd["lengths"]], f3)
+    torch.cuda.synchronize()
+    ef3 = np.abs(f3.cpu().numpy() - gd["feats"]).max()
+    lat, feats, joints, _ = _run_sample(e, dev, syn.make_batch(64))
+    ej = np.abs(joints.cpu().numpy() - g["joints"]).max()
+    ops = O.TorchOps("float32")
+    zu = syn._rng(41, "dec_half_unit").standard_normal((8, 1, 256)).astype(np.float32)
+    lens = [196, 120, 196, 64, 33, 196, 150, 196]
+    bv = O.to_backend(ops, sdv1)
+    fr = O.vae_decode(ops, bv, ops.asarray(zu), lens)
+    jr = ops.to_numpy(O.feats2joints(ops, fr, ops.asarray(mean), ops.asarray(std)))
+    errs = {}
+    for dh in (0, 2, 6):
+        e.set_option("dec_half", dh)
+        if dh == 6:
+            e.finalize()                              # (a value the probe may veto: un-finalizes a probed handle)
+        fu = torch.zeros(8, 196, 263, device=dev); ju = torch.zeros(8, 196, 22, 3, device=dev)
+        e.vae_decode(_cuda(zu, dev), lens, fu)
+        e.feats2joints(fu, 8, 196, ju)
+        torch.cuda.synchronize()
+        errs[dh] = (max(float(np.abs(ju.cpu().numpy()[i, :n] - jr[i, :n]).max()) for i, n in enumerate(lens)), fu.clone())
+    print("dec_half forced: ragged decode fixture feats %.3e, bs-64 pipeline joints %.3e; unit-normal latents joints vs oracle: x3 %.3e, half %.3e"
+          % (ef3, ej, errs[0][0], errs[2][0]))
+    assert ef3 < 1e-4 and ej < 5e-4
+    assert errs[0][0] < 5e-5 and errs[0][0] < errs[2][0] < 1e-3
+    if e.numeric_status()["decode_half_ok"]:
+        assert (errs[6][1] - errs[2][1]).abs().max().item() < 5e-5
+    e.close()
+
+
 def test_first_decoder_layer_projected_once_and_access_options_change_nothing(dev, golden_dir):
     """"dec_l0_once" (default on): decoder layer 0's in-projection over ONE sample's positional rows, read by every (sample, head)
     attention workgroup -- against the per-sample form: same kernels and products, so the reference's ragged MldVae.decode fixture

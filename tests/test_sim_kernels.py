@@ -1088,3 +1088,57 @@ def test_range_probe_keeps_or_replaces_the_split_kernels_sim():
     e.close()
     assert s1["loop_split_ok"] == 0 and s1["probe_err_loop"] > _lib.PROBE_TOL, s1
     assert err < 1e-3 and s1["nonfinite_values"] == 0, (err, s1)
+
+
+def test_decoder_self_attention_on_half_qkv_sim(ow, aow):
+    """"dec_half" (opt-in, default 0; kernels/dec_half.hpp): the decoder's self-attention block with Q | K | V kept as one half per element -- the in-projection
+    on half rows x split weights with transposed products and a half staging tile (64- and 96-row strips; ragged lengths, a partial last strip,
+    all-padding strips skipped), layer 0's once-per-call projection converted by qkv_to_half_kernel, the key-blocked attention on plain half operands
+    with its P V product transposed (lengths that end inside a 32-key block, more query tiles than a wave's first slot, T > 128) -- against the oracle
+    (cross_attention.py:323-345, mld_vae.py:186-248) and against the fp32-Q|K|V x3 form of the same handle.  The difference between the two forms is
+    the rounding of Q | K | V and of the block's input rows to half: 1e-4 .. 2e-4 on the features of these short sequences and unit-normal latents, what
+    tools/precision_attribution_decoder.py's emulation of the form reads for the same case (2.1e-4) -- the reason the form is opt-in."""
+    ops, _, bv = ow
+    for B, T, lens in ((3, 24, [24, 13, 7]), (2, 136, [136, 71]), (1, 68, [53])):
+        e = simlib.sim_engine(max_batch=B, max_frames=T, num_inference_steps=2, precision=1)
+        e.set_option("gemm_small_m", 0)
+        z = syn._rng(21, f"dh{B}").standard_normal((B, 1, 256)).astype(np.float32)
+        ref = np.asarray(O.vae_decode(ops, bv, z, lens))
+        outs = {}
+        for dh in (0, 1, 6):
+            e.set_option("dec_half", dh)
+            feats = np.full((B, max(lens), 263), np.nan, np.float32)
+            n0 = e.launch_counts()[1]
+            e.vae_decode(z, lens, feats)
+            outs[dh] = (feats, e.launch_counts()[1] - n0)
+            assert np.isfinite(feats).all() and np.abs(feats - ref).max() < (5e-4 if dh else 2e-5), (B, T, dh, np.abs(feats - ref).max())
+            for i, n in enumerate(lens):
+                assert np.all(feats[i, n:] == 0)
+        d = np.abs(outs[1][0] - outs[0][0]).max()
+        assert 1e-6 < d < 5e-4, d
+        assert np.abs(outs[6][0] - outs[1][0]).max() < 2e-5            # strip height changes the staging only
+        # layer 0 of a B > 1 call pays one conversion launch more; every other layer's pair of launches is a pair again
+        assert outs[1][1] == outs[0][1] + (1 if B > 1 else 0), (outs[0][1], outs[1][1])
+        e.set_option("dec_l0_once", 0)                                 # layer 0 through the strip kernel like the others
+        e.set_option("dec_half", 1)
+        feats = np.full((B, max(lens), 263), np.nan, np.float32)
+        e.vae_decode(z, lens, feats)
+        assert np.abs(feats - outs[1][0]).max() < 5e-4              # (the once-per-call projection multiplies fp32 rows, the strip kernel half rows)
+        assert np.abs(feats - ref).max() < 5e-4
+        e.close()
+    # the actor decoder (actor_vae.py:209-235) shares the layer: same option, sinusoidal queries
+    opsa, _, bva = aow
+    za = syn._rng(22, "dha").standard_normal((3, 1, 256)).astype(np.float32)
+    alens = [24, 9, 17]
+    aref = np.asarray(O.actor_decode(opsa, bva, za, alens))
+    aeng = simlib.sim_action_engine(max_batch=4, max_frames=24, num_inference_steps=2, precision=1)
+    aeng.set_option("gemm_small_m", 0)
+    got = {}
+    for dh in (0, 1):
+        aeng.set_option("dec_half", dh)
+        feats = np.full((3, 24, 150), np.nan, np.float32)
+        aeng.vae_decode(za, alens, feats)
+        assert np.abs(feats - aref).max() < 2e-4
+        got[dh] = feats
+    aeng.close()
+    assert 0 < np.abs(got[1] - got[0]).max() < 5e-4
