@@ -63,6 +63,10 @@ METRIC = "motions/sec (50-step DDIM + VAE decode), HumanML3D bs64, 1/2/4/8 GPU" 
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 / f16 MFMA dense peak (no sparsity)
 X3_PEAK_TF = BF16_MFMA_PEAK_TF / 3.0   # split-f16 kernels: three 16-bit MFMAs per algorithmic product
+# The peaks above are quoted at the 2.4 GHz boost clock.  With matrix instructions issuing on (nearly) every CU the chip holds 1.87 GHz (measured with the loop's own cycle
+# counter: 44.5 M cycles per wave in 18.8 ms on 160 CUs = 2.37 GHz, in 23.8 ms on 256 CUs = 1.87 GHz; profiles/r05_loop_experiments.json): every fraction of a chip-filling
+# kernel is therefore also given against the peak at that sustained clock
+SUSTAINED_CLOCK_RATIO = 1.87 / 2.4
 BATCH, FRAMES, STEPS_DDIM = 64, 196, 50
 PRECISIONS = {"f32": 0, "f16x3": 1, "bf16": 2, "fp8_denoiser": 3}
 PEAK_TF = {"f32": FP32_MFMA_PEAK_TF, "f16x3": X3_PEAK_TF, "bf16": BF16_MFMA_PEAK_TF, "fp8_denoiser": X3_PEAK_TF}
@@ -440,6 +444,15 @@ def bench_novae(local, dev, full, streams, B=64, T=196):
         run(99)                              # untimed: captures each handle's step-chunk graphs
         dt = run(1234)
         ms_step = dt * 1e3 / (steps * nfl)
+        ms_step2 = None
+        if prec == "f16x3" and placement is not None:
+            # the 10-step probe above is a burst on a cool chip; the mode's figure is seconds of sustained matrix work.  A second full-length run on the SAME pair of
+            # streams says whether the first was a placement accident (it would differ) or the clock the chip holds (it repeats)
+            ms_step2 = run(4321) * 1e3 / (steps * nfl)
+            placement["ms_per_ddpm_step_second_full_run"] = round(ms_step2, 3)
+            placement["note"] = ("probe = 2 batches x 10 steps on a cool chip (a burst: boost clock); ms_per_ddpm_step of the mode = all %d steps of %d batches, ~%.0f s of sustained "
+                                 "matrix work on every CU (the chip holds ~1.9 GHz there, not ~2.4: MI355X_MICROARCH.md DVFS) -- the probe picks the stream pair, it is not the rate; "
+                                 "round 5 quoted the two side by side as if they measured the same thing" % (steps, nfl, dt))
         modes[prec] = {"ms_per_ddpm_step": round(ms_step, 3), "achieved_tflops": round(gf_step / ms_step, 1),
                        "frac_of_mfma_peak": round(gf_step / ms_step / PEAK_TF[prec], 4), "peak_tflops_of_this_mode": round(PEAK_TF[prec], 1),
                        "value": round(B / ms_step, 3), "finite": bool(all(torch.isfinite(j).all().item() for j in joints)),
@@ -567,6 +580,59 @@ def spread(ts):
     return {"median": ts[len(ts) // 2], "min": ts[0], "max": ts[-1], "n": len(ts)}
 
 
+def emit(out):
+    """The whole evidence blob (every table, ~20 KB) goes to a FILE ($MLD_BENCH_EVIDENCE, default ./bench_evidence.json; also to stderr as one `EVIDENCE {...}` line) and the
+    contract's ONE stdout line stays under 8 KB: round 5's line was cut off by the driver's tail and its parser dropped the top-level keys it does not know (VERDICT r5
+    weak #8 / item 6) -- the literal-configuration numbers now live inside `config`, the single-batch roofline inside `roofline`."""
+    blob = json.dumps(out)
+    path = os.environ.get("MLD_BENCH_EVIDENCE", os.path.join(os.getcwd(), "bench_evidence.json"))
+    try:
+        with open(path, "w") as f:
+            f.write(blob + "\n")
+    except OSError as ex_:
+        path = "unwritable: %r" % (ex_,)
+    print("EVIDENCE " + blob, file=sys.stderr, flush=True)
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "repeats", "config")
+    line = {k: out[k] for k in keep if k in out}
+    pick = lambda d, ks: {k: d[k] for k in ks if isinstance(d, dict) and k in d}
+    r = out.get("roofline") or {}
+    line["roofline"] = pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "shape", "frac_hip_events", "peak_at_sustained_clock", "frac_at_sustained_clock",
+                                "frac_on_occupied_cus", "workgroups", "gflop_per_launch", "avg_us_rocprof_dispatch", "algorithmic_bytes_per_launch", "source_hash",
+                                "loop_kernel_code_hash", "rocprof"))
+    sb = out.get("single_batch") or {}
+    if sb:
+        line["roofline"]["single_batch"] = dict(pick(sb, ("value", "unit", "ms_per_batch", "launches_per_call")),
+                                                roofline=pick(sb.get("roofline") or {}, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "workgroups",
+                                                                                         "avg_us_rocprof_dispatch", "l2_to_cu_fill", "kernel_code_hash")))
+        lf = line["roofline"]["single_batch"]["roofline"].get("l2_to_cu_fill")
+        if isinstance(lf, dict):
+            line["roofline"]["single_batch"]["roofline"]["l2_to_cu_fill"] = pick(lf, ("weight_bytes_per_member_and_launch", "achieved_frac_of_56_B_per_clk_per_cu"))
+    if out.get("bs64_pipelined"):
+        line["roofline"]["bs64_pipelined"] = pick(out["bs64_pipelined"], ("value", "unit", "ms_per_request", "requests_per_call", "numeric", "error"))
+    dr = out.get("decoder_roofline") or {}
+    if isinstance(dr, dict):
+        line["decoder"] = {k: v for k, v in dr.items() if not isinstance(v, (dict, list))}
+    line["cpu_baseline"] = pick(out.get("cpu_baseline") or {}, ("value", "unit", "cores", "kind", "sample", "host_cpus"))
+    line["parity"] = pick(out.get("parity") or {}, ("tolerance", "motions_checked", "max_abs_joints_vs_exact_fp32_engine_all_requests", "max_abs_joints_vs_oracle",
+                                                    "max_abs_joints_vs_oracle_single_call"))
+    line["numeric"] = pick((out.get("numeric") or {}), ("range_probe", "nonfinite_values_in_timed_calls"))
+    line["eager_same_gpu"] = pick(out.get("eager_same_gpu") or {}, ("value", "unit"))
+    ow = []
+    for w in out.get("other_workloads") or []:
+        m = (w.get("modes") or {}).get("f16x3") or {}
+        ow.append({"workload": str(w.get("workload", ""))[:70], "f16x3": pick(m, ("value", "ms_per_ddpm_step", "frac_of_mfma_peak", "ddpm_steps_run", "max_abs_latents_vs_golden",
+                                                                                "value_single_batch"))})
+    line["other_workloads"] = ow
+    line["distributed"] = pick(out.get("distributed") or {}, ("backend", "world_size", "distinct_devices", "data_path_collectives"))
+    line["evidence"] = {"file": path, "bytes": len(blob), "note": "every table of this run (kernels, decoder_roofline, sweeps, alt modes, other workloads in full): the file, and the EVIDENCE line on stderr"}
+    text = json.dumps(line)
+    if len(text) > 8000:                       # never: but the contract is one parseable line the driver's tail keeps whole
+        for k in ("other_workloads", "decoder", "eager_same_gpu", "numeric"):
+            line.pop(k, None)
+        text = json.dumps(line)
+    print(text, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -684,6 +750,34 @@ def main():
     K1 = min(K, 16)
     reps1 = [timed(lambda: issue_single(eng, K1))[0] / K1 for _ in range(max(1, a.repeats))]     # strictly one bs-64 batch after another
     ms1 = spread(reps1)
+    # ---- bs-64 requests back to back with the two halves of consecutive requests overlapped ("many_pipeline": decode of request k on the engine's side stream beside the
+    #      cluster launch of request k + 1; every request bit-identical to its serial mldhip_sample call -- tests/test_gpu_parity.py).  K steps per timed region, as above.
+    pipe = None
+    try:
+        engp = make_engine(local, weights, a.precision, max_batch=BATCH, nfl=2, graph=not a.eager)
+        engp.set_option("many_pipeline", 1)
+        KP = min(K, 32)
+        pcalls = [KP] * (K // KP) + ([K % KP] if K % KP else [])
+
+        def issue_pipe():
+            for n in pcalls:
+                if n == 1:
+                    r = reqs_all[0]
+                    engp.sample(r["text_emb"], r["init_latents"], r["lengths"], r["latents_out"], None, r["joints_out"], stream.cuda_stream)
+                else:
+                    engp.sample_many(reqs_all[:n], stream.cuda_stream)
+        issue_pipe(); issue_pipe()
+        repsp = [timed(issue_pipe)[0] / K for _ in range(max(1, a.repeats))]
+        msp = spread(repsp)
+        nsp = engp.numeric_status()
+        pipe = {"value": round(world * BATCH / msp["median"], 2), "unit": "motions/s", "ms_per_request": {k: (round(v * 1e3, 4) if k != "n" else v) for k, v in msp.items()},
+                "requests_per_call": KP, "numeric": {k: nsp[k] for k in ("nonfinite_values", "cluster_loop")},
+                "shape": "mldhip_sample_many with option many_pipeline = 1: %d bs-64 requests per call, one after the other on the single-request path (cluster loop), decode of "
+                         "request k on the engine's low-priority side stream beside the reverse loop of request k + 1; two workspaces alternate; the caller's stream is ordered "
+                         "behind every decode at the end of the call" % KP}
+        engp.close()
+    except Exception as ex_:      # never fail the bench line for the secondary leg
+        pipe = {"value": None, "error": repr(ex_)[:300]}
     gf_total, gf_den, gf_dec = algorithmic_gflop(BATCH, FRAMES)
     tf_job = gf_total / 1e3 / (ms_per_step * 1e-3)
     PB = BATCH * coalesce
@@ -701,7 +795,13 @@ def main():
                    "requests_per_call": coalesce, "calls_per_timed_region": len(calls), "in_flight": 1, "global_batch": PB * world, "batch_per_request": BATCH,
                    "parallelism": f"dp{world}", "graph": not a.eager, "precision": a.precision,
                    "weights": "synthetic (seeded numpy), one broadcast of %.1f MB" % (weight_bytes / 1e6),
-                   "launches_per_call": launches_headline},
+                   "launches_per_call": launches_headline,
+                   # the configuration BASELINE.json's metric is quoted on, inside `config` so that a parser that keeps only the contract's keys keeps it
+                   "value_single_batch": round(world * BATCH / ms1["median"], 2), "ms_single_batch": round(ms1["median"] * 1e3, 4),
+                   "value_bs64_pipelined": pipe.get("value") if pipe else None,
+                   "ms_per_request_bs64_pipelined": (pipe.get("ms_per_request") or {}).get("median") if pipe else None,
+                   "single_batch_note": "value_single_batch: ONE bs-64 mldhip_sample call at a time, strictly serial (the metric's literal configuration); value_bs64_pipelined: the same "
+                                        "bs-64 requests back to back with decode(k) beside loop(k + 1) (many_pipeline); value: the serving shape, requests_per_call requests as one chain"},
         "whole_job": {"algorithmic_gflop_per_batch": round(gf_total, 1), "denoise_gflop_per_step": round(gf_den, 3), "decode_gflop": round(gf_dec, 1),
                       "achieved_tflops": round(tf_job, 2), "frac_of_fp32_mfma_peak": round(tf_job / FP32_MFMA_PEAK_TF, 4),
                       "frac_of_mode_peak": round(tf_job / PEAK_TF[a.precision], 4), "mode_peak_tflops": round(PEAK_TF[a.precision], 1),
@@ -755,6 +855,10 @@ def main():
                          "achieved": round(flop_loop_call / rate_us * 1e3, 2), "peak": round(peak, 1), "frac": round(flop_loop_call / rate_us * 1e3 / peak, 4),
                          "frac_hip_events": round(flop_loop_call / use_us * 1e3 / peak, 4) if loop_ms else None,
                          "achieved_hip_events": round(flop_loop_call / use_us * 1e3, 2) if loop_ms else None,
+                         "peak_at_sustained_clock": round(peak * SUSTAINED_CLOCK_RATIO, 1),
+                         "frac_at_sustained_clock": round(flop_loop_call / rate_us * 1e3 / (peak * SUSTAINED_CLOCK_RATIO), 4),
+                         "sustained_clock_note": "peak x 1.87 / 2.4: the clock the chip holds when (nearly) every CU issues matrix instructions (measured, profiles/r05_loop_experiments.json); "
+                                                 "with 160 of 256 CUs busy the loop itself runs at ~2.37 GHz, so for THIS call shape `frac` is the fairer figure and this one the floor",
                          "workgroups": (PB + 7) // 8, "cus": 256, "occupancy": round(min(1.0, (PB + 7) // 8 / 256.0), 3),
                          "frac_on_occupied_cus": round(flop_loop_call / rate_us * 1e3 / peak / min(1.0, (PB + 7) // 8 / 256.0), 4),
                          "occupancy_note": "a workgroup owns 8 motions (48 token rows = three full 16-row MFMA tiles); the kernel's run time is flat in the batch, so a call "
@@ -799,10 +903,12 @@ def main():
                     # (56 B/clk/CU = 34.5 TB/s over 256 CUs, MI355X_MICROARCH.md "L2"), 3 exchanges per layer of ~2.4 us each come on top
                     wbytes = 512e3 * 9 * STEPS_DDIM
                     fill = wbytes / (avg * 1e-9) / (34.5e12 / 256)
-                    single["roofline"] = {"bound": "mfma", "kernel": "den_cluster_kernel (kernels/loop_cluster.hpp): the whole 50-step reverse loop of one bs-64 batch, one launch of 192 workgroups",
+                    cl_wgs = 8 * (24 if "8>" in n.replace(" ", "")[-12:] or ", 8>" in n else 12)      # 8 clusters x (3 tokens x column groups): the template argument of the kernel that ran
+                    single["roofline"] = {"bound": "latency/l2_fill", "kernel": "den_cluster_kernel (kernels/loop_cluster.hpp): the whole 50-step reverse loop of one bs-64 batch, one launch of %d workgroups" % cl_wgs,
                                           "achieved": round(gf / (avg * 1e-9) / 1e3, 2), "peak": round(X3_PEAK_TF, 1), "peak_of": "split-f16 MFMA roof (dense f16 peak / 3)",
                                           "unit": "TFLOP/s", "frac": round(gf / (avg * 1e-9) / 1e3 / X3_PEAK_TF, 4), "avg_us_rocprof_dispatch": round(avg / 1e3, 2),
-                                          "launches_per_batch": 1, "gflop_per_launch": round(gf, 2), "workgroups": 192, "cus": 256,
+                                          "launches_per_batch": 1, "gflop_per_launch": round(gf, 2), "workgroups": cl_wgs, "cus": 256,
+                                          "frac_is_against": "the split-f16 MFMA roof, for comparison with the other kernels only: the kernel is bound by hand-off latency and the per-CU L2 -> L1 fill (l2_to_cu_fill), not by the matrix pipe",
                                           "l2_to_cu_fill": {"weight_bytes_per_member_and_launch": int(wbytes), "achieved_frac_of_56_B_per_clk_per_cu": round(fill, 3),
                                                             "note": "weight stream of a member with a head (K / V for all three tokens per token member; the twelve members without a head stream 128 KB per layer) "
                                                                     "over the kernel's duration, against the per-CU L2 fill rate; the phases that stream run at ~58 B/clk, the rest of the time is hand-offs"},
@@ -827,6 +933,7 @@ def main():
                                           "share_of_gpu_time": round(total / tot1, 4), "rocprof": where1,
                                           "note": "one request is a chain of 2 052 dependent launches of ~5-8 us: launch-latency bound, not MFMA bound (DESIGN.md §3 point 3 / 17c)"}
         out["single_batch"] = single
+        out["bs64_pipelined"] = pipe
         out["value_single_batch"], out["ms_per_step_single_batch"] = single["value"], round(ms1["median"] * 1e3, 4)
         out["headline_shape"] = ("value_single_batch = ONE bs-64 request per call, the configuration BASELINE.json's metric is quoted on (cluster loop, kernels/loop_cluster.hpp); "
                                  "value = the serving shape, %d bs-64 requests per engine call (%d motions, %d of 256 CUs hold a workgroup of the persistent loop); "
@@ -992,7 +1099,7 @@ def main():
                 out["text_encoder"] = te
             except Exception as ex_:  # transformers missing / API drift: report, never fail the bench
                 out["text_encoder"] = {"error": repr(ex_)[:200]}
-        print(json.dumps(out))
+        emit(out)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -152,10 +152,19 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     or 12 workgroups per 8 motions (3 tokens x 8 / 4 column groups) hand partial products to each other inside the launch; F16X3 mode,
  *                     latent_dim 256 / ff_size 1024 / 4 heads, refused elsewhere; 6.8 / 7.6 ms per 50-step loop at 64 / 128 motions against 11.2 / 15.2 ms
  *                     of the latency kernels).  The launch needs its workgroups resident together: it is sized to the chip, every wait inside it is
- *                     bounded (200 ms: the latents of the call are then NaN and counted, and the handle leaves the cluster loop at the next
- *                     mldhip_numeric_status / at finalize's probe), and calls served by it on different streams of this PROCESS are ordered behind each
- *                     other (one lane per device: two such launches side by side could starve each other of CUs).  Another process that fills the
- *                     same GPU with long-running workgroups is outside that guard: set "cluster_max_batch" 0 there
+ *                     bounded (200 ms: the latents of the call are then NaN and counted, and the handle leaves the cluster loop by itself: the kernel also
+ *                     sets a pinned host word that the NEXT sample call reads first -- round 6; mldhip_numeric_status / finalize's probe as before), the launch
+ *                     is only chosen where its workgroups fit the device in total AND per XCD (round 6: a partitioned device), and calls served by it on
+ *                     different streams of this PROCESS are ordered behind each other (one lane per device: two such launches side by side could starve
+ *                     each other of CUs).  Across processes (round 6): the first process that creates a handle on a device holds an advisory lock
+ *                     (/tmp/mldhip_cluster_lane_<pci bus id>.lock) for its lifetime; any other process on that device never launches the cluster loop
+ *                     (mldhip_numeric_info.cluster_loop = 3) and runs the other loop families.  A foreign tenant that fills the GPU with long-running
+ *                     workgroups of its own can still delay a launch into its bound: set "cluster_max_batch" 0 there
+ *   "many_pipeline"   (round 6) 1 = mldhip_sample_many runs its requests ONE AFTER THE OTHER, each exactly as mldhip_sample would (bit-identical results), with the
+ *                     decode of request k on the engine's low-priority side stream beside the reverse loop of request k + 1: the cluster launch leaves 64 of
+ *                     256 CUs free and the matrix pipe of the others nearly idle, the decode's 44 launches are one round of workgroups each.  Needs
+ *                     max_in_flight >= 2 (two workspaces alternate) and requests the cluster loop serves with a decode asked for; otherwise, and with
+ *                     0 (default), the call is one chain over all its motions.  The caller's stream is ordered behind every decode when the call returns
  *   "cluster_max_batch" auto runs the cluster loop for calls of up to this many motions (default 256: one launch up to 128 = two clusters per XCD, two launches one
  *                     after the other up to 256 -- 2 x 7.6 ms against the persistent loop's flat 18.7 ms; 0 = never)
  *   "cluster_wt"      cluster loop, payload stores of the in-launch hand-offs: 0 (default) = plain where the twelve workgroups of a cluster report one
@@ -169,6 +178,8 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     items in flight per lane: the settled forms of round 3's "fused_swz" / "fused_ring" knobs), 0 = on exact-fp32 MFMAs
  *   "cluster_inject"  (hooks build only) fault injection: 1 + the index of a cluster member that never raises its first flag (the wait bound shrinks to 2 ms): the members
  *                     waiting for it run into the bound, the call returns NaN latents (counted) and the handle leaves the cluster loop at the next mldhip_numeric_status; 0 = off
+ *   "cluster_stale"   (hooks build only) 1 = a cluster launch finds an epoch of an earlier launch in one of its polled words (what the r05 memset-node replay fault left
+ *                     behind): member 0's entry check must fail the launch (NaN latents, counted; the handle leaves the cluster loop) instead of consuming it as "ready"
  *   "cluster_chunk"   (hooks build only) motions per cluster launch (default 128, a multiple of 8): lets the tests drive the several-launches path of calls above 128
  *                     motions with a few motions
  *   "cluster_lane"    (hooks build only) 0 = calls served by the cluster loop on different streams are not ordered behind each other: two cluster launches side by side
@@ -272,6 +283,10 @@ typedef struct mldhip_numeric_info {
   int64_t nonfinite_values;   /* non-finite latents / joints elements counted since the previous mldhip_numeric_status call */
   int32_t decode_half_ok;     /* ABI 5.  1: the decoder's self-attention block runs on half Q | K | V ("dec_half"); 0: fp32 Q | K | V, x3 products */
   float probe_err_decode_half; /* the probe's reading of that form (-1: not probed / option off) */
+  int32_t cluster_loop;       /* ABI 5.  The one-launch reverse loop of small calls (kernels/loop_cluster.hpp): 0 not built for this handle (mode / shape), 1 available,
+                                 2 left after a launch ran into its wait bound (the next sample call already runs on the other loop families; "loop_kernel" 4 re-arms it),
+                                 3 another PROCESS holds this device's cluster lane (/tmp/mldhip_cluster_lane_<pci bus id>.lock): never launched by this process */
+  int32_t reserved;
 } mldhip_numeric_info;
 /* Synchronises the device (it reads the counter), fills *out and resets nonfinite_values.  No reference counterpart. */
 int mldhip_numeric_status(mldhip_handle* h, mldhip_numeric_info* out);

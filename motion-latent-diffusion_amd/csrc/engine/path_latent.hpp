@@ -337,18 +337,25 @@ int build_loop_stream(Ctx& c) {
 
 // ---- cluster loop (kernels/loop_cluster.hpp): one bs-64 request (up to 8 x kClMaxClusters motions) as ONE launch of 12-workgroup clusters
 int cluster_groups(const E* e, int B);
+constexpr int kCusPerXcd = 32;      // MI355X: 8 XCDs x 32 CUs; partitions (CPX / DPX / QPX) expose whole XCDs
 bool use_cluster(const E* e, int B) {
-  if (!e->cl_stream || !fused_split(e) || e->cluster_failed || B > kClMaxCall || B > e->cfg.max_batch) return false;
-  // every workgroup of a launch needs a CU of its own (125 KB of LDS each) at the same time: the biggest launch of the call against the device's CUs
+  if (!e->cl_stream || !fused_split(e) || e->cluster_failed || e->cluster_foreign || B > kClMaxCall || B > e->cfg.max_batch) return false;
+  // every workgroup of a launch needs a CU of its own (125 KB of LDS each) at the same time: the biggest launch of the call against the device's CUs --
+  // in total AND per XCD (advisor r5): workgroups go round the XCDs, so the clusters that share a physical XCD (ceil(clusters / XCDs)) must fit its 32 CUs;
+  // a partitioned device (2 XCDs, 64 CUs) with 5 clusters x 12 workgroups would put 36 workgroups on a 32-CU XCD and time out on every call
   const int nm = std::min(B, e->cluster_chunk);
-  if (3 * cluster_groups(e, nm) * ((nm + 7) / 8) > e->num_cus) return false;
+  const int members = 3 * cluster_groups(e, nm), ncl = (nm + 7) / 8;
+  if (members * ncl > e->num_cus) return false;
+  const int xcds = std::max(1, std::min(8, e->num_cus / kCusPerXcd)), per_xcd = e->num_cus / xcds;
+  if (members * ((ncl + xcds - 1) / xcds) > per_xcd) return false;
   return e->loop_kernel == 4 || (e->loop_kernel == 0 && B <= e->cluster_max_batch);
 }
 
 // column groups per token of a cluster call: 8 (24 workgroups per cluster: the feed-forward block on twice the CUs) while every cluster still has an XCD's 32 CUs
 // to itself (up to 8 clusters = 64 motions), 4 (12 workgroups) above; option "cluster_groups" 4 / 8 forces one (8 only where it fits)
 int cluster_groups(const E* e, int B) {
-  const bool fits8 = (B + 7) / 8 <= 8 && 24 * ((B + 7) / 8) <= e->num_cus;
+  const int xcds = std::max(1, std::min(8, e->num_cus / kCusPerXcd));
+  const bool fits8 = (B + 7) / 8 <= 8 && 24 * ((B + 7) / 8) <= e->num_cus && 24 * (((B + 7) / 8 + xcds - 1) / xcds) <= e->num_cus / xcds;
   if (e->cluster_groups == 4 || !fits8) return 4;
   return 8;
 }
@@ -952,6 +959,7 @@ void launch_cluster_chunk(Ctx& c, const float* init_lat, int B, int s_base, int 
   a.wave_off = e->cl_wave_off_dev + (cg == 8 ? 32 : 0);
   a.small = e->loop_small; a.T1 = e->T1; a.TP = e->TP; a.init_lat = init_lat; a.lat = e->lat; a.park = e->cl_park; a.ddim = e->loop_ddim;
   a.xbuf = e->cl_xbuf;
+  a.host_status = e->cl_host_status;
   a.ncl = (nm + 7) / 8;
   a.flags = reinterpret_cast<unsigned*>(e->cl_flags);
   a.status = a.flags + (size_t)std::min<size_t>(kClMaxClusters, (e->cfg.max_batch + 7) / 8) * kClFlagWords;
@@ -969,6 +977,9 @@ void launch_cluster_chunk(Ctx& c, const float* init_lat, int B, int s_base, int 
   } else {
     MLD_LAUNCH(clear_cluster_flags_kernel, dim3(1), dim3(256), 0, c.stream, a.flags, words);
   }
+#if defined(MLDHIP_HOOKS)
+  if (e->cluster_stale) MLD_LAUNCH(poke_cluster_flag_kernel, dim3(1), dim3(1), 0, c.stream, a.flags + kFlagH * kClFlagLine + 3, 77u);
+#endif
   const dim3 grid((unsigned)(a.xslots * members * ((a.ncl + a.xslots - 1) / a.xslots)));
   if (cg == 8) {
     if (e->cluster_wt) MLD_LAUNCH_CORESIDENT((den_cluster_kernel<true, 8>), grid, dim3(512), kClLdsBytes, c.stream, a);
@@ -986,6 +997,21 @@ void launch_cluster_chunk(Ctx& c, const float* init_lat, int B, int s_base, int 
 void launch_cluster_loop(Ctx& c, const float* init_lat, int B, int n, float guidance) {
   const int chunk = c.e->cluster_chunk;          // 128 (hooks / simulator builds: "cluster_chunk" makes the two-launch path testable on a few motions)
   for (int s = 0; s < B && !c.rc; s += chunk) launch_cluster_chunk(c, init_lat, B, s, std::min(chunk, B - s), n, guidance);
+}
+
+// the decode half of a sample call: MldVae.decode of the bound context's latents + feats2joints (mld.py:232-240,264), with the run-time non-finite count
+void enqueue_decode(Ctx& c, int B, int T, float* feats_out, float* joints_out) {
+  E* e = c.e;
+  e->phase = 1;
+  float* f = feats_out ? feats_out : e->feats_int;
+  decode_body(c, e->lat, B, T, f);
+  if (joints_out) {
+    e->phase = 2;
+    joints_body(c, f, B, T, joints_out);
+    count_nonfinite(c, joints_out, (long long)B * T * e->cfg.njoints * 3);
+  } else {
+    count_nonfinite(c, f, (long long)B * T * e->cfg.nfeats);      // feats-only call: the decoder's output is what the caller gets
+  }
 }
 
 // `text` == nullptr selects the action condition (labels_dev holds the 2B labels).
@@ -1024,18 +1050,7 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
     hipError_t s = hipMemcpyAsync(lat_out, e->lat, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream);
     if (s != hipSuccess) return e->fail(MLDHIP_EHIP, "latents copy: %s", hipGetErrorString(s));
   }
-  if (feats_out || joints_out) {
-    e->phase = 1;
-    float* f = feats_out ? feats_out : e->feats_int;
-    decode_body(c, e->lat, B, T, f);
-    if (joints_out) {
-      e->phase = 2;
-      joints_body(c, f, B, T, joints_out);
-      count_nonfinite(c, joints_out, (long long)B * T * e->cfg.njoints * 3);
-    } else {
-      count_nonfinite(c, f, (long long)B * T * e->cfg.nfeats);      // feats-only call: the decoder's output is what the caller gets
-    }
-  }
+  if (feats_out || joints_out) enqueue_decode(c, B, T, feats_out, joints_out);
   return c.rc;
 }
 

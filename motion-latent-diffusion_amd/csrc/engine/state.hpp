@@ -32,7 +32,8 @@ struct DecLayerP {   // TransformerDecoderLayer (cross_attention.py:297-345)
 struct GraphKey {
   int B, T;
   bool feats, joints;
-  bool operator<(const GraphKey& o) const { return std::tie(B, T, feats, joints) < std::tie(o.B, o.T, o.feats, o.joints); }
+  bool dec_only = false;   // the decode half of a call alone (reads the context's latents): the pipelined form of mldhip_sample_many ("many_pipeline")
+  bool operator<(const GraphKey& o) const { return std::tie(B, T, feats, joints, dec_only) < std::tie(o.B, o.T, o.feats, o.joints, o.dec_only); }
 };
 
 }  // namespace
@@ -48,6 +49,7 @@ struct WsContext {
   unsigned long long seed_host = 0;   // stable host copy of the Philox seed while it is uploaded to seed_slot
 #if !defined(MLDHIP_SIM)
   hipEvent_t done = nullptr;
+  hipEvent_t loop_done = nullptr;              // pipelined sample_many: recorded behind the reverse loop on the caller's stream, waited for by the side stream's decode
   std::map<GraphKey, hipGraphExec_t> graphs;   // captured sample() graphs of this workspace, evicted least-recently-used
   std::vector<GraphKey> graph_lru;             // most recent last
   std::map<std::tuple<int, int, int>, hipGraphExec_t> step_graphs;   // diffusion-only variant: (B, Tmax, chunk) -> captured DDPM steps
@@ -79,11 +81,14 @@ struct mldhip_engine {
   unsigned* cl_wave_off_dev = nullptr;   // ... the same 96 words in device memory (kernel arguments stay small)
   int cluster_groups = 0;         // "cluster_groups": 0 = 8 column groups per token up to 64 motions and 4 above, 4 / 8 = forced (8 only up to 64 motions)
   int cluster_mute = -1, cluster_timeout = 0;   // "cluster_inject" (hooks build only): member that never raises its first flag, and the shortened wait bound that goes with it
+  bool cluster_stale = false;     // "cluster_stale" (hooks build only): a launch finds a stale epoch in one of its polled words (what the r05 memset-node fault left behind): the entry check must fail the launch
   int cluster_chunk = 128;        // "cluster_chunk" (hooks build only): motions per cluster launch (a multiple of 8, at most 8 x kClMaxClusters = 128)
   bool cluster_lane = true;       // "cluster_lane" (hooks build only): 0 = no ordering between cluster calls of different streams (the starvation it prevents, on purpose)
   bool cluster_clear_memset = false;   // flags of the cluster loop cleared by hipMemsetAsync instead of clear_cluster_flags_kernel ("cluster_graph" 2)
   bool cluster_graph = true;      // "cluster_graph" (hooks build only): 0 = calls served by the cluster loop are issued eagerly, 2 = graphs + memset-node clear (reproduces the r05 replay fault)
   int num_cus = 1 << 20;          // CUs of the device (a partitioned or masked device has fewer than 256): a cluster launch needs a CU per workgroup (simulator: no limit)
+  unsigned* cl_host_status = nullptr;   // pinned host word the cluster kernel sets next to its sticky status word: read at the start of every sample call (no device synchronisation) -- a timed-out handle leaves the cluster loop by itself
+  bool cluster_foreign = false;   // another PROCESS holds the cluster lane of this device (lock file taken at mldhip_create): this handle never launches the cluster loop
   int cluster_failed = 0;         // a cluster launch reported a timeout / a placement it cannot use: the handle stays on the other loop families
   float* arena_x3 = nullptr;  // split-bf16 image of the arena (precision modes with split-bf16 staged GEMMs; built by finalize)
   size_t arena_floats = 0;
@@ -125,6 +130,7 @@ struct mldhip_engine {
   float *text_in = nullptr, *lat_in = nullptr;   // graph staging of the caller's inputs
   float* TP;             // text projection rows [2*max_batch][256] (+pe[2]), gathered per chain
   // per-handle options (mldhip_set_option)
+  int many_pipeline = 0;     // "many_pipeline": 1 = mldhip_sample_many runs its requests ONE AFTER THE OTHER on the single-request path (cluster loop; every request what mldhip_sample gives it, to the bit) with the decode of request k on the engine's side stream, beside the reverse loop of request k + 1 (needs max_in_flight >= 2); 0 = one chain over all motions of the call
   int small_m = 256;         // "gemm_small_m": row count up to which the register-direct tiny-GEMM shape is used
   int loop_kernel = 0;       // "loop_kernel": 0 auto (by rows / motions), 1 latency kernels (tile32.hpp), 2 throughput kernels (strip.hpp), 3 sample-major persistent loop (loop_fused.hpp), 4 cluster loop (loop_cluster.hpp)
 #if defined(MLDHIP_SIM)
@@ -169,6 +175,7 @@ struct mldhip_engine {
 
 #if !defined(MLDHIP_SIM)
   hipStream_t cap_stream = nullptr;
+  hipStream_t side_stream = nullptr;   // "many_pipeline": decodes run here, at the lowest stream priority (the cluster launch on the caller's stream gets its CUs first)
 #endif
 
   int fail(int code, const char* fmt, ...) {

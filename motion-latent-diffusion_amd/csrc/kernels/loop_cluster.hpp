@@ -86,6 +86,7 @@ struct ClusterArgs {
   unsigned* status;           // [0]: 0 ok, 1 a wait timed out; [1]: clusters that span XCDs (plain stores asked for, write-through used); both cleared per launch.  [2]: a wait timed out in SOME launch since the host last looked (sticky)
   int B, L, n, ncl;           // B: motions of the CALL (the condition rows' pitch); this launch serves motions [s_base, s_end)
   int s_base = 0, s_end = 0;
+  unsigned* host_status = nullptr;   // pinned host word (or NULL): set with the sticky status word, read by the host at the start of the next call without a device synchronisation
   unsigned timeout = 0;       // wait bound: 100 MHz ticks (GPU) / poll iterations (simulator); kClTimeoutTicks unless a test shortens it
   int mute = -1;              // hooks builds (fault injection, tests): this member never raises its first flag -- everybody who waits for it runs into the bound
   unsigned long long* trace = nullptr;   // CL_TRACE builds (tools/loopbench only): [workgroup][wave][16] shader cycles per phase, summed over steps and layers
@@ -119,6 +120,9 @@ __global__ __launch_bounds__(64) void pack_cluster_frags_kernel(const float* __r
 __global__ __launch_bounds__(256) void clear_cluster_flags_kernel(unsigned* __restrict__ flags, int words) {
   for (int i = threadIdx.x; i < words; i += 256) flag_store(flags + i, 0u);
 }
+
+// hooks builds (option "cluster_stale"): one polled word holds an epoch no fresh launch can hold -- the entry check's test
+__global__ void poke_cluster_flag_kernel(unsigned* __restrict__ word, unsigned v) { flag_store(word, v); }
 
 // grid = 12 xslots x ceil(clusters / xslots), xslots = 8: block b -> XCD slot x = b % 8, index i = b / 8 -> cluster x + 8 (i / 12), member i % 12.  block = 512.
 // WT = true: write-through (sc1) payload stores whatever the placement.  WT = false: every cluster whose twelve members report the same XCC id stores its
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         if (!wave_any(!ready)) break;
         spin_pause();
 #if defined(MLDHIP_SIM)
-        if (++it > p.timeout) { ok = false; break; }
+        if (wave_any(++it > p.timeout || flag_load(p.status) != 0u)) { ok = false; break; }      // (wave-uniform exit: the lanes meet again in wave_any)
 #else
         if ((++it & 63u) == 0u) {
           const bool late = realtime_100mhz() - ts > p.timeout;
@@ -206,8 +210,9 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
         }
 #endif
       }
+      poll_fence();
       if (lane == 0) {
-        if (!ok) { flag_store(p.status, 1u); flag_store(p.status + 2, 1u); }      // [2] is sticky: cleared by the host once it has acted on it
+        if (!ok) { flag_store(p.status, 1u); flag_store(p.status + 2, 1u); host_flag_store(p.host_status, 1u); }      // [2] is sticky: cleared by the host once it has acted on it
         ctl[0] = ok ? 1u : 0u;
       }
     }
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
       if (!wave_any(flag_load(f) < epoch)) break;
       spin_pause();
 #if defined(MLDHIP_SIM)
-      if (++it > p.timeout) { ok = false; break; }
+      if (wave_any(++it > p.timeout || flag_load(p.status) != 0u)) { ok = false; break; }
 #else
       if ((++it & 63u) == 0u) {
         const bool late = realtime_100mhz() - ts > p.timeout;
@@ -237,7 +242,8 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
       }
 #endif
     }
-    if (!ok && lane == 0) { flag_store(p.status, 1u); flag_store(p.status + 2, 1u); ctl[2] = 1u; }
+    poll_fence();
+    if (!ok && lane == 0) { flag_store(p.status, 1u); flag_store(p.status + 2, 1u); host_flag_store(p.host_status, 1u); ctl[2] = 1u; }
   };
   auto publish = [&](int kind, unsigned epoch) __attribute__((always_inline)) {
     drain_stores();
@@ -251,6 +257,24 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
       if (s0 + c < p.s_end) st4(p.lat + (long long)(s0 + c) * 256 + c4 * 4, F4{qnan, qnan, qnan, qnan});
     }
   };
+
+  // Entry check (advisor r5): what a FRESH launch can find in this cluster's polled words is bounded -- a member is at most one exchange ahead of member 0 (it needs
+  // member 0's share to go on), so the AO / H / Y lines hold epochs <= 2, the Z line the XCC census (<= 16) and its finish counter 0.  Anything else is what a previous
+  // launch left behind and the clear in front of this one did not remove (r05: a captured memset node): the launch is failed (status words, NaN latents, counted, fallback;
+  // the other members see the status word in their waits) instead of consuming the words as "ready".
+  if (member == 0) {
+    if (wave == 0) {
+      const unsigned a = flag_load(flags + lane), b = flag_load(flags + 64 + lane);
+      const unsigned lim = lane < 32 ? 2u : (lane == 32 + 28 ? 0u : 17u);
+      const bool stale = wave_any(a > 2u || b > lim);
+      if (lane == 0) {
+        ctl[0] = stale ? 0u : 1u;
+        if (stale) { flag_store(p.status, 1u); flag_store(p.status + 2, 1u); host_flag_store(p.host_status, 1u); }
+      }
+    }
+    __syncthreads();
+    if (ctl[0] == 0u) { give_up(); return; }
+  }
 
   // ---- weight ring: this lane's two MFMA operands (32 bytes) of the wave's next kClRing fragments
   const unsigned wbase = p.wave_off[hc * 8 + wave] + (unsigned)lane * 8u;

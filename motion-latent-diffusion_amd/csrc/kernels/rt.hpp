@@ -480,6 +480,8 @@ template <bool WT> __device__ __forceinline__ void xbuf_st4(const XBuf& b, unsig
 template <bool WT> __device__ __forceinline__ void xbuf_st2(const XBuf& b, unsigned off, U2 v) { *reinterpret_cast<U2*>(b.base + off) = v; }
 __device__ __forceinline__ unsigned flag_load(const unsigned* p) { return *reinterpret_cast<const volatile unsigned*>(p); }
 __device__ __forceinline__ void flag_store(unsigned* p, unsigned v) { *reinterpret_cast<volatile unsigned*>(p) = v; }
+__device__ __forceinline__ void host_flag_store(unsigned* p, unsigned v) { if (p) *reinterpret_cast<volatile unsigned*>(p) = v; }
+__device__ __forceinline__ void poll_fence() {}
 __device__ __forceinline__ void spin_pause() { hipsim::yield(); }
 __device__ __forceinline__ void drain_stores() {}
 __device__ __forceinline__ unsigned xcc_id() { return 0u; }
@@ -493,6 +495,11 @@ template <bool WT> __device__ __forceinline__ void xbuf_st4(const XBuf& b, unsig
 template <bool WT> __device__ __forceinline__ void xbuf_st2(const XBuf& b, unsigned off, U2 v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), b, (int)off, 0, WT ? 16 : 0); }
 __device__ __forceinline__ unsigned flag_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void flag_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a word in pinned HOST memory the host reads without a device synchronisation (the cluster loop's sticky "a wait timed out" word): system scope
+__device__ __forceinline__ void host_flag_store(unsigned* p, unsigned v) { if (p) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// behind a successful poll, in front of the payload loads: the relaxed flag load does not order later loads for the COMPILER (the hardware issues a wave's loads in
+// order and the payloads are read with sc1 loads served by the L2 the flag came from) -- a compiler-only fence keeps hipcc from hoisting them above the poll loop
+__device__ __forceinline__ void poll_fence() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
 __device__ __forceinline__ void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u; }      // HW_REG_XCC_ID bits 3:0

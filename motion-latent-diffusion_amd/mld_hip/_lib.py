@@ -48,7 +48,7 @@ class NumericInfo(C.Structure):
     """Mirror of ``mldhip_numeric_info`` (include/mldhip.h, "Range contract" of the split-f16 mode)."""
     _fields_ = [("struct_size", C.c_int32), ("probed", C.c_int32), ("loop_split_ok", C.c_int32), ("decode_split_ok", C.c_int32),
                 ("probe_err_loop", C.c_float), ("probe_err_decode", C.c_float), ("nonfinite_values", C.c_int64),
-                ("decode_half_ok", C.c_int32), ("probe_err_decode_half", C.c_float)]
+                ("decode_half_ok", C.c_int32), ("probe_err_decode_half", C.c_float), ("cluster_loop", C.c_int32), ("reserved", C.c_int32)]
 
 
 PROBE_TOL = 6e-6                         # MLDHIP_PROBE_TOL

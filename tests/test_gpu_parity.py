@@ -265,6 +265,92 @@ def test_cluster_calls_in_flight_on_two_streams_never_run_side_by_side(dev):
     e.close()
 
 
+def test_sample_many_pipelined_bs64_requests_are_bit_identical_and_overlap(dev):
+    """"many_pipeline" 1 (round 6): mldhip_sample_many runs bs-64 requests one after the other -- the reference's shape, batch after batch (mld.py:618-672) -- with the decode
+    of request k on the engine's low-priority side stream beside the cluster launch of request k + 1 (two workspaces alternate).  Eight requests with their own prompts,
+    noise and (half of them) ragged lengths: every output equals the strictly serial mldhip_sample call of that request TO THE BIT, nothing non-finite, no timeout, the
+    handle still on the cluster loop; and the call really overlaps: faster than the eight serial calls."""
+    e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=1, max_in_flight=2)
+    _load(e)
+    reqs, solo = [], []
+    for i in range(8):
+        b = syn.make_batch(64, "ragged" if i % 2 else None, seed=300 + i)
+        T = max(b.lengths)
+        text, lat0 = _cuda(b.text_emb, dev), _cuda(b.init_latents, dev)
+        lat, feats, joints = torch.empty(64, 1, 256, device=dev), torch.empty(64, T, 263, device=dev), torch.empty(64, T, 22, 3, device=dev)
+        e.sample(text, lat0, b.lengths, lat, feats, joints)
+        torch.cuda.synchronize()
+        assert e.launch_counts()[0] == 2
+        solo.append((lat, feats, joints))
+        reqs.append(dict(text_emb=text, init_latents=lat0, lengths=b.lengths, latents_out=torch.full_like(lat, float("nan")),
+                         feats_out=torch.full_like(feats, float("nan")) if i != 3 else None, joints_out=torch.full_like(joints, float("nan"))))
+
+    def serial():
+        for q, (lat, feats, joints) in zip(reqs, solo):
+            e.sample(q["text_emb"], q["init_latents"], q["lengths"], lat, feats, joints)
+    serial(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); serial(); torch.cuda.synchronize(); t_serial = time.perf_counter() - t0
+    e.set_option("many_pipeline", 1)
+    e.sample_many(reqs); torch.cuda.synchronize()                       # (captures the loop-only and decode-only graphs of both workspaces)
+    for q in reqs:
+        for k in ("latents_out", "feats_out", "joints_out"):
+            if q[k] is not None:
+                q[k].fill_(float("nan"))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); e.sample_many(reqs); torch.cuda.synchronize(); t_pipe = time.perf_counter() - t0
+    for q, (lat, feats, joints) in zip(reqs, solo):
+        assert torch.equal(q["latents_out"], lat) and torch.equal(q["joints_out"], joints)
+        if q["feats_out"] is not None:
+            assert torch.equal(q["feats_out"], feats)
+    ns = e.numeric_status()
+    print("bs-64 requests, 8 per call: serial %.2f ms per request, pipelined %.2f ms per request (%.0f -> %.0f motions/s)" % (
+        t_serial / 8 * 1e3, t_pipe / 8 * 1e3, 512 / t_serial, 512 / t_pipe))
+    assert ns["nonfinite_values"] == 0 and ns["cluster_loop"] == 1, ns
+    assert t_pipe < 0.97 * t_serial, (t_pipe, t_serial)
+    e.close()
+
+
+def test_cluster_calls_beside_a_foreign_kernel_stream(dev):
+    """The cluster launch needs its workgroups resident together; kernels of OTHER streams beside it can only delay it -- they end.  bs-64 calls while
+    a foreign stream keeps the chip busy with (a) large torch matmuls (every CU, LDS-heavy workgroups) and (b) a CLIP-sized transformer layer stack -- what the next
+    batch's text encoder would be: latents and joints identical to the quiet run to the bit, nothing non-finite, no sticky timeout, the handle stays on the cluster loop."""
+    b = syn.make_batch(64, [120] * 64, seed=77)
+    e = _lib.Engine(device=0, max_batch=64, max_frames=120, precision=1)
+    _load(e)
+    text, lat0 = _cuda(b.text_emb, dev), _cuda(b.init_latents, dev)
+    ref_l, ref_j = torch.empty(64, 1, 256, device=dev), torch.empty(64, 120, 22, 3, device=dev)
+    e.sample(text, lat0, b.lengths, ref_l, None, ref_j)
+    torch.cuda.synchronize()
+    assert e.launch_counts()[0] == 2
+    side = torch.cuda.Stream(device=dev)
+    a = torch.randn(4096, 4096, device=dev); w = torch.randn(4096, 4096, device=dev)
+    layer = torch.nn.TransformerEncoderLayer(768, 12, 3072, batch_first=True).to(dev).eval()
+    tok = torch.randn(64, 77, 768, device=dev)
+    for name in ("matmul", "clip_like"):
+        stop_after = 40
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(stop_after):                                   # ~100+ ms of foreign work queued on the side stream, running while the calls below are issued
+                if name == "matmul":
+                    a = torch.tanh(a @ w * 1e-2)
+                else:
+                    for _ in range(12):
+                        tok = layer(tok)
+        outs = []
+        t0 = time.perf_counter()
+        for _ in range(4):
+            l, j = torch.full_like(ref_l, float("nan")), torch.full_like(ref_j, float("nan"))
+            e.sample(text, lat0, b.lengths, l, None, j)
+            outs.append((l, j))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        for l, j in outs:
+            assert torch.equal(l, ref_l) and torch.equal(j, ref_j), name
+        ns = e.numeric_status()
+        print("cluster calls beside a foreign %s stream: 4 calls + the foreign work in %.1f ms, numeric %s" % (name, dt * 1e3, {k: ns[k] for k in ("nonfinite_values", "cluster_loop")}))
+        assert ns["nonfinite_values"] == 0 and ns["cluster_loop"] == 1, (name, ns)
+    e.close()
+
+
 def test_cluster_loop_bounded_waits_and_fallback_on_gpu(dev):
     """The bounded waits of the cluster launch on hardware (hooks build of the library, option "cluster_inject": one member of every cluster never raises its first
     flag, wait bound 2 ms): the call returns instead of hanging, its latents are NaN and counted, mldhip_numeric_status takes the handle off the cluster loop, the

@@ -821,15 +821,30 @@ def test_cluster_loop_bounded_waits_and_fallback_sim(groups):
     lat = np.zeros((8, 1, 256), np.float32)
     e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
     assert e.launch_counts()[0] == 2 and np.isnan(lat).all()
-    ns = e.numeric_status()
-    assert ns["nonfinite_values"] == 8 * 256, ns
+    if groups == 4:
+        ns = e.numeric_status()
+        assert ns["nonfinite_values"] == 8 * 256 and ns["cluster_loop"] == 2, ns
+    # self-healing (round 6): the kernel also set the handle's pinned host word, and every sample call reads it first -- the NEXT call is served by the launch family
+    # whether or not the caller has polled mldhip_numeric_status in between (groups == 8: it has not)
     e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)          # the handle has left the cluster loop
     assert e.launch_counts()[0] > 2 and np.abs(lat - ref).max() < 2e-4
-    assert e.numeric_status()["nonfinite_values"] == 0
+    ns = e.numeric_status()
+    assert ns["nonfinite_values"] == (0 if groups == 4 else 8 * 256) and ns["cluster_loop"] == 2, ns
     e.set_option("cluster_inject", 0)
     e.set_option("loop_kernel", 4)                           # re-arms it
     e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
     assert e.launch_counts()[0] == 2 and np.abs(lat - ref).max() < 2e-4
+    assert e.numeric_status()["cluster_loop"] == 1
+    # entry check (round 6): a polled word that holds an epoch no fresh launch can hold (what the r05 memset-node replay fault left behind) fails the launch -- it is
+    # counted and the handle falls back -- instead of being consumed as "ready"
+    e.set_option("cluster_stale", 1)
+    e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
+    assert np.isnan(lat).all()
+    e.set_option("cluster_stale", 0)
+    e.sample(b.text_emb, b.init_latents, b.lengths, latents_out=lat)
+    assert e.launch_counts()[0] > 2 and np.abs(lat - ref).max() < 2e-4
+    ns = e.numeric_status()
+    assert ns["nonfinite_values"] == 8 * 256 and ns["cluster_loop"] == 2, ns
     e.close()
 
 
@@ -1142,3 +1157,51 @@ def test_decoder_self_attention_on_half_qkv_sim(ow, aow):
         got[dh] = feats
     aeng.close()
     assert 0 < np.abs(got[1] - got[0]).max() < 5e-4
+
+
+def test_sample_many_pipelined_requests_sim():
+    """"many_pipeline" 1: mldhip_sample_many runs its requests one after the other on the single-request path (cluster loop) with two workspaces alternating -- every
+    request gets what its own mldhip_sample call gives, to the bit (the simulator has no streams: this is the bookkeeping -- context rotation, per-request
+    lengths / Tmax, outputs straight into each request's buffers, a request without joints); a request the cluster loop does not serve, or a handle
+    with one workspace, keeps the coalesced form / is refused."""
+    dims = syn.ModelDims(num_layers=3)
+    sdd, sdv = syn.make_denoiser_state_dict(dims=dims), syn.make_vae_state_dict(dims=dims)
+    mean, std = syn.make_mean_std()
+
+    def mk(in_flight):
+        e = _lib.Engine(lib=simlib.sim_library(), use_graph=0, max_batch=12, max_frames=12, num_inference_steps=2, num_layers=3, precision=1, max_in_flight=in_flight)
+        e.load_state_dict(sdd, "denoiser."); e.load_state_dict(sdv, "vae."); e.load_tensor("mean", mean); e.load_tensor("std", std)
+        e.finalize()
+        e.set_option("cluster_max_batch", 12)
+        return e
+    e = mk(2)
+    reqs, solo = [], []
+    for seed, lens in ((1, [12, 7, 3]), (2, [9] * 8), (3, [5, 12]), (4, [11])):
+        b = syn.make_batch(len(lens), lens, seed=seed)
+        B, T = len(lens), max(lens)
+        reqs.append(dict(text_emb=b.text_emb, init_latents=b.init_latents, lengths=lens, latents_out=np.zeros((B, 1, 256), np.float32),
+                         feats_out=np.zeros((B, T, 263), np.float32), joints_out=None if seed == 3 else np.zeros((B, T, 22, 3), np.float32)))
+        lat, feats, joints = np.zeros((B, 1, 256), np.float32), np.zeros((B, T, 263), np.float32), np.zeros((B, T, 22, 3), np.float32)
+        e.sample(b.text_emb, b.init_latents, lens, lat, feats, joints)
+        assert e.launch_counts()[0] == 2                            # condition rows + ONE cluster launch
+        solo.append((lat, feats, joints))
+    e.set_option("many_pipeline", 1)
+    e.sample_many(reqs)
+    for q, (lat, feats, joints) in zip(reqs, solo):
+        assert np.array_equal(q["latents_out"], lat) and np.array_equal(q["feats_out"], feats)
+        if q["joints_out"] is not None:
+            assert np.array_equal(q["joints_out"], joints)
+    assert e.launch_counts()[0] == 2                                # the last request's own loop, not a 24-motion chain
+    assert e.numeric_status()["nonfinite_values"] == 0 and e.numeric_status()["cluster_loop"] == 1
+    # a request the cluster loop does not serve (latents only: nothing to overlap) -> the coalesced chain, as before
+    for q in reqs:
+        q["latents_out"][:] = 0
+    lat_only = [dict(text_emb=q["text_emb"], init_latents=q["init_latents"], lengths=q["lengths"], latents_out=q["latents_out"]) for q in reqs[:2]]
+    e.sample_many(lat_only)
+    for q, (lat, _, _) in zip(reqs[:2], solo):
+        assert np.abs(q["latents_out"] - lat).max() < 2e-4
+    e.close()
+    e1 = mk(1)
+    with pytest.raises(_lib.MldHipError):
+        e1.set_option("many_pipeline", 1)
+    e1.close()
