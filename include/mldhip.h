@@ -29,6 +29,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: the declarations of this header are its only exports */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define MLDHIP_ABI_VERSION 5
 
@@ -60,13 +64,14 @@ enum {                     /* arithmetic mode of the matrix kernels.  In EVERY m
                                      2 048-motion call).  Rounds 1-2 split into bf16 halves (16 mantissa bits, 30x the error: the
                                      reverse loop could not use it); ABI value and behaviour of the other entry points unchanged. */
   MLDHIP_PREC_BF16X3_DECODE = 1,  /* the name rounds 1-2 gave mode 1 (kept for source compatibility) */
-  MLDHIP_PREC_BF16 = 2,           /* operands of EVERY GEMM rounded to bf16 (one v_mfma_f32_16x16x32_bf16 per tile and K chunk):
+  MLDHIP_PREC_BF16 = 2            /* operands of EVERY GEMM rounded to bf16 (one v_mfma_f32_16x16x32_bf16 per tile and K chunk):
                                      the "bf16" of BASELINE.json configs[1].  Does NOT meet the 1e-3 joint contract on the
                                      synthetic weights; bench.py reports its measured error next to its throughput, and
                                      profiles/r03_precision_ab.json attributes it per GEMM class. */
-  MLDHIP_PREC_FP8_DENOISER = 3    /* BASELINE.json configs[4]: the reverse-loop GEMMs on v_mfma_f32_16x16x32_fp8_fp8 (OCP e4m3;
-                                     weights scaled per tensor, activation rows per row, powers of two), decoder GEMMs
-                                     split-f16.  Latent models only.  Error reported by bench.py, not asserted. */
+  /* 3 was MLDHIP_PREC_FP8_DENOISER (BASELINE.json configs[4]: the reverse-loop GEMMs on v_mfma_f32_16x16x32_fp8_fp8) through ABI 4.  Retired in ABI 5 (VERDICT r5
+     item 7: "faster than split-f16 or gone"): measured latents off by 11.9 on |x| ~ 73 AND slower than split-f16 (profiles/r03_precision_ab.json attributes the error
+     per GEMM class: e4m3's 3-bit mantissa costs 2^-4 per operand whatever the scaling -- an fp8 reverse loop cannot meet a 1e-3 joint contract under guidance 7.5 x 50
+     steps).  mldhip_create refuses the value; config 5 runs in F16X3. */
 };
 
 /* Mirrors the keys of configs/config_mld_humanml3d.yaml + configs/modules/{denoiser,motion_vae,
@@ -185,8 +190,8 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "cluster_lane"    (hooks build only) 0 = calls served by the cluster loop on different streams are not ordered behind each other: two cluster launches side by side
  *                     starve each other of CUs until the 200 ms wait bound fails both (tools/two_streams.py shows it); 1 (default, and always in the production library):
  *                     one lane per device and process
- *   "cluster_graph"   (hooks build only) 1 (default) = calls served by the cluster loop replay captured graphs like every other call; 0 = eager issue;
- *                     2 = graphs with the flags cleared by a hipMemsetAsync node instead of clear_cluster_flags_kernel: reproduces the r05 replay fault
+ *   "cluster_graph"   (hooks build only) 1 (default) = calls served by the cluster loop replay captured graphs like every other call; 0 = eager issue.  (Round 5's value 2 --
+ *                     flags cleared by a captured hipMemsetAsync node, which reproduced that round's replay fault -- is gone: "cluster_stale" exercises what it led to.)
  *   "fused_dbg"       (hooks build only, include/mldhip_hooks.h; unknown to the production library) 5 = the F16X3 persistent loop with per-phase cycle counters of the first 64 workgroups (same arithmetic, same
  *                     results), read back with mldhip_profile_trace("den_loop_phases") (tools/trace_loop.py); 0 (default) = off.  The
  *                     measurement builds that compute WRONG results (no weight stream, no MFMAs, ...) are not in the library any
@@ -417,6 +422,9 @@ int mldhip_get_launch_counts(mldhip_handle* h, int32_t* out_host /*[3]*/);
 const char* mldhip_last_error(mldhip_handle* h /* may be NULL */);
 int mldhip_abi_version(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: the declarations of this header are its only exports */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* Measurement hook (no reference counterpart): enqueue ONE named kernel of the path `iters` times on
  * `stream` at its production shape for batch B / Tmax T; writes its algorithmic FLOPs per launch.
@@ -29,6 +33,9 @@ int mldhip_profile_trace(mldhip_handle* h, const char* name, int32_t B, int32_t 
  * "den_cluster_xbuf" (B = cluster index: the exchange region the last cluster-loop call left, kernels/loop_cluster.hpp) and "den_cluster_status" (the status
  * words of the last cluster-loop call: [0] a wait timed out, [1] a cluster spanned XCDs, [2] the sticky timeout word). */
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -58,13 +58,12 @@ int staged_prec(const E* e) {
   switch (e->cfg.precision) {
     case MLDHIP_PREC_BF16X3_DECODE: return (big && e->split_decode_ok) ? PREC_BF16X3 : PREC_F32;   // split_decode_ok: finalize's range probe
     case MLDHIP_PREC_BF16: return PREC_BF16;
-    case MLDHIP_PREC_FP8_DENOISER: return big ? PREC_BF16X3 : PREC_F32;
     default: return PREC_F32;
   }
 }
 // Operand format of the latent reverse loop's GEMMs (tile32.hpp / strip.hpp / the 32x64 staged FFN2)
 int loop_prec(const E* e) {
-  return e->cfg.precision == MLDHIP_PREC_BF16 ? PREC_BF16 : e->cfg.precision == MLDHIP_PREC_FP8_DENOISER ? PREC_FP8 : PREC_F32;
+  return e->cfg.precision == MLDHIP_PREC_BF16 ? PREC_BF16 : PREC_F32;
 }
 
 // Operand format of the LATENCY family (tile32.hpp: one bs-64 batch at a time): the split-f16 mode runs them on split-f16 MFMAs too
@@ -126,7 +125,6 @@ void gemm(Ctx& c, const GemmArgs& a_, int nz = 1) {
 void gemm_tile_32x64(Ctx& c, const GemmArgs& a, int prec, int nz = 1) {
   const dim3 grid((a.M + 31) / 32, (a.N + 63) / 64, nz);
   if (prec == PREC_BF16) launch_staged<2, 2, 1, 2, false, PREC_BF16>(c, a, grid);
-  else if (prec == PREC_FP8) launch_staged<2, 2, 1, 2, false, PREC_FP8>(c, a, grid);
   else launch_staged<2, 2, 1, 2, false, PREC_F32>(c, a, grid);
   count(c);
   check_launch(c, "gemm_32x64");

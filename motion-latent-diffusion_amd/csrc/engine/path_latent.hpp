@@ -33,7 +33,6 @@ void tile32(Ctx& c, const Tile32Args& a_, int nz) {
     if (a.trace && prec == PREC_BF16X3) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, true, PREC_BF16X3, MODE>), grid, dim3(512), kT32LdsBytes, c.stream, a); } \
     else if (a.trace) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, true, PREC_F32, MODE>), grid, dim3(512), kT32LdsBytes, c.stream, a); }  \
     else if (prec == PREC_BF16) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, PREC_BF16, MODE>), grid, dim3(512), kT32LdsBytes, c.stream, a); } \
-    else if (prec == PREC_FP8) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, PREC_FP8, MODE>), grid, dim3(512), kT32LdsBytes, c.stream, a); }   \
     else if (prec == PREC_BF16X3) { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, PREC_BF16X3, MODE>), grid, dim3(512), kT32LdsBytes, c.stream, a); } \
     else { MLD_LAUNCH((gemm_tile32_kernel<MT, NS, false, PREC_F32, MODE>), grid, dim3(512), kT32LdsBytes, c.stream, a); }              \
   } while (0)
@@ -70,7 +69,6 @@ void strip(Ctx& c, const Tile32Args& a_, int nsrc) {
 #define MLD_STRIP(NS, NSRC, ATTN, ACT, CT, NW)                                                                                     \
   do {                                                                                                                             \
     if (prec == PREC_BF16) { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_BF16, ACT, CT, NW>), grid, dim3(64 * NW), (strip_lds_bytes<NSRC, CT>()), c.stream, a); } \
-    else if (prec == PREC_FP8) { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_FP8, ACT, CT, NW>), grid, dim3(64 * NW), (strip_lds_bytes<NSRC, CT>()), c.stream, a); } \
     else { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_F32, ACT, CT, NW>), grid, dim3(64 * NW), (strip_lds_bytes<NSRC, CT>()), c.stream, a); }       \
   } while (0)
   // 8 waves per workgroup (one 16-row tile per wave) unless "strip_waves" says 4
@@ -161,7 +159,6 @@ long long den_slab(const E* e) { return (long long)6 * e->cfg.max_batch * 256; }
 void den_qkv(Ctx& c, const DenView& v, const EncLayerP& L, const ASrc& x) {
   Tile32Args a;
   a.src[0] = x; a.nz0 = 1; a.W = L.in_w; a.ldw = 256; a.bias = L.in_b; a.Y = v.QKV; a.ldy = 768; a.M = 3 * v.R; a.N = 768;
-  a.wscale = L.s_in;
   if (v.strip) strip(c, a, 1); else tile32(c, a, 1);
 }
 // out-projection of the 3-token self-attention (computed while the A tile is assembled) -> raw slab Po
@@ -169,7 +166,6 @@ void den_outproj(Ctx& c, const DenView& v, const EncLayerP& L) {
   Tile32Args a;
   a.src[0].base = v.QKV; a.src[0].attn_R = v.R;
   a.nz0 = 1; a.W = L.out_w; a.ldw = 256; a.P = v.Po; a.pstride = 0; a.M = 3 * v.R; a.N = 256;
-  a.wscale = L.s_out;
   if (v.strip) strip(c, a, 1); else tile32(c, a, 1);
 }
 // h1 = LN1(x + out_proj) assembled on load (written to H1), FF = gelu(h1 W1^T + b1)
@@ -178,7 +174,6 @@ void den_ffn1(Ctx& c, const DenView& v, const EncLayerP& L, const float* xn) {
   Tile32Args a;
   a.src[0] = combine_src(v.Po, 1, 0, L.out_b, xn, L.n1_w, L.n1_b, v.H1);
   a.nz0 = 1; a.W = L.l1_w; a.ldw = 256; a.bias = L.l1_b; a.act = 1; a.Y = v.FF; a.ldy = F; a.M = 3 * v.R; a.N = F;
-  a.wscale = L.s_l1;
   if (v.strip) strip(c, a, 1); else tile32(c, a, 1);
 }
 // FFN2 -> raw slabs Pf (ff_size/256 K-slices on the latency kernels, one full-K slab on the throughput kernels);
@@ -191,15 +186,12 @@ void den_ffn2(Ctx& c, const DenView& v, const EncLayerP& L) {
     const int nz = v.ffn_slabs, Kz = F / nz;
     GemmArgs g = lin_args(v.FF, F, Kz, L.l2_w, nullptr, v.Pf, 256, 3 * v.R, 256);
     g.ldw = F; g.sA = Kz; g.sW = Kz; g.sY = den_slab(c.e);
-    // fp8: the FFN activations (post-GELU, |x| <~ 10) get a static scale of 16 (saturation at 28); weights per tensor
-    g.ascale = 16.f; g.wscale = L.s_l2; g.oscale = 1.0f / (g.ascale * g.wscale);
     gemm_tile_32x64(c, g, loop_prec(c.e), nz);
     return;
   }
   Tile32Args a;
   a.src[0] = plain_src(v.FF, F);
   a.nz0 = F / 256; a.W = L.l2_w; a.ldw = F; a.P = v.Pf; a.pstride = den_slab(c.e); a.M = 3 * v.R; a.N = 256;
-  a.wscale = L.s_l2;
   tile32(c, a, F / 256);
 }
 ASrc den_layer_output(E* e, const DenView& v, const EncLayerP& L, float* write_back) {   // LN2(sum Pf + b2 + h1)
@@ -234,7 +226,6 @@ void denoiser_body(Ctx& c, const DenView& v) {
       a.nz0 = 1;
       a.W = P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".weight"); a.ldw = 512;
       a.P = v.Ps; a.pstride = den_slab(e); a.M = 3 * v.R; a.N = 256;
-      a.wscale = e->den_skip_scale.empty() ? 1.f : e->den_skip_scale[i];
       if (v.strip) strip(c, a, 2); else tile32(c, a, 2);
       x = combine_src(v.Ps, v.skip_slabs, den_slab(e), P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".bias"), nullptr,
                       nullptr, nullptr, v.Ha);
@@ -456,7 +447,7 @@ int build_ffn_streams(Ctx& c) {
   e->gemm_stream_of.clear();
   e->final_stream = nullptr;
   if (e->ffn_streams) { (void)hipFree(e->ffn_streams); e->ffn_streams = nullptr; }
-  const bool split = e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE || e->cfg.precision == MLDHIP_PREC_FP8_DENOISER;
+  const bool split = e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE;
   if (!split || is_novae(e) || e->cfg.latent_dim != 256 || e->cfg.ff_size != 1024) return 0;
   std::vector<std::pair<const float*, const float*>> layers;
   if (e->group_ready[1]) for (auto& L : e->dec) layers.push_back({L.l1_w, L.l2_w});
@@ -971,12 +962,7 @@ void launch_cluster_chunk(Ctx& c, const float* init_lat, int B, int s_base, int 
 #endif
   // every polled word is zero at the start of every call (Guideline 16 "Re-initialise every call")
   const int words = (int)(a.status - a.flags) + 2;        // the flags and the two per-launch status words (status[2] is sticky: cluster_timed_out)
-  if (e->cluster_clear_memset) {
-    hipError_t st = hipMemsetAsync(a.flags, 0, (size_t)words * sizeof(unsigned), c.stream);
-    if (st != hipSuccess) { c.rc = e->fail(MLDHIP_EHIP, "cluster loop: memset: %s", hipGetErrorString(st)); return; }
-  } else {
-    MLD_LAUNCH(clear_cluster_flags_kernel, dim3(1), dim3(256), 0, c.stream, a.flags, words);
-  }
+  MLD_LAUNCH(clear_cluster_flags_kernel, dim3(1), dim3(256), 0, c.stream, a.flags, words);      // (a kernel, NOT a memset node: replays of a captured hipMemsetAsync left address-like words here on this runtime, DESIGN.md 3a -- the entry check of the kernel now catches such a launch)
 #if defined(MLDHIP_HOOKS)
   if (e->cluster_stale) MLD_LAUNCH(poke_cluster_flag_kernel, dim3(1), dim3(1), 0, c.stream, a.flags + kFlagH * kClFlagLine + 3, 77u);
 #endif

@@ -18,7 +18,6 @@ struct Param {
 
 struct EncLayerP {   // TransformerEncoderLayer (cross_attention.py:236-272)
   const float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
-  float s_in = 1.f, s_out = 1.f, s_l1 = 1.f, s_l2 = 1.f;   // MLDHIP_PREC_FP8_DENOISER: per-tensor power-of-two weight scales
 };
 struct DecLayerP {   // TransformerDecoderLayer (cross_attention.py:297-345)
   const float *in_w, *in_b, *out_w, *out_b;
@@ -84,8 +83,7 @@ struct mldhip_engine {
   bool cluster_stale = false;     // "cluster_stale" (hooks build only): a launch finds a stale epoch in one of its polled words (what the r05 memset-node fault left behind): the entry check must fail the launch
   int cluster_chunk = 128;        // "cluster_chunk" (hooks build only): motions per cluster launch (a multiple of 8, at most 8 x kClMaxClusters = 128)
   bool cluster_lane = true;       // "cluster_lane" (hooks build only): 0 = no ordering between cluster calls of different streams (the starvation it prevents, on purpose)
-  bool cluster_clear_memset = false;   // flags of the cluster loop cleared by hipMemsetAsync instead of clear_cluster_flags_kernel ("cluster_graph" 2)
-  bool cluster_graph = true;      // "cluster_graph" (hooks build only): 0 = calls served by the cluster loop are issued eagerly, 2 = graphs + memset-node clear (reproduces the r05 replay fault)
+  bool cluster_graph = true;      // "cluster_graph" (hooks build only): 0 = calls served by the cluster loop are issued eagerly
   int num_cus = 1 << 20;          // CUs of the device (a partitioned or masked device has fewer than 256): a cluster launch needs a CU per workgroup (simulator: no limit)
   unsigned* cl_host_status = nullptr;   // pinned host word the cluster kernel sets next to its sticky status word: read at the start of every sample call (no device synchronisation) -- a timed-out handle leaves the cluster loop by itself
   bool cluster_foreign = false;   // another PROCESS holds the cluster lane of this device (lock file taken at mldhip_create): this handle never launches the cluster loop
@@ -93,7 +91,6 @@ struct mldhip_engine {
   float* arena_x3 = nullptr;  // split-bf16 image of the arena (precision modes with split-bf16 staged GEMMs; built by finalize)
   size_t arena_floats = 0;
   std::vector<EncLayerP> den;      // execution order
-  std::vector<float> den_skip_scale;   // fp8 weight scales of denoiser.encoder.linear_blocks.i
   std::vector<DecLayerP> dec;
   std::vector<EncLayerP> venc;     // VAE encoder layers (same layer type as the denoiser's)
   std::vector<DecLayerP> ndec;     // no-VAE variant: denoiser.decoder.layers.* (TransformerDecoder, cross_attention.py:195-233)

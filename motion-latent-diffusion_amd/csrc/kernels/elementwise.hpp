@@ -40,17 +40,6 @@ __global__ __launch_bounds__(256) void init_chain_kernel(const float* __restrict
   X0[(long long)(2 * Rc + Bc + b) * 256 + d] = TP[(long long)(B + b0 + b) * 256 + d];
 }
 
-// max |x| over n floats (one workgroup; finalize-time only: per-tensor fp8 weight scales)
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
-  __shared__ float sh[4];
-  float m = 0.f;
-  for (long long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
-  m = max64(m);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
-}
-
 // Split-bf16 image of the weight arena (finalize-time; precision modes that run staged GEMMs on split-bf16 MFMAs): every aligned
 // group of 32 floats -- one 32-wide K chunk of one weight row, tensors start on 64-float boundaries and the staged GEMMs take K % 32 == 0
 // -- becomes the 32 words a staged GEMM keeps in LDS for it: 16 words of bf16 high parts (element 2w in the low half of word w), then

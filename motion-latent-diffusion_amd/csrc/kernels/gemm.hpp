@@ -40,8 +40,6 @@ struct GemmArgs {
   const float* g1 = nullptr; const float* b1 = nullptr;
   const float* cvec = nullptr; int ldcvec = 0;           // + cvec[row / rows_per_group] then LN(g2,b2)
   const float* g2 = nullptr; const float* b2 = nullptr;
-  float ascale = 1.f, wscale = 1.f, oscale = 1.f;        // PREC_FP8: operands are multiplied by a/wscale before the e4m3
-                                                         // conversion, the accumulator by oscale = 1/(ascale*wscale)
   unsigned long long* trace = nullptr;   // measurement only (staged kernels): 8 timestamps per wave
   int w_split = 0;                       // PREC_BF16X3: W points into the pre-split copy of the weight arena (elementwise.hpp split_bf16_weights_kernel)
 };
@@ -112,8 +110,7 @@ constexpr int gemm_lds_bytes() {    // the chunk double buffer, or the output ti
 // PREC (staged path only): PREC_F32 = exact fp32 MFMA; PREC_BF16X3 = split-bf16 (rt.hpp): operands are split into
 //                 bf16 hi/lo planes while they are written to LDS (same LDS footprint as fp32), 3 bf16 MFMAs
 //                 per tile per K chunk; PREC_BF16 = operands rounded to bf16 (RNE) at the LDS store, one
-//                 v_mfma_f32_16x16x32_bf16 per tile and chunk; PREC_FP8 = operands scaled (per-tensor powers of two)
-//                 and rounded to OCP e4m3, one v_mfma_f32_16x16x32_fp8_fp8 per tile and chunk.  Accumulation, bias,
+//                 v_mfma_f32_16x16x32_bf16 per tile and chunk.  Accumulation, bias,
 //                 residual, LayerNorm and the stored result are fp32 in every mode.
 // KCS (staged path only): K / 32, compile time, so that the whole chunk pipeline is straight-line code: any
 //                 runtime branch around a prefetch load makes hipcc's vmcnt bookkeeping conservative and the
@@ -239,10 +236,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
           // row image: [32 x bf16 | unused]; this thread owns k = 4*c4 .. 4*c4+3 -> words 2*c4, 2*c4+1
           unsigned* rowp = reinterpret_cast<unsigned*>(dst + row * kGemmLdsStride);
           *reinterpret_cast<uint2_t*>(rowp + c4 * 2) = uint2_t{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
-        } else if constexpr (PREC == PREC_FP8) {
-          // row image: [32 x e4m3 | unused]; this thread owns word c4
-          const float sc = j < NLA ? p.ascale : p.wscale;
-          reinterpret_cast<unsigned*>(dst + row * kGemmLdsStride)[c4] = pack_fp8x4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
         } else {
           // row image: [32 x bf16 hi | 32 x bf16 lo | pad]; this thread owns k = 4*c4 .. 4*c4+3
           if (p.w_split && j >= NLA) { st4(dst + row * kGemmLdsStride + c4 * 4, v); continue; }   // W was split at finalize (split_bf16_weights_kernel): already the row image
@@ -290,29 +283,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         blo[t] = rp[4 + g];
       }
     };
-    U2 a8[MREP], b8[NREP];
-    auto mma_narrow = [&](int buf) {       // PREC_BF16 / PREC_FP8: one matrix instruction per tile and K chunk
+    auto mma_narrow = [&](int buf) {       // PREC_BF16: one matrix instruction per tile and K chunk
       const float* as = smem + buf * ROWS * kGemmLdsStride + (wm * MREP * 16 + r) * kGemmLdsStride;
       const float* ws = smem + buf * ROWS * kGemmLdsStride + (BM + wn * NREP * 16 + r) * kGemmLdsStride;
-      if constexpr (PREC == PREC_BF16) {
 #pragma unroll
-        for (int t = 0; t < MREP; ++t) ahi[t] = reinterpret_cast<const U4*>(as + t * 16 * kGemmLdsStride)[g];
+      for (int t = 0; t < MREP; ++t) ahi[t] = reinterpret_cast<const U4*>(as + t * 16 * kGemmLdsStride)[g];
 #pragma unroll
-        for (int t = 0; t < NREP; ++t) bhi[t] = reinterpret_cast<const U4*>(ws + t * 16 * kGemmLdsStride)[g];
+      for (int t = 0; t < NREP; ++t) bhi[t] = reinterpret_cast<const U4*>(ws + t * 16 * kGemmLdsStride)[g];
 #pragma unroll
-        for (int a = 0; a < MREP; ++a)
+      for (int a = 0; a < MREP; ++a)
 #pragma unroll
-          for (int b = 0; b < NREP; ++b) acc[a][b] = mfma_bf16_16x16x32(ahi[a], bhi[b], acc[a][b]);
-      } else {
-#pragma unroll
-        for (int t = 0; t < MREP; ++t) a8[t] = reinterpret_cast<const U2*>(as + t * 16 * kGemmLdsStride)[g];
-#pragma unroll
-        for (int t = 0; t < NREP; ++t) b8[t] = reinterpret_cast<const U2*>(ws + t * 16 * kGemmLdsStride)[g];
-#pragma unroll
-        for (int a = 0; a < MREP; ++a)
-#pragma unroll
-          for (int b = 0; b < NREP; ++b) acc[a][b] = mfma_fp8_16x16x32(a8[a], b8[b], acc[a][b]);
-      }
+        for (int b = 0; b < NREP; ++b) acc[a][b] = mfma_bf16_16x16x32(ahi[a], bhi[b], acc[a][b]);
     };
     auto compute_bf16 = [&]() {
 #pragma unroll
@@ -368,12 +349,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
     }
   }
   if (SPLIT) acc[0][0] += acc2;
-  if constexpr (PREC == PREC_FP8) {
-#pragma unroll
-    for (int a = 0; a < MREP; ++a)
-#pragma unroll
-      for (int b = 0; b < NREP; ++b) acc[a][b] *= p.oscale;
-  }
   if constexpr (TRACE) ts[3] = clock_pinned();              // main loop done
   auto trace_out = [&]() {
     if constexpr (TRACE) {

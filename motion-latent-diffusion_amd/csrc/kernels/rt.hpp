@@ -370,7 +370,7 @@ __device__ __forceinline__ f32x4 mfma_x3_16x16x32(U4 a, U4 b, f32x4 c) {
 
 // ---- reduced-precision operand formats of the GEMM kernels (operands only: accumulation, bias, residual, LayerNorm,
 // softmax and every stored activation stay fp32).  PREC codes shared by gemm.hpp / tile32.hpp / strip.hpp:
-enum : int { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2, PREC_FP8 = 3 };
+enum : int { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16 = 2 };      // (3 was PREC_FP8: retired in round 6 with the mode, include/mldhip.h)
 
 // two floats -> packed bf16 pair, round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950), element 0 in the low half
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
@@ -382,20 +382,6 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, v);
 #endif
 }
-// four floats -> four OCP e4m3 bytes (element 0 in the low byte), saturating at +-448
-constexpr float kFp8Max = 448.0f;
-__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
-  a = fminf(fmaxf(a, -kFp8Max), kFp8Max); b = fminf(fmaxf(b, -kFp8Max), kFp8Max);
-  c = fminf(fmaxf(c, -kFp8Max), kFp8Max); d = fminf(fmaxf(d, -kFp8Max), kFp8Max);
-#if defined(MLDHIP_SIM)
-  return hipsim::fp8_e4m3_bits(a) | (hipsim::fp8_e4m3_bits(b) << 8) | (hipsim::fp8_e4m3_bits(c) << 16) | (hipsim::fp8_e4m3_bits(d) << 24);
-#else
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-  return (unsigned)w;
-#endif
-}
-// v_mfma_f32_16x16x32_fp8_fp8: lane l supplies A[row = l&15][k = 8*(l>>4) + j] and B[k][col = l&15], j = 0..7 as 8 bytes
 struct alignas(8) U2 { unsigned x, y; };
 // ds_read_b64_tr_b16: the LDS transpose read of gfx950.  Inside each 16-lane group the lanes' 8-byte reads form a [4][16] block of
 // 16-bit elements (lane L supplies row L / 4, columns 4 (L % 4) .. + 3: its own 8-byte aligned address, any row stride) and lane i
@@ -412,23 +398,6 @@ __device__ __forceinline__ U2 lds_read_tr16_b64(const unsigned* p) {
   return __builtin_bit_cast(U2, v);
 #endif
 }
-__device__ __forceinline__ f32x4 mfma_fp8_16x16x32(U2 a, U2 b, f32x4 c) {
-#if defined(MLDHIP_SIM)
-  const unsigned av[2] = {a.x, a.y}, bv[2] = {b.x, b.y};
-  return hipsim::mfma_fp8_16x16x32(av, bv, c);
-#else
-  return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(__builtin_bit_cast(long, a), __builtin_bit_cast(long, b), c, 0, 0, 0);
-#endif
-}
-// largest power of two s with s * amax <= 256 (keeps e4m3's 3 mantissa bits on the big elements, headroom below 448);
-// amax == 0 -> 1.  Power-of-two scales make quantise / de-quantise exact.
-__device__ __forceinline__ float fp8_pow2_scale(float amax) {
-  if (!(amax > 0.f)) return 1.f;
-  int e;
-  (void)frexpf(amax, &e);            // amax = m * 2^e, m in [0.5, 1)
-  return ldexpf(1.f, 8 - e);          // s * amax = m * 256 in [128, 256)
-}
-
 // scheduling fence: nothing moves across it.  The register-direct weight rings of loop_fused.hpp / ffn_strip.hpp depend on it -- without
 // a fence after every item, hipcc's scheduler sinks each `global_load` of the ring down to its first use (it trades the prefetch
 // distance for register pressure) and the kernels run one L2 round trip per item (r03: s_waitcnt vmcnt(0) behind every load).

@@ -57,7 +57,8 @@ __device__ __forceinline__ void strip_mma(const float* a, int ast, const float* 
 #pragma unroll
         for (int t = 0; t < RT; ++t) acc[c][t] = mfma_f32_16x16x4(x[t][h].w, y[c][h].w, acc[c][t]);
     }
-  } else if constexpr (PREC == PREC_BF16) {
+  } else {
+    static_assert(PREC == PREC_BF16, "operand format");
     U4 x[RT], y[CT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) x[t] = reinterpret_cast<const U4*>(a + t * 16 * ast)[kc * 4 + g];
@@ -67,16 +68,6 @@ __device__ __forceinline__ void strip_mma(const float* a, int ast, const float* 
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int t = 0; t < RT; ++t) acc[c][t] = mfma_bf16_16x16x32(x[t], y[c], acc[c][t]);
-  } else {
-    U2 x[RT], y[CT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) x[t] = reinterpret_cast<const U2*>(a + t * 16 * ast)[kc * 4 + g];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) y[c] = reinterpret_cast<const U2*>(w + c * 64 * wst)[g];
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-      for (int t = 0; t < RT; ++t) acc[c][t] = mfma_fp8_16x16x32(x[t], y[c], acc[c][t]);
   }
 }
 
@@ -106,7 +97,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
 #endif
   float* As = smem;                          // [32][ST]
   float* Ws = smem + 32 * ST;                // [2][BN][kStripWStride]
-  float* rsc = Ws + 2 * BN * kStripWStride;  // [32] 1 / (row scale * wscale) (PREC_FP8)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, rt0 = 0;
   if constexpr (TRACE) { rt0 = realtime_100mhz(); ts[0] = clock_pinned(); }
@@ -135,7 +125,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
     float* dst = Ws + (c & 1) * BN * kStripWStride;
 #pragma unroll
     for (int j = 0; j < WJ; ++j)           // "lane" = the 16-byte slot within the chunk
-      st_operand<PREC>(dst + (wrow + 8 * NW * j) * kStripWStride, wc4, ring[c % RD][j], p.wscale);
+      st_operand<PREC>(dst + (wrow + 8 * NW * j) * kStripWStride, wc4, ring[c % RD][j]);
   };
 
   // epilogue bias of this lane's output columns, fetched now (clamped, unconditional)
@@ -265,25 +255,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
     for (int i = 0; i < RPW; ++i) breg[i] = ld4(s1.base + (long long)rows[i] * s1.ld + lane * 4);
   }
   if constexpr (TRACE) ts[1] = clock_pinned();             // A rows assembled, the first RD weight chunks landed
-  float ascale[RPW];
+  constexpr int SEG = PREC == PREC_F32 ? 256 : 128;   // words one 256-wide K segment takes in a row
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) ascale[i] = 1.f;
-  if constexpr (PREC == PREC_FP8) {          // per-row power-of-two scale over the whole K of the row
-    float am[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) am[i] = max64(NSRC == 2 ? fmaxf(f4absmax(areg[i]), f4absmax(breg[i])) : f4absmax(areg[i]));
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      ascale[i] = fp8_pow2_scale(am[i]);
-      if (lane == 0) rsc[wave + i * NW] = 1.0f / (ascale[i] * p.wscale);
-    }
-  }
-  constexpr int SEG = PREC == PREC_F32 ? 256 : PREC == PREC_BF16 ? 128 : 64;   // words one 256-wide K segment takes in a row
-#pragma unroll
-  for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * NW) * ST, lane, areg[i], ascale[i]);
+  for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * NW) * ST, lane, areg[i]);
   if constexpr (NSRC == 2) {
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * NW) * ST + SEG, lane, breg[i], ascale[i]);
+    for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * NW) * ST + SEG, lane, breg[i]);
   }
 
   // ---- main loop: one barrier per K chunk; chunk kc multiplies while kc+1 is written to the other LDS buffer and
@@ -320,14 +297,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? ((ATTN || NSRC == 2) ? 2 : 4) : 
   }
 
   // ---- epilogue: 16 lanes write 64 contiguous bytes per row (raw partial slab, or bias + activation)
-  if constexpr (PREC == PREC_FP8) {
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-      for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[c][t][i] *= rsc[(wr + t) * 16 + g * 4 + i];
-  }
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
     const int col = n0 + (wc + 4 * c) * 16 + r;

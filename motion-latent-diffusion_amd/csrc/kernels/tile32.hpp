@@ -46,26 +46,26 @@ struct Tile32Args {
   float* P = nullptr;            // partial epilogue when non-null: P[z][M][N] = acc (raw)
   long long pstride = 0;
   int M = 0, N = 0;
-  float wscale = 1.f;            // PREC_FP8: per-tensor power-of-two scale of W (the A rows are scaled per row in-kernel)
   int w_split = 0;               // PREC_BF16X3: W points into the pre-split (hi | lo half) image of the weight arena (elementwise.hpp)
   unsigned long long* trace = nullptr;   // measurement only: 8 timestamps per wave (see mldhip_profile_trace)
 };
 
 constexpr int kT32Stride = 264;                         // LDS row stride (floats): 256 + 8 pad (= 8 mod 16: conflict-free ds_read_b128, gemm.hpp kGemmLdsStride)
-constexpr int kT32LdsFloats = (32 + 64) * kT32Stride + 32;   // A tile + W tile + per-row operand scales (PREC_FP8)
+constexpr int kT32LdsFloats = (32 + 64) * kT32Stride + 32;   // A tile + W tile (+ 32 spare words: the per-row scales of the fp8 mode retired in round 6)
 constexpr int kT32LdsBytes = kT32LdsFloats * 4;              // 101,504 B -> one workgroup per CU
 
 // ---- operand formats shared by the loop kernels (tile32 / strip): an LDS row holds 256 K-values of one A or W row as
-// fp32 (256 words), bf16 (128 words) or e4m3 (64 words); lane l of the storing wave owns k = 4l..4l+3; a fragment of the
+// fp32 (256 words) or 16-bit formats (128 / 2 x 128 words); lane l of the storing wave owns k = 4l..4l+3; a fragment of the
 // 32-wide K chunk kc is lane (r, g)'s 8 values -- k = 32kc + 8g .. + 7 in the packed formats (rt.hpp MFMA operand layouts),
 // k = 32kc + 4g .. + 3 and 32kc + 16 + 4g .. + 3 in fp32 (any pairing is legal when A and W agree; this one is LDS-conflict free).
 template <int PREC>
-__device__ __forceinline__ void st_operand(float* row, int lane, F4 v, float scale) {
+__device__ __forceinline__ void st_operand(float* row, int lane, F4 v) {
   if constexpr (PREC == PREC_F32) {
     st4(row + lane * 4, v);
   } else if constexpr (PREC == PREC_BF16) {
     *reinterpret_cast<U2*>(reinterpret_cast<unsigned*>(row) + lane * 2) = U2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
-  } else if constexpr (PREC == PREC_BF16X3) {
+  } else {
+    static_assert(PREC == PREC_BF16X3, "operand format");
     // split-f16 image, the one split_bf16_weights_kernel writes: per 32-wide K chunk 16 words of high halves, then 16 of low halves
     unsigned h0, l0, h1, l1;
     split16_pair(v.x, v.y, h0, l0);
@@ -73,12 +73,10 @@ __device__ __forceinline__ void st_operand(float* row, int lane, F4 v, float sca
     unsigned* d = reinterpret_cast<unsigned*>(row) + (lane >> 3) * 32 + (lane & 7) * 2;
     *reinterpret_cast<U2*>(d) = U2{h0, h1};
     *reinterpret_cast<U2*>(d + 16) = U2{l0, l1};
-  } else {
-    reinterpret_cast<unsigned*>(row)[lane] = pack_fp8x4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
   }
 }
 // one 32-wide K chunk of a 16x16 tile: acc += A_frag . B_frag (fp32: 8 MFMAs alternating over two accumulators to hide
-// the dependent-issue latency; bf16 / fp8: one MFMA, accumulators alternate by chunk parity; split-f16: three MFMAs, the two
+// the dependent-issue latency; bf16: one MFMA, accumulators alternate by chunk parity; split-f16: three MFMAs, the two
 // cross terms in acc0 and the hi x hi term in acc1)
 template <int PREC>
 __device__ __forceinline__ void mma_chunk(const float* arow, const float* wrow, int kc, int g, f32x4& acc0, f32x4& acc1) {
@@ -100,17 +98,13 @@ __device__ __forceinline__ void mma_chunk(const float* arow, const float* wrow, 
     acc1 = mfma_f32_16x16x4(a1.y, b1.y, acc1);
     acc0 = mfma_f32_16x16x4(a1.z, b1.z, acc0);
     acc1 = mfma_f32_16x16x4(a1.w, b1.w, acc1);
-  } else if constexpr (PREC == PREC_BF16) {
+  } else {
+    static_assert(PREC == PREC_BF16, "operand format");
     const U4 a = reinterpret_cast<const U4*>(arow)[kc * 4 + g], b = reinterpret_cast<const U4*>(wrow)[kc * 4 + g];
     if (kc & 1) acc1 = mfma_bf16_16x16x32(a, b, acc1);
     else acc0 = mfma_bf16_16x16x32(a, b, acc0);
-  } else {
-    const U2 a = reinterpret_cast<const U2*>(arow)[kc * 4 + g], b = reinterpret_cast<const U2*>(wrow)[kc * 4 + g];
-    if (kc & 1) acc1 = mfma_fp8_16x16x32(a, b, acc1);
-    else acc0 = mfma_fp8_16x16x32(a, b, acc0);
   }
 }
-__device__ __forceinline__ float f4absmax(F4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 
 // Independent wave reductions issued back to back: the DPP chains of different rows interleave.
 template <int N>
@@ -137,7 +131,7 @@ __device__ __forceinline__ F4 f4add(F4 a, F4 b) { return F4{a.x + b.x, a.y + b.y
 // wait per element -- cdna_hip_programming.md, "three .s-level traps" (c)).
 // (Passing K through LDS in two 128-wide pieces so that two workgroups fit a CU was measured: +2.9 % with four batches in
 // flight, -10 % for one batch; removed -- kernels/strip.hpp is the throughput form.  profiles/r01_v17_xcd_kh_ab.txt.)
-// PREC: operand format of the MFMAs (rt.hpp PREC_F32 / PREC_BF16 / PREC_FP8 / PREC_BF16X3 = split-f16, 3 MFMAs of 16 cycles per 32-wide
+// PREC: operand format of the MFMAs (rt.hpp PREC_F32 / PREC_BF16 / PREC_BF16X3 = split-f16, 3 MFMAs of 16 cycles per 32-wide
 // K chunk instead of 8 of 32; the A prologue and the epilogue stay fp32).
 // MODE: how the A rows are obtained is a COMPILE-TIME property of the launch.  NS0 = 0: MODE 0 = plain rows (src[0] / src[1] by K slice),
 // MODE 1 = 3-token attention outputs; NS0 > 0: MODE 0 = every K slice combines src[0]'s slabs, MODE 1 = slices >= nz0 read src[1] as
@@ -151,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
   static_assert(MODE == 0 || MODE == 1, "source mode");
   constexpr bool kAttn = NS0 == 0 && MODE == 1;       // A rows = attention outputs
   constexpr bool kTwo = NS0 > 0 && MODE == 1;         // combine source + a plain second source
-  static_assert(PREC == PREC_F32 || PREC == PREC_BF16 || PREC == PREC_FP8 || PREC == PREC_BF16X3, "operand format");
+  static_assert(PREC == PREC_F32 || PREC == PREC_BF16 || PREC == PREC_BF16X3, "operand format");
   constexpr int RPW = MT / 8;                 // A rows assembled per wave
   constexpr int KW = 256, ST = kT32Stride;    // K columns resident in LDS, LDS row stride (floats)
 #if defined(MLDHIP_SIM)
@@ -161,7 +155,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
 #endif
   float* As = smem;                          // [MT][ST]
   float* Ws = smem + MT * ST;                // [64][ST]
-  float* rsc = smem + (MT + 64) * ST;        // [MT] 1 / (row scale * wscale) (PREC_FP8)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // (An XCD-aware tile order -- block b runs on XCD b % 8; give each XCD a contiguous range of column tiles so that it
   // pulls 1/8 of the weight panel instead of all of it -- was measured SLOWER: 6 825 vs 7 260 motions/s at 4 batches in
@@ -302,23 +295,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
   const float* wp = Ws + (ct * 16 + r) * ST;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   {
-    float ascale[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) ascale[i] = 1.f;
-    if constexpr (PREC == PREC_FP8) {          // per-row power-of-two scale of the assembled A rows (one wave owns a row)
-      float am[RPW];
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) am[i] = max64(f4absmax(areg[i]));
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        ascale[i] = fp8_pow2_scale(am[i]);
-        if (lane == 0) rsc[wave + i * 8] = 1.0f / (ascale[i] * p.wscale);
-      }
-    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if constexpr (PREC == PREC_BF16X3) break;
-      st_operand<PREC>(Ws + (wave + i * 8) * ST, lane, wreg[i], p.wscale);
+      st_operand<PREC>(Ws + (wave + i * 8) * ST, lane, wreg[i]);
     }
     if constexpr (PREC == PREC_BF16X3) {
       if (p.w_split) {                          // W came from the pre-split image: the loaded words ARE the row image
@@ -326,11 +306,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
         for (int i = 0; i < 8; ++i) st4(Ws + (wave + i * 8) * ST + lane * 4, wreg[i]);
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) st_operand<PREC>(Ws + (wave + i * 8) * ST, lane, wreg[i], p.wscale);
+        for (int i = 0; i < 8; ++i) st_operand<PREC>(Ws + (wave + i * 8) * ST, lane, wreg[i]);
       }
     }
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * 8) * ST, lane, areg[i], ascale[i]);
+    for (int i = 0; i < RPW; ++i) st_operand<PREC>(As + (wave + i * 8) * ST, lane, areg[i]);
     if constexpr (tracing) ts[2] = clock_pinned();      // tile parked in LDS (this wave)
     __syncthreads();
     if constexpr (tracing) ts[3] = clock_pinned();      // barrier passed
@@ -351,10 +331,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tile32_kernel(Tile32Args p) {
   //      transposed the tile through LDS was measured SLOWER (+0.7-1.8 k cycles: two barriers + an LDS
   //      round trip cost more than the wider stores save; profiles/r01_v5).
   const int col = n0 + ct * 16 + r;
-  if constexpr (PREC == PREC_FP8) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] *= rsc[rt * 16 + g * 4 + i];
-  }
   if (col < p.N && kh == 0) {
     if (p.P) {
       float* P = p.P + z * p.pstride;

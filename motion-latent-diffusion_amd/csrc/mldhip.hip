@@ -177,8 +177,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   if (cfg->scheduler_type == MLDHIP_SCHED_DDIM &&
       (cfg->num_inference_steps - 1) * (cfg->num_train_timesteps / cfg->num_inference_steps) + cfg->steps_offset >= cfg->num_train_timesteps)
     return bad("steps_offset pushes the first timestep past num_train_timesteps");
-  if (cfg->precision < MLDHIP_PREC_F32 || cfg->precision > MLDHIP_PREC_FP8_DENOISER) return bad("unsupported precision");
-  if (cfg->precision == MLDHIP_PREC_FP8_DENOISER && novae) return bad("MLDHIP_PREC_FP8_DENOISER applies to the latent models' reverse loop");
+  if (cfg->precision == 3) return bad("precision 3 (MLDHIP_PREC_FP8_DENOISER of ABI <= 4) was retired in ABI 5: it met no tolerance and was slower than MLDHIP_PREC_F16X3 (include/mldhip.h)");
+  if (cfg->precision < MLDHIP_PREC_F32 || cfg->precision > MLDHIP_PREC_BF16) return bad("unsupported precision");
   if (cfg->max_in_flight < 1 || cfg->max_in_flight > 8) return bad("max_in_flight must be 1..8");
 #if !defined(MLDHIP_SIM)
   int ndev = 0;
@@ -322,7 +322,6 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
 #define MLD_T32_ATTR(NS)                                                                                                    \
   MLD_T32_ATTR1(32, NS, false, PREC_F32) MLD_T32_ATTR1(32, NS, true, PREC_F32) MLD_T32_ATTR1(16, NS, false, PREC_F32) MLD_T32_ATTR1(16, NS, true, PREC_F32) \
   MLD_T32_ATTR1(32, NS, false, PREC_BF16) MLD_T32_ATTR1(16, NS, false, PREC_BF16)                                             \
-  MLD_T32_ATTR1(32, NS, false, PREC_FP8) MLD_T32_ATTR1(16, NS, false, PREC_FP8)                                               \
   MLD_T32_ATTR1(32, NS, false, PREC_BF16X3) MLD_T32_ATTR1(16, NS, false, PREC_BF16X3)                                         \
   MLD_T32_ATTR1(32, NS, true, PREC_BF16X3) MLD_T32_ATTR1(16, NS, true, PREC_BF16X3)
   MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4)
@@ -330,21 +329,18 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
 #undef MLD_T32_ATTR1
 #define MLD_STRIP_ATTR(NS, NSRC, ACT, CT)                                                                                   \
   (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, NSRC, false, PREC_F32, ACT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<NSRC, CT>())); \
-  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, NSRC, false, PREC_BF16, ACT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<NSRC, CT>())); \
-  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, NSRC, false, PREC_FP8, ACT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<NSRC, CT>()));
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, NSRC, false, PREC_BF16, ACT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<NSRC, CT>()));;
   MLD_STRIP_ATTR(1, 2, 0, 1) MLD_STRIP_ATTR(2, 2, 0, 1)
   MLD_STRIP_ATTR(0, 1, 0, 2) MLD_STRIP_ATTR(1, 1, 0, 2) MLD_STRIP_ATTR(1, 1, 1, 2) MLD_STRIP_ATTR(2, 1, 0, 2)
 #undef MLD_STRIP_ATTR
 #define MLD_STRIP_ATTR8(NS, ACT)                                                                                            \
   (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 1, false, PREC_F32, ACT, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<1, 2>())); \
-  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 1, false, PREC_BF16, ACT, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<1, 2>())); \
-  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 1, false, PREC_FP8, ACT, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<1, 2>()));
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 1, false, PREC_BF16, ACT, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<1, 2>()));;
   MLD_STRIP_ATTR8(0, 0) MLD_STRIP_ATTR8(1, 0) MLD_STRIP_ATTR8(1, 1) MLD_STRIP_ATTR8(2, 0)
 #undef MLD_STRIP_ATTR8
 #define MLD_STRIP_ATTR8S(NS)                                                                                                \
   (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 2, false, PREC_F32, 0, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<2, 1>())); \
-  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 2, false, PREC_BF16, 0, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<2, 1>())); \
-  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 2, false, PREC_FP8, 0, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<2, 1>()));
+  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 2, false, PREC_BF16, 0, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<2, 1>()));;
   MLD_STRIP_ATTR8S(1) MLD_STRIP_ATTR8S(2)
   (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<1, 1, false, PREC_F32, 1, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<1, 2>()));
   (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<2, 1, false, PREC_F32, 0, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<1, 2>()));
@@ -460,7 +456,8 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "cluster_lane") {
     e->cluster_lane = value != 0;       // hooks build only: 0 = cluster calls of different streams are NOT ordered behind each other (reproduces the co-residency starvation: tools/two_streams.py)
   } else if (n == "cluster_graph") {
-    e->cluster_graph = value != 0; e->cluster_clear_memset = value == 2;     // hooks build only: 0 eager issue, 1 (default) graphs, 2 graphs with the flags cleared by a memset node (the r05 replay fault; tools/dbg_cluster.py)
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "cluster_graph must be 0 (eager issue) or 1 (graphs); 2 (the memset-node clear that reproduced the r05 replay fault) was removed in round 6: the kernel's entry check covers the case");
+    e->cluster_graph = value != 0;      // hooks build only
   } else if (n == "fused_dbg") {
     if (value != 0 && value != 5) return e->fail(MLDHIP_EINVAL, "fused_dbg must be 0 or 5 (phase counters; the builds with wrong results live in tools/loopbench only)");
     if (value == 5 && !e->trace_buf && hipMalloc((void**)&e->trace_buf, (size_t)512 * 8 * 8 * sizeof(uint64_t)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(trace)");
@@ -804,29 +801,7 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
   Ctx c{e, stream};
   const int D = e->cfg.latent_dim, TD = time_width(e), n = e->cfg.num_inference_steps;
   HIP_TRY(e, hipDeviceSynchronize());                   // no call may be in flight on any context while tables are rebuilt
-  if (e->cfg.precision == MLDHIP_PREC_FP8_DENOISER && e->group_ready[0]) {
-    // per-tensor power-of-two scales of the loop GEMMs' weights: s * max|w| in [128, 256) (rt.hpp fp8_pow2_scale)
-    bind_context(e, 0);
-    const int nb = (e->cfg.num_layers - 1) / 2;
-    std::vector<std::pair<const float*, long long>> tens;
-    const long long DD = (long long)D * D, DF = (long long)D * e->cfg.ff_size;
-    for (auto& L : e->den) { tens.push_back({L.in_w, 3 * DD}); tens.push_back({L.out_w, DD}); tens.push_back({L.l1_w, DF}); tens.push_back({L.l2_w, DF}); }
-    for (int i = 0; i < nb; ++i) tens.push_back({P(e, "denoiser.encoder.linear_blocks." + std::to_string(i) + ".weight"), 2 * DD});
-    std::vector<float> amax(tens.size());
-    for (size_t i = 0; i < tens.size(); ++i) {
-      MLD_LAUNCH(absmax_kernel, dim3(1), dim3(256), 0, stream, tens[i].first, tens[i].second, e->temb0_one);
-      if (check_launch(c, "absmax")) return c.rc;
-      HIP_TRY(e, hipMemcpyAsync(&amax[i], e->temb0_one, sizeof(float), hipMemcpyDeviceToHost, stream));
-      HIP_TRY(e, hipStreamSynchronize(stream));
-    }
-    auto sc = [](float a) { if (!(a > 0.f)) return 1.f; int ex; (void)std::frexp(a, &ex); return std::ldexp(1.f, 8 - ex); };
-    for (size_t l = 0; l < e->den.size(); ++l) {
-      e->den[l].s_in = sc(amax[4 * l]); e->den[l].s_out = sc(amax[4 * l + 1]); e->den[l].s_l1 = sc(amax[4 * l + 2]); e->den[l].s_l2 = sc(amax[4 * l + 3]);
-    }
-    e->den_skip_scale.clear();
-    for (int i = 0; i < nb; ++i) e->den_skip_scale.push_back(sc(amax[4 * e->den.size() + i]));
-  }
-  if (e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE || e->cfg.precision == MLDHIP_PREC_FP8_DENOISER) {
+  if (e->cfg.precision == MLDHIP_PREC_BF16X3_DECODE) {
     // the staged GEMMs of these modes run on split-bf16 MFMAs: split the weights once, here, not in every workgroup
     if (!e->arena_x3 && hipMalloc((void**)&e->arena_x3, e->arena_floats * sizeof(float)) != hipSuccess) return e->fail(MLDHIP_EHIP, "hipMalloc(split weights)");
     const long long groups = (long long)((e->arena_floats + 31) / 32);   // arena_floats is a multiple of kAlign = 64

@@ -29,6 +29,23 @@ def test_library_exports_every_declared_symbol():
     assert lib.mldhip_abi_version() == _lib.ABI_VERSION
 
 
+def test_library_exports_only_the_declared_symbols():
+    """the dynamic symbol table of the production library holds the declarations of include/mldhip.h and nothing else -- no kernel __device_stub__s, no
+    members of the handle type, no measurement hooks (-fvisibility=hidden + the version script csrc/mldhip.map); the hooks build adds exactly its two entry points."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    if not os.path.exists(_lib.DEFAULT_LIB) or not (shutil.which("nm") or os.path.exists(nm)):
+        pytest.skip("libmldhip.so not built yet / no nm")
+
+    def exported(path):
+        out = subprocess.run([nm, "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+        return sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert exported(_lib.DEFAULT_LIB) == _header_symbols()
+    if os.path.exists(_lib.HOOKS_LIB):
+        assert exported(_lib.HOOKS_LIB) == sorted(_header_symbols() + ["mldhip_profile_kernel", "mldhip_profile_trace"])
+
+
 def test_library_contains_gfx950_code_object():
     if not os.path.exists(_lib.DEFAULT_LIB):
         pytest.skip("libmldhip.so not built yet")

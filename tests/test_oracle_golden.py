@@ -189,3 +189,35 @@ def test_second_weight_family_matches_reference(golden_dir):
     assert np.abs(np.asarray(lat) - g["latents"]).max() < 5e-3
     assert np.abs(np.asarray(f) - g["feats"]).max() < 2e-4
     assert np.abs(np.asarray(j) - g["joints"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("case", ["small", "large"])
+def test_small_and_large_latent_regimes_match_reference(golden_dir, case):
+    """tests/golden/pipeline_b8_latent_scales.npz (oracle/make_golden_latent_scales.py: the reference's own modules): the two regimes no other fixture
+    reaches -- |latent| max 7.5 (second weight family, encoder.norm x 0.06, start noise x 0.1) and |latent| max 312 (start noise x 6.5) -- through the oracle: full 50-step
+    DDIM + decode + joints, B = 8 ragged, nothing subsampled.  Latent tolerance relative to the magnitude (5e-3 on |x| ~ 80 elsewhere)."""
+    g = _load(golden_dir, "pipeline_b8_latent_scales.npz")
+    sdd, sdv, b = syn.latent_scale_case(case)
+    ops = O.TorchOps("float32")
+    mean, std = syn.make_mean_std()
+    lat_ref = g[case + "_latents"]
+    assert (np.abs(lat_ref).max() < 10) if case == "small" else (np.abs(lat_ref).max() > 300)
+    j, f, lat = O.sample(ops, O.to_backend(ops, sdd), O.to_backend(ops, sdv), ops.asarray(b.text_emb), ops.asarray(b.init_latents), b.lengths, mean, std, return_intermediates=True)
+    assert np.abs(np.asarray(lat) - lat_ref).max() < 5e-3 * max(1.0, np.abs(lat_ref).max() / 80.0)
+    assert np.abs(np.asarray(f) - g[case + "_feats"]).max() < 2e-4
+    assert np.abs(np.asarray(j) - g[case + "_joints"]).max() < 1e-3
+
+
+def test_every_feature_frame_of_the_bs64_fixture(golden_dir):
+    """tests/golden/pipeline_b64_feats.npz (oracle/make_golden_b64_feats.py): MldVae.decode's features, all 196 frames of every 4th motion of the
+    bs-64 pipeline fixture, against the oracle's decode of the fixture's own latents -- and consistent with what pipeline_b64.npz already holds (last frame, joints)."""
+    g, gf = _load(golden_dir, "pipeline_b64.npz"), _load(golden_dir, "pipeline_b64_feats.npz")
+    motions = [int(m) for m in gf["motions"]]
+    assert gf["feats"].shape == (len(motions), 196, 263) and np.array_equal(gf["feats"][:, -1], g["feats_frame_last"][motions])
+    ops = O.TorchOps("float32")
+    bv = O.to_backend(ops, syn.make_vae_state_dict())
+    mean, std = syn.make_mean_std()
+    f = O.vae_decode(ops, bv, ops.asarray(g["latents"][motions]), [196] * len(motions))
+    assert np.abs(np.asarray(f) - gf["feats"]).max() < 2e-4
+    j = np.asarray(O.feats2joints(ops, ops.asarray(gf["feats"]), ops.asarray(mean), ops.asarray(std)))
+    assert np.abs(j - g["joints"][motions]).max() < 1e-4

@@ -12,7 +12,7 @@ ap.add_argument("--layers", type=int, default=3)
 ap.add_argument("--steps", type=int, default=1)
 ap.add_argument("--B", type=int, default=8)
 ap.add_argument("--wt", type=int, default=1)
-ap.add_argument("--graph", type=int, default=0)
+ap.add_argument("--graph", type=int, default=0, choices=(0, 1))      # (2 = the memset-node clear of round 5: removed in round 6 with the engine option)
 ap.add_argument("--repeat", type=int, default=1)
 ap.add_argument("--full", type=int, default=0)
 ap.add_argument("--sync", type=int, default=1)
