@@ -247,8 +247,8 @@ int mldhip_set_option(mldhip_handle* h, const char* name, int64_t value);
  * there is a guard, in three parts:
  *  1. PROBE (mldhip_finalize_weights, option "range_probe"): the handle runs its own split-f16 kernels and its exact-fp32
  *     kernels on one probe batch built from the loaded weights (8 motions, seeded unit-normal latents / condition rows: two
- *     reverse steps of the persistent loop and of the cluster loop (its 24-workgroup form: the 12-workgroup form differs in the order of two
- *     sums only) and one denoiser call of the latency kernels at the first and last timestep; one
+ *     reverse steps of the persistent loop and of the cluster loop (both of its forms since round 6: 24 workgroups per cluster, what calls of up to 64 motions
+ *     run, and 12, what calls of 65 .. 256 motions run) and one denoiser call of the latency kernels at the first and last timestep; one
  *     decode of 4 x 64 frames) and compares: err = max|split - fp32| / max|fp32| (for the two loop steps: max|split - fp32| of the
  *     latents / max|latents - start noise| / (2 guidance_scale - 1), i.e. relative to the update the steps made, whatever the schedule).
  *     Diffusion-only variant: one denoiser call on 4 CFG rows x 128 frames, reported as probe_err_decode / decode_split_ok (all of its

@@ -639,8 +639,6 @@ void ffn_block(Ctx& c, const float* x, float* y, int M, const float* w1, const f
                const float* gamma, const float* beta, int ragged_T) {
   E* e = c.e;
   const int D = e->cfg.latent_dim, F = e->cfg.ff_size;
-  // in the arena AND on a 32-float group boundary of it: the split image is built per aligned group (mldhip_finalize_weights)
-  auto in_arena = [&](const float* w) { return w >= e->arena && w < e->arena + e->arena_floats && (w - e->arena) % 32 == 0; };
   if (staged_prec(e) == PREC_BF16X3 && e->ffn_strip && D == 256 && F == 1024 && M > e->small_m && !e->trace_on && e->ffn_stream_of.count(w1)) {
     // register-direct form (kernels/ffn_strip.hpp): weights from the layer's fragment-ordered stream, 96- or 64-row strips
     FfnArgs a;

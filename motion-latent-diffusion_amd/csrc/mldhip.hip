@@ -661,21 +661,33 @@ int range_probe(mldhip_handle* e, hipStream_t stream, const float* user_text = n
 #endif
       if (probe_cluster) {
         e->split_loop_ok = true;
-        std::vector<float> hc_;
-        {
-          ClusterLane lane(e, c.stream, true);
-          launch_cluster_loop(c, sample.p, Bp, std::min(2, n), guidance);
-        }
-        if (c.rc) return c.rc;
-        if (down(e->lat, (size_t)Bp * D, hc_)) return e->fail(MLDHIP_EHIP, "range probe: copy");
-        if (cluster_timed_out(e)) {
-          // the device did not keep the launch's workgroups resident together (a wait ran into its 200 ms bound): not an arithmetic verdict -- the handle leaves the cluster loop
-          e->cluster_failed = 1;
-        } else {
-          float d2 = 0.f;
-          bool fin2 = true;
-          for (size_t i = 0; i < hc_.size(); ++i) { fin2 = fin2 && std::isfinite(hc_[i]); d2 = std::max(d2, std::fabs(hc_[i] - hb[i])); }
-          worst = std::max(worst, !fin2 ? std::numeric_limits<float>::infinity() : (m > 0.f ? d2 / m / amp : (d2 > 0.f ? std::numeric_limits<float>::infinity() : 0.f)));
+        // both forms (advisor r5): 8 column groups per token (24 workgroups per cluster: calls of up to 64 motions -- what a probe batch of 8 picks by itself) and 4 (12 workgroups:
+        // calls of 65 .. 256 motions); they differ in how linear1 / linear2 / the skip linear are split over members and waves, i.e. in the order of sums
+        const int cg_saved = e->cluster_groups;
+        struct RestoreCG { mldhip_handle* e; int v; ~RestoreCG() { e->cluster_groups = v; } } restore_cg{e, cg_saved};
+        const int first = cluster_groups(e, Bp);      // what the handle picks for the probe batch: 8 unless the device is small or the option says 4
+        for (int form = 0; form < 2 && !e->cluster_failed; ++form) {
+          if (form == 1) {
+            e->cluster_groups = first == 8 ? 4 : 8;
+            if (cluster_groups(e, Bp) == first) break;      // the other form is not available on this device: nothing new to run
+          }
+          std::vector<float> hc_;
+          {
+            ClusterLane lane(e, c.stream, true);
+            launch_cluster_loop(c, sample.p, Bp, std::min(2, n), guidance);
+          }
+          if (c.rc) return c.rc;
+          if (down(e->lat, (size_t)Bp * D, hc_)) return e->fail(MLDHIP_EHIP, "range probe: copy");
+          if (cluster_timed_out(e)) {
+            // the device did not keep the launch's workgroups resident together (a wait ran into its 200 ms bound): not an arithmetic verdict -- the handle leaves the cluster loop
+            e->cluster_failed = 1;
+            if (e->cl_host_status) *e->cl_host_status = 0u;
+          } else {
+            float d2 = 0.f;
+            bool fin2 = true;
+            for (size_t i = 0; i < hc_.size(); ++i) { fin2 = fin2 && std::isfinite(hc_[i]); d2 = std::max(d2, std::fabs(hc_[i] - hb[i])); }
+            worst = std::max(worst, !fin2 ? std::numeric_limits<float>::infinity() : (m > 0.f ? d2 / m / amp : (d2 > 0.f ? std::numeric_limits<float>::infinity() : 0.f)));
+          }
         }
       }
     }
