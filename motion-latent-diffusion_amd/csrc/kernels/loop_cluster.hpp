@@ -246,6 +246,12 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
     if (!ok && lane == 0) { flag_store(p.status, 1u); flag_store(p.status + 2, 1u); host_flag_store(p.host_status, 1u); ctl[2] = 1u; }
   };
   auto publish = [&](int kind, unsigned epoch) __attribute__((always_inline)) {
+#if defined(CL_EXP) && (CL_EXP & 2)
+    // measurement build (WRONG results, tools/loopbench only): the flag goes up without waiting for the payload stores or for the other waves -- the upper bound of what
+    // cheaper publishes (per-wave flags, no workgroup barrier) could buy (profiles/r06_loop_experiments.json)
+    if (tid == 0) flag_store(flags + kind * kClFlagLine + member, epoch);
+    return;
+#endif
     drain_stores();
     __syncthreads();
     if (tid == 0 && !(member == p.mute && epoch == 1u)) flag_store(flags + kind * kClFlagLine + member, epoch);
@@ -341,8 +347,15 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
     float s[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) s[i] = i < nr ? (v[i].x + v[i].y) + (v[i].z + v[i].w) : 0.f;
+#if defined(CL_EXP) && (CL_EXP & 4)
+    // measurement build (WRONG results, tools/loopbench only): no cross-lane reductions in the LayerNorms -- the upper bound of what row statistics published by the
+    // producers of Y / the out-projection partials could buy
+#define CL_SUM64(x) (x)
+#else
+#define CL_SUM64(x) sum64(x)
+#endif
 #pragma unroll
-    for (int i = 0; i < 6; ++i) if (i < nr) s[i] = sum64(s[i]);
+    for (int i = 0; i < 6; ++i) if (i < nr) s[i] = CL_SUM64(s[i]);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       if (i < nr) {
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void den_cluster_kernel(ClusterArgs p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) if (i < nr) s[i] = sum64(s[i]);
+    for (int i = 0; i < 6; ++i) if (i < nr) s[i] = CL_SUM64(s[i]);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       if (i < nr) {

@@ -137,7 +137,7 @@ __device__ __forceinline__ float max_groups(float v) {
 // totals are read through SGPRs (v_readlane) -- no ds_bpermute on the dependent chain.
 __device__ __forceinline__ float sum64(float v) {
   v = sum16(v);
-#if defined(MLDHIP_SIM)
+#if defined(MLDHIP_SIM) || defined(MLD_SUM64_SWAP)
   return sum_groups(v);
 #else
   const int b = __builtin_bit_cast(int, v);
