@@ -34,6 +34,7 @@
 #if !defined(MLDHIP_SIM)
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #endif
 
@@ -83,12 +84,22 @@ bool cluster_lane_owned(int device) {
   if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); st = 1; return true; }
   for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.') *c = '_';
   const std::string path = std::string("/tmp/mldhip_cluster_lane_") + bus + ".lock";      // (a fixed directory: processes with different TMPDIRs must meet at one file)
-  const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-  if (fd < 0) { st = 1; return true; }                        // no lock file possible (read-only /tmp): behave as before
+  // O_NOFOLLOW + regular-file check: /tmp is shared, the name is predictable -- never write through somebody's symlink.  Another user's file (created under their umask) may
+  // not be writable: flock works on a read-only descriptor too, only the pid note is skipped then.
+  int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
+  bool writable = fd >= 0;
+  if (fd >= 0) (void)fchmod(fd, 0666);                        // (ours if we created it; EPERM otherwise: ignored)
+  else fd = open(path.c_str(), O_RDONLY | O_CLOEXEC | O_NOFOLLOW);
+  struct stat sb;
+  if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {      // no lock file possible (read-only /tmp, a symlink in its place): no coordination, behave as before
+    if (fd >= 0) close(fd);
+    st = 1;
+    return true;
+  }
   if (flock(fd, LOCK_EX | LOCK_NB) == 0) {                    // fd stays open for the life of the process; the owner's pid goes into the file
     char buf[32];
     const int n = snprintf(buf, sizeof buf, "%ld\n", (long)getpid());
-    if (ftruncate(fd, 0) == 0 && pwrite(fd, buf, (size_t)n, 0) == n) {}
+    if (writable && ftruncate(fd, 0) == 0 && pwrite(fd, buf, (size_t)n, 0) == n) {}
     st = 1;
     return true;
   }
