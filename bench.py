@@ -463,7 +463,9 @@ def bench_novae(local, dev, full, streams, B=64, T=196):
     return {"workload": "config_novae_humanml3d.yaml (raw-motion diffusion, trans_dec d=512), bs=64, T=196, DDPM, CFG 7.5 -> joints; "
                         "%d batches in flight on one handle (one stream each); f16x3: all 1000 DDPM steps run per batch, other modes %d" % (nfl, 1000 if full else 100),
             "unit": "motions/s of the 1000-step sampler (= 64 / (1000 x ms_per_ddpm_step))", "extrapolated_from_steps": "per mode: see modes[*].extrapolated_from_steps (f16x3: none)",
-            "algorithmic_gflop_per_ddpm_step": round(gf_step, 1), "kernel_launches_per_ddpm_step": 114, "modes": modes, "stream_placement": placement,
+            "algorithmic_gflop_per_ddpm_step": round(gf_step, 1), "kernel_launches_per_ddpm_step": 78,
+            "cross_fold": "round 6: LayerNorm 1 + the two-token cross-attention sub-layer + LayerNorm 2 of every layer are ONE launch on vectors folded from the memory tokens (exact algebra; "
+                          "no query GEMM, no out-projection GEMM: 26 of a step's 1 290 algorithmic GFLOP are not executed as products any more -- the fractions above still divide the reference's count by the time)", "modes": modes, "stream_placement": placement,
             "error_vs_reference": "f32: tests/test_gpu_parity.py::test_novae_full_length_1000_steps_vs_reference_golden; every mode: "
                                   "tools/ab_precision.py -> profiles/r03_precision_ab.json",
             "peaks": "f32: fp32 MFMA 157.3 TF; f16x3: dense 16-bit MFMA peak / 3 (three MFMAs per product) = 833 TF; bf16: 2500 TF"}

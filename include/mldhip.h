@@ -221,6 +221,11 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     on split-f16 MFMAs reading the pre-split weight image, 0 = on exact-fp32 MFMAs
  *   "strip_gemm"      F16X3 / FP8 modes, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:
  *                     1 (default) = row-strip kernels with register-direct weights (kernels/gemm_strip_x3.hpp), 0 = staged tiles
+ *   "cross_fold"      diffusion-only variant (latent width 512, 4 heads), every mode: 1 (default) = LayerNorm 1 + the cross-attention sub-layer + LayerNorm 2 of a trans_dec layer
+ *                     run as ONE launch (kernels/novae.hpp cross2_fold_ln_kernel).  The memory is two tokens per sample, so (x Wq^T + bq) . k = x . (Wq^T k) + bq . k and
+ *                     Wo (p1 v1 + p2 v2) = p1 (Wo v1) + p2 (Wo v2): the query and out-projection GEMMs become 16 dot products / axpys of length 512 per row against vectors
+ *                     folded from the memory tokens (time token: per layer and scheduler step at finalize; text tokens: once per call) -- exact algebra, fp32; 0 = the five
+ *                     launches (LayerNorm, query GEMM, two-key attention, out-projection GEMM, LayerNorm)
  *   "gemm_pipe"       F16X3 mode, diffusion-only variant (latent width 512): 1 (default) = its K >= 512 GEMMs at >= 2 048 rows run on the
  *                     software-pipelined 128 x 256 tile (kernels/gemm_pipe.hpp: fragments of chunk c + 1 are read while chunk c is
  *                     multiplied, one barrier per 32-wide K chunk; same products in the same order as the 64 x 128 staged tile,

@@ -57,9 +57,24 @@ void novae_memory_kv(Ctx& c, const float* src, int rows, float* dst, long long d
   gemm(c, g, e->cfg.num_layers);
 }
 
+// Memory tokens folded through the cross-attention's query and out projections (kernels/novae.hpp cross_fold_kernel): kv [L][ntok][2D] -> w, u [L][ntok][H][D], c [L][ntok][H]
+void novae_fold_memory(Ctx& c, const float* kv, int ntok, long long kv_layer_stride, float* w, float* u, float* cc) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim, H = e->cfg.num_heads, L = e->cfg.num_layers;
+  if (D != 512 || H != 4) return;                  // (the folded form is built for config 4's shape; cross_fold_on() says the same)
+  MLD_LAUNCH((cross_fold_kernel<512, 128>), dim3((unsigned)ntok, (unsigned)H, (unsigned)L), dim3(256), kCrossFoldLdsBytes, c.stream, kv, kv_layer_stride,
+             e->ndec[0].cin_w, e->ndec[0].cin_b, e->ndec[0].cout_w, (long long)e->ndec_layer_stride, w, u, (long long)ntok * H * D, cc, (long long)ntok * H, ntok);
+  count(c);
+  check_launch(c, "cross_fold");
+}
+bool cross_fold_on(const E* e) { return e->cross_fold && e->cfg.latent_dim == 512 && e->cfg.num_heads == 4 && !e->trace_on; }
+
+// the time token's folded vectors of this call: layer l at w + l * tokens * H * D (u likewise), c + l * tokens * H
+struct NovaeFold { const float* w; const float* u; const float* c; long long tokens; };
+
 // MldDenoiser.forward, trans_dec branch, for the M = R*T rows whose zero-padded features are in e->FF [M][KP].
 // tkv: K|V of the time token, layer l at tkv + l*tkv_stride; text-token K|V in e->XKV [L][2*max_batch][2D].
-void novae_denoiser_body(Ctx& c, int R, int T, const float* tkv, long long tkv_stride, float* eps_out) {
+void novae_denoiser_body(Ctx& c, int R, int T, const float* tkv, long long tkv_stride, const NovaeFold& tf, float* eps_out) {
   E* e = c.e;
   const int D = e->cfg.latent_dim, F = e->cfg.ff_size, NF = e->cfg.nfeats, KP = novae_kp(e), M = R * T;
   gemm(c, lin_args(e->FF, KP, KP, e->WskelP, P(e, "denoiser.pose_embd.bias"), e->X0, D, M, D));
@@ -72,6 +87,19 @@ void novae_denoiser_body(Ctx& c, int R, int T, const float* tkv, long long tkv_s
     gemm(c, lin_args(e->X0, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
     novae_self_attention(c, R, T);
     gemm(c, lin_args(e->AO, D, D, L.out_w, L.out_b, e->Ha, D, M, D));
+    if (cross_fold_on(e)) {
+      // LayerNorm 1 + the whole two-token cross-attention sub-layer + LayerNorm 2 in one launch, on the folded memory tokens (kernels/novae.hpp): no query GEMM, no
+      // out-projection GEMM, two LayerNorm passes less -- 5 launches and 26 GFLOP of a layer's 143 become ~30 us of streaming
+      const size_t H = (size_t)e->cfg.num_heads, Bm2 = (size_t)2 * e->cfg.max_batch;
+      Cross2LnArgs a;
+      a.Ha = e->Ha; a.X = e->X0; a.g1 = L.n1_w; a.b1 = L.n1_b;
+      a.wt = tf.w + (size_t)l * tf.tokens * H * D; a.ut = tf.u + (size_t)l * tf.tokens * H * D; a.ct = tf.c + (size_t)l * tf.tokens * H;
+      a.wx = e->XKW + (size_t)l * Bm2 * H * D; a.ux = e->XKU + (size_t)l * Bm2 * H * D; a.cx = e->XKC + (size_t)l * Bm2 * H;
+      a.bo = L.cout_b; a.g2 = L.n2_w; a.b2 = L.n2_b; a.Y = e->X0; a.M = M; a.T = T;
+      MLD_LAUNCH((cross2_fold_ln_kernel<512, 128>), dim3((unsigned)(R * ((T + kC2Rows - 1) / kC2Rows))), dim3(256), kC2LdsBytes, c.stream, a);
+      count(c);
+      check_launch(c, "cross2_fold_ln");
+    } else {
     novae_ln(c, e->Ha, e->X0, L.n1_w, L.n1_b, e->H1, M);
     gemm(c, lin_args(e->H1, D, D, L.cin_w, L.cin_b, e->Hb, D, M, D));                    // cross-attention queries
     MLD_LAUNCH((cross2_kernel<512, 128>), dim3((M + 3) / 4), dim3(256), 0, c.stream, (const float*)e->Hb, tkv + (size_t)l * tkv_stride,
@@ -80,6 +108,7 @@ void novae_denoiser_body(Ctx& c, int R, int T, const float* tkv, long long tkv_s
     check_launch(c, "cross2");
     gemm(c, lin_args(e->AO, D, D, L.cout_w, L.cout_b, e->Ha, D, M, D));
     novae_ln(c, e->Ha, e->H1, L.n2_w, L.n2_b, e->X0, M);
+    }
     GemmArgs f1 = lin_args(e->X0, D, D, L.l1_w, L.l1_b, e->FF, F, M, F);
     f1.act = ACT_GELU;
     gemm(c, f1);
@@ -101,11 +130,23 @@ void novae_pad_input(Ctx& c, const float* x, long long rows, int dup) {
   check_launch(c, "dup_pad_rows");
 }
 
+void novae_fold_text(Ctx& c, int rows) {
+  E* e = c.e;
+  const int D = e->cfg.latent_dim, H = e->cfg.num_heads, L = e->cfg.num_layers;
+  const long long tok = (long long)2 * e->cfg.max_batch;
+  MLD_LAUNCH((cross_fold_kernel<512, 128>), dim3((unsigned)rows, (unsigned)H, (unsigned)L), dim3(256), kCrossFoldLdsBytes, c.stream, (const float*)e->XKV, tok * 2 * D,
+             e->ndec[0].cin_w, e->ndec[0].cin_b, e->ndec[0].cout_w, (long long)e->ndec_layer_stride, e->XKW, e->XKU, tok * H * D, e->XKC, tok * H, rows);
+  count(c);
+  check_launch(c, "cross_fold_text");
+}
+
 // text token of the memory: emb_proj(text) + mem_pos.pe[1] -> TP [rows][D], then its K|V for every layer -> XKV
 void novae_text_memory(Ctx& c, const float* text, int rows) {
   E* e = c.e;
   text_projection(c, text, rows, e->TP);
   novae_memory_kv(c, e->TP, rows, e->XKV, (long long)2 * e->cfg.max_batch * 2 * e->cfg.latent_dim);
+  // ... and their folded forms: ONCE per call, the text tokens do not depend on the step.  (Token r of layer l sits at [l][r] of buffers laid out for 2 * max_batch tokens.)
+  if (cross_fold_on(e)) novae_fold_text(c, rows);
 }
 
 // MLD.forward after the text encoder with vae_type 'no' (mld.py:232-242,264,290-360), in three pieces so that the step
@@ -131,7 +172,8 @@ int novae_steps(E* e, hipStream_t stream, int B, int T, int s0, int s1, const fl
   e->phase = 0;
   for (int s = s0; s < s1 && !c.rc; ++s) {
     novae_pad_input(c, e->lat, (long long)B * T, 2);                                      // torch.cat([latents] * 2)
-    novae_denoiser_body(c, 2 * B, T, e->TKV + (size_t)s * 2 * D, (long long)n * 2 * D, e->feats_int);
+    const size_t Hn = (size_t)e->cfg.num_heads;
+    novae_denoiser_body(c, 2 * B, T, e->TKV + (size_t)s * 2 * D, (long long)n * 2 * D, NovaeFold{e->TKW + (size_t)s * Hn * D, e->TKU + (size_t)s * Hn * D, e->TKC + (size_t)s * Hn, n}, e->feats_int);
     MLD_LAUNCH(cfg_ddpm_step_kernel, dim3((unsigned)std::min<long long>(4096, (nel / 4 + 255) / 256)), dim3(256), 0, stream,
                (const float*)e->feats_int, (const float*)(e->feats_int + nel), (const float*)e->lat,
                step_noise ? step_noise + (size_t)s * nel : (const float*)nullptr, e->lat, nel, guidance,

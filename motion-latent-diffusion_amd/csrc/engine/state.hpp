@@ -97,6 +97,8 @@ struct mldhip_engine {
   size_t ndec_layer_stride = 0;
   float* seed_slot = nullptr;     // 8 bytes of workspace: the Philox seed of the call whose captured step graphs are running
   float *TKV = nullptr, *XKV = nullptr, *TKV_one = nullptr;   // memory-token K|V per layer: time [L][n][2D], text [L][2*max_batch][2D]
+  // ... folded through the cross-attention's query / out projections (kernels/novae.hpp cross_fold_kernel, "cross_fold"): w | u [L][tokens][H][D], c [L][tokens][H]
+  float *TKW = nullptr, *TKU = nullptr, *TKC = nullptr, *XKW = nullptr, *XKU = nullptr, *XKC = nullptr, *TKW_one = nullptr, *TKU_one = nullptr, *TKC_one = nullptr;
   size_t dec_layer_stride = 0;     // floats between consecutive decoder layers' tensors
 
   // ---- schedule
@@ -149,6 +151,7 @@ struct mldhip_engine {
   int dec_half = 0;          // "dec_half": OPT-IN (default 0 = fp32 Q | K | V and split x3 products: gemm_strip_x3.hpp, attention.hpp).  1 / 4 / 6: split mode, decoder self-attention block on half Q | K | V (kernels/dec_half.hpp): in-projection with half activation rows x split weights (2 matrix instructions per product), Q | K | V stored as halves, attention on plain half operands -- kept only where finalize's probe reads it below MLDHIP_PROBE_TOL_HALF on the handle's weights; 2 = without that veto (A/B tools).  Off by default because it is not safe in general: profiles/r06_decoder_precision.json (heavy-tailed weights on O(1) latents: 6.7e-4 .. 8.8e-4 on the joints)
   int tile_x3 = 1;           // "tile_x3": split-f16 mode runs the latency kernels (tile32.hpp) on split-f16 MFMAs too (0: exact fp32)
   int strip_gemm = 1;        // "strip_gemm": split modes, decoder / encoder in-projection, out-projection (+ LayerNorms) and skip linears on the row-strip kernels (kernels/gemm_strip_x3.hpp); 0 = the staged 64 x 128 / 64 x 256 tiles
+  int cross_fold = 1;        // "cross_fold": diffusion-only variant: LayerNorm 1 + the two-token cross-attention sub-layer (query GEMM, attention, out-projection GEMM) + LayerNorm 2 of a trans_dec layer as ONE launch on vectors folded from the memory tokens (kernels/novae.hpp cross2_fold_ln_kernel; exact algebra); 0 = the five launches
   int gemm_pipe = 1;         // "gemm_pipe": diffusion-only variant, split modes: the K >= 512 GEMMs on the software-pipelined 128 x 256 tile (kernels/gemm_pipe.hpp): 1 = launches of >= 2 048 rows, 2 = always (tests); 0 = the 64 x 128 staged tile
   int gemm_pipe_min_rows = 2048;   // (not an option) row count from which the big tile is used: below it its 128-row tiles leave most CUs without a workgroup
   int strip_ffn2_split = 2;  // "strip_ffn2_split": K slices (= raw slabs) of FFN2 on the throughput kernels: 1 or 2

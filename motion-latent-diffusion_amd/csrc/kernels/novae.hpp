@@ -425,6 +425,166 @@ __global__ __launch_bounds__(256) void cross2_kernel(const float* __restrict__ q
 }
 
 // ----------------------------------------------------------------------------------------------
+// The cross-attention sub-layer of the trans_dec denoiser WITHOUT its two GEMMs (round 6).  Its memory is two tokens per sample, so per head h
+//   s_j = (x Wq_h^T + bq_h) . k_j / sqrt(128) = x . w_j + c_j        with  w_j = Wq_h^T k_j / sqrt(128)  (a 512-vector),  c_j = bq_h . k_j / sqrt(128)
+//   out_proj(concat_h (p_1 v_1 + p_2 v_2)_h) = bo + sum_h (p_1^h u_1^h + p_2^h u_2^h)        with  u_j^h = Wo[:, head h] v_j^h  (a 512-vector)
+// -- exact algebra (cross_attention.py:336-339, F.multi_head_attention_forward), the two-token form of the decoder's 1-key shortcut: the query projection and the
+// out-projection (2 x 2 M 512^2 multiply-adds per layer, 26 GFLOP at M = 25 088) become 16 dot products / axpys of length 512 per row against vectors that depend on
+// the memory tokens only.  cross_fold_kernel builds them: for the time token of every (layer, scheduler step) at finalize, for the text tokens once per call.
+//   kv [L][ntok][2 D] (k | v; layer stride skv), Wq = in_proj_weight rows [0, D), bq, Wo = out_proj.weight [D][D] (layer stride sw) ->
+//   w, u [L][ntok][H][D] (layer stride sfold), c [L][ntok][H] (layer stride sc).  grid = (ntok, H, L), block = 256.
+constexpr int kCrossFoldLdsBytes = (2 * 128 + 4) * 4;
+template <int D, int HD>
+__global__ __launch_bounds__(256) void cross_fold_kernel(const float* __restrict__ kv, long long skv, const float* __restrict__ Wq, const float* __restrict__ bq,
+                                                         const float* __restrict__ Wo, long long sw, float* __restrict__ w, float* __restrict__ u, long long sfold,
+                                                         float* __restrict__ cc, long long sc, int ntok) {
+  constexpr int H = D / HD;
+#if defined(MLDHIP_SIM)
+  float* sh = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
+#else
+  extern __shared__ __attribute__((aligned(16))) float sh_fold[];      // kCrossFoldLdsBytes
+  float* sh = sh_fold;
+#endif
+  float* ks = sh;            // [HD]
+  float* vs = sh + HD;       // [HD]
+  float* red = sh + 2 * HD;  // [4]
+  const int tok = blockIdx.x, h = blockIdx.y, l = blockIdx.z, tid = threadIdx.x;
+  const float* kvp = kv + (long long)l * skv + (long long)tok * 2 * D + h * HD;
+  const float* wq = Wq + (long long)l * sw, *bqp = bq + (long long)l * sw, *wo = Wo + (long long)l * sw;
+  const float scale = rsqrtf((float)HD);
+  float part = 0.f;
+  if (tid < HD) { const float k = kvp[tid]; ks[tid] = k; vs[tid] = kvp[D + tid]; part = bqp[h * HD + tid] * k; }
+  part = sum64(part);
+  if ((tid & 63) == 0) red[tid >> 6] = part;
+  __syncthreads();
+  if (tid == 0) cc[(long long)l * sc + (long long)tok * H + h] = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+  float* wout = w + (long long)l * sfold + ((long long)tok * H + h) * D;
+  float* uout = u + (long long)l * sfold + ((long long)tok * H + h) * D;
+  for (int c = tid; c < D; c += 256) {
+    float a = 0.f, b = 0.f;
+    const float* wr = wo + (long long)c * D + h * HD;
+#pragma unroll 8
+    for (int d = 0; d < HD; ++d) {
+      a = fmaf(ks[d], wq[(long long)(h * HD + d) * D + c], a);      // coalesced over c
+      b = fmaf(wr[d], vs[d], b);
+    }
+    wout[c] = a * scale;
+    uout[c] = b;
+  }
+}
+
+// [self-attention out-projection output Ha] + residual X -> LayerNorm 1 -> folded two-token cross-attention + residual -> LayerNorm 2 -> Y, one launch (it replaces
+// add_layernorm, the query GEMM, cross2_kernel, the out-projection GEMM and the second add_layernorm of a trans_dec layer: mld_denoiser.py:208-221 via
+// cross_attention.py:323-345).  A workgroup (4 waves) serves kC2Rows consecutive rows of ONE sample: the sample's sixteen folded vectors (8 of the time token, shared
+// by every sample of the step, 8 of its text token) sit in LDS; a wave owns a row at a time, a lane the 8 columns c * 256 + 4 lane .. + 3 (add_layernorm_rows_kernel's map).
+constexpr int kC2Rows = 28;
+constexpr int kC2LdsBytes = (16 * 512 + 16) * 4;
+struct Cross2LnArgs {
+  const float* Ha; const float* X;                 // [M][512] each: sub-layer output (bias included) and its residual
+  const float* g1; const float* b1;                // LayerNorm 1
+  const float* wt; const float* ut; const float* ct;      // time token of this (layer, step): [H][512], [H][512], [H]
+  const float* wx; const float* ux; const float* cx;      // text tokens of this layer: [R][H][512], [R][H][512], [R][H]
+  const float* bo;                                 // out_proj.bias [512]
+  const float* g2; const float* b2;                // LayerNorm 2
+  float* Y; int M, T;
+};
+template <int D, int HD>
+__global__ __launch_bounds__(256) void cross2_fold_ln_kernel(Cross2LnArgs p) {
+  static_assert(D == 512 && HD == 128, "four heads, two 256-column chunks per lane");
+  constexpr int H = 4, NC = 2;
+#if defined(MLDHIP_SIM)
+  float* sm = reinterpret_cast<float*>(hipsim::blk().dyn_smem.data());
+#else
+  extern __shared__ __attribute__((aligned(16))) float sm_c2[];
+  float* sm = sm_c2;
+#endif
+  float* Wl = sm;                  // [8][512]: w of (time, h = 0..3), (text, h = 0..3)
+  float* Ul = sm + 8 * D;          // [8][512]: u likewise
+  float* Cl = sm + 16 * D;         // [8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (p.T + kC2Rows - 1) / kC2Rows;
+  const int smp = blockIdx.x / per, r0 = (blockIdx.x % per) * kC2Rows;
+  for (int i = tid; i < H * D / 4; i += 256) {
+    st4(Wl + i * 4, ld4(p.wt + i * 4));
+    st4(Wl + H * D + i * 4, ld4(p.wx + (long long)smp * H * D + i * 4));
+    st4(Ul + i * 4, ld4(p.ut + i * 4));
+    st4(Ul + H * D + i * 4, ld4(p.ux + (long long)smp * H * D + i * 4));
+  }
+  if (tid < H) { Cl[tid] = p.ct[tid]; Cl[H + tid] = p.cx[smp * H + tid]; }
+  __syncthreads();
+  F4 gm1[NC], bt1[NC], gm2[NC], bt2[NC], bo[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int o = c * 256 + lane * 4;
+    gm1[c] = ld4(p.g1 + o); bt1[c] = ld4(p.b1 + o); gm2[c] = ld4(p.g2 + o); bt2[c] = ld4(p.b2 + o); bo[c] = ld4(p.bo + o);
+  }
+  auto layer_norm = [&](F4 (&x)[NC], const F4 (&gm)[NC], const F4 (&bt)[NC]) __attribute__((always_inline)) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) s += (x[c].x + x[c].y) + (x[c].z + x[c].w);
+    const float mean = sum64(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      x[c].x -= mean; x[c].y -= mean; x[c].z -= mean; x[c].w -= mean;
+      q += (x[c].x * x[c].x + x[c].y * x[c].y) + (x[c].z * x[c].z + x[c].w * x[c].w);
+    }
+    const float rstd = rsqrtf(sum64(q) * (1.0f / D) + kLnEps);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      x[c].x = x[c].x * rstd * gm[c].x + bt[c].x; x[c].y = x[c].y * rstd * gm[c].y + bt[c].y;
+      x[c].z = x[c].z * rstd * gm[c].z + bt[c].z; x[c].w = x[c].w * rstd * gm[c].w + bt[c].w;
+    }
+  };
+  for (int t = r0 + wave; t < r0 + kC2Rows && t < p.T; t += 4) {      // (wave-uniform bounds)
+    const long long row = (long long)smp * p.T + t;
+    F4 x[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const F4 a = ld4(p.Ha + row * D + c * 256 + lane * 4), rres = ld4(p.X + row * D + c * 256 + lane * 4);
+      x[c] = F4{a.x + rres.x, a.y + rres.y, a.z + rres.z, a.w + rres.w};
+    }
+    layer_norm(x, gm1, bt1);                                           // h1 = LayerNorm1(x + self-attention)
+    float sc[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const F4 wv = ld4(Wl + v * D + c * 256 + lane * 4);
+        d += (x[c].x * wv.x + x[c].y * wv.y) + (x[c].z * wv.z + x[c].w * wv.w);
+      }
+      sc[v] = d;
+    }
+#pragma unroll
+    for (int v = 0; v < 8; ++v) sc[v] = sum64(sc[v]) + Cl[v];
+    float pa[H], pb[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float m = fmaxf(sc[h], sc[H + h]);
+      const float ea = expf(sc[h] - m), eb = expf(sc[H + h] - m);
+      const float inv = 1.0f / (ea + eb);
+      pa[h] = ea * inv; pb[h] = eb * inv;
+    }
+    F4 y[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      F4 o = bo[c];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const F4 ua = ld4(Ul + h * D + c * 256 + lane * 4), ub = ld4(Ul + (H + h) * D + c * 256 + lane * 4);
+        o.x += pa[h] * ua.x + pb[h] * ub.x; o.y += pa[h] * ua.y + pb[h] * ub.y;
+        o.z += pa[h] * ua.z + pb[h] * ub.z; o.w += pa[h] * ua.w + pb[h] * ub.w;
+      }
+      y[c] = F4{x[c].x + o.x, x[c].y + o.y, x[c].z + o.z, x[c].w + o.w};
+    }
+    layer_norm(y, gm2, bt2);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) st4(p.Y + row * D + c * 256 + lane * 4, y[c]);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11) -> four N(0,1) draws per call through Box-Muller.  Counter-based, so the
 // noise of (seed, step, element) does not depend on launch geometry: the in-engine replacement for the
 // torch.randn(model_output.shape) inside DDPMScheduler.step (diffusers; call site mld.py:345-346).

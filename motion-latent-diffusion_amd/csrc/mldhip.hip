@@ -244,6 +244,12 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
     want(&e->WskelP, D * KPn);
     want(&e->feats_int, 2 * Bm * Tm * NF); want(&e->joints_int, Bm * Tm * cfg->njoints * 3);
     want(&e->TKV, L * n * 2 * D); want(&e->XKV, L * 2 * Bm * 2 * D); want(&e->TKV_one, L * 2 * D);
+    {
+      const size_t Hn = (size_t)cfg->num_heads;      // folded memory tokens ("cross_fold"): w, u [L][tokens][H][D], c [L][tokens][H]
+      want(&e->TKW, L * n * Hn * D); want(&e->TKU, L * n * Hn * D); want(&e->TKC, L * n * Hn);
+      want(&e->XKW, L * 2 * Bm * Hn * D); want(&e->XKU, L * 2 * Bm * Hn * D); want(&e->XKC, L * 2 * Bm * Hn);
+      want(&e->TKW_one, L * Hn * D); want(&e->TKU_one, L * Hn * D); want(&e->TKC_one, L * Hn);
+    }
     want(&e->seed_slot, 2);
   } else {
   want(&e->X0, rows * D); want(&e->Ha, rows * D); want(&e->Hb, rows * D); want(&e->H1, rows * D); want(&e->LNO, rows * D);
@@ -315,6 +321,8 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   (void)hipFuncSetAttribute((const void*)strip_inproj_h_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, inproj_h_lds_bytes<4>());
   (void)hipFuncSetAttribute((const void*)strip_inproj_h_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, inproj_h_lds_bytes<6>());
   (void)hipFuncSetAttribute((const void*)attn_flash128_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFlash128LdsBytes);
+  (void)hipFuncSetAttribute((const void*)cross2_fold_ln_kernel<512, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, kC2LdsBytes);
+  (void)hipFuncSetAttribute((const void*)cross_fold_kernel<512, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, kCrossFoldLdsBytes);
   (void)hipFuncSetAttribute((const void*)attn_decode_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_x3_lds_bytes<4>());
   (void)hipFuncSetAttribute((const void*)gemm_pipe_x3_kernel<2, 4, 4, 4, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (gemm_pipe_lds_bytes<2, 4, 4, 4>()));
   (void)hipFuncSetAttribute((const void*)gemm_pipe_x3_kernel<2, 4, 4, 4, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (gemm_pipe_lds_bytes<2, 4, 4, 4>()));
@@ -511,6 +519,9 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "tile_x3") {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "tile_x3 must be 0 or 1");
     e->tile_x3 = (int)value;
+  } else if (n == "cross_fold") {
+    if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "cross_fold must be 0 or 1");
+    e->cross_fold = (int)value;
   } else if (n == "gemm_pipe") {
     if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "gemm_pipe must be 0 (off), 1 (auto: launches of >= 2 048 rows) or 2 (always)");
     e->gemm_pipe = (int)value;
@@ -853,6 +864,7 @@ int mldhip_finalize_weights(mldhip_handle* e, void* stream_) {
     if (is_novae(e)) {
       // the time token's K|V for every (layer, scheduler step) depend on weights only; pose_embd.weight padded to KP
       novae_memory_kv(c, e->T1, n, e->TKV, (long long)n * 2 * D);
+      novae_fold_memory(c, e->TKV, n, (long long)n * 2 * D, e->TKW, e->TKU, e->TKC);      // ... and so do their folded forms ("cross_fold")
       const int NF = e->cfg.nfeats, KP = novae_kp(e);
       MLD_LAUNCH(pad_cols_kernel, dim3((D * KP + 255) / 256), dim3(256), 0, stream, P(e, "denoiser.pose_embd.weight"), e->WskelP, D, NF, KP);
       if (check_launch(c, "pad_cols")) return c.rc;
@@ -1400,9 +1412,10 @@ int mldhip_denoiser_forward_novae(mldhip_handle* e, const float* sample_dev, int
   HIP_TRY(e, hipStreamSynchronize(stream));   // `host` is a stack temporary
   time_mlp(c, e->temb0_one, e->temb0_one + TD, e->t1_one, 1);
   novae_memory_kv(c, e->t1_one, 1, e->TKV_one, (long long)2 * D);
+  novae_fold_memory(c, e->TKV_one, 1, (long long)2 * D, e->TKW_one, e->TKU_one, e->TKC_one);
   novae_text_memory(c, text_emb_dev, R);
   novae_pad_input(c, sample_dev, (long long)R * T, 1);
-  novae_denoiser_body(c, R, T, e->TKV_one, (long long)2 * D, out_dev);
+  novae_denoiser_body(c, R, T, e->TKV_one, (long long)2 * D, NovaeFold{e->TKW_one, e->TKU_one, e->TKC_one, 1}, out_dev);
   return c.rc;
 }
 

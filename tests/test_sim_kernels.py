@@ -296,7 +296,7 @@ def test_novae_full_sample_sim(neng, now):
     assert np.abs(joints - jr).max() < 2e-4
     den, dec, jn = neng.launch_counts()
     # text memory 2 + steps * (pad + embed 2 + 2 layers * 11 + final norm/proj 2 + step)
-    assert den == 2 + 4 * (1 + 2 + 2 * 11 + 2 + 1) and dec == 0 and jn == 1
+    assert den == 3 + 4 * (1 + 2 + 2 * 7 + 2 + 1) and dec == 0 and jn == 1      # (7 launches per layer since "cross_fold": 11 before; + the text tokens' fold in the prologue)
 
 
 def test_novae_denoiser_forward_staged_gemms_sim(now):
@@ -1205,3 +1205,28 @@ def test_sample_many_pipelined_requests_sim():
     with pytest.raises(_lib.MldHipError):
         e1.set_option("many_pipeline", 1)
     e1.close()
+
+
+def test_novae_cross_attention_folded_into_one_launch_sim(now):
+    """"cross_fold" (default 1; kernels/novae.hpp cross_fold_kernel / cross2_fold_ln_kernel): LayerNorm 1 + the two-token cross-attention sub-layer + LayerNorm 2 of a
+    trans_dec layer (mld_denoiser.py:208-221, cross_attention.py:323-345) as ONE launch on vectors folded from the memory tokens -- (x Wq^T + bq) . k = x . (Wq^T k) + bq . k
+    and Wo (p1 v1 + p2 v2) = p1 Wo v1 + p2 Wo v2, exact algebra -- against the oracle and against the five-launch form of the same handle (query GEMM, cross2_kernel,
+    out-projection GEMM, two LayerNorm passes): ragged lengths, a T that is not a multiple of the rows a workgroup serves, 4 launches less per layer."""
+    ops, bd = now
+    g = syn._rng(33, "crossfold")
+    for R, T, lens in ((4, 30, [30, 17, 30, 9]), (2, 57, [57, 40])):
+        e = simlib.sim_novae_engine(num_layers=2, max_batch=4, max_frames=64, num_inference_steps=4)
+        x = g.standard_normal((R, T, 263)).astype(np.float32)
+        te = (0.5 * g.standard_normal((R, 1, 768))).astype(np.float32)
+        ref = np.asarray(O.denoiser_forward_novae(ops, bd, x, 321, te, lens))
+        outs, launches = {}, {}
+        for cf in (1, 0):
+            e.set_option("cross_fold", cf)
+            out = np.full((R, T, 263), np.nan, np.float32)
+            n0 = e.launch_counts()[0]                                  # (this entry point does not reset the counters: differences)
+            e.denoiser_forward_novae(x, 321, te, lens, T, out)
+            outs[cf], launches[cf] = out, e.launch_counts()[0] - n0
+            assert np.isfinite(out).all() and np.abs(out - ref).max() < 5e-5, (cf, np.abs(out - ref).max())
+        assert 0 < np.abs(outs[1] - outs[0]).max() < 2e-5
+        assert launches[0] - launches[1] == 4 * 2 - 1, launches       # five launches -> one, per layer; the folded form folds the text tokens once per call
+        e.close()
