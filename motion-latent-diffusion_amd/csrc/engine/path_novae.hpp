@@ -14,12 +14,12 @@ void novae_ln(Ctx& c, const float* x, const float* res, const float* g, const fl
   check_launch(c, "add_layernorm_rows");
 }
 
-void novae_self_attention(Ctx& c, int R, int T) {
+void novae_self_attention(Ctx& c, int R, int T, bool force_flash = false) {
   E* e = c.e;
   const int H = e->cfg.num_heads, nkt = pick_nkt(T), nqt = (T + 15) / 16;
   dim3 grid(R * H, (nqt + 7) / 8), block(512);
   const int* nolens = nullptr;    // the reference passes no key-padding mask to the trans_dec denoiser (mld_denoiser.py:215)
-  if (staged_prec(e) == PREC_BF16X3 && T <= 256 && (e->flash_attn == 2 || (e->flash_attn == 1 && R * H >= 512)) && e->cfg.latent_dim == H * 128) {
+  if (staged_prec(e) == PREC_BF16X3 && T <= 256 && (e->flash_attn == 2 || (e->flash_attn == 1 && (R * H >= 512 || force_flash))) && e->cfg.latent_dim == H * 128) {
     // key-blocked form (attention.hpp attn_flash128_x3_kernel): one workgroup per (sample, head), K / V in blocks of 32 keys
     MLD_LAUNCH(attn_flash128_x3_kernel, dim3(R * H), dim3(512), kFlash128LdsBytes, c.stream, (const float*)e->QKV, e->AO, nolens, T, H);
     count(c);
@@ -74,19 +74,28 @@ struct NovaeFold { const float* w; const float* u; const float* c; long long tok
 
 // MldDenoiser.forward, trans_dec branch, for the M = R*T rows whose zero-padded features are in e->FF [M][KP].
 // tkv: K|V of the time token, layer l at tkv + l*tkv_stride; text-token K|V in e->XKV [L][2*max_batch][2D].
-void novae_denoiser_body(Ctx& c, int R, int T, const float* tkv, long long tkv_stride, const NovaeFold& tf, float* eps_out) {
+// cfg_dup: the rows of samples [R / 2, R) are copies of those of [0, R / 2) (torch.cat([latents] * 2), mld.py:325) and only R / 2 samples' features are in e->FF -- the two CFG
+// halves differ in their TEXT token only, which enters at the first cross-attention: the embedding, layer 0's in-projection, self-attention and out-projection run on half the
+// rows and the folded cross-attention launch of layer 0 reads them for both halves (needs "cross_fold"; novae_cfg_dedup() decides)
+bool novae_cfg_dedup(const E* e, int R) { return cross_fold_on(e) && R % 2 == 0 && R >= 2; }
+void novae_denoiser_body(Ctx& c, int R, int T, const float* tkv, long long tkv_stride, const NovaeFold& tf, float* eps_out, bool cfg_dup = false) {
   E* e = c.e;
   const int D = e->cfg.latent_dim, F = e->cfg.ff_size, NF = e->cfg.nfeats, KP = novae_kp(e), M = R * T;
-  gemm(c, lin_args(e->FF, KP, KP, e->WskelP, P(e, "denoiser.pose_embd.bias"), e->X0, D, M, D));
-  MLD_LAUNCH(add_pe_mod_kernel, dim3(std::min(4096, (M * (D / 4) + 255) / 256)), dim3(256), 0, c.stream, e->X0,
-             P(e, "denoiser.query_pos.pe"), (long long)M, T, D);
+  const bool dup = cfg_dup && novae_cfg_dedup(e, R);
+  const int M0 = dup ? M / 2 : M, R0 = dup ? R / 2 : R;              // rows / samples in front of layer 0's cross-attention
+  gemm(c, lin_args(e->FF, KP, KP, e->WskelP, P(e, "denoiser.pose_embd.bias"), e->X0, D, M0, D));
+  MLD_LAUNCH(add_pe_mod_kernel, dim3(std::min(4096, (M0 * (D / 4) + 255) / 256)), dim3(256), 0, c.stream, e->X0,
+             P(e, "denoiser.query_pos.pe"), (long long)M0, T, D);
   count(c);
   check_launch(c, "add_pe_mod");
   for (int l = 0; l < e->cfg.num_layers && !c.rc; ++l) {
     const DecLayerP& L = e->ndec[l];
-    gemm(c, lin_args(e->X0, D, D, L.in_w, L.in_b, e->QKV, 3 * D, M, 3 * D));
-    novae_self_attention(c, R, T);
-    gemm(c, lin_args(e->AO, D, D, L.out_w, L.out_b, e->Ha, D, M, D));
+    const bool half = dup && l == 0;
+    const int Ml = half ? M0 : M;
+    float* xc = e->X0;                                                 // the layer's stream after the cross-attention block (layer 0 of a de-duplicated batch: H1, the launch must not write where the other half still reads)
+    gemm(c, lin_args(e->X0, D, D, L.in_w, L.in_b, e->QKV, 3 * D, Ml, 3 * D));
+    novae_self_attention(c, half ? R0 : R, T, half);
+    gemm(c, lin_args(e->AO, D, D, L.out_w, L.out_b, e->Ha, D, Ml, D));
     if (cross_fold_on(e)) {
       // LayerNorm 1 + the whole two-token cross-attention sub-layer + LayerNorm 2 in one launch, on the folded memory tokens (kernels/novae.hpp): no query GEMM, no
       // out-projection GEMM, two LayerNorm passes less -- 5 launches and 26 GFLOP of a layer's 143 become ~30 us of streaming
@@ -95,7 +104,8 @@ void novae_denoiser_body(Ctx& c, int R, int T, const float* tkv, long long tkv_s
       a.Ha = e->Ha; a.X = e->X0; a.g1 = L.n1_w; a.b1 = L.n1_b;
       a.wt = tf.w + (size_t)l * tf.tokens * H * D; a.ut = tf.u + (size_t)l * tf.tokens * H * D; a.ct = tf.c + (size_t)l * tf.tokens * H;
       a.wx = e->XKW + (size_t)l * Bm2 * H * D; a.ux = e->XKU + (size_t)l * Bm2 * H * D; a.cx = e->XKC + (size_t)l * Bm2 * H;
-      a.bo = L.cout_b; a.g2 = L.n2_w; a.b2 = L.n2_b; a.Y = e->X0; a.M = M; a.T = T;
+      if (half) { xc = e->H1; a.src_mod = R0; }
+      a.bo = L.cout_b; a.g2 = L.n2_w; a.b2 = L.n2_b; a.Y = xc; a.M = M; a.T = T;
       MLD_LAUNCH((cross2_fold_ln_kernel<512, 128>), dim3((unsigned)(R * ((T + kC2Rows - 1) / kC2Rows))), dim3(256), kC2LdsBytes, c.stream, a);
       count(c);
       check_launch(c, "cross2_fold_ln");
@@ -109,11 +119,11 @@ void novae_denoiser_body(Ctx& c, int R, int T, const float* tkv, long long tkv_s
     gemm(c, lin_args(e->AO, D, D, L.cout_w, L.cout_b, e->Ha, D, M, D));
     novae_ln(c, e->Ha, e->H1, L.n2_w, L.n2_b, e->X0, M);
     }
-    GemmArgs f1 = lin_args(e->X0, D, D, L.l1_w, L.l1_b, e->FF, F, M, F);
+    GemmArgs f1 = lin_args(xc, D, D, L.l1_w, L.l1_b, e->FF, F, M, F);
     f1.act = ACT_GELU;
     gemm(c, f1);
     gemm(c, lin_args(e->FF, F, F, L.l2_w, L.l2_b, e->Ha, D, M, D));
-    novae_ln(c, e->Ha, e->X0, L.n3_w, L.n3_b, e->X0, M);       // in place: a wave reads its whole row before writing it
+    novae_ln(c, e->Ha, xc, L.n3_w, L.n3_b, e->X0, M);          // (in place when xc == X0: a wave reads its whole row before writing it)
   }
   novae_ln(c, e->X0, nullptr, P(e, "denoiser.decoder.norm.weight"), P(e, "denoiser.decoder.norm.bias"), e->H1, M);
   GemmArgs f = lin_args(e->H1, D, D, P(e, "denoiser.pose_proj.weight"), P(e, "denoiser.pose_proj.bias"), eps_out, NF, M, NF);
@@ -171,9 +181,10 @@ int novae_steps(E* e, hipStream_t stream, int B, int T, int s0, int s1, const fl
   const float guidance = e->cfg.guidance_scale > 1.0f ? e->cfg.guidance_scale : 1.0f;
   e->phase = 0;
   for (int s = s0; s < s1 && !c.rc; ++s) {
-    novae_pad_input(c, e->lat, (long long)B * T, 2);                                      // torch.cat([latents] * 2)
+    const bool dedup = novae_cfg_dedup(e, 2 * B);
+    novae_pad_input(c, e->lat, (long long)B * T, dedup ? 1 : 2);                          // torch.cat([latents] * 2) (one copy when the halves are de-duplicated)
     const size_t Hn = (size_t)e->cfg.num_heads;
-    novae_denoiser_body(c, 2 * B, T, e->TKV + (size_t)s * 2 * D, (long long)n * 2 * D, NovaeFold{e->TKW + (size_t)s * Hn * D, e->TKU + (size_t)s * Hn * D, e->TKC + (size_t)s * Hn, n}, e->feats_int);
+    novae_denoiser_body(c, 2 * B, T, e->TKV + (size_t)s * 2 * D, (long long)n * 2 * D, NovaeFold{e->TKW + (size_t)s * Hn * D, e->TKU + (size_t)s * Hn * D, e->TKC + (size_t)s * Hn, n}, e->feats_int, dedup);
     MLD_LAUNCH(cfg_ddpm_step_kernel, dim3((unsigned)std::min<long long>(4096, (nel / 4 + 255) / 256)), dim3(256), 0, stream,
                (const float*)e->feats_int, (const float*)(e->feats_int + nel), (const float*)e->lat,
                step_noise ? step_noise + (size_t)s * nel : (const float*)nullptr, e->lat, nel, guidance,

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void cross_fold_kernel(const float* __restrict
 // cross_attention.py:323-345).  A workgroup (4 waves) serves kC2Rows consecutive rows of ONE sample: the sample's sixteen folded vectors (8 of the time token, shared
 // by every sample of the step, 8 of its text token) sit in LDS; a wave owns a row at a time, a lane the 8 columns c * 256 + 4 lane .. + 3 (add_layernorm_rows_kernel's map).
 constexpr int kC2Rows = 28;
-constexpr int kC2LdsBytes = (16 * 512 + 16) * 4;
+constexpr int kC2LdsBytes = (16 * 512 + 16 + 5 * 512) * 4;      // the sample's 16 folded vectors, 8 score constants, the five parameter rows: 43 KB
 struct Cross2LnArgs {
   const float* Ha; const float* X;                 // [M][512] each: sub-layer output (bias included) and its residual
   const float* g1; const float* b1;                // LayerNorm 1
@@ -487,9 +487,47 @@ struct Cross2LnArgs {
   const float* bo;                                 // out_proj.bias [512]
   const float* g2; const float* b2;                // LayerNorm 2
   float* Y; int M, T;
+  int src_mod = 0;                                 // > 0: Ha / X hold src_mod samples only and sample s reads sample s % src_mod's rows (layer 0 of a CFG batch: both halves share the rows in front of the first cross-attention)
 };
+// Eight per-lane partial sums -> the eight totals, in every lane: a reduce-scatter over the lane-swap instructions instead of eight 64-lane butterflies.
+// v_permlane32_swap(a, b) exchanges a's upper 32 lanes with b's lower 32: a' + b' then holds the xor-32 pair sums of a in the lower half and of b in the upper half -- ONE
+// swap + add folds TWO values; the same over 16-lane rows; the last four steps are DPP adds inside a row.  Row q of the two surviving registers holds the total of value
+// (q & 1) * 4 + (q >> 1) resp. + 2: eight v_readlane bring them back as wave-uniform scalars.  28 instructions against 8 x 11.
+__device__ __forceinline__ void sum64_x8(float (&v)[8]) {
+#if defined(MLDHIP_SIM)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = sum64(v[i]);
+#else
+  float a[4], b[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float x = v[i], y = v[i + 4];
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    a[i] = x + y;                                  // lower half: pair sums of v[i]; upper half: of v[i + 4]
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float x = a[i], y = a[i + 2];
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    b[i] = x + y;                                  // even rows: a[i]; odd rows: a[i + 2]
+  }
+  b[0] = sum16(b[0]);
+  b[1] = sum16(b[1]);
+  // rows (16-lane groups) 0..3 of b[i]: row 0 = lower half, even -> v[i]; row 1 = lower half, odd -> v[i + 2]; row 2 = upper half, even -> v[i + 4]; row 3 -> v[i + 6]
+  const int b0 = __builtin_bit_cast(int, b[0]), b1 = __builtin_bit_cast(int, b[1]);
+  v[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b0, 0));
+  v[2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b0, 16));
+  v[4] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b0, 32));
+  v[6] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b0, 48));
+  v[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b1, 0));
+  v[3] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b1, 16));
+  v[5] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b1, 32));
+  v[7] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b1, 48));
+#endif
+}
+
 template <int D, int HD>
-__global__ __launch_bounds__(256) void cross2_fold_ln_kernel(Cross2LnArgs p) {
+__global__ __launch_bounds__(256, 2) void cross2_fold_ln_kernel(Cross2LnArgs p) {
   static_assert(D == 512 && HD == 128, "four heads, two 256-column chunks per lane");
   constexpr int H = 4, NC = 2;
 #if defined(MLDHIP_SIM)
@@ -501,6 +539,7 @@ __global__ __launch_bounds__(256) void cross2_fold_ln_kernel(Cross2LnArgs p) {
   float* Wl = sm;                  // [8][512]: w of (time, h = 0..3), (text, h = 0..3)
   float* Ul = sm + 8 * D;          // [8][512]: u likewise
   float* Cl = sm + 16 * D;         // [8]
+  float* Pl = Cl + 16;             // [5][512]: LayerNorm 1 gain / bias, LayerNorm 2 gain / bias, out_proj.bias (read per row: 40 registers less, a workgroup more per CU)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (p.T + kC2Rows - 1) / kC2Rows;
   const int smp = blockIdx.x / per, r0 = (blockIdx.x % per) * kC2Rows;
@@ -510,15 +549,25 @@ __global__ __launch_bounds__(256) void cross2_fold_ln_kernel(Cross2LnArgs p) {
     st4(Ul + i * 4, ld4(p.ut + i * 4));
     st4(Ul + H * D + i * 4, ld4(p.ux + (long long)smp * H * D + i * 4));
   }
-  if (tid < H) { Cl[tid] = p.ct[tid]; Cl[H + tid] = p.cx[smp * H + tid]; }
-  __syncthreads();
-  F4 gm1[NC], bt1[NC], gm2[NC], bt2[NC], bo[NC];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int o = c * 256 + lane * 4;
-    gm1[c] = ld4(p.g1 + o); bt1[c] = ld4(p.b1 + o); gm2[c] = ld4(p.g2 + o); bt2[c] = ld4(p.b2 + o); bo[c] = ld4(p.bo + o);
+  if (tid < D / 4) {
+    st4(Pl + tid * 4, ld4(p.g1 + tid * 4)); st4(Pl + D + tid * 4, ld4(p.b1 + tid * 4));
+    st4(Pl + 2 * D + tid * 4, ld4(p.g2 + tid * 4)); st4(Pl + 3 * D + tid * 4, ld4(p.b2 + tid * 4));
+    st4(Pl + 4 * D + tid * 4, ld4(p.bo + tid * 4));
   }
-  auto layer_norm = [&](F4 (&x)[NC], const F4 (&gm)[NC], const F4 (&bt)[NC]) __attribute__((always_inline)) {
+  if (tid < H) { Cl[tid] = p.ct[tid]; Cl[H + tid] = p.cx[smp * H + tid]; }
+  // the first row of this wave is in flight while the vectors are staged; inside the loop the NEXT row is requested before the current one is worked on
+  auto row_of = [&](int t) { return (long long)smp * p.T + t; };
+  const int ssrc = p.src_mod > 0 ? smp % p.src_mod : smp;
+  auto src_of = [&](int t) { return (long long)ssrc * p.T + t; };
+  F4 xa[NC], xr[NC];
+  int t = r0 + wave;
+  const int t_end = (r0 + kC2Rows < p.T ? r0 + kC2Rows : p.T);
+  if (t < t_end) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { xa[c] = ld4(p.Ha + src_of(t) * D + c * 256 + lane * 4); xr[c] = ld4(p.X + src_of(t) * D + c * 256 + lane * 4); }
+  }
+  __syncthreads();
+  auto layer_norm = [&](F4 (&x)[NC], const float* gm, const float* bt) __attribute__((always_inline)) {
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) s += (x[c].x + x[c].y) + (x[c].z + x[c].w);
@@ -532,19 +581,21 @@ __global__ __launch_bounds__(256) void cross2_fold_ln_kernel(Cross2LnArgs p) {
     const float rstd = rsqrtf(sum64(q) * (1.0f / D) + kLnEps);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      x[c].x = x[c].x * rstd * gm[c].x + bt[c].x; x[c].y = x[c].y * rstd * gm[c].y + bt[c].y;
-      x[c].z = x[c].z * rstd * gm[c].z + bt[c].z; x[c].w = x[c].w * rstd * gm[c].w + bt[c].w;
+      const F4 g = ld4(gm + c * 256 + lane * 4), b = ld4(bt + c * 256 + lane * 4);
+      x[c].x = x[c].x * rstd * g.x + b.x; x[c].y = x[c].y * rstd * g.y + b.y;
+      x[c].z = x[c].z * rstd * g.z + b.z; x[c].w = x[c].w * rstd * g.w + b.w;
     }
   };
-  for (int t = r0 + wave; t < r0 + kC2Rows && t < p.T; t += 4) {      // (wave-uniform bounds)
-    const long long row = (long long)smp * p.T + t;
+  for (; t < t_end; t += 4) {                                          // (wave-uniform bounds)
+    const long long row = row_of(t);
     F4 x[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const F4 a = ld4(p.Ha + row * D + c * 256 + lane * 4), rres = ld4(p.X + row * D + c * 256 + lane * 4);
-      x[c] = F4{a.x + rres.x, a.y + rres.y, a.z + rres.z, a.w + rres.w};
+    for (int c = 0; c < NC; ++c) x[c] = F4{xa[c].x + xr[c].x, xa[c].y + xr[c].y, xa[c].z + xr[c].z, xa[c].w + xr[c].w};
+    if (t + 4 < t_end) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { xa[c] = ld4(p.Ha + src_of(t + 4) * D + c * 256 + lane * 4); xr[c] = ld4(p.X + src_of(t + 4) * D + c * 256 + lane * 4); }
     }
-    layer_norm(x, gm1, bt1);                                           // h1 = LayerNorm1(x + self-attention)
+    layer_norm(x, Pl, Pl + D);                                         // h1 = LayerNorm1(x + self-attention)
     float sc[8];
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
@@ -556,20 +607,20 @@ __global__ __launch_bounds__(256) void cross2_fold_ln_kernel(Cross2LnArgs p) {
       }
       sc[v] = d;
     }
-#pragma unroll
-    for (int v = 0; v < 8; ++v) sc[v] = sum64(sc[v]) + Cl[v];
+    sum64_x8(sc);
     float pa[H], pb[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      const float m = fmaxf(sc[h], sc[H + h]);
-      const float ea = expf(sc[h] - m), eb = expf(sc[H + h] - m);
+      const float sa = sc[h] + Cl[h], sb = sc[H + h] + Cl[H + h];
+      const float m = fmaxf(sa, sb);
+      const float ea = expf(sa - m), eb = expf(sb - m);
       const float inv = 1.0f / (ea + eb);
       pa[h] = ea * inv; pb[h] = eb * inv;
     }
     F4 y[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      F4 o = bo[c];
+      F4 o = ld4(Pl + 4 * D + c * 256 + lane * 4);
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         const F4 ua = ld4(Ul + h * D + c * 256 + lane * 4), ub = ld4(Ul + (H + h) * D + c * 256 + lane * 4);
@@ -578,7 +629,7 @@ __global__ __launch_bounds__(256) void cross2_fold_ln_kernel(Cross2LnArgs p) {
       }
       y[c] = F4{x[c].x + o.x, x[c].y + o.y, x[c].z + o.z, x[c].w + o.w};
     }
-    layer_norm(y, gm2, bt2);
+    layer_norm(y, Pl + 2 * D, Pl + 3 * D);
 #pragma unroll
     for (int c = 0; c < NC; ++c) st4(p.Y + row * D + c * 256 + lane * 4, y[c]);
   }
