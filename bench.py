@@ -780,7 +780,9 @@ def main():
                          "request k on the engine's low-priority side stream beside the reverse loop of request k + 1; two workspaces alternate; the caller's stream is ordered "
                          "behind every decode at the end of the call" % KP}
         engp.close()
-    except Exception as ex_:      # never fail the bench line for the secondary leg
+    except Exception as ex_:      # never fail the single-process bench line for the secondary leg
+        if dist:                  # ... but under torch.distributed a rank that skipped its barriers would hang the others: fail loudly instead
+            raise
         pipe = {"value": None, "error": repr(ex_)[:300]}
     gf_total, gf_den, gf_dec = algorithmic_gflop(BATCH, FRAMES)
     tf_job = gf_total / 1e3 / (ms_per_step * 1e-3)

@@ -511,6 +511,7 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
     if (value != 0 && value != 1) return e->fail(MLDHIP_EINVAL, "many_pipeline must be 0 (one chain over all motions of a mldhip_sample_many call) or 1 (request after request, decodes on the side stream)");
     if (value && e->ctxs.size() < 2) return e->fail(MLDHIP_EINVAL, "many_pipeline needs two workspaces: create the handle with max_in_flight >= 2");
     e->many_pipeline = (int)value;
+    return MLDHIP_OK;                   // (host-side orchestration only: nothing a captured graph bakes in changes -- the graphs stay)
   } else if (n == "dec_half") {
     if (value < 0 || value > 6 || value == 3 || value == 5) return e->fail(MLDHIP_EINVAL, "dec_half must be 0 (fp32 Q|K|V, split x3 products), 1 (half Q|K|V; strip height by launch size), 4 or 6 (1 with 64- / 96-row in-projection strips always) or 2 (1, but never overruled by finalize's probe)");
     // the probe's reading of the form is part of finalize: switching it on (with the veto in force) on a probed handle that has not read it asks for finalize again

@@ -307,6 +307,28 @@ def test_sample_many_pipelined_bs64_requests_are_bit_identical_and_overlap(dev):
         t_serial / 8 * 1e3, t_pipe / 8 * 1e3, 512 / t_serial, 512 / t_pipe))
     assert ns["nonfinite_values"] == 0 and ns["cluster_loop"] == 1, ns
     assert t_pipe < 0.99 * t_serial, (t_pipe, t_serial)      # (half of these requests are ragged and short: their decodes are small; bench.py times the T = 196 shape: 7.98 -> 6.98 ms)
+    e.set_option("many_pipeline", 0)                                    # (host-side orchestration only: the captured graphs stay)
+    e.sample(reqs[0]["text_emb"], reqs[0]["init_latents"], reqs[0]["lengths"], solo[0][0], solo[0][1], solo[0][2])
+    torch.cuda.synchronize()
+    assert torch.equal(solo[0][0], reqs[0]["latents_out"])
+    e.close()
+    # the same orchestration without graphs (use_graph = 0: eager issue of the two halves on the two streams)
+    e = _lib.Engine(device=0, max_batch=64, max_frames=196, precision=1, max_in_flight=2, use_graph=0)
+    _load(e)
+    outs = []
+    for q in reqs[:3]:
+        lat, joints = torch.empty_like(q["latents_out"]), torch.empty_like(q["joints_out"])
+        e.sample(q["text_emb"], q["init_latents"], q["lengths"], lat, None, joints)
+        outs.append((lat, joints))
+    torch.cuda.synchronize()
+    e.set_option("many_pipeline", 1)
+    for q in reqs[:3]:
+        q["latents_out"].fill_(float("nan")); q["joints_out"].fill_(float("nan"))
+    e.sample_many([dict(q, feats_out=None) for q in reqs[:3]])
+    torch.cuda.synchronize()
+    for q, (lat, joints) in zip(reqs[:3], outs):
+        assert torch.equal(q["latents_out"], lat) and torch.equal(q["joints_out"], joints)
+    assert e.numeric_status()["nonfinite_values"] == 0
     e.close()
 
 
