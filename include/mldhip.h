@@ -233,9 +233,6 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *   "strip_min_rows"  auto picks the column-split throughput kernels when the reverse loop has >= this many token rows (6 x batch; default
  *                     768 = 128 motions) -- in the modes whose latency kernels run fp32 / bf16 / fp8; in the F16X3 mode the split-f16
  *                     latency kernels serve every call below the persistent loop's threshold (15.2 vs 18.4 ms at 128 motions)
- *   "strip_wide"      throughput kernels: 32 x 128 tiles for the wide GEMMs: 0 = auto (N >= 512), 1 = never, 2 = whenever N % 128 == 0
- *   "strip_waves"     throughput kernels: waves per workgroup of the 32 x 128 tiles, 4 or 8 (default 8)
- *   "strip_ffn2_split" throughput kernels: K slices (raw slabs) of the FFN2 GEMM, 1 or 2 (default 2)
  *   "flash_attn"      split-f16 modes, frame-level self-attention of the decoder / encoder: key-blocked online-softmax kernel with
  *                     two workgroups per CU (kernels/attention.hpp attn_flash_x3_kernel): 0 = never, 1 = auto (default: calls
  *                     with >= 512 (sample, head) pairs), 2 = always.  The diffusion-only variant (head dim 128) has its own form of

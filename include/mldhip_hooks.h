@@ -3,7 +3,7 @@
  * libmldhip.so exports the sampling surface of include/mldhip.h only.  `make -C motion-latent-diffusion_amd/csrc hooks` builds the same sources with
  * -DMLDHIP_HOOKS into mld_hip/libmldhip_hooks.so, which additionally exports the two entry points below, knows the options "fused_dbg", "cluster_graph",
  * "cluster_lane", "cluster_chunk", "cluster_stale" and "cluster_inject" (documented with the production options in mldhip.h) and carries the traced instantiations of the loop
- * kernels.  tools/trace_*.py, tools/ab_strip_opts.py, tools/ab_coalesce.py, tools/dbg_cluster.py and tools/two_streams.py load that library
+ * kernels.  tools/trace_*.py, tools/ab_coalesce.py, tools/dbg_cluster.py and tools/two_streams.py load that library
  * (mld_hip._lib.hooks_library()), and so does ONE GPU test (fault injection into the cluster loop's bounded waits); bench.py, every other test and the mld_hip
  * package do not. */
 #ifndef MLDHIP_HOOKS_H_

@@ -63,7 +63,7 @@ void strip(Ctx& c, const Tile32Args& a_, int nsrc) {
   a.trace = c.e->trace_on;
   const bool attn = a.src[0].attn_R > 0;
   const int ns = attn ? 0 : a.src[0].nsplit;
-  const bool wide = !attn && nsrc == 1 && a.N % 128 == 0 && (c.e->strip_wide == 2 || (c.e->strip_wide == 0 && a.N >= 512));
+  const bool wide = !attn && nsrc == 1 && a.N % 128 == 0 && a.N >= 512;      // (round 2's "strip_wide" / "strip_waves" / "strip_ffn2_split" knobs were retired in round 6: the settled forms are how it works)
   const dim3 grid((a.M + 31) / 32, wide ? a.N / 128 : (a.N + 63) / 64, 1);
   const int prec = loop_prec(c.e);
 #define MLD_STRIP(NS, NSRC, ATTN, ACT, CT, NW)                                                                                     \
@@ -71,16 +71,14 @@ void strip(Ctx& c, const Tile32Args& a_, int nsrc) {
     if (prec == PREC_BF16) { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_BF16, ACT, CT, NW>), grid, dim3(64 * NW), (strip_lds_bytes<NSRC, CT>()), c.stream, a); } \
     else { MLD_LAUNCH((gemm_strip_kernel<NS, NSRC, ATTN, PREC_F32, ACT, CT, NW>), grid, dim3(64 * NW), (strip_lds_bytes<NSRC, CT>()), c.stream, a); }       \
   } while (0)
-  // 8 waves per workgroup (one 16-row tile per wave) unless "strip_waves" says 4
+  // 8 waves per workgroup (one 16-row tile per wave)
 #define MLD_STRIP_W(NS, NSRC, ATTN, ACT)                                            \
   do {                                                                              \
-    if (wide && c.e->strip_waves == 8) MLD_STRIP(NS, NSRC, ATTN, ACT, 2, 8);        \
-    else if (wide) MLD_STRIP(NS, NSRC, ATTN, ACT, 2, 4);                            \
-    else if (c.e->strip_waves == 8) MLD_STRIP(NS, NSRC, ATTN, ACT, 1, 8);           \
-    else MLD_STRIP(NS, NSRC, ATTN, ACT, 1, 4);                                      \
+    if (wide) MLD_STRIP(NS, NSRC, ATTN, ACT, 2, 8);                                 \
+    else MLD_STRIP(NS, NSRC, ATTN, ACT, 1, 8);                                      \
   } while (0)
   if (a.trace) {                              // measurement builds (mldhip_profile_trace): the fp32 8-wave kernels of the encoder layer
-    if (prec != PREC_F32 || c.e->strip_waves != 8 || nsrc != 1) { c.rc = c.e->fail(MLDHIP_EINVAL, "strip: traces exist for the fp32 8-wave layer kernels only"); return; }
+    if (prec != PREC_F32 || nsrc != 1) { c.rc = c.e->fail(MLDHIP_EINVAL, "strip: traces exist for the fp32 8-wave layer kernels only"); return; }
     if (attn) { MLD_LAUNCH((gemm_strip_kernel<0, 1, true, PREC_F32, 0, 1, 8, true>), grid, dim3(512), (strip_lds_bytes<1, 1>()), c.stream, a); }
     else if (wide && ns == 1 && a.act == 1) { MLD_LAUNCH((gemm_strip_kernel<1, 1, false, PREC_F32, 1, 2, 8, true>), grid, dim3(512), (strip_lds_bytes<1, 2>()), c.stream, a); }
     else if (wide && ns == 2 && a.act == 0) { MLD_LAUNCH((gemm_strip_kernel<2, 1, false, PREC_F32, 0, 2, 8, true>), grid, dim3(512), (strip_lds_bytes<1, 2>()), c.stream, a); }
@@ -90,13 +88,13 @@ void strip(Ctx& c, const Tile32Args& a_, int nsrc) {
     return;
   }
   if (a.act != 0 && !(a.act == 1 && ns == 1 && nsrc == 1 && !attn)) { c.rc = c.e->fail(MLDHIP_EINVAL, "strip: activation %d is built for the FFN1 shape only", a.act); return; }
-  if (attn && nsrc == 1) { if (c.e->strip_waves == 8) MLD_STRIP(0, 1, true, 0, 1, 8); else MLD_STRIP(0, 1, true, 0, 1, 4); }
+  if (attn && nsrc == 1) MLD_STRIP(0, 1, true, 0, 1, 8);
   else if (ns == 0 && nsrc == 1) MLD_STRIP_W(0, 1, false, 0);
   else if (ns == 1 && nsrc == 1 && a.act == 1) MLD_STRIP_W(1, 1, false, 1);
   else if (ns == 1 && nsrc == 1) MLD_STRIP_W(1, 1, false, 0);
   else if (ns == 2 && nsrc == 1) MLD_STRIP_W(2, 1, false, 0);
-  else if (ns == 1 && nsrc == 2) { if (c.e->strip_waves == 8) MLD_STRIP(1, 2, false, 0, 1, 8); else MLD_STRIP(1, 2, false, 0, 1, 4); }
-  else if (ns == 2 && nsrc == 2) { if (c.e->strip_waves == 8) MLD_STRIP(2, 2, false, 0, 1, 8); else MLD_STRIP(2, 2, false, 0, 1, 4); }
+  else if (ns == 1 && nsrc == 2) MLD_STRIP(1, 2, false, 0, 1, 8);
+  else if (ns == 2 && nsrc == 2) MLD_STRIP(2, 2, false, 0, 1, 8);
   else { c.rc = c.e->fail(MLDHIP_EINVAL, "strip: unsupported source (slabs %d, segments %d)", ns, nsrc); return; }
 #undef MLD_STRIP_W
 #undef MLD_STRIP
@@ -149,7 +147,7 @@ DenView den_view(E* e, int R) {
   v.R = R;
   v.strip = use_strip(e, 3 * R);
   // throughput kernels: K slices of FFN2 no narrower than 256 (the staged GEMM takes K in {256, 512, 1024})
-  v.ffn_slabs = v.strip ? std::min(e->strip_ffn2_split, e->cfg.ff_size / 256) : e->cfg.ff_size / 256;
+  v.ffn_slabs = v.strip ? std::min(2, e->cfg.ff_size / 256) : e->cfg.ff_size / 256;
   v.skip_slabs = v.strip ? 1 : 2;
   return v;
 }

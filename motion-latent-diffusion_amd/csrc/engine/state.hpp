@@ -142,8 +142,6 @@ struct mldhip_engine {
   int fused_dbg = 0;         // "fused_dbg": 5 = the split-mode loop with its phase counters (same arithmetic, mldhip_profile_trace "den_loop_phases"); 0 = off
   int fused_min_batch = 0;   // "fused_min_batch": auto picks the sample-major loop from this many motions per call up; 0 = by operand format (320 split-f16, 1 280 fp32)
   int strip_min_rows = 768;  // "strip_min_rows": auto switches to the throughput kernels at 6B >= this many token rows
-  int strip_wide = 0;        // "strip_wide": 32 x 128 strip tiles for the wide GEMMs: 0 auto (N >= 512), 1 never, 2 whenever N % 128 == 0
-  int strip_waves = 8;       // "strip_waves": waves per workgroup of the 32 x 128 strip tiles: 4 (two row tiles per wave) or 8 (one)
   int flash_attn = 1;        // "flash_attn": split-bf16 frame-level self-attention key-blocked (attention.hpp attn_flash_x3_kernel): 0 never, 1 auto (>= 512 (sample, head) pairs), 2 always
   int ffn_strip = 1;         // "ffn_strip": register-direct decoder kernels (ffn_strip.hpp, gemm_strip_x3.hpp): 0 off, 1 auto strip height, 4 / 6 = 64 / 96 rows always
   int dec_tail = 1;          // "dec_tail": out-projection + norms + feed-forward block of a decoder layer as one launch (chip-filling launches, split modes)
@@ -154,7 +152,6 @@ struct mldhip_engine {
   int cross_fold = 1;        // "cross_fold": diffusion-only variant: LayerNorm 1 + the two-token cross-attention sub-layer (query GEMM, attention, out-projection GEMM) + LayerNorm 2 of a trans_dec layer as ONE launch on vectors folded from the memory tokens (kernels/novae.hpp cross2_fold_ln_kernel; exact algebra); 0 = the five launches
   int gemm_pipe = 1;         // "gemm_pipe": diffusion-only variant, split modes: the K >= 512 GEMMs on the software-pipelined 128 x 256 tile (kernels/gemm_pipe.hpp): 1 = launches of >= 2 048 rows, 2 = always (tests); 0 = the 64 x 128 staged tile
   int gemm_pipe_min_rows = 2048;   // (not an option) row count from which the big tile is used: below it its 128-row tiles leave most CUs without a workgroup
-  int strip_ffn2_split = 2;  // "strip_ffn2_split": K slices (= raw slabs) of FFN2 on the throughput kernels: 1 or 2
 
   // ---- numeric contract of the split-f16 mode (mldhip_numeric_status; include/mldhip.h "Range contract")
 #if defined(MLDHIP_SIM)

@@ -346,12 +346,6 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
   MLD_T32_ATTR(0) MLD_T32_ATTR(1) MLD_T32_ATTR(2) MLD_T32_ATTR(4)
 #undef MLD_T32_ATTR
 #undef MLD_T32_ATTR1
-#define MLD_STRIP_ATTR(NS, NSRC, ACT, CT)                                                                                   \
-  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, NSRC, false, PREC_F32, ACT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<NSRC, CT>())); \
-  (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, NSRC, false, PREC_BF16, ACT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<NSRC, CT>()));;
-  MLD_STRIP_ATTR(1, 2, 0, 1) MLD_STRIP_ATTR(2, 2, 0, 1)
-  MLD_STRIP_ATTR(0, 1, 0, 2) MLD_STRIP_ATTR(1, 1, 0, 2) MLD_STRIP_ATTR(1, 1, 1, 2) MLD_STRIP_ATTR(2, 1, 0, 2)
-#undef MLD_STRIP_ATTR
 #define MLD_STRIP_ATTR8(NS, ACT)                                                                                            \
   (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 1, false, PREC_F32, ACT, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<1, 2>())); \
   (void)hipFuncSetAttribute((const void*)gemm_strip_kernel<NS, 1, false, PREC_BF16, ACT, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (strip_lds_bytes<1, 2>()));;
@@ -492,12 +486,6 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "strip_min_rows") {
     if (value < 1) return e->fail(MLDHIP_EINVAL, "strip_min_rows must be >= 1");
     e->strip_min_rows = (int)std::min<int64_t>(value, 1 << 30);
-  } else if (n == "strip_wide") {
-    if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "strip_wide must be 0 (auto), 1 (never) or 2 (always)");
-    e->strip_wide = (int)value;
-  } else if (n == "strip_waves") {
-    if (value != 4 && value != 8) return e->fail(MLDHIP_EINVAL, "strip_waves must be 4 or 8");
-    e->strip_waves = (int)value;
   } else if (n == "flash_attn") {
     if (value < 0 || value > 2) return e->fail(MLDHIP_EINVAL, "flash_attn must be 0 (never), 1 (auto) or 2 (always)");
     e->flash_attn = (int)value;
@@ -532,9 +520,6 @@ int mldhip_set_option(mldhip_handle* e, const char* name, int64_t value) {
   } else if (n == "ffn_strip") {
     if (value != 0 && value != 1 && value != 3 && value != 4 && value != 6) return e->fail(MLDHIP_EINVAL, "ffn_strip must be 0 (off), 1 (auto: 64- or 96-row strips by launch size), 3, 4 or 6");
     e->ffn_strip = (int)value;
-  } else if (n == "strip_ffn2_split") {
-    if (value != 1 && value != 2) return e->fail(MLDHIP_EINVAL, "strip_ffn2_split must be 1 or 2");
-    e->strip_ffn2_split = (int)value;
   } else if (n == "gemm_small_m") {
     if (value < 0) return e->fail(MLDHIP_EINVAL, "gemm_small_m must be >= 0");
     e->small_m = (int)std::min<int64_t>(value, 1 << 30);

@@ -512,24 +512,6 @@ def test_bf16_mode_decoder_gemms_sim(ow):
     e.close()
 
 
-@pytest.mark.parametrize("wide,split", [(1, 1), (2, 1), (1, 2)])
-def test_strip_family_tile_and_split_options_sim(ow, wide, split):
-    """The throughput kernels' tile width (32x64 / 32x128) and FFN2 K-split (1 or 2 raw slabs) options vs the oracle."""
-    ops, bd, _ = ow
-    e = simlib.sim_engine(max_batch=11, max_frames=8, num_inference_steps=2)
-    e.set_option("loop_kernel", 2)
-    e.set_option("strip_wide", wide)
-    e.set_option("strip_ffn2_split", split)
-    g = syn._rng(21, "strip")
-    R = 22
-    x = g.standard_normal((R, 1, 256)).astype(np.float32)
-    te = g.standard_normal((R, 1, 768)).astype(np.float32)
-    out = np.zeros((R, 1, 256), np.float32)
-    e.denoiser_forward(x, 741, te, R, out)
-    assert np.abs(out - np.asarray(O.denoiser_forward(ops, bd, x, 741, te))).max() < 5e-5
-    e.close()
-
-
 def test_split_bf16_attention_odd_key_tiles_sim(ow):
     """attn_decode_x3_kernel with an ODD number of key tiles (T = 100 -> 7 tiles: the last 32-key block of P.V is half empty)
     and ragged lengths, inside the split-bf16 decoder: features within 2e-4 of the fp32 oracle."""
@@ -581,25 +563,6 @@ def test_novae_split_bf16_gemms_and_attention_sim(now):
     d3 = np.abs(out3 - out).max()
     print("novae x3 denoiser err with the key-blocked attention", err3, "difference to the two-phase kernel", d3)
     assert 1e-7 < err3 < 3e-4 and 0 < d3 < 2e-4
-    e.close()
-
-
-def test_strip_family_four_wave_workgroups_sim(ow):
-    """strip_waves = 4 (two 16-row tiles per wave) is the A/B twin of the default 8-wave workgroups: same tiles, same summation
-    order, hence bit-identical results."""
-    e = simlib.sim_engine(max_batch=11, max_frames=8, num_inference_steps=2)
-    e.set_option("loop_kernel", 2)
-    g = syn._rng(21, "strip")
-    R = 22
-    x = g.standard_normal((R, 1, 256)).astype(np.float32)
-    te = g.standard_normal((R, 1, 768)).astype(np.float32)
-    outs = []
-    for waves in (8, 4):
-        e.set_option("strip_waves", waves)
-        out = np.zeros((R, 1, 256), np.float32)
-        e.denoiser_forward(x, 741, te, R, out)
-        outs.append(out)
-    assert np.array_equal(outs[0], outs[1])
     e.close()
 
 
