@@ -170,6 +170,8 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     256 CUs free and the matrix pipe of the others nearly idle, the decode's 44 launches are one round of workgroups each.  Needs
  *                     max_in_flight >= 2 (two workspaces alternate) and requests the cluster loop serves with a decode asked for; otherwise, and with
  *                     0 (default), the call is one chain over all its motions.  The caller's stream is ordered behind every decode when the call returns
+ *                     (requests of one cluster launch each -- up to 128 motions -- also get their inputs and condition rows staged on a third engine stream
+ *                     beside the previous request's launch; the request buffers must be the caller's stream's products, as for every entry point)
  *   "cluster_max_batch" auto runs the cluster loop for calls of up to this many motions (default 256: one launch up to 128 = two clusters per XCD, two launches one
  *                     after the other up to 256 -- 2 x 7.6 ms against the persistent loop's flat 18.7 ms; 0 = never)
  *   "cluster_wt"      cluster loop, payload stores of the in-launch hand-offs: 0 (default) = plain where the twelve workgroups of a cluster report one

@@ -958,10 +958,12 @@ void launch_cluster_chunk(Ctx& c, const float* init_lat, int B, int s_base, int 
 #endif
   // every polled word is zero at the start of every call (Guideline 16 "Re-initialise every call")
   const int words = (int)(a.status - a.flags) + 2;        // the flags and the two per-launch status words (status[2] is sticky: cluster_timed_out)
+  if (e->sample_part != 2)
   MLD_LAUNCH(clear_cluster_flags_kernel, dim3(1), dim3(256), 0, c.stream, a.flags, words);      // (a kernel, NOT a memset node: replays of a captured hipMemsetAsync left address-like words here on this runtime, DESIGN.md 3a -- the entry check of the kernel now catches such a launch)
 #if defined(MLDHIP_HOOKS)
-  if (e->cluster_stale) MLD_LAUNCH(poke_cluster_flag_kernel, dim3(1), dim3(1), 0, c.stream, a.flags + kFlagH * kClFlagLine + 3, 77u);
+  if (e->cluster_stale && e->sample_part != 2) MLD_LAUNCH(poke_cluster_flag_kernel, dim3(1), dim3(1), 0, c.stream, a.flags + kFlagH * kClFlagLine + 3, 77u);
 #endif
+  if (e->sample_part == 1) return;               // (the pipelined form captures what precedes the launch as a graph of its own)
   const dim3 grid((unsigned)(a.xslots * members * ((a.ncl + a.xslots - 1) / a.xslots)));
   if (cg == 8) {
     if (e->cluster_wt) MLD_LAUNCH_CORESIDENT((den_cluster_kernel<true, 8>), grid, dim3(512), kClLdsBytes, c.stream, a);
@@ -1005,10 +1007,13 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
   const float guidance = e->cfg.guidance_scale > 1.0f ? e->cfg.guidance_scale : 1.0f;
   e->launches[0] = e->launches[1] = e->launches[2] = 0;
   e->phase = 0;
-  if (text) text_projection(c, text, 2 * B, e->TP);
-  else action_rows(c, 2 * B, B, e->TP);
+  if (e->sample_part != 2) {
+    if (text) text_projection(c, text, 2 * B, e->TP);
+    else action_rows(c, 2 * B, B, e->TP);
+  }
   if (use_cluster(e, B)) {
     launch_cluster_loop(c, init_lat, B, n, guidance);
+    if (e->sample_part == 1) return c.rc;
   } else if (use_fused(e, B)) {
     launch_fused_loop(c, init_lat, B, n, guidance);
   } else {
@@ -1026,7 +1031,7 @@ int enqueue_sample(E* e, hipStream_t stream, const float* text, const float* ini
       check_launch(c, "den_final_step");
     }
   }
-  if (c.rc) return c.rc;
+  if (c.rc || e->sample_part == 2) return c.rc;    // (part 2: the launch alone; the pipelined form counts non-finite latents on its side stream, in front of the decode)
   count_nonfinite(c, e->lat, (long long)B * D);
   if (lat_out) {
     hipError_t s = hipMemcpyAsync(lat_out, e->lat, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream);

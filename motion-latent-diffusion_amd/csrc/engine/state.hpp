@@ -32,7 +32,8 @@ struct GraphKey {
   int B, T;
   bool feats, joints;
   bool dec_only = false;   // the decode half of a call alone (reads the context's latents): the pipelined form of mldhip_sample_many ("many_pipeline")
-  bool operator<(const GraphKey& o) const { return std::tie(B, T, feats, joints, dec_only) < std::tie(o.B, o.T, o.feats, o.joints, o.dec_only); }
+  int part = 0;            // loop-only graphs of the pipelined form: 1 = what precedes the cluster launch (condition rows, flag clear), 2 = the cluster launch + its non-finite count; 0 = everything
+  bool operator<(const GraphKey& o) const { return std::tie(B, T, feats, joints, dec_only, part) < std::tie(o.B, o.T, o.feats, o.joints, o.dec_only, o.part); }
 };
 
 }  // namespace
@@ -48,6 +49,7 @@ struct WsContext {
   unsigned long long seed_host = 0;   // stable host copy of the Philox seed while it is uploaded to seed_slot
 #if !defined(MLDHIP_SIM)
   hipEvent_t done = nullptr;
+  hipEvent_t pre_done = nullptr;               // pipelined sample_many: recorded on the engine's prep stream behind a request's input staging + condition rows + flag clear
   hipEvent_t loop_done = nullptr;              // pipelined sample_many: recorded behind the reverse loop on the caller's stream, waited for by the side stream's decode
   std::map<GraphKey, hipGraphExec_t> graphs;   // captured sample() graphs of this workspace, evicted least-recently-used
   std::vector<GraphKey> graph_lru;             // most recent last
@@ -169,9 +171,12 @@ struct mldhip_engine {
 
   int launches[3] = {0, 0, 0};
   int phase = 0;
+  int sample_part = 0;       // while a loop-only graph of the pipelined form is captured: which part enqueue_sample issues (GraphKey.part)
 
 #if !defined(MLDHIP_SIM)
   hipStream_t cap_stream = nullptr;
+  hipStream_t prep_stream = nullptr;   // "many_pipeline": the inputs, condition rows and flag clear of request k + 1 run here, beside the cluster launch of request k
+  hipEvent_t many_start = nullptr;     // ... ordered behind what the caller's stream held when the call came in
   hipStream_t side_stream = nullptr;   // "many_pipeline": decodes run here, at the lowest stream priority (the cluster launch on the caller's stream gets its CUs first)
 #endif
 

@@ -278,7 +278,7 @@ int mldhip_create(const mldhip_config* cfg, int device, mldhip_handle** out) {
     if (hipMalloc((void**)&x.lens, 2 * Bm * sizeof(int32_t)) != hipSuccess || hipMalloc((void**)&x.lens2, Bm * sizeof(int32_t)) != hipSuccess ||
         hipMalloc((void**)&x.labels, 2 * Bm * sizeof(int32_t)) != hipSuccess) { e->err = "hipMalloc(lens) failed"; return fail_create(MLDHIP_EHIP); }
 #if !defined(MLDHIP_SIM)
-    if (hipEventCreateWithFlags(&x.done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x.loop_done, hipEventDisableTiming) != hipSuccess) { e->err = "event create failed"; return fail_create(MLDHIP_EHIP); }
+    if (hipEventCreateWithFlags(&x.done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x.loop_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x.pre_done, hipEventDisableTiming) != hipSuccess) { e->err = "event create failed"; return fail_create(MLDHIP_EHIP); }
 #endif
   }
   bind_context(e, 0);
@@ -375,9 +375,12 @@ void mldhip_destroy(mldhip_handle* e) {
     for (auto& kv : x.step_graphs) (void)hipGraphExecDestroy(kv.second);
     if (x.done) (void)hipEventDestroy(x.done);
     if (x.loop_done) (void)hipEventDestroy(x.loop_done);
+    if (x.pre_done) (void)hipEventDestroy(x.pre_done);
   }
   if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
   if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
+  if (e->prep_stream) (void)hipStreamDestroy(e->prep_stream);
+  if (e->many_start) (void)hipEventDestroy(e->many_start);
 #endif
   if (e->arena) (void)hipFree(e->arena);
   if (e->arena_x3) (void)hipFree(e->arena_x3);
@@ -958,8 +961,10 @@ int graph_for(mldhip_handle* e, const GraphKey& key, bool text_condition, hipGra
       enqueue_decode(cd, key.B, key.T, key.feats ? e->feats_int : nullptr, key.joints ? e->joints_int : nullptr);
       rc = cd.rc;
     } else {
+      e->sample_part = key.part;
       rc = enqueue_sample(e, e->cap_stream, text_condition ? e->text_in : nullptr, e->lat_in, key.B, key.T, nullptr,
                           key.feats ? e->feats_int : nullptr, key.joints ? e->joints_int : nullptr);
+      e->sample_part = 0;
     }
     hipError_t s = hipStreamEndCapture(e->cap_stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -1054,6 +1059,7 @@ namespace {
 // of workgroups each on an idle chip) run beside it on the CUs it leaves free.
 //   caller's stream S:  [wait ws(k) free] inputs(k) -> loop(k) -> record loop_done(k)                 ... after the last request: wait for every decode
 //   side stream D:                                               wait loop_done(k) -> decode(k) -> outputs(k) -> record ws(k).done
+// (requests of one cluster launch each -- every bs-64 request -- move inputs(k) and what precedes the launch to a third stream: the schedule in the body below.)
 // Two workspaces alternate (request k + 2 waits for decode k).  D has the lowest stream priority: a cluster launch needs its workgroups resident together, the
 // decode's workgroups are short and independent of it -- they can only delay it, and they end.  The lane (ClusterLane) is held for the whole call; its event is
 // recorded on S behind the join.  Every request gets exactly what mldhip_sample gives it (same kernels, same graphs' machine code): bit-identical, tested.
@@ -1071,40 +1077,96 @@ int sample_many_pipelined(mldhip_handle* e, const mldhip_request* rq, int nreq, 
 #else
   hipStream_t side = stream;
 #endif
-  std::vector<int> used;
+  bool replay = false, split = false;
+#if !defined(MLDHIP_SIM)
+  replay = e->cfg.use_graph && e->cluster_graph;
+  // Replayed calls whose requests are ONE cluster launch each get the tighter schedule (three streams):
+  //   prep stream P:      [ws(k+1): loop k-1 and decode k-1 done] inputs(k+1) -> condition rows + flag clear (a graph, GraphKey.part 1) -> record pre_done(k+1)
+  //   caller's stream S:  wait pre_done(k) -> cluster launch(k) (issued directly) -> record loop_done(k)
+  //   side stream D:      wait loop_done(k) -> non-finite count, latents out, lengths -> decode(k) (a graph) -> outputs(k) -> record ws(k).done
+  // so on S the cluster kernels follow each other with two event packets between them, and the decode of request k (lowest priority) becomes ready at the same instant as
+  // the launch of request k + 1.  (First form of the round: everything but the decode on S -- 76 us between consecutive cluster kernels, in which the decode's first dozen
+  // kernels took the chip before the launch did: profiles/r06_trace_pipeline.log.)
+  split = replay;
+  for (int i = 0; i < nreq; ++i) split = split && use_cluster(e, rq[i].B) && rq[i].B <= e->cluster_chunk;
+  if (split && !e->prep_stream) {
+    HIP_TRY(e, hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->many_start, hipEventDisableTiming));
+  }
+#endif
+  std::vector<int> used, ctx_of(nreq, 0);
   int rc = MLDHIP_OK;
+#if !defined(MLDHIP_SIM)
+  hipStream_t prep = split ? e->prep_stream : stream;
+  if (split) {
+    HIP_TRY(e, hipEventRecord(e->many_start, stream));
+    HIP_TRY(e, hipStreamWaitEvent(prep, e->many_start, 0));          // the requests' inputs are the caller's stream's products
+  }
+  if (replay) for (int i = 0; i < nreq; ++i) {                        // two contexts alternate
+    ctx_of[i] = int(e->next_ctx++ % e->ctxs.size());
+    if (std::find(used.begin(), used.end(), ctx_of[i]) == used.end()) used.push_back(ctx_of[i]);
+  }
+  auto stage_pre = [&](int i) -> int {           // inputs of request i into its context + what precedes its cluster launch
+    const mldhip_request& r = rq[i];
+    WsContext& x = e->ctxs[ctx_of[i]];
+    bind_context(e, ctx_of[i]);
+    if (x.used) HIP_TRY(e, hipStreamWaitEvent(prep, x.done, 0));      // the context's last decode (request i - 2, or an earlier call)
+    if (split && i >= 2) HIP_TRY(e, hipStreamWaitEvent(prep, x.loop_done, 0));   // ... and its last cluster launch (on S; nothing to wait for when prep IS S)
+    const float* text = action ? nullptr : r.text_emb_dev;
+    if (action) {
+      HIP_TRY(e, hipMemsetAsync(e->labels_dev, 0, (size_t)r.B * sizeof(int32_t), prep));
+      HIP_TRY(e, hipMemcpyAsync(e->labels_dev + r.B, r.actions_host, (size_t)r.B * sizeof(int32_t), hipMemcpyHostToDevice, prep));
+    }
+    if (text) HIP_TRY(e, hipMemcpyAsync(e->text_in, text, (size_t)2 * r.B * TD * sizeof(float), hipMemcpyDeviceToDevice, prep));
+    HIP_TRY(e, hipMemcpyAsync(e->lat_in, r.init_latents_dev, (size_t)r.B * D * sizeof(float), hipMemcpyDeviceToDevice, prep));
+    if (split) {
+      hipGraphExec_t pre = nullptr;
+      GraphKey kp{r.B, 0, false, false}; kp.part = 1;
+      if (int rc2 = graph_for(e, kp, text != nullptr, &pre)) return rc2;
+      HIP_TRY(e, hipGraphLaunch(pre, prep));
+      HIP_TRY(e, hipEventRecord(x.pre_done, prep));
+    }
+    return MLDHIP_OK;
+  };
+  if (replay && (rc = stage_pre(0))) return rc;
+#endif
   for (int i = 0; i < nreq && !rc; ++i) {
     const mldhip_request& r = rq[i];
     const int B = r.B, T = tmax[i];
     const bool want_j = r.joints_out_dev != nullptr, want_f = r.feats_out_dev != nullptr || want_j;
-    const int k = int(e->next_ctx++ % e->ctxs.size());
-    WsContext& x = e->ctxs[k];
-#if !defined(MLDHIP_SIM)
-    if (x.used) HIP_TRY(e, hipStreamWaitEvent(stream, x.done, 0));      // the workspace's previous user (request i - 2's decode on D, or an earlier call)
-#endif
-    bind_context(e, k);
-    if (std::find(used.begin(), used.end(), k) == used.end()) used.push_back(k);
-    HIP_TRY(e, hipMemcpyAsync(e->lens_dev, r.lengths_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    if (action) {
-      HIP_TRY(e, hipMemsetAsync(e->labels_dev, 0, (size_t)B * sizeof(int32_t), stream));
-      HIP_TRY(e, hipMemcpyAsync(e->labels_dev + B, r.actions_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    }
-    bool replay = false;
-#if !defined(MLDHIP_SIM)
-    replay = e->cfg.use_graph && e->cluster_graph;
-#endif
     const float* text = action ? nullptr : r.text_emb_dev;
     if (replay) {
 #if !defined(MLDHIP_SIM)
-      if (text) HIP_TRY(e, hipMemcpyAsync(e->text_in, text, (size_t)2 * B * TD * sizeof(float), hipMemcpyDeviceToDevice, stream));
-      HIP_TRY(e, hipMemcpyAsync(e->lat_in, r.init_latents_dev, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      WsContext& x = e->ctxs[ctx_of[i]];
+      bind_context(e, ctx_of[i]);
       hipGraphExec_t loop = nullptr, dec = nullptr;
-      if ((rc = graph_for(e, GraphKey{B, T, false, false}, text != nullptr, &loop))) break;
-      if ((rc = graph_for(e, GraphKey{B, T, want_f, want_j, true}, text != nullptr, &dec))) break;
-      HIP_TRY(e, hipGraphLaunch(loop, stream));
-      if (r.latents_out_dev) HIP_TRY(e, hipMemcpyAsync(r.latents_out_dev, e->lat, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      GraphKey kd{B, T, want_f, want_j}; kd.dec_only = true;
+      if ((rc = graph_for(e, kd, text != nullptr, &dec))) break;
+      if (split) {
+        HIP_TRY(e, hipStreamWaitEvent(stream, x.pre_done, 0));
+        // the launch itself is issued directly, not as a graph of one kernel (a graph launch puts its own packets in front of its first node)
+        e->sample_part = 2;
+        rc = enqueue_sample(e, stream, text ? e->text_in : nullptr, e->lat_in, B, 0, nullptr, nullptr, nullptr);
+        e->sample_part = 0;
+        if (rc) break;
+      } else {
+        GraphKey kl{B, T, false, false};
+        if ((rc = graph_for(e, kl, text != nullptr, &loop))) break;
+        HIP_TRY(e, hipGraphLaunch(loop, stream));
+        if (r.latents_out_dev) HIP_TRY(e, hipMemcpyAsync(r.latents_out_dev, e->lat, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      }
       HIP_TRY(e, hipEventRecord(x.loop_done, stream));
+      if (i + 1 < nreq && (rc = stage_pre(i + 1))) break;                // request i + 1: on the prep stream beside this launch (split), or behind it on S
+      bind_context(e, ctx_of[i]);
       HIP_TRY(e, hipStreamWaitEvent(side, x.loop_done, 0));
+      if (split) {
+        Ctx cs{e, side};
+        count_nonfinite(cs, e->lat, (long long)B * D);
+        if ((rc = cs.rc)) break;
+        if (r.latents_out_dev) HIP_TRY(e, hipMemcpyAsync(r.latents_out_dev, e->lat, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, side));
+      }
+      // the lengths are the decode's alone (the latent loop has no masks): copied on the side stream, in order behind the decode that used this context last
+      HIP_TRY(e, hipMemcpyAsync(e->lens_dev, r.lengths_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, side));
       HIP_TRY(e, hipGraphLaunch(dec, side));
       if (r.feats_out_dev) HIP_TRY(e, hipMemcpyAsync(r.feats_out_dev, e->feats_int, (size_t)B * T * NF * sizeof(float), hipMemcpyDeviceToDevice, side));
       if (r.joints_out_dev) HIP_TRY(e, hipMemcpyAsync(r.joints_out_dev, e->joints_int, (size_t)B * T * NJ * sizeof(float), hipMemcpyDeviceToDevice, side));
@@ -1112,7 +1174,19 @@ int sample_many_pipelined(mldhip_handle* e, const mldhip_request* rq, int nreq, 
       x.used = true;
 #endif
     } else {
-      // eager issue (no graphs: the simulator; hooks builds with "cluster_graph" 0): the same two halves, outputs straight into the caller's buffers
+      // eager issue (no graphs: the simulator; hooks builds with "cluster_graph" 0): the two halves one behind the other per request, outputs straight into the caller's buffers
+      const int k = int(e->next_ctx++ % e->ctxs.size());
+      WsContext& x = e->ctxs[k];
+#if !defined(MLDHIP_SIM)
+      if (x.used) HIP_TRY(e, hipStreamWaitEvent(stream, x.done, 0));
+#endif
+      bind_context(e, k);
+      if (std::find(used.begin(), used.end(), k) == used.end()) used.push_back(k);
+      HIP_TRY(e, hipMemcpyAsync(e->lens_dev, r.lengths_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+      if (action) {
+        HIP_TRY(e, hipMemsetAsync(e->labels_dev, 0, (size_t)B * sizeof(int32_t), stream));
+        HIP_TRY(e, hipMemcpyAsync(e->labels_dev + B, r.actions_host, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+      }
       if ((rc = enqueue_sample(e, stream, text, r.init_latents_dev, B, T, r.latents_out_dev, nullptr, nullptr))) break;
 #if !defined(MLDHIP_SIM)
       HIP_TRY(e, hipEventRecord(x.loop_done, stream));

@@ -18,6 +18,12 @@ def parse(path):
         inside = [r for r in rows if int(a["End_Timestamp"]) <= int(r["Start_Timestamp"]) < int(b["Start_Timestamp"])]
         between.append(len(inside))
     import statistics as st
+    if os.environ.get("TRACE_GAP_DETAIL") and len(cl) > 3:    # what started between two consecutive cluster launches, microseconds after the first one ended
+        a, b = cl[2], cl[3]
+        t0 = int(a["End_Timestamp"])
+        for r in rows:
+            if t0 - 20000 <= int(r["Start_Timestamp"]) < int(b["Start_Timestamp"]) + 30000 and r is not a:
+                print("   %+8.1f us  %6.1f us  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Kernel_Name"][:70]), file=sys.stderr)
     gsmall = [g for g in gaps if g < 2000]                   # (the gap between two calls holds the join + host work)
     print(json.dumps({"cluster_launches": len(cl), "duration_us": {"median": round(st.median(dur), 1), "min": round(min(dur), 1), "max": round(max(dur), 1)},
                       "gap_to_next_cluster_launch_us": {"median": round(st.median(gsmall), 1), "min": round(min(gsmall), 1), "max": round(max(gsmall), 1)},
