@@ -202,12 +202,12 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     (the split kernels are used unconditionally), 2 = as 1, and the first text-conditioned mldhip_sample after finalize
  *                     repeats the reverse-loop part on the first 8 motions of ITS batch (the caller's embeddings and start noise) before
  *                     it samples: the verdict then covers a real prompt batch, not only the seeded one.  Setting it un-finalizes the handle
- *   "ffn_strip"       F16X3 / FP8 modes, decoder / encoder layers: strip height of the register-direct kernels (kernels/ffn_strip.hpp,
+ *   "ffn_strip"       F16X3 mode, decoder / encoder layers: strip height of the register-direct kernels (kernels/ffn_strip.hpp,
  *                     kernels/gemm_strip_x3.hpp): 1 (default) = by launch size -- more than 512 strips of 64 rows: 96-row strips for the
  *                     GEMMs, 48-row strips at two workgroups per CU for the feed-forward block; else 64 rows (one bs-64 request: 196
  *                     strips on 256 CUs instead of 131 longer ones); 6 / 4 = 96 / 64 rows always, 3 = 48 rows for the feed-forward
  *                     block (96 for the GEMMs); 0 = feed-forward block as the two staged GEMMs of kernels/gemm.hpp
- *   "dec_tail"        F16X3 / FP8 modes, chip-filling launches: 1 (default) = a decoder layer's out-projection + residual + norm1 +
+ *   "dec_tail"        F16X3 mode, chip-filling launches: 1 (default) = a decoder layer's out-projection + residual + norm1 +
  *                     cross-attention vector + norm2 + feed-forward block as ONE launch (kernels/ffn_strip.hpp TAIL form: the block
  *                     input never goes to HBM), 0 = two launches
  *   "dec_l0_once"     every mode: 1 (default) = the first decoder layer's in-projection runs over ONE sample's rows: its input is
@@ -221,7 +221,7 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     64- / 96-row in-projection strips; 2 = 1 without the probe's veto (A/B tools)
  *   "tile_x3"         F16X3 mode: 1 (default) = the latency kernels of the reverse loop (kernels/tile32.hpp, one request at a time) multiply
  *                     on split-f16 MFMAs reading the pre-split weight image, 0 = on exact-fp32 MFMAs
- *   "strip_gemm"      F16X3 / FP8 modes, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:
+ *   "strip_gemm"      F16X3 mode, decoder / encoder in-projection, out-projection (+ residual + LayerNorms) and skip linears:
  *                     1 (default) = row-strip kernels with register-direct weights (kernels/gemm_strip_x3.hpp), 0 = staged tiles
  *   "cross_fold"      diffusion-only variant (latent width 512, 4 heads), every mode: 1 (default) = LayerNorm 1 + the cross-attention sub-layer + LayerNorm 2 of a trans_dec layer
  *                     run as ONE launch (kernels/novae.hpp cross2_fold_ln_kernel).  The memory is two tokens per sample, so (x Wq^T + bq) . k = x . (Wq^T k) + bq . k and
@@ -233,7 +233,7 @@ int mldhip_finalize_weights(mldhip_handle* h, void* stream);
  *                     multiplied, one barrier per 32-wide K chunk; same products in the same order as the 64 x 128 staged tile,
  *                     results identical to the bit), 2 = at any row count (tests), 0 = the 64 x 128 staged tile of kernels/gemm.hpp
  *   "strip_min_rows"  auto picks the column-split throughput kernels when the reverse loop has >= this many token rows (6 x batch; default
- *                     768 = 128 motions) -- in the modes whose latency kernels run fp32 / bf16 / fp8; in the F16X3 mode the split-f16
+ *                     768 = 128 motions) -- in the modes whose latency kernels run fp32 / bf16; in the F16X3 mode the split-f16
  *                     latency kernels serve every call below the persistent loop's threshold (15.2 vs 18.4 ms at 128 motions)
  *   "flash_attn"      split-f16 modes, frame-level self-attention of the decoder / encoder: key-blocked online-softmax kernel with
  *                     two workgroups per CU (kernels/attention.hpp attn_flash_x3_kernel): 0 = never, 1 = auto (default: calls
@@ -279,7 +279,7 @@ int mldhip_set_option(mldhip_handle* h, const char* name, int64_t value);
  * the half form exists for weights that pass the probe: same 4 x 64 frames on UNIT-normal latents, against the exact-fp32 decode of the same latents,
  * bound MLDHIP_PROBE_TOL_HALF = 3e-5 (a decode error of e ends ~ 7.5 e x max|feats| on the joints: 2.5e-4 at most); above it, or with the option
  * off, the block runs on fp32 Q | K | V and x3 products (decode_half_ok = 0).
- * The other modes: F32 has no such limits; BF16 / FP8 are reported-only modes whose errors bench.py prints. */
+ * The other modes: F32 has no such limits; BF16 is a reported-only mode whose errors bench.py prints. */
 #define MLDHIP_PROBE_TOL 6e-6f
 #define MLDHIP_PROBE_TOL_HALF 3e-5f
 typedef struct mldhip_numeric_info {

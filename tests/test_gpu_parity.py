@@ -336,6 +336,53 @@ def test_sample_many_pipelined_bs64_requests_are_bit_identical_and_overlap(dev):
     e.close()
 
 
+def test_sample_many_pipelined_repeated_mixed_calls_stay_bit_identical(dev):
+    """The three-stream schedule of "many_pipeline" (prep / caller / side stream, two workspaces) under repetition and mixed use: requests of 16 .. 128 motions (one
+    cluster launch each: inputs and condition rows staged on the prep stream beside the previous launch), a call that also holds a 200-motion request (two launches: the
+    whole call falls back to the two-stream form), plain mldhip_sample calls in between (the workspaces change hands between entry points), all on a stream of the
+    caller's own.  Every output of every round equals the request's serial mldhip_sample result to the bit; nothing non-finite, no timeout."""
+    e = _lib.Engine(device=0, max_batch=256, max_frames=196, precision=1, max_in_flight=2)
+    _load(e)
+    sizes = [64, 16, 128, 64, 40, 64, 200]
+    reqs, solo = [], []
+    for i, B in enumerate(sizes):
+        b = syn.make_batch(B, "ragged" if i % 2 else None, seed=900 + i)
+        T = max(b.lengths)
+        text, lat0 = _cuda(b.text_emb, dev), _cuda(b.init_latents, dev)
+        lat, joints = torch.empty(B, 1, 256, device=dev), torch.empty(B, T, 22, 3, device=dev)
+        e.sample(text, lat0, b.lengths, lat, None, joints)
+        solo.append((lat, joints))
+        reqs.append(dict(text_emb=text, init_latents=lat0, lengths=b.lengths, latents_out=torch.empty_like(lat), feats_out=None, joints_out=torch.empty_like(joints)))
+    torch.cuda.synchronize()
+    e.set_option("many_pipeline", 1)
+    st = torch.cuda.Stream()
+    scratch = (torch.empty_like(solo[1][0]), torch.empty_like(solo[1][1]))
+    for it in range(9):
+        for q in reqs:
+            q["latents_out"].fill_(float("nan")); q["joints_out"].fill_(float("nan"))
+        torch.cuda.synchronize()
+        if it % 3 == 0:
+            e.sample_many(reqs[:6], st.cuda_stream)
+            done = range(6)
+        elif it % 3 == 1:
+            e.sample_many(reqs[:3], st.cuda_stream)
+            e.sample(reqs[1]["text_emb"], reqs[1]["init_latents"], reqs[1]["lengths"], scratch[0], None, scratch[1], st.cuda_stream)
+            e.sample_many(reqs[3:6], st.cuda_stream)
+            done = range(6)
+        else:
+            e.sample_many([reqs[0], reqs[6], reqs[2], reqs[4]], st.cuda_stream)
+            done = (0, 6, 2, 4)
+        st.synchronize()
+        for i in done:
+            assert torch.equal(reqs[i]["latents_out"], solo[i][0]), (it, i)
+            assert torch.equal(reqs[i]["joints_out"], solo[i][1]), (it, i)
+        if it % 3 == 1:
+            assert torch.equal(scratch[0], solo[1][0]) and torch.equal(scratch[1], solo[1][1])
+    ns = e.numeric_status()
+    assert ns["nonfinite_values"] == 0 and ns["cluster_loop"] == 1, ns
+    e.close()
+
+
 def test_cluster_calls_beside_a_foreign_kernel_stream(dev):
     """The cluster launch needs its workgroups resident together; kernels of OTHER streams beside it can only delay it -- they end.  bs-64 calls while
     a foreign stream keeps the chip busy with (a) large torch matmuls (every CU, LDS-heavy workgroups) and (b) a CLIP-sized transformer layer stack -- what the next
