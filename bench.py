@@ -32,6 +32,7 @@ three f16 MFMAs per algorithmic product, so their roof is the dense f16 MFMA pea
 """
 import argparse
 import csv
+import ctypes as C
 import glob
 import hashlib
 import json
@@ -115,6 +116,22 @@ def algorithmic_gflop(B, T, D=256, F=1024, L=9, NF=263, steps=STEPS_DDIM):
     dec = L * (lin(md, D, 3 * D) + lin(md, D, D) + 4.0 * md * T * D + lin(md, D, F) + lin(md, F, D) + 2 * lin(B, D, D)) \
         + (L - 1) / 2 * lin(md, 2 * D, D) + lin(md, D, NF)
     return (den * steps + dec) / 1e9, den / 1e9, dec / 1e9
+
+
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block (C-level writers included: libc's buffers are flushed on both edges)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
 
 
 def source_hash():
@@ -686,7 +703,10 @@ def main():
     if world > 1 or "WORLD_SIZE" in os.environ:      # under torchrun the collective path runs at every world size, 1 included
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        with stdout_to_stderr():                     # RCCL prints its version banner on stdout when the communicator comes up: rank 0's stdout is ONE JSON line
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
 
     K = a.steps
     coalesce = max(1, min(32, a.coalesce, K))
